@@ -1,0 +1,269 @@
+"""Known-answer tests that pin the TF1 semantics (S1..S12) the oracle restates.
+
+The reference ships no tests and TF cannot run here, so every expected value below
+is derived by hand from the TF 1.10 op definitions cited in oracle/imm_oracle.py, and the torch
+oracle is also cross-checked against the independent fp64 loop code in oracle/np_ref.py.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import imm_oracle as O
+from oracle import np_ref as R
+
+
+def t(a):
+    return torch.as_tensor(np.asarray(a, dtype=np.float32))
+
+
+# ---- S1: SAME padding ----------------------------------------------------------------------
+def test_same_pad_formula():
+    assert O.same_pad(128, 3, 1) == (1, 1, 128)
+    assert O.same_pad(128, 7, 1) == (3, 3, 128)
+    assert O.same_pad(128, 3, 2) == (0, 1, 64)      # extra pixel bottom/right, none top/left
+    assert O.same_pad(16, 1, 1) == (0, 0, 16)
+    assert O.same_pad(5, 3, 2) == (1, 1, 3)
+
+
+def test_stride2_same_alignment_delta():
+    # delta image at (0,0), delta kernel at tap (0,0): with pad_top=0 the output (0,0) sees input (0,0)
+    x = torch.zeros(1, 4, 4, 1); x[0, 0, 0, 0] = 1.0
+    w = torch.zeros(3, 3, 1, 1); w[0, 0, 0, 0] = 1.0
+    y = O.conv2d_same(x, w, None, stride=2)
+    assert y.shape == (1, 2, 2, 1)
+    assert y[0, 0, 0, 0] == 1.0 and y.sum() == 1.0
+    # centre tap (1,1) reads input (2*oy+1, 2*ox+1): a delta at (1,1) lands on output (0,0)
+    x = torch.zeros(1, 4, 4, 1); x[0, 1, 1, 0] = 1.0
+    w = torch.zeros(3, 3, 1, 1); w[1, 1, 0, 0] = 1.0
+    y = O.conv2d_same(x, w, None, stride=2)
+    assert y[0, 0, 0, 0] == 1.0 and y.sum() == 1.0
+    # PyTorch padding=1 would instead need the delta at (0,0) for the centre tap -> must differ
+    x = torch.zeros(1, 4, 4, 1); x[0, 0, 0, 0] = 1.0
+    assert O.conv2d_same(x, w, None, stride=2).sum() == 0.0
+
+
+def test_conv_is_cross_correlation():
+    x = torch.zeros(1, 5, 5, 1); x[0, 2, 2, 0] = 1.0
+    w = torch.arange(9, dtype=torch.float32).reshape(3, 3, 1, 1)
+    y = O.conv2d_same(x, w)[0, :, :, 0]
+    # out[oy,ox] = sum w[ky,kx] x[oy+ky-1, ox+kx-1] -> the kernel appears flipped around the delta
+    assert y[1, 1] == 8.0 and y[3, 3] == 0.0 and y[2, 2] == 4.0 and y[1, 3] == 6.0
+
+
+@pytest.mark.parametrize('k,s,h', [(3, 1, 6), (3, 2, 6), (7, 1, 9), (1, 1, 4), (3, 2, 7)])
+def test_conv_vs_numpy_loops(k, s, h):
+    rng = np.random.default_rng(k * 10 + s)
+    x = rng.standard_normal((2, h, h, 3)).astype(np.float32)
+    w = rng.standard_normal((k, k, 3, 4)).astype(np.float32)
+    b = rng.standard_normal(4).astype(np.float32)
+    y = O.conv2d_same(t(x), t(w), t(b), s).numpy()
+    np.testing.assert_allclose(y, R.conv2d_same(x, w, b, s), rtol=1e-5, atol=1e-5)
+
+
+# ---- S2 / S3: resize ------------------------------------------------------------------------
+def test_legacy_upsample2x_ramp():
+    x = t([0., 1., 2., 3.]).reshape(1, 1, 4, 1).repeat(1, 4, 1, 1)
+    y = O.resize_bilinear(x, 8, 8)[0, 0, :, 0]
+    # out[2i]=in[i], out[2i+1]=(in[i]+in[min(i+1,n-1)])/2  (no half-pixel offset; last sample repeats)
+    np.testing.assert_allclose(y.numpy(), [0, .5, 1, 1.5, 2, 2.5, 3, 3], atol=1e-7)
+    # F.interpolate(align_corners=False) uses half-pixel centres and gives [0,.25,.75,...]: must differ
+    z = torch.nn.functional.interpolate(x.permute(0, 3, 1, 2), scale_factor=2, mode='bilinear',
+                                        align_corners=False)[0, 0, 0]
+    assert abs(float(z[1]) - 0.25) < 1e-6 and abs(float(y[1]) - 0.5) < 1e-7
+
+
+def test_legacy_downsample_is_strided_pick():
+    m = O.smooth_mask(128, 128).reshape(1, 128, 128, 1)
+    for s in (128, 64, 32, 16, 8):
+        r = 128 // s
+        np.testing.assert_array_equal(O.loss_mask_at(m, s).numpy(), m[:, ::r, ::r].numpy())
+
+
+def test_align_corners_resize():
+    x = t([0., 1., 2., 3.]).reshape(1, 4, 1, 1).repeat(1, 1, 4, 1)
+    y = O.resize_bilinear(x, 2, 2, align_corners=True)[0, :, 0, 0]
+    np.testing.assert_allclose(y.numpy(), [0., 3.], atol=1e-7)   # src = dst*(in-1)/(out-1)
+    x32 = torch.arange(32, dtype=torch.float32).reshape(1, 32, 1, 1).repeat(1, 1, 32, 1)
+    y16 = O.resize_bilinear(x32, 16, 16, align_corners=True)[0, :, 0, 0]
+    np.testing.assert_allclose(y16.numpy(), np.arange(16) * 31.0 / 15.0, rtol=1e-6)
+
+
+@pytest.mark.parametrize('ac', [False, True])
+def test_resize_vs_numpy_loops(ac):
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((2, 4, 4, 3)).astype(np.float32)
+    np.testing.assert_allclose(O.resize_bilinear(t(x), 8, 8, ac).numpy(), R.resize_bilinear(x, 8, 8, ac),
+                               rtol=1e-6, atol=1e-6)
+    x = rng.standard_normal((1, 8, 8, 2)).astype(np.float32)
+    np.testing.assert_allclose(O.resize_bilinear(t(x), 4, 4, ac).numpy(), R.resize_bilinear(x, 4, 4, ac),
+                               rtol=1e-6, atol=1e-6)
+
+
+# ---- S4: batch norm --------------------------------------------------------------------------
+def test_batch_norm_biased_unbiased():
+    x = t([1., 2., 3., 6.]).reshape(4, 1, 1, 1)
+    y, (mm, mv) = O.batch_norm(x, torch.ones(1), torch.zeros(1), torch.zeros(1), torch.ones(1), True)
+    mean, var = 3.0, (4 + 1 + 0 + 9) / 4.0          # biased 3.5
+    np.testing.assert_allclose(y.flatten().numpy(), (np.array([1, 2, 3, 6.]) - mean) / math.sqrt(var + 1e-3),
+                               rtol=1e-6)
+    assert abs(float(mm) - 0.01 * mean) < 1e-7                      # 0*0.99 + 3*0.01
+    assert abs(float(mv) - (0.99 + 0.01 * var * 4 / 3)) < 1e-6      # unbiased into the moving average
+    ye, (mm2, mv2) = O.batch_norm(x, torch.ones(1), torch.zeros(1), mm, mv, False)
+    np.testing.assert_allclose(ye.flatten().numpy(), (np.array([1, 2, 3, 6.]) - float(mm)) / math.sqrt(float(mv) + 1e-3),
+                               rtol=1e-6)
+    assert mm2 is mm and mv2 is mv
+
+
+def test_batch_norm_vs_numpy():
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((2, 3, 3, 5)).astype(np.float32) * 3 + 1
+    g = rng.standard_normal(5).astype(np.float32); b = rng.standard_normal(5).astype(np.float32)
+    y, (mm, mv) = O.batch_norm(t(x), t(g), t(b), torch.zeros(5), torch.ones(5), True)
+    yr, mean, var, unb = R.batch_norm_train(x, g, b)
+    np.testing.assert_allclose(y.numpy(), yr, rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(mv.numpy(), 0.99 + 0.01 * unb, rtol=1e-5)
+
+
+# ---- S7: soft-argmax / gaussians --------------------------------------------------------------
+def test_softargmax_uniform_and_peak():
+    mu, py, px = O.soft_argmax(torch.zeros(2, 16, 16, 3))
+    assert float(mu.abs().max()) < 1e-6 and abs(float(py[0, 0, 0]) - 1 / 16) < 1e-7
+    h = torch.zeros(1, 16, 16, 1); h[0, 5, 11, 0] = 16 * 200.0   # row/col means = 200 at (5, 11)
+    mu, _, _ = O.soft_argmax(h)
+    lin = lambda i: -1 + 2 * i / 15
+    assert abs(float(mu[0, 0, 0]) - lin(5)) < 1e-5 and abs(float(mu[0, 0, 1]) - lin(11)) < 1e-5
+
+
+def test_softargmax_two_point_closed_form():
+    # row means: a at row 0, 0 elsewhere -> p0 = e^a/(e^a+15); mu_y = sum p_i lin_i = (p0-p_rest)*(-1) ...
+    a = 2.0
+    h = torch.zeros(1, 16, 16, 1); h[0, 0, :, 0] = a
+    mu, py, _ = O.soft_argmax(h)
+    p0 = math.exp(a) / (math.exp(a) + 15)
+    pr = 1 / (math.exp(a) + 15)
+    exp_mu = p0 * (-1) + pr * sum(-1 + 2 * i / 15 for i in range(1, 16))
+    assert abs(float(py[0, 0, 0]) - p0) < 1e-6 and abs(float(mu[0, 0, 0]) - exp_mu) < 1e-6
+    assert abs(float(mu[0, 0, 1])) < 1e-6    # column means are all a/16 -> uniform
+
+
+def test_gaussian_rot_analytic():
+    g = O.gaussian_maps(torch.zeros(1, 1, 2), [16, 16], 10.0, 'rot')[0, :, :, 0]
+    for (i, j) in [(0, 0), (7, 8), (15, 3)]:
+        yl, xl = -1 + 2 * i / 15, -1 + 2 * j / 15
+        assert abs(float(g[i, j]) - math.exp(-100 * (yl * yl + xl * xl))) < 1e-7   # no 1/2 factor
+    mu = t([[[0.2, -0.6]]])
+    g = O.gaussian_maps(mu, [16, 16], 10.0, 'rot')[0, :, :, 0]
+    i, j = 9, 3
+    yl, xl = -1 + 2 * i / 15, -1 + 2 * j / 15
+    assert abs(float(g[i, j]) - math.exp(-100 * ((yl - .2) ** 2 + (xl + .6) ** 2))) < 1e-6
+
+
+@pytest.mark.parametrize('mode', ['rot', 'flat', 'ankush'])
+def test_gaussian_modes_vs_numpy(mode):
+    rng = np.random.default_rng(7)
+    mu = rng.uniform(-0.9, 0.9, (2, 3, 2)).astype(np.float32)
+    g = O.gaussian_maps(t(mu), [8, 8], 10.0, mode).numpy()
+    np.testing.assert_allclose(g, R.gaussian_maps(mu, 8, 10.0, mode), rtol=2e-5, atol=1e-6)
+    with pytest.raises(ValueError):
+        O.gaussian_maps(t(mu), [8, 8], 10.0, 'nope')
+
+
+def test_softargmax_vs_numpy():
+    rng = np.random.default_rng(11)
+    h = (rng.standard_normal((2, 16, 16, 4)) * 3).astype(np.float32)
+    mu, py, px = O.soft_argmax(t(h))
+    rmu, rpy, rpx = R.soft_argmax(h)
+    np.testing.assert_allclose(mu.numpy(), rmu, atol=1e-6)
+    np.testing.assert_allclose(py.numpy(), rpy, atol=1e-6)
+    np.testing.assert_allclose(px.numpy(), rpx, atol=1e-6)
+
+
+# ---- S8: max pool ---------------------------------------------------------------------------
+def test_max_pool_vs_numpy():
+    rng = np.random.default_rng(13)
+    x = rng.standard_normal((2, 6, 6, 3)).astype(np.float32)
+    np.testing.assert_array_equal(O.max_pool2(t(x)).numpy(), R.max_pool2(x))
+
+
+# ---- S9: clip + Adam -----------------------------------------------------------------------
+def test_clip_by_norm():
+    g = t([3., 4.])
+    np.testing.assert_allclose(O.clip_by_norm(g, 1.0).numpy(), [0.6, 0.8], rtol=1e-6)
+    np.testing.assert_allclose(O.clip_by_norm(g, 10.0).numpy(), [3., 4.], rtol=1e-6)   # below c: untouched
+    np.testing.assert_allclose(O.clip_by_norm(g, 1.0).numpy(), R.clip_by_norm(g.numpy(), 1.0), rtol=1e-6)
+
+
+def test_adam_first_step_epsilon_placement():
+    # TF form: p -= lr*sqrt(1-b2)/(1-b1) * m/(sqrt(v)+eps) with m=(1-b1)g, v=(1-b2)g^2 at t=1
+    P = {'x/w': t([1.0])}
+    opt = O.new_adam_state(P)
+    g = 1e-4
+    newP = O.adam_apply(P, {'x/w': t([g])}, opt, lr=1e-3)
+    m, v = 0.1 * g, 0.001 * g * g
+    exp = 1.0 - 1e-3 * math.sqrt(1 - 0.999) / (1 - 0.9) * m / (math.sqrt(v) + 1e-8)
+    assert abs(float(newP['x/w']) - exp) < 1e-7   # fp32 parameter
+    # the "epsilon-hat" (Kingma) form would give 1 - lr*g/(|g|+eps): differs measurably at g=1e-4..1e-7
+    p2, _, _ = R.adam_step(np.array([1.0]), np.array([g]), np.zeros(1), np.zeros(1), 1, 1e-3)
+    assert abs(float(p2[0]) - exp) < 1e-12
+    assert opt['t'] == 1
+
+
+def test_learning_rate_staircase():
+    assert O.learning_rate(0) == 1e-3 and O.learning_rate(99999) == 1e-3
+    assert abs(O.learning_rate(100000) - 0.95e-3) < 1e-12
+    assert abs(O.learning_rate(250000, lr_multiple=2.0) - 2 * 1e-3 * 0.95 ** 2) < 1e-12
+
+
+# ---- loss pieces ---------------------------------------------------------------------------
+def test_smooth_mask_shape_values():
+    m = O.smooth_mask(128, 128)
+    assert m.shape == (128, 128)
+    assert float(m[:10].abs().max()) == 0.0 and float(m[-10:].abs().max()) == 0.0
+    assert abs(float(m[64, 64]) - 1.0) < 1e-7
+    s = 0.5 + 0.5 * math.tanh(-1.0 / 0.4)
+    assert abs(float(m[10, 64]) - s) < 1e-6      # first sample of the up-step
+    assert abs(float(m[64, 117]) - s) < 1e-6     # last sample of the down-step (mirrored)
+
+
+def test_running_avg_gradient_path():
+    # loss_k = m/wl with wl = a + 0.01(m-a): d/dm = 1/wl - 0.01 m/wl^2 (no stop_gradient, base_model.py:39-50)
+    a = torch.tensor(1.6)
+    m = torch.tensor(2.5, requires_grad=True)
+    wl = O.exp_running_avg(m, a)
+    (m / wl).backward()
+    wlv = 1.6 + 0.01 * (2.5 - 1.6)
+    assert abs(float(m.grad) - (1 / wlv - 0.01 * 2.5 / wlv ** 2)) < 1e-6
+
+
+def test_weight_decay_only_on_kernels():
+    cfg = O.default_model_config()
+    P, S = O.init_params(cfg, 128)
+    wl = float(O.weight_decay_loss(P))
+    manual = sum(1e-5 * 0.5 * float((v.double() ** 2).sum()) for k, v in P.items() if k.endswith('/w'))
+    assert abs(wl - manual) < 1e-9 * max(1, manual)
+    assert len(P) == 96 and sum(v.numel() for v in P.values()) == 4138067   # SURVEY §2a op table
+    assert max(float(v.abs().max()) for k, v in P.items() if k.endswith('/w')) <= 0.02 + 1e-9  # truncation
+
+
+def test_param_counts_other_configs():
+    for k, n in ((30, 4189287), (50, 4240507)):
+        P, _ = O.init_params(O.default_model_config(k), 128)
+        assert sum(v.numel() for v in P.values()) == n
+    P, _ = O.init_params(O.default_model_config(30), 256)
+    assert sum(v.numel() for v in P.values()) == 4201959
+    assert O.render_sizes(O.default_model_config(), 128) == [128, 64, 32, 16]
+    assert O.render_sizes(O.default_model_config(), 256) == [256, 128, 64, 32, 16]
+
+
+def test_errors_match_reference_types():
+    cfg = O.default_model_config()
+    P, S = O.init_params(cfg, 128)
+    inp = O.synthetic_inputs(1, 128)
+    del inp['mask']
+    with pytest.raises(RuntimeError):
+        O.forward(P, S, inp, cfg)
+    cfg2 = O.Cfg(cfg); cfg2['reconstruction_loss'] = 'huber'
+    with pytest.raises(ValueError):
+        O.forward(P, S, O.synthetic_inputs(1, 128), cfg2)
