@@ -1,0 +1,112 @@
+"""ctypes binding of libimm_hip.so (the C-ABI declared in include/imm_hip.h).
+
+There is NO fallback: if the library is missing or a call fails this raises.  The product path never
+routes through the CPU oracle.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libimm_hip.so')
+
+IMM_BF16, IMM_F16 = 0, 1
+CONV_BIAS, CONV_RELU, CONV_STATS, CONV_MASK, CONV_OUT_F32 = 1, 2, 4, 8, 16
+SSE_BLOCKS = 512
+ABI_VERSION = 1
+
+
+class ImmHipError(RuntimeError):
+    pass
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        'batch', 'hi', 'wi', 'ci', 'ldx', 'ho', 'wo', 'co', 'ldy', 'kh', 'kw', 'stride', 'pad_t', 'pad_l',
+        'updiv', 'kpad', 'flags', 'ldmask')]
+
+
+class OptHParams(C.Structure):
+    _fields_ = [('lr_start', C.c_float), ('lr_decay', C.c_float), ('lr_step', C.c_int32), ('lr_multiple', C.c_float),
+                ('beta1', C.c_float), ('beta2', C.c_float), ('eps', C.c_float), ('clip', C.c_float),
+                ('grad_scale', C.c_float)]
+
+
+_P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
+_SIGS = {
+    'imm_abi_version': [],
+    'imm_device_info': [_P],
+    'imm_graph_begin': [_P],
+    'imm_graph_end': [_P, C.POINTER(C.c_void_p)],
+    'imm_graph_launch': [_P, _P],
+    'imm_graph_destroy': [_P],
+    'imm_pack_weights': [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    'imm_conv2d': [C.POINTER(ConvDesc), _I, _P, _P, _P, _P, _P, _P, _P],
+    'imm_conv_stats_blocks': [C.POINTER(ConvDesc)],
+    'imm_conv2d_wgrad': [C.POINTER(ConvDesc), _I, _P, _P, _I, _P, _I, _P],
+    'imm_conv2d_wgrad_reduce': [_P, _I, _I, _I, _I, _I, _I, _I, _P, _P],
+    'imm_colsum': [_P, _I, _L, _I, _I, _I, _P, _P, _P],
+    'imm_colsum_blocks': [_L, _I],
+    'imm_bn_finalize': [_P, _I, _I, _L, _P, _P, _F, _F, _I, _P, _P, _P, _P, _P, _P, _P],
+    'imm_bn_apply_relu': [_P, _I, _L, _I, _I, _P, _P, _I, _P, _I, _P],
+    'imm_bn_bwd_reduce': [_P, _I, _P, _I, _I, _L, _I, _P, _P, _P, _P, _I, _P, _P],
+    'imm_bn_bwd_blocks': [_L, _I],
+    'imm_bn_bwd_finalize': [_P, _I, _I, _L, _P, _P, _P, _P, _P, _P],
+    'imm_bn_bwd_apply': [_P, _I, _P, _I, _I, _L, _I, _P, _P, _P, _P, _I, _P, _P, _I, _P],
+    'imm_upsample2x_fwd': [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    'imm_upsample2x_bwd': [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    'imm_resize_ac_fwd': [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    'imm_resize_ac_bwd': [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    'imm_maxpool2_fwd': [_P, _P, _I, _I, _I, _I, _I, _P],
+    'imm_maxpool2_bwd': [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    'imm_pack_image': [_P, _P, _I, _L, _P],
+    'imm_softargmax_gauss_fwd': [_P, _I, _I, _I, _I, _I, _F, _I, _P, _P, _P, _P, _I, _I, _P],
+    'imm_softargmax_gauss_bwd': [_P, _I, _I, _I, _I, _I, _I, _F, _I, _P, _P, _P, _P, _I, _P],
+    'imm_gauss_render_f32': [_P, _I, _I, _F, _I, _P, _P],
+    'imm_vgg_conv1_1_fwd': [_P, _P, _I, _I, _I, _P, _P, _P, _I, _P],
+    'imm_vgg_conv1_1_bwd': [_P, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P, _I, _P],
+    'imm_masked_sse': [_P, _P, _I, _I, _I, _I, _P, _I, _P, _P],
+    'imm_masked_sse_f32': [_P, _I, _P, _I, _I, _I, _I, _P, _P, _P],
+    'imm_perceptual_finalize': [_P, _I, _P, _P, _I, _P, _P, _P],
+    'imm_tap_grad': [_P, _I, _P, _P, _I, _I, _I, _I, _P, _I, _P, _I, _I, _P],
+    'imm_weight_decay_loss': [_P, _P, _P, _P, _I, _P, _P, _P, _P],
+    'imm_clip_adam_step': [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, C.POINTER(OptHParams), _P],
+}
+
+_lib = None
+
+
+def declared_symbols():
+    return sorted(list(_SIGS) + ['imm_last_error'])
+
+
+def load():
+    """Load (once) and return the ctypes handle; raises ImmHipError if the library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImmHipError('libimm_hip.so not found at %s: build it with `python imm_amd/build.py` '
+                          '(there is no CPU fallback for the product path)' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    lib.imm_last_error.restype = C.c_char_p
+    lib.imm_last_error.argtypes = []
+    for name, args in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = C.c_int
+    v = lib.imm_abi_version()
+    if v != ABI_VERSION:
+        raise ImmHipError('libimm_hip.so ABI %d != expected %d' % (v, ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise ImmHipError('%s failed (%d): %s' % (what, rc, load().imm_last_error().decode()))
+
+
+def call(name, *args):
+    rc = getattr(load(), name)(*args)
+    if rc != 0:
+        raise ImmHipError('%s failed (%d): %s' % (name, rc, load().imm_last_error().decode()))

@@ -1,0 +1,203 @@
+// bottleneck.hip — IMM landmark bottleneck on gfx950: K-channel spatial soft-argmax -> (y,x) landmarks
+// -> isotropic Gaussian maps, forward and backward, one workgroup per sample.
+//
+// Reference: imm/models/imm_model.py:252-264 (reduce_mean over the other axis, softmax over this
+// axis, expectation against linspace(-1,1,n)) and :34-78 get_gaussian_maps mode 'rot'
+// (exp(-((y-mu_y)^2+(x-mu_x)^2)*inv_std^2), the mode every shipped config uses,
+// configs/experiments/celeba-10pts.yaml:27).  Modes 'flat' / 'ankush' are rejected loudly by the host.
+//
+// The whole heat-map of a sample (h*w*K f32: 10 KB at 16x16xK=10, 120 KB at 32x32x30) is staged in
+// the CU's 160 KB LDS once; row/column means, the two softmaxes and the render then run out of LDS.
+// HBM traffic per sample = the heat-map read + mu/probabilities + the s*s*K 16-bit map written
+// straight into the renderer's concat buffer (channel offset given by the pointer, stride ldg).
+#include "common.h"
+
+#define BT_THREADS 256
+
+__device__ __forceinline__ float lin_pm1(int i, int n) { return n > 1 ? -1.f + 2.f * (float)i / (float)(n - 1) : -1.f; }
+
+template <typename ET>
+__global__ __launch_bounds__(BT_THREADS) void softargmax_gauss_fwd_kernel(
+    const float* __restrict__ heat, int ldh, int h, int w, int K, float inv_std, int s, float* __restrict__ mu,
+    float* __restrict__ py, float* __restrict__ px, uint16_t* __restrict__ gauss, int ldg) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* sheat = sm;                      // [h*w][K]
+  float* rmean = sheat + h * w * K;       // [h][K] row means -> probabilities
+  float* cmean = rmean + h * K;           // [w][K]
+  float* smu = cmean + w * K;             // [K][2]
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* hb = heat + (int64_t)b * h * w * ldh;
+  for (int i = tid; i < h * w * K; i += BT_THREADS) {
+    const int p = i / K, k = i - p * K;
+    sheat[i] = hb[(int64_t)p * ldh + k];
+  }
+  __syncthreads();
+  // means over the other axis (imm_model.py:254)
+  for (int i = tid; i < (h + w) * K; i += BT_THREADS) {
+    if (i < h * K) {
+      const int r = i / K, k = i - r * K;
+      float acc = 0.f;
+      for (int x = 0; x < w; ++x) acc += sheat[(r * w + x) * K + k];
+      rmean[i] = acc / (float)w;
+    } else {
+      const int ii = i - h * K;
+      const int cidx = ii / K, k = ii - cidx * K;
+      float acc = 0.f;
+      for (int y = 0; y < h; ++y) acc += sheat[(y * w + cidx) * K + k];
+      cmean[ii] = acc / (float)h;
+    }
+  }
+  __syncthreads();
+  // softmax + expectation, one thread per (axis, k)  (imm_model.py:255-258)
+  for (int i = tid; i < 2 * K; i += BT_THREADS) {
+    const int axis = i / K, k = i - axis * K;
+    float* v = axis == 0 ? rmean : cmean;
+    const int n = axis == 0 ? h : w;
+    float mx = -INFINITY;
+    for (int j = 0; j < n; ++j) mx = fmaxf(mx, v[j * K + k]);
+    float den = 0.f;
+    for (int j = 0; j < n; ++j) { const float e = expf(v[j * K + k] - mx); v[j * K + k] = e; den += e; }
+    float ex = 0.f;
+    float* pout = (axis == 0 ? py : px) + (int64_t)b * n * K;
+    for (int j = 0; j < n; ++j) {
+      const float p = v[j * K + k] / den;
+      pout[j * K + k] = p;
+      ex += p * lin_pm1(j, n);
+    }
+    smu[k * 2 + axis] = ex;
+    mu[((int64_t)b * K + k) * 2 + axis] = ex;
+  }
+  __syncthreads();
+  // render (imm_model.py:48-59, transposed to NHWC at :77)
+  if (gauss != nullptr) {
+    const float i2 = inv_std * inv_std;
+    for (int i = tid; i < s * s * K; i += BT_THREADS) {
+      const int p = i / K, k = i - p * K;
+      const int yy = p / s, xx = p - yy * s;
+      const float dy = lin_pm1(yy, s) - smu[k * 2], dx = lin_pm1(xx, s) - smu[k * 2 + 1];
+      gauss[((int64_t)b * s * s + p) * ldg + k] = ET::from_f32(expf(-(dy * dy + dx * dx) * i2));
+    }
+  }
+}
+
+// backward: dG -> dmu (through the Gaussian) -> d row/col means (through softmax-expectation) -> dheat
+template <typename ET>
+__global__ __launch_bounds__(BT_THREADS) void softargmax_gauss_bwd_kernel(
+    const uint16_t* __restrict__ dgauss, int ldg, int h, int w, int K, float inv_std, int s,
+    const float* __restrict__ mu, const float* __restrict__ py, const float* __restrict__ px,
+    uint16_t* __restrict__ dheat, int lddh) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* dmu = sm;              // [K][2]
+  float* drow = dmu + 2 * K;    // [h][K]  d loss / d row-mean
+  float* dcol = drow + h * K;   // [w][K]
+  __shared__ float red[4];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float i2 = inv_std * inv_std;
+  // dmu[k][axis] = sum_p dG*G*2*inv_std^2*(coord - mu)
+  for (int k = 0; k < K; ++k) {
+    const float my = mu[((int64_t)b * K + k) * 2], mx = mu[((int64_t)b * K + k) * 2 + 1];
+    float ay = 0.f, ax = 0.f;
+    for (int p = tid; p < s * s; p += BT_THREADS) {
+      const int yy = p / s, xx = p - yy * s;
+      const float dy = lin_pm1(yy, s) - my, dx = lin_pm1(xx, s) - mx;
+      const float g = expf(-(dy * dy + dx * dx) * i2);
+      const float dg = ET::to_f32(dgauss[((int64_t)b * s * s + p) * ldg + k]) * g * 2.f * i2;
+      ay += dg * dy;
+      ax += dg * dx;
+    }
+    ay = block_sum_256(ay, red);
+    ax = block_sum_256(ax, red);
+    if (tid == 0) { dmu[k * 2] = ay; dmu[k * 2 + 1] = ax; }
+  }
+  __syncthreads();
+  // mu = sum_j p_j lin_j, p = softmax(r):  dr_j = p_j (lin_j - mu) dmu
+  for (int i = tid; i < (h + w) * K; i += BT_THREADS) {
+    if (i < h * K) {
+      const int j = i / K, k = i - j * K;
+      const float p = py[(int64_t)b * h * K + i];
+      drow[i] = p * (lin_pm1(j, h) - mu[((int64_t)b * K + k) * 2]) * dmu[k * 2];
+    } else {
+      const int ii = i - h * K;
+      const int j = ii / K, k = ii - j * K;
+      const float p = px[(int64_t)b * w * K + ii];
+      dcol[ii] = p * (lin_pm1(j, w) - mu[((int64_t)b * K + k) * 2 + 1]) * dmu[k * 2 + 1];
+    }
+  }
+  __syncthreads();
+  // row mean = sum_x heat/w, col mean = sum_y heat/h
+  for (int i = tid; i < h * w * lddh; i += BT_THREADS) {
+    const int p = i / lddh, k = i - p * lddh;
+    float v = 0.f;
+    if (k < K) {
+      const int yy = p / w, xx = p - yy * w;
+      v = drow[yy * K + k] / (float)w + dcol[xx * K + k] / (float)h;
+    }
+    dheat[(int64_t)b * h * w * lddh + i] = ET::from_f32(v);
+  }
+}
+
+__global__ void gauss_render_f32_kernel(const float* __restrict__ mu, int K, float inv_std, int s, float* __restrict__ out,
+                                        int64_t total) {
+  const float i2 = inv_std * inv_std;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int k = (int)(idx % K);
+    int64_t t = idx / K;
+    const int xx = (int)(t % s); t /= s;
+    const int yy = (int)(t % s);
+    const int64_t b = t / s;
+    const float dy = lin_pm1(yy, s) - mu[(b * K + k) * 2], dx = lin_pm1(xx, s) - mu[(b * K + k) * 2 + 1];
+    out[idx] = expf(-(dy * dy + dx * dx) * i2);
+  }
+}
+
+static const size_t kMaxDynLds = 160 * 1024 - 1024;
+
+template <typename K_>
+static int set_dyn_lds(K_ kernel, size_t bytes) {
+  if (bytes > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return imm_fail(IMM_E_HIP, "hipFuncSetAttribute(dyn LDS %zu): %s", bytes, hipGetErrorString(e));
+  }
+  return 0;
+}
+
+extern "C" int imm_softargmax_gauss_fwd(const float* heat, int ldh, int batch, int h, int w, int k, float inv_std, int s,
+                                        float* mu, float* py, float* px, void* gauss_out, int ldg, int dtype,
+                                        void* stream) {
+  IMM_REQUIRE(heat && mu && py && px, "softargmax_fwd: null");
+  IMM_REQUIRE(batch > 0 && h > 0 && w > 0 && k > 0 && ldh >= k && s > 0, "softargmax_fwd: dims");
+  IMM_REQUIRE(gauss_out == nullptr || ldg >= k, "softargmax_fwd: ldg");
+  const size_t lds = sizeof(float) * ((size_t)h * w * k + (size_t)(h + w) * k + 2 * (size_t)k);
+  if (lds > kMaxDynLds) return imm_fail(IMM_E_UNSUPPORTED, "softargmax_fwd: heat-map %dx%dx%d needs %zu B LDS", h, w, k, lds);
+  IMM_DISPATCH_DTYPE(dtype, {
+    if (set_dyn_lds(softargmax_gauss_fwd_kernel<ET>, lds)) return IMM_E_HIP;
+    hipLaunchKernelGGL((softargmax_gauss_fwd_kernel<ET>), dim3(batch), dim3(BT_THREADS), lds, (hipStream_t)stream, heat,
+                       ldh, h, w, k, inv_std, s, mu, py, px, (uint16_t*)gauss_out, ldg);
+  });
+  IMM_CHECK_LAUNCH("imm_softargmax_gauss_fwd");
+  return 0;
+}
+
+extern "C" int imm_softargmax_gauss_bwd(const void* dgauss, int ldg, int dtype, int batch, int h, int w, int k,
+                                        float inv_std, int s, const float* mu, const float* py, const float* px,
+                                        void* dheat, int lddh, void* stream) {
+  IMM_REQUIRE(dgauss && mu && py && px && dheat, "softargmax_bwd: null");
+  IMM_REQUIRE(batch > 0 && h > 0 && w > 0 && k > 0 && ldg >= k && lddh >= k && s > 0, "softargmax_bwd: dims");
+  const size_t lds = sizeof(float) * (2 * (size_t)k + (size_t)(h + w) * k);
+  IMM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((softargmax_gauss_bwd_kernel<ET>), dim3(batch), dim3(BT_THREADS), lds,
+                                               (hipStream_t)stream, (const uint16_t*)dgauss, ldg, h, w, k, inv_std, s, mu,
+                                               py, px, (uint16_t*)dheat, lddh));
+  IMM_CHECK_LAUNCH("imm_softargmax_gauss_bwd");
+  return 0;
+}
+
+extern "C" int imm_gauss_render_f32(const float* mu, int batch, int k, float inv_std, int s, float* out, void* stream) {
+  IMM_REQUIRE(mu && out && batch > 0 && k > 0 && s > 0, "gauss_render: args");
+  const int64_t total = (int64_t)batch * s * s * k;
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(gauss_render_f32_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, mu, k, inv_std, s, out, total);
+  IMM_CHECK_LAUNCH("imm_gauss_render_f32");
+  return 0;
+}

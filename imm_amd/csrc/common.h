@@ -1,0 +1,107 @@
+// common.h — shared device helpers for libimm_hip.so (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/imm_hip.h"
+
+#define IMM_WAVE 64
+
+// ---------------------------------------------------------------------------------------------
+// error plumbing (thread-local message; no exceptions cross the C boundary)
+// ---------------------------------------------------------------------------------------------
+extern thread_local char imm_err_buf[512];
+int imm_fail(int code, const char* fmt, ...);
+
+#define IMM_REQUIRE(cond, ...)                              \
+  do {                                                      \
+    if (!(cond)) return imm_fail(IMM_E_INVALID, __VA_ARGS__); \
+  } while (0)
+
+#define IMM_CHECK_LAUNCH(name)                                                       \
+  do {                                                                               \
+    hipError_t e__ = hipGetLastError();                                              \
+    if (e__ != hipSuccess) return imm_fail(IMM_E_HIP, "%s: %s", name, hipGetErrorString(e__)); \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// 16-bit element traits: storage is uint16_t in memory; arithmetic in f32; MFMA operand vectors
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+struct BF16 {
+  static constexpr int kEnum = IMM_BF16;
+  __device__ static __forceinline__ float to_f32(uint16_t u) { return __uint_as_float(((uint32_t)u) << 16); }
+  __device__ static __forceinline__ uint16_t from_f32(float f) {  // round to nearest even
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // quiet NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+  }
+  __device__ static __forceinline__ f32x4_t mfma(uint4 a, uint4 b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b),
+                                                   c, 0, 0, 0);
+  }
+};
+
+struct F16 {
+  static constexpr int kEnum = IMM_F16;
+  __device__ static __forceinline__ float to_f32(uint16_t u) { return (float)__builtin_bit_cast(_Float16, u); }
+  __device__ static __forceinline__ uint16_t from_f32(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
+  __device__ static __forceinline__ f32x4_t mfma(uint4 a, uint4 b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b),
+                                                  c, 0, 0, 0);
+  }
+};
+
+// unpack / pack 8 16-bit values held in a uint4
+template <typename ET>
+__device__ __forceinline__ void unpack8(const uint4& v, float (&f)[8]) {
+  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f[2 * i] = ET::to_f32((uint16_t)(w[i] & 0xffffu));
+    f[2 * i + 1] = ET::to_f32((uint16_t)(w[i] >> 16));
+  }
+}
+template <typename ET>
+__device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
+  uint32_t w[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    w[i] = (uint32_t)ET::from_f32(f[2 * i]) | ((uint32_t)ET::from_f32(f[2 * i + 1]) << 16);
+  return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// dispatch on the runtime dtype enum
+#define IMM_DISPATCH_DTYPE(dtype, ...)                                          \
+  do {                                                                          \
+    if ((dtype) == IMM_BF16) { using ET = BF16; __VA_ARGS__; }                  \
+    else if ((dtype) == IMM_F16) { using ET = F16; __VA_ARGS__; }               \
+    else return imm_fail(IMM_E_INVALID, "unknown dtype %d", (int)(dtype));      \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// reductions
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// block-wide sum for blockDim.x == 256; result valid on every thread. `red` = 4 floats of LDS.
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wid] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+static inline int imm_div_up(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,377 @@
+// conv_igemm.hip — implicit-GEMM convolution on gfx950 matrix cores (forward + data gradient).
+//
+// Replaces tf.nn.conv2d(SAME)+bias_add (imm/tf_utils/nn_utils.py:100,108), the frozen VGG
+// conv+bias+relu (imm/models/selfsup/vgg16.py:182-189,230) and tf.gradients of both w.r.t. their
+// input.  GEMM view: M = batch*ho*wo output pixels, N = output channels, K = kh*kw*ci with the
+// channel index fastest (NHWC), so one 16-byte vector = 8 consecutive channels of one filter tap.
+//
+// Tile: BM pixels x BN channels x BK=32, 256 threads = 4 waves.  Both operand tiles live in LDS as
+// [row][32 k] (64-byte rows, 16-byte chunks XOR-swizzled so that ds_read_b128 of 16 rows x 4 chunks
+// is conflict-free on the 64-bank LDS).  Global->register->LDS staging is double-buffered: the next
+// K tile's vectors are in flight while the current tile feeds v_mfma_f32_16x16x32_{bf16,f16}.
+// The MFMA is issued as D[n][m] (weights as the row operand) so every lane ends up holding 4
+// CONSECUTIVE channels of one pixel -> 8-byte (16-bit out) / 16-byte (f32 out) NHWC stores.
+// Epilogue: bias, ReLU, ReLU-backward mask, and deterministic per-M-block batch-norm partial sums.
+#include "common.h"
+
+struct ConvArgs {
+  const uint16_t* x;
+  const uint16_t* wt;
+  const float* bias;
+  void* y;
+  float* stats;
+  const uint16_t* mask;
+  int M, hi, wi, ci8, ldx;
+  int ho, wo, co, ldy;
+  int kh, kw, stride, pad_t, pad_l, updiv;
+  int kpad, KT, ntaps;
+  int flags, ldmask;
+  int n_nblk;
+};
+
+__device__ __forceinline__ int lds_chunk_idx(int row, int chunk) {
+  // 64-byte rows; swizzle so the four 16-lane service groups of ds_read_b128 hit 16 distinct slots
+  return row * 4 + (chunk ^ (((row >> 3) & 1) * 3));
+}
+
+template <typename ET, int BM, int BN, int WGM, int WGN>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
+  constexpr int TM = BM / WGM, TN = BN / WGN;
+  constexpr int MT = TM / 16, NT = TN / 16;
+  constexpr int A_PASSES = BM / 64;
+  constexpr int B_CHUNKS = BN * 4;
+  constexpr int B_PASSES = (B_CHUNKS + 255) / 256;
+  static_assert(WGM * WGN == 4, "4 waves");
+  static_assert(BM % 64 == 0 && TM % 16 == 0 && TN % 16 == 0, "tile");
+
+  __shared__ uint4 smem[2 * (BM + BN) * 4];
+  constexpr int BUF = (BM + BN) * 4;   // uint4 per stage: A rows then B rows
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WGN, wn = wid % WGN;
+  const int nblk = blockIdx.x % a.n_nblk, mblk = blockIdx.x / a.n_nblk;
+  const int m0 = mblk * BM, n0 = nblk * BN;
+
+  // ---- per-thread loader state ---------------------------------------------------------------
+  const int chunk = tid & 3, r0 = tid >> 2;
+  int by[A_PASSES], bx[A_PASSES];
+  int64_t pbase[A_PASSES];
+#pragma unroll
+  for (int i = 0; i < A_PASSES; ++i) {
+    const int m = m0 + i * 64 + r0;
+    if (m < a.M) {
+      const int hw = a.ho * a.wo;
+      const int img = m / hw, rem = m - img * hw;
+      const int oy = rem / a.wo, ox = rem - oy * a.wo;
+      by[i] = oy * a.stride - a.pad_t;
+      bx[i] = ox * a.stride - a.pad_l;
+      pbase[i] = (int64_t)img * a.hi * a.wi;
+    } else {
+      by[i] = -(1 << 28); bx[i] = -(1 << 28); pbase[i] = 0;
+    }
+  }
+  // K-chunk cursor of this thread: k8 = kt*4 + chunk -> (tap=(ky,kx), c8)
+  int c8 = chunk, tap = 0, ky = 0, kx = 0;
+  while (c8 >= a.ci8) { c8 -= a.ci8; ++tap; if (++kx == a.kw) { kx = 0; ++ky; } }
+
+  uint4 ra[A_PASSES], rb[B_PASSES];
+  const uint4 zero4 = make_uint4(0, 0, 0, 0);
+
+  auto load_tile = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < A_PASSES; ++i) {
+      int iy = by[i] + ky, ix = bx[i] + kx;
+      bool ok = tap < a.ntaps;
+      if (a.updiv == 2) { ok = ok && (((iy | ix) & 1) == 0); iy >>= 1; ix >>= 1; }
+      ok = ok && ((unsigned)iy < (unsigned)a.hi) && ((unsigned)ix < (unsigned)a.wi);
+      ra[i] = zero4;
+      if (ok) ra[i] = *(const uint4*)(a.x + ((pbase[i] + (int64_t)iy * a.wi + ix) * a.ldx + c8 * 8));
+    }
+#pragma unroll
+    for (int j = 0; j < B_PASSES; ++j) {
+      const int cidx = j * 256 + tid;
+      rb[j] = zero4;
+      if (cidx < B_CHUNKS) {
+        const int n = n0 + (cidx >> 2);
+        if (n < a.co) rb[j] = *(const uint4*)(a.wt + ((int64_t)n * a.kpad + kt * 32 + chunk * 8));
+      }
+    }
+    // advance the cursor by one K tile (4 chunks)
+    c8 += 4;
+    while (c8 >= a.ci8) { c8 -= a.ci8; ++tap; if (++kx == a.kw) { kx = 0; ++ky; } }
+  };
+  auto store_tile = [&](int buf) {
+    uint4* Ab = smem + buf * BUF;
+    uint4* Bb = Ab + BM * 4;
+#pragma unroll
+    for (int i = 0; i < A_PASSES; ++i) Ab[lds_chunk_idx(i * 64 + r0, chunk)] = ra[i];
+#pragma unroll
+    for (int j = 0; j < B_PASSES; ++j) {
+      const int cidx = j * 256 + tid;
+      if (cidx < B_CHUNKS) Bb[lds_chunk_idx(cidx >> 2, chunk)] = rb[j];
+    }
+  };
+
+  f32x4_t acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+
+  const int frow = lane & 15, fchunk = lane >> 4;
+  for (int kt = 0; kt < a.KT; ++kt) {
+    const int buf = kt & 1;
+    const bool more = (kt + 1) < a.KT;
+    if (more) load_tile(kt + 1);
+    uint4 af[MT], bf[NT];
+    const uint4* Ab = smem + buf * BUF;
+    const uint4* Bb = Ab + BM * 4;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) af[i] = Ab[lds_chunk_idx(wm * TM + i * 16 + frow, fchunk)];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) bf[j] = Bb[lds_chunk_idx(wn * TN + j * 16 + frow, fchunk)];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] = ET::mfma(bf[j], af[i], acc[i][j]);
+    if (more) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue ------------------------------------------------------------------------------
+  // lane holds D[n = 4*(lane>>4)+r][m = lane&15] of each 16x16 tile
+  const bool f_bias = a.flags & IMM_CONV_BIAS, f_relu = a.flags & IMM_CONV_RELU;
+  const bool f_stats = a.flags & IMM_CONV_STATS, f_mask = a.flags & IMM_CONV_MASK;
+  const bool f_f32 = a.flags & IMM_CONV_OUT_F32;
+  float s1[NT][4], s2[NT][4];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { s1[j][r] = 0.f; s2[j][r] = 0.f; }
+
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int n = n0 + wn * TN + j * 16 + 4 * (lane >> 4);
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (f_bias) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) if (n + r < a.co) bv[r] = a.bias[n + r];
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int m = m0 + wm * TM + i * 16 + (lane & 15);
+      const bool mok = m < a.M;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[r] = acc[i][j][r] + bv[r];
+        if (f_relu) v[r] = fmaxf(v[r], 0.f);
+      }
+      if (f_mask && mok) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (n + r < a.co) {
+            const float ref = ET::to_f32(a.mask[(int64_t)m * a.ldmask + n + r]);
+            if (!(ref > 0.f)) v[r] = 0.f;
+          }
+      }
+      if (f_stats && mok) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s1[j][r] += v[r]; s2[j][r] += v[r] * v[r]; }
+      }
+      if (mok) {
+        if (f_f32) {
+          float* yp = (float*)a.y + (int64_t)m * a.ldy + n;
+          if (n + 3 < a.co) {
+            *(float4*)yp = make_float4(v[0], v[1], v[2], v[3]);
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (n + r < a.co) yp[r] = v[r];
+          }
+        } else {
+          uint16_t* yp = (uint16_t*)a.y + (int64_t)m * a.ldy + n;
+          uint16_t h[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) h[r] = ET::from_f32(v[r]);
+          if (n + 3 < a.co) {
+            *(uint2*)yp = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (n + r < a.co) yp[r] = h[r];
+          }
+        }
+      }
+    }
+  }
+
+  if (f_stats) {
+    // reduce over the 16 pixel-lanes of each channel quad, then over the WGM wave rows through LDS
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+          s1[j][r] += __shfl_xor(s1[j][r], o, 64);
+          s2[j][r] += __shfl_xor(s2[j][r], o, 64);
+        }
+      }
+    float* red = (float*)smem;  // [WGM][2][BN]; the main loop ended with a barrier
+    if ((lane & 15) == 0) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int nl = wn * TN + j * 16 + 4 * (lane >> 4) + r;
+          red[(wm * 2 + 0) * BN + nl] = s1[j][r];
+          red[(wm * 2 + 1) * BN + nl] = s2[j][r];
+        }
+    }
+    __syncthreads();
+    if (tid < BN && n0 + tid < a.co) {
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < WGM; ++w) { t1 += red[(w * 2 + 0) * BN + tid]; t2 += red[(w * 2 + 1) * BN + tid]; }
+      a.stats[((int64_t)mblk * 2 + 0) * a.co + n0 + tid] = t1;
+      a.stats[((int64_t)mblk * 2 + 1) * a.co + n0 + tid] = t2;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side: tile selection + launch
+// ---------------------------------------------------------------------------------------------
+struct TileCfg { int bm, bn; };
+
+static int g_num_cu = 0;
+static int num_cu() {
+  if (g_num_cu == 0) {
+    hipDeviceProp_t p;
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess)
+      g_num_cu = p.multiProcessorCount;
+    if (g_num_cu <= 0) g_num_cu = 256;
+  }
+  return g_num_cu;
+}
+
+static TileCfg pick_tile(int64_t M, int co) {
+  // candidates in order of preference (largest tile first); take the first that fills the chip
+  TileCfg cands[3];
+  int nc = 0;
+  if (co > 64) { cands[nc++] = {128, 128}; cands[nc++] = {128, 64}; cands[nc++] = {64, 64}; }
+  else if (co > 32) { cands[nc++] = {128, 64}; cands[nc++] = {64, 64}; }
+  else if (co > 16) { cands[nc++] = {128, 32}; }
+  else { cands[nc++] = {128, 16}; }
+  const int64_t want = 2LL * num_cu();
+  for (int i = 0; i < nc; ++i) {
+    const int64_t blocks = ((M + cands[i].bm - 1) / cands[i].bm) * ((co + cands[i].bn - 1) / cands[i].bn);
+    if (blocks >= want) return cands[i];
+  }
+  return cands[nc - 1];
+}
+
+static int validate_desc(const imm_conv_desc* d) {
+  IMM_REQUIRE(d != nullptr, "conv: null desc");
+  IMM_REQUIRE(d->batch > 0 && d->hi > 0 && d->wi > 0 && d->ho > 0 && d->wo > 0 && d->co > 0, "conv: dims");
+  IMM_REQUIRE(d->ci > 0 && d->ci % 8 == 0, "conv: ci=%d must be a positive multiple of 8", d->ci);
+  IMM_REQUIRE(d->ldx >= d->ci && d->ldx % 8 == 0, "conv: ldx=%d (ci=%d) must be a multiple of 8", d->ldx, d->ci);
+  IMM_REQUIRE(d->ldy >= d->co && d->ldy % 4 == 0, "conv: ldy=%d (co=%d) must be a multiple of 4", d->ldy, d->co);
+  IMM_REQUIRE(d->kh > 0 && d->kw > 0 && d->stride > 0, "conv: kernel/stride");
+  IMM_REQUIRE(d->updiv == 1 || d->updiv == 2, "conv: updiv must be 1 or 2");
+  IMM_REQUIRE(d->kpad % 32 == 0 && d->kpad >= d->kh * d->kw * d->ci, "conv: kpad=%d too small / unaligned", d->kpad);
+  IMM_REQUIRE((int64_t)d->batch * d->ho * d->wo < (1LL << 31), "conv: M overflow");
+  return 0;
+}
+
+extern "C" int imm_conv_stats_blocks(const imm_conv_desc* d) {
+  if (validate_desc(d)) return IMM_E_INVALID;
+  const int64_t M = (int64_t)d->batch * d->ho * d->wo;
+  const TileCfg t = pick_tile(M, d->co);
+  return (int)((M + t.bm - 1) / t.bm);
+}
+
+template <typename ET, int BM, int BN, int WGM, int WGN>
+static void launch_cfg(const ConvArgs& a, hipStream_t s) {
+  const int mblk = (a.M + BM - 1) / BM;
+  hipLaunchKernelGGL((conv_igemm_kernel<ET, BM, BN, WGM, WGN>), dim3(mblk * a.n_nblk), dim3(256), 0, s, a);
+}
+
+template <typename ET>
+static int conv_launch(const imm_conv_desc* d, const void* x, const void* wt, const float* bias, void* y,
+                       float* stats, const void* mask, hipStream_t s) {
+  ConvArgs a;
+  a.x = (const uint16_t*)x; a.wt = (const uint16_t*)wt; a.bias = bias; a.y = y; a.stats = stats;
+  a.mask = (const uint16_t*)mask;
+  a.M = d->batch * d->ho * d->wo;
+  a.hi = d->hi; a.wi = d->wi; a.ci8 = d->ci / 8; a.ldx = d->ldx;
+  a.ho = d->ho; a.wo = d->wo; a.co = d->co; a.ldy = d->ldy;
+  a.kh = d->kh; a.kw = d->kw; a.stride = d->stride; a.pad_t = d->pad_t; a.pad_l = d->pad_l; a.updiv = d->updiv;
+  a.kpad = d->kpad; a.KT = d->kpad / 32; a.ntaps = d->kh * d->kw;
+  a.flags = d->flags; a.ldmask = d->ldmask;
+  const TileCfg t = pick_tile(a.M, a.co);
+  a.n_nblk = (a.co + t.bn - 1) / t.bn;
+  if (t.bm == 128 && t.bn == 128) launch_cfg<ET, 128, 128, 2, 2>(a, s);
+  else if (t.bm == 128 && t.bn == 64) launch_cfg<ET, 128, 64, 2, 2>(a, s);
+  else if (t.bm == 64 && t.bn == 64) launch_cfg<ET, 64, 64, 2, 2>(a, s);
+  else if (t.bm == 128 && t.bn == 32) launch_cfg<ET, 128, 32, 4, 1>(a, s);
+  else launch_cfg<ET, 128, 16, 4, 1>(a, s);
+  IMM_CHECK_LAUNCH("imm_conv2d");
+  return 0;
+}
+
+extern "C" int imm_conv2d(const imm_conv_desc* d, int dtype, const void* x, const void* wt, const float* bias,
+                          void* y, float* stats_partial, const void* mask_ref, void* stream) {
+  if (validate_desc(d)) return IMM_E_INVALID;
+  IMM_REQUIRE(x && wt && y, "conv: null tensor");
+  IMM_REQUIRE(!(d->flags & IMM_CONV_BIAS) || bias, "conv: bias flag without bias");
+  IMM_REQUIRE(!(d->flags & IMM_CONV_STATS) || stats_partial, "conv: stats flag without buffer");
+  IMM_REQUIRE(!(d->flags & IMM_CONV_MASK) || (mask_ref && d->ldmask >= d->co), "conv: mask flag without mask/ldmask");
+  IMM_REQUIRE(((uintptr_t)x % 16 == 0) && ((uintptr_t)wt % 16 == 0) && ((uintptr_t)y % 16 == 0), "conv: 16-byte alignment");
+  IMM_DISPATCH_DTYPE(dtype, return conv_launch<ET>(d, x, wt, bias, y, stats_partial, mask_ref, (hipStream_t)stream));
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight packing: f32 HWIO master -> 16-bit Wt[rows][kpad]
+// ---------------------------------------------------------------------------------------------
+template <typename ET>
+__global__ void pack_weights_kernel(const float* __restrict__ w, uint16_t* __restrict__ wt, int mode, int kh, int kw,
+                                    int ci_real, int co_real, int c_pad, int rows, int kpad) {
+  const int64_t total = (int64_t)rows * kpad;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int n = (int)(idx / kpad), k = (int)(idx - (int64_t)n * kpad);
+    const int tap = k / c_pad, c = k - tap * c_pad;
+    float v = 0.f;
+    if (tap < kh * kw) {
+      if (mode == 0) {
+        if (n < co_real && c < ci_real) v = w[((int64_t)tap * ci_real + c) * co_real + n];
+      } else {
+        const int kyf = kh - 1 - tap / kw, kxf = kw - 1 - tap % kw;
+        if (n < ci_real && c < co_real) v = w[(((int64_t)kyf * kw + kxf) * ci_real + n) * co_real + c];
+      }
+    }
+    wt[idx] = ET::from_f32(v);
+  }
+}
+
+extern "C" int imm_pack_weights(const float* w, void* wt, int dtype, int mode, int kh, int kw, int ci_real,
+                                int co_real, int c_pad, int rows, int kpad, void* stream) {
+  IMM_REQUIRE(w && wt, "pack_weights: null");
+  IMM_REQUIRE(mode == 0 || mode == 1, "pack_weights: mode");
+  IMM_REQUIRE(c_pad % 8 == 0 && kpad % 32 == 0 && kpad >= kh * kw * c_pad, "pack_weights: padding");
+  IMM_REQUIRE(c_pad >= (mode == 0 ? ci_real : co_real), "pack_weights: c_pad too small");
+  IMM_REQUIRE(rows >= (mode == 0 ? co_real : ci_real), "pack_weights: rows too small");
+  const int64_t total = (int64_t)rows * kpad;
+  const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  IMM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((pack_weights_kernel<ET>), dim3(blocks), dim3(256), 0,
+                                               (hipStream_t)stream, w, (uint16_t*)wt, mode, kh, kw, ci_real,
+                                               co_real, c_pad, rows, kpad));
+  IMM_CHECK_LAUNCH("imm_pack_weights");
+  return 0;
+}

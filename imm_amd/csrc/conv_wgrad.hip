@@ -1,0 +1,255 @@
+// conv_wgrad.hip — filter gradient of the implicit-GEMM convolution on gfx950 matrix cores.
+//
+// tf.gradients of tf.nn.conv2d w.r.t. `w` (imm/tf_utils/nn_utils.py:100; applied at
+// imm/train/cnn_train_multi.py:157,231).  GEMM view:
+//     dW[kk][n] = sum_p  A[p][kk] * dY[p][n],   kk = (ky*kw+kx)*ci + c,  p = output pixel
+// with A the same im2col gather the forward kernel uses.  The contraction index p is the STRIDED
+// index of both operands in NHWC memory, so staging transposes: each thread loads 8 channels of
+// TWO neighbouring pixels (2 x 16 B), pairs them into 8 dwords {pixel p, pixel p+1} and writes
+// them down 8 rows of an LDS image [row = kk or n][32 pixels]; MFMA fragments are then plain
+// 16-byte row reads, exactly as in the forward kernel (same XOR swizzle).
+// The pixel range is split over `nsplit` blocks per tile; each writes its f32 partial tile to
+// slab[split][kpad][co]; imm_conv2d_wgrad_reduce sums slabs in a fixed order (deterministic).
+#include "common.h"
+
+struct WgradArgs {
+  const uint16_t* x;
+  const uint16_t* dy;
+  float* slab;
+  int P;            // batch*ho*wo
+  int hi, wi, ci8, ldx;
+  int ho, wo, co, lddy;
+  int kh, kw, stride, pad_t, pad_l;
+  int kpad, ntaps;
+  int n_kblk, n_nblk, nsplit, p_per_split;
+};
+
+__device__ __forceinline__ int wg_dword_idx(int row, int pp) {
+  // LDS image: 64-byte rows = 16 dwords (32 pixels); chunk = pp>>2 swizzled like the forward kernel
+  return row * 16 + ((((pp >> 2) ^ (((row >> 3) & 1) * 3))) << 2) + (pp & 3);
+}
+__device__ __forceinline__ int wg_chunk_idx(int row, int chunk) {
+  return row * 4 + (chunk ^ (((row >> 3) & 1) * 3));
+}
+
+template <typename ET, int BK, int BN, int WGK, int WGN>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
+  constexpr int TK = BK / WGK, TN = BN / WGN;
+  constexpr int KT_ = TK / 16, NT = TN / 16;
+  constexpr int A_PASSES = BK / 128;              // 16 k8-groups x 16 pixel pairs per pass
+  static_assert(BK % 128 == 0, "BK multiple of 128");
+  static_assert(WGK * WGN == 4, "4 waves");
+  constexpr int BUF = (BK + BN) * 4;              // uint4 per stage
+
+  __shared__ uint4 smem[2 * BUF];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wk = wid / WGN, wn = wid % WGN;
+  int bid = blockIdx.x;
+  const int nblk = bid % a.n_nblk; bid /= a.n_nblk;
+  const int kblk = bid % a.n_kblk; bid /= a.n_kblk;
+  const int split = bid;
+  const int k0 = kblk * BK, n0 = nblk * BN;
+  const int p_begin = split * a.p_per_split;
+  const int p_end = min(a.P, p_begin + a.p_per_split);
+
+  // ---- loader state ---------------------------------------------------------------------------
+  const int pp = tid & 15, g = tid >> 4;          // pixel pair / 8-channel group
+  // A: group g of pass i covers kk = k0 + (i*16+g)*8 .. +7 -> fixed (tap, c8) per thread
+  int a_ky[A_PASSES], a_kx[A_PASSES], a_c8[A_PASSES];
+  bool a_ok[A_PASSES];
+#pragma unroll
+  for (int i = 0; i < A_PASSES; ++i) {
+    const int k8 = (k0 >> 3) + i * 16 + g;
+    const int tap = k8 / a.ci8;
+    a_c8[i] = k8 - tap * a.ci8;
+    a_ky[i] = tap / a.kw;
+    a_kx[i] = tap - a_ky[i] * a.kw;
+    a_ok[i] = tap < a.ntaps;
+  }
+  const bool b_ok = (g < BN / 8) && (n0 + g * 8 < a.lddy);   // dY channel group inside the row
+  // pixel cursor for this thread's first pixel (p_begin + 2*pp); second pixel is +1
+  int pcur = p_begin + 2 * pp;
+  int img, oy, ox;
+  {
+    const int hw = a.ho * a.wo;
+    img = pcur / hw; const int rem = pcur - img * hw; oy = rem / a.wo; ox = rem - oy * a.wo;
+  }
+
+  uint4 ra[A_PASSES][2], rb[2];
+  const uint4 zero4 = make_uint4(0, 0, 0, 0);
+
+  auto load_tile = [&]() {
+    // the two pixels of the pair (ox even start, wo even => same row; handled generally below)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      int qi = img, qy = oy, qx = ox + q;
+      if (qx >= a.wo) { qx -= a.wo; if (++qy == a.ho) { qy = 0; ++qi; } }
+      const bool pok = (pcur + q) < p_end;
+#pragma unroll
+      for (int i = 0; i < A_PASSES; ++i) {
+        const int iy = qy * a.stride - a.pad_t + a_ky[i], ix = qx * a.stride - a.pad_l + a_kx[i];
+        const bool ok = pok && a_ok[i] && ((unsigned)iy < (unsigned)a.hi) && ((unsigned)ix < (unsigned)a.wi);
+        ra[i][q] = zero4;
+        if (ok) ra[i][q] = *(const uint4*)(a.x + ((((int64_t)qi * a.hi + iy) * a.wi + ix) * a.ldx + a_c8[i] * 8));
+      }
+      rb[q] = zero4;
+      if (pok && b_ok) rb[q] = *(const uint4*)(a.dy + ((int64_t)(pcur + q) * a.lddy + n0 + g * 8));
+    }
+    // advance 32 pixels
+    pcur += 32;
+    ox += 32;
+    while (ox >= a.wo) { ox -= a.wo; if (++oy == a.ho) { oy = 0; ++img; } }
+  };
+  auto store_tile = [&](int buf) {
+    uint32_t* Ab = (uint32_t*)(smem + buf * BUF);
+    uint32_t* Bb = Ab + BK * 16;
+#pragma unroll
+    for (int i = 0; i < A_PASSES; ++i) {
+      const uint32_t lo[4] = {ra[i][0].x, ra[i][0].y, ra[i][0].z, ra[i][0].w};
+      const uint32_t hi[4] = {ra[i][1].x, ra[i][1].y, ra[i][1].z, ra[i][1].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = (i * 16 + g) * 8 + 2 * j;
+        Ab[wg_dword_idx(row, pp)] = (lo[j] & 0xffffu) | (hi[j] << 16);
+        Ab[wg_dword_idx(row + 1, pp)] = (lo[j] >> 16) | (hi[j] & 0xffff0000u);
+      }
+    }
+    if (g < BN / 8) {
+      const uint32_t lo[4] = {rb[0].x, rb[0].y, rb[0].z, rb[0].w};
+      const uint32_t hi[4] = {rb[1].x, rb[1].y, rb[1].z, rb[1].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = g * 8 + 2 * j;
+        Bb[wg_dword_idx(row, pp)] = (lo[j] & 0xffffu) | (hi[j] << 16);
+        Bb[wg_dword_idx(row + 1, pp)] = (lo[j] >> 16) | (hi[j] & 0xffff0000u);
+      }
+    }
+  };
+
+  f32x4_t acc[KT_][NT];
+#pragma unroll
+  for (int i = 0; i < KT_; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int nsteps = (p_end - p_begin + 31) / 32;
+  if (nsteps > 0) {
+    load_tile();
+    store_tile(0);
+  }
+  __syncthreads();
+  const int frow = lane & 15, fchunk = lane >> 4;
+  for (int st = 0; st < nsteps; ++st) {
+    const int buf = st & 1;
+    const bool more = (st + 1) < nsteps;
+    if (more) load_tile();
+    const uint4* Ab = smem + buf * BUF;
+    const uint4* Bb = Ab + BK * 4;
+    uint4 af[KT_], bf[NT];
+#pragma unroll
+    for (int i = 0; i < KT_; ++i) af[i] = Ab[wg_chunk_idx(wk * TK + i * 16 + frow, fchunk)];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) bf[j] = Bb[wg_chunk_idx(wn * TN + j * 16 + frow, fchunk)];
+#pragma unroll
+    for (int i = 0; i < KT_; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] = ET::mfma(bf[j], af[i], acc[i][j]);   // D[n][kk]
+    if (more) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // lane holds D[n = 4*(lane>>4)+r][kk = lane&15] -> 4 consecutive n of one kk: 16-byte store
+  float* out = a.slab + (int64_t)split * a.kpad * a.co;
+#pragma unroll
+  for (int i = 0; i < KT_; ++i) {
+    const int kk = k0 + wk * TK + i * 16 + (lane & 15);
+    if (kk >= a.kpad) continue;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int n = n0 + wn * TN + j * 16 + 4 * (lane >> 4);
+      float* op = out + (int64_t)kk * a.co + n;
+      if (n + 3 < a.co && (a.co & 3) == 0) {
+        *(float4*)op = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (n + r < a.co) op[r] = acc[i][j][r];
+      }
+    }
+  }
+}
+
+template <typename ET, int BK, int BN, int WGK, int WGN>
+static void wg_launch_cfg(const WgradArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL((conv_wgrad_kernel<ET, BK, BN, WGK, WGN>), dim3(a.n_kblk * a.n_nblk * a.nsplit), dim3(256), 0, s, a);
+}
+
+static int wgrad_bn(int co) { return co > 64 ? 128 : co > 32 ? 64 : co > 16 ? 32 : 16; }
+
+template <typename ET>
+static int wgrad_launch(const imm_conv_desc* d, const void* x, const void* dy, int lddy, float* slab, int nsplit,
+                        hipStream_t s) {
+  WgradArgs a;
+  a.x = (const uint16_t*)x; a.dy = (const uint16_t*)dy; a.slab = slab;
+  a.P = d->batch * d->ho * d->wo;
+  a.hi = d->hi; a.wi = d->wi; a.ci8 = d->ci / 8; a.ldx = d->ldx;
+  a.ho = d->ho; a.wo = d->wo; a.co = d->co; a.lddy = lddy;
+  a.kh = d->kh; a.kw = d->kw; a.stride = d->stride; a.pad_t = d->pad_t; a.pad_l = d->pad_l;
+  a.kpad = d->kpad; a.ntaps = d->kh * d->kw;
+  const int bn = wgrad_bn(d->co);
+  a.n_kblk = (d->kpad + 127) / 128;
+  a.n_nblk = (d->co + bn - 1) / bn;
+  a.nsplit = nsplit;
+  int pps = (a.P + nsplit - 1) / nsplit;
+  pps = (pps + 31) / 32 * 32;
+  a.p_per_split = pps;
+  if (bn == 128) wg_launch_cfg<ET, 128, 128, 2, 2>(a, s);
+  else if (bn == 64) wg_launch_cfg<ET, 128, 64, 2, 2>(a, s);
+  else if (bn == 32) wg_launch_cfg<ET, 128, 32, 4, 1>(a, s);
+  else wg_launch_cfg<ET, 128, 16, 4, 1>(a, s);
+  IMM_CHECK_LAUNCH("imm_conv2d_wgrad");
+  return 0;
+}
+
+extern "C" int imm_conv2d_wgrad(const imm_conv_desc* d, int dtype, const void* x, const void* dy, int lddy,
+                                float* slab, int nsplit, void* stream) {
+  IMM_REQUIRE(d && x && dy && slab, "wgrad: null");
+  IMM_REQUIRE(d->ci > 0 && d->ci % 8 == 0 && d->ldx % 8 == 0 && d->ldx >= d->ci, "wgrad: ci/ldx must be multiples of 8");
+  IMM_REQUIRE(lddy % 8 == 0 && lddy >= d->co, "wgrad: lddy=%d must be a multiple of 8 and >= co", lddy);
+  IMM_REQUIRE(d->updiv == 1, "wgrad: desc must be the forward convolution");
+  IMM_REQUIRE(d->kpad % 32 == 0 && d->kpad >= d->kh * d->kw * d->ci, "wgrad: kpad");
+  IMM_REQUIRE(nsplit >= 1, "wgrad: nsplit");
+  IMM_REQUIRE(d->wo % 2 == 0, "wgrad: output width must be even (pixel pairs)");
+  IMM_REQUIRE(((uintptr_t)x % 16 == 0) && ((uintptr_t)dy % 16 == 0) && ((uintptr_t)slab % 16 == 0), "wgrad: alignment");
+  IMM_DISPATCH_DTYPE(dtype, return wgrad_launch<ET>(d, x, dy, lddy, slab, nsplit, (hipStream_t)stream));
+  return 0;
+}
+
+// dw[(tap*ci_real + c)*co + n] = sum_s slab[s][(tap*ci_pad + c)][n]
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int nsplit, int ntaps, int ci_pad, int ci_real,
+                                    int co, int kpad, float* __restrict__ dw) {
+  const int64_t total = (int64_t)ntaps * ci_real * co;
+  const int64_t sstride = (int64_t)kpad * co;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int n = (int)(idx % co);
+    const int64_t tc = idx / co;
+    const int c = (int)(tc % ci_real), tap = (int)(tc / ci_real);
+    const float* sp = slab + ((int64_t)tap * ci_pad + c) * co + n;
+    float acc = 0.f;
+    for (int s = 0; s < nsplit; ++s) acc += sp[s * sstride];
+    dw[idx] = acc;
+  }
+}
+
+extern "C" int imm_conv2d_wgrad_reduce(const float* slab, int nsplit, int kh, int kw, int ci_pad, int ci_real, int co,
+                                       int kpad, float* dw, void* stream) {
+  IMM_REQUIRE(slab && dw && nsplit >= 1, "wgrad_reduce: args");
+  IMM_REQUIRE(ci_real <= ci_pad && kpad >= kh * kw * ci_pad, "wgrad_reduce: padding");
+  const int64_t total = (int64_t)kh * kw * ci_real * co;
+  const int blocks = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, slab, nsplit, kh * kw,
+                     ci_pad, ci_real, co, kpad, dw);
+  IMM_CHECK_LAUNCH("imm_conv2d_wgrad_reduce");
+  return 0;
+}

@@ -1,0 +1,615 @@
+// elementwise.hip — HBM-bound passes of the IMM step on gfx950: batch-norm finalize/apply/backward,
+// bilinear resampling, 2x2 max pooling, input packing, bias-gradient column sums.
+// All 16-bit tensors are NHWC with C % 8 == 0 and pixel stride % 8 == 0, so every lane moves
+// 16-byte vectors (8 channels); reductions write per-block partials that a finalize kernel sums in
+// a fixed order (deterministic, no atomics, nothing to zero).
+//
+// Reference call sites: tf.layers.batch_normalization(fused=True)+relu imm/tf_utils/nn_utils.py:201-209;
+// tf.image.resize_images imm/models/imm_model.py:175; resize_bilinear(align_corners=True) :334;
+// tf.nn.max_pool imm/models/selfsup/ops.py:16-26; tf.nn.bias_add gradient nn_utils.py:108.
+#include "common.h"
+
+#define EW_THREADS 256
+
+static inline int ew_blocks(int64_t work_items, int cap = 16384) {
+  int64_t b = (work_items + EW_THREADS - 1) / EW_THREADS;
+  if (b < 1) b = 1;
+  return (int)(b > cap ? cap : b);
+}
+
+#define EW_REQUIRE_VEC(c, ld, name) \
+  IMM_REQUIRE((c) > 0 && (c) % 8 == 0 && (ld) % 8 == 0 && (ld) >= (c), name ": C=%d ld=%d must be multiples of 8", (int)(c), (int)(ld))
+
+// ---------------------------------------------------------------------------------------------
+// input packing
+// ---------------------------------------------------------------------------------------------
+template <typename ET>
+__global__ void pack_image_kernel(const float* __restrict__ src, uint4* __restrict__ dst, int64_t npix) {
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (int64_t)gridDim.x * blockDim.x) {
+    const float f[8] = {src[p * 3], src[p * 3 + 1], src[p * 3 + 2], 0.f, 0.f, 0.f, 0.f, 0.f};
+    dst[p] = pack8<ET>(f);
+  }
+}
+
+extern "C" int imm_pack_image(const float* src, void* dst, int dtype, int64_t npix, void* stream) {
+  IMM_REQUIRE(src && dst && npix > 0, "pack_image: args");
+  IMM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((pack_image_kernel<ET>), dim3(ew_blocks(npix)), dim3(EW_THREADS), 0,
+                                               (hipStream_t)stream, src, (uint4*)dst, npix));
+  IMM_CHECK_LAUNCH("imm_pack_image");
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// batch norm forward
+// ---------------------------------------------------------------------------------------------
+__global__ void bn_finalize_kernel(const float* __restrict__ partial, int nblk, int c, double count,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                   float momentum, int training, float* moving_mean, float* moving_var,
+                                   float* scale, float* shift, float* mean_out, float* rstd_out) {
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= c) return;
+  float mean, var;
+  if (training) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+      s1 += (double)partial[((int64_t)b * 2 + 0) * c + ch];
+      s2 += (double)partial[((int64_t)b * 2 + 1) * c + ch];
+    }
+    const double m = s1 / count;
+    double v = s2 / count - m * m;
+    if (v < 0.0) v = 0.0;
+    mean = (float)m; var = (float)v;
+    const double unbiased = count > 1.0 ? v * count / (count - 1.0) : v;
+    moving_mean[ch] = moving_mean[ch] * momentum + mean * (1.f - momentum);
+    moving_var[ch] = moving_var[ch] * momentum + (float)unbiased * (1.f - momentum);
+  } else {
+    mean = moving_mean[ch]; var = moving_var[ch];
+  }
+  const float rstd = rsqrtf(var + eps);
+  const float sc = gamma[ch] * rstd;
+  scale[ch] = sc;
+  shift[ch] = beta[ch] - mean * sc;
+  mean_out[ch] = mean;
+  rstd_out[ch] = rstd;
+}
+
+extern "C" int imm_bn_finalize(const float* partial, int nblk, int c, int64_t count, const float* gamma,
+                               const float* beta, float eps, float momentum, int training, float* moving_mean,
+                               float* moving_var, float* scale, float* shift, float* mean, float* rstd, void* stream) {
+  IMM_REQUIRE(gamma && beta && moving_mean && moving_var && scale && shift && mean && rstd, "bn_finalize: null");
+  IMM_REQUIRE(!training || (partial && nblk > 0), "bn_finalize: training needs partial sums");
+  IMM_REQUIRE(c > 0 && count > 0, "bn_finalize: dims");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + 63) / 64), dim3(64), 0, (hipStream_t)stream, partial, nblk, c,
+                     (double)count, gamma, beta, eps, momentum, training, moving_mean, moving_var, scale, shift, mean, rstd);
+  IMM_CHECK_LAUNCH("imm_bn_finalize");
+  return 0;
+}
+
+template <typename ET>
+__global__ void bn_apply_kernel(const uint16_t* __restrict__ y, int64_t npix, int c8n, int ldy,
+                                const float* __restrict__ scale, const float* __restrict__ shift, int relu,
+                                uint16_t* __restrict__ x, int ldx) {
+  const int64_t total = npix * c8n;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p = idx / c8n;
+    const int cg = (int)(idx - p * c8n);
+    float f[8];
+    unpack8<ET>(*(const uint4*)(y + p * ldy + cg * 8), f);
+    const float4 sa = *(const float4*)(scale + cg * 8), sb = *(const float4*)(scale + cg * 8 + 4);
+    const float4 ha = *(const float4*)(shift + cg * 8), hb = *(const float4*)(shift + cg * 8 + 4);
+    const float sc[8] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w};
+    const float sh[8] = {ha.x, ha.y, ha.z, ha.w, hb.x, hb.y, hb.z, hb.w};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      f[i] = f[i] * sc[i] + sh[i];
+      if (relu) f[i] = fmaxf(f[i], 0.f);
+    }
+    *(uint4*)(x + p * ldx + cg * 8) = pack8<ET>(f);
+  }
+}
+
+extern "C" int imm_bn_apply_relu(const void* y, int dtype, int64_t npix, int c, int ldy, const float* scale,
+                                 const float* shift, int relu, void* x_out, int ldx, void* stream) {
+  IMM_REQUIRE(y && scale && shift && x_out && npix > 0, "bn_apply: null");
+  EW_REQUIRE_VEC(c, ldy, "bn_apply(y)");
+  EW_REQUIRE_VEC(c, ldx, "bn_apply(x)");
+  IMM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_apply_kernel<ET>), dim3(ew_blocks(npix * (c / 8))), dim3(EW_THREADS),
+                                               0, (hipStream_t)stream, (const uint16_t*)y, npix, c / 8, ldy, scale,
+                                               shift, relu, (uint16_t*)x_out, ldx));
+  IMM_CHECK_LAUNCH("imm_bn_apply_relu");
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// batch norm backward (+ fused ReLU backward):  dz = dout * [scale*y+shift > 0]
+//   s1 = sum dz, s2 = sum dz*xhat;  dgamma = s2, dbeta = s1
+//   dy = gamma*rstd * (dz - s1/N - xhat*s2/N)
+// ---------------------------------------------------------------------------------------------
+static int col_reduce_blocks(int64_t npix, int c) {
+  const int tpp = c / 8;
+  const int rows = EW_THREADS / tpp;
+  int64_t b = (npix + (int64_t)rows * 16 - 1) / ((int64_t)rows * 16);   // >= 16 pixels per thread
+  if (b < 1) b = 1;
+  if (b > 1024) b = 1024;
+  return (int)b;
+}
+
+extern "C" int imm_bn_bwd_blocks(int64_t npix, int c) {
+  if (c <= 0 || c % 8 || c / 8 > EW_THREADS || EW_THREADS % (c / 8)) return IMM_E_UNSUPPORTED;
+  return col_reduce_blocks(npix, c);
+}
+extern "C" int imm_colsum_blocks(int64_t npix, int c) { return imm_bn_bwd_blocks(npix, c); }
+
+// shared tail: thread-private 8-channel accumulators (NS sums each) -> per-block partial[blk][NS][c]
+template <int NS>
+__device__ __forceinline__ void col_reduce_tail(float (&acc)[NS][8], int c, int tpp, int rows, float* out_blk) {
+  __shared__ float red[EW_THREADS * NS * 8];
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) red[(tid * NS + s) * 8 + i] = acc[s][i];
+  __syncthreads();
+  for (int t = tid; t < NS * c; t += EW_THREADS) {
+    const int s = t / c, ch = t - s * c;
+    const int cg = ch >> 3, e = ch & 7;
+    float v = 0.f;
+    for (int r = 0; r < rows; ++r) v += red[((r * tpp + cg) * NS + s) * 8 + e];
+    out_blk[(int64_t)s * c + ch] = v;
+  }
+}
+
+template <typename ET>
+__global__ __launch_bounds__(EW_THREADS) void bn_bwd_reduce_kernel(
+    const uint16_t* __restrict__ dout, int lddo, const uint16_t* __restrict__ y, int ldy, int64_t npix, int c,
+    const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
+    const float* __restrict__ rstd, int relu, float* __restrict__ partial) {
+  const int tpp = c / 8, rows = EW_THREADS / tpp;
+  const int r = threadIdx.x / tpp, cg = threadIdx.x - r * tpp;
+  const int64_t per_blk = (npix + gridDim.x - 1) / gridDim.x;
+  const int64_t p0 = (int64_t)blockIdx.x * per_blk;
+  const int64_t p1 = p0 + per_blk < npix ? p0 + per_blk : npix;
+  float sc[8], sh[8], mu[8], rs[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    sc[i] = scale[cg * 8 + i]; sh[i] = shift[cg * 8 + i]; mu[i] = mean[cg * 8 + i]; rs[i] = rstd[cg * 8 + i];
+  }
+  float acc[2][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
+  for (int64_t p = p0 + r; p < p1; p += rows) {
+    float d[8], v[8];
+    unpack8<ET>(*(const uint4*)(dout + p * lddo + cg * 8), d);
+    unpack8<ET>(*(const uint4*)(y + p * ldy + cg * 8), v);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float dz = d[i];
+      if (relu && !(v[i] * sc[i] + sh[i] > 0.f)) dz = 0.f;
+      acc[0][i] += dz;
+      acc[1][i] += dz * ((v[i] - mu[i]) * rs[i]);
+    }
+  }
+  col_reduce_tail<2>(acc, c, tpp, rows, partial + (int64_t)blockIdx.x * 2 * c);
+}
+
+extern "C" int imm_bn_bwd_reduce(const void* dout, int lddo, const void* y, int ldy, int dtype, int64_t npix, int c,
+                                 const float* scale, const float* shift, const float* mean, const float* rstd,
+                                 int relu, float* partial, void* stream) {
+  IMM_REQUIRE(dout && y && scale && shift && mean && rstd && partial && npix > 0, "bn_bwd_reduce: null");
+  EW_REQUIRE_VEC(c, lddo, "bn_bwd_reduce(dout)");
+  EW_REQUIRE_VEC(c, ldy, "bn_bwd_reduce(y)");
+  const int nblk = imm_bn_bwd_blocks(npix, c);
+  if (nblk < 0) return imm_fail(IMM_E_UNSUPPORTED, "bn_bwd_reduce: C=%d unsupported (C/8 must divide 256)", c);
+  IMM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_bwd_reduce_kernel<ET>), dim3(nblk), dim3(EW_THREADS), 0,
+                                               (hipStream_t)stream, (const uint16_t*)dout, lddo, (const uint16_t*)y,
+                                               ldy, npix, c, scale, shift, mean, rstd, relu, partial));
+  IMM_CHECK_LAUNCH("imm_bn_bwd_reduce");
+  return 0;
+}
+
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int c, double count,
+                                       const float* __restrict__ gamma, const float* __restrict__ rstd,
+                                       float* dgamma, float* dbeta, float* coef) {
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= c) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int b = 0; b < nblk; ++b) {
+    s1 += (double)partial[((int64_t)b * 2 + 0) * c + ch];
+    s2 += (double)partial[((int64_t)b * 2 + 1) * c + ch];
+  }
+  dbeta[ch] = (float)s1;
+  dgamma[ch] = (float)s2;
+  coef[ch] = gamma[ch] * rstd[ch];
+  coef[c + ch] = (float)(s1 / count);
+  coef[2 * c + ch] = (float)(s2 / count);
+}
+
+extern "C" int imm_bn_bwd_finalize(const float* partial, int nblk, int c, int64_t count, const float* gamma,
+                                   const float* rstd, float* dgamma, float* dbeta, float* coef, void* stream) {
+  IMM_REQUIRE(partial && gamma && rstd && dgamma && dbeta && coef && nblk > 0 && c > 0 && count > 0, "bn_bwd_finalize: args");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 63) / 64), dim3(64), 0, (hipStream_t)stream, partial, nblk, c,
+                     (double)count, gamma, rstd, dgamma, dbeta, coef);
+  IMM_CHECK_LAUNCH("imm_bn_bwd_finalize");
+  return 0;
+}
+
+template <typename ET>
+__global__ void bn_bwd_apply_kernel(const uint16_t* __restrict__ dout, int lddo, const uint16_t* __restrict__ y,
+                                    int ldy, int64_t npix, int c8n, int c, const float* __restrict__ scale,
+                                    const float* __restrict__ shift, const float* __restrict__ mean,
+                                    const float* __restrict__ rstd, int relu, const float* __restrict__ coef,
+                                    uint16_t* __restrict__ dy, int lddy) {
+  const int64_t total = npix * c8n;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p = idx / c8n;
+    const int cg = (int)(idx - p * c8n);
+    float d[8], v[8], o[8];
+    unpack8<ET>(*(const uint4*)(dout + p * lddo + cg * 8), d);
+    unpack8<ET>(*(const uint4*)(y + p * ldy + cg * 8), v);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int ch = cg * 8 + i;
+      float dz = d[i];
+      if (relu && !(v[i] * scale[ch] + shift[ch] > 0.f)) dz = 0.f;
+      const float xhat = (v[i] - mean[ch]) * rstd[ch];
+      o[i] = coef[ch] * (dz - coef[c + ch] - xhat * coef[2 * c + ch]);
+    }
+    *(uint4*)(dy + p * lddy + cg * 8) = pack8<ET>(o);
+  }
+}
+
+extern "C" int imm_bn_bwd_apply(const void* dout, int lddo, const void* y, int ldy, int dtype, int64_t npix, int c,
+                                const float* scale, const float* shift, const float* mean, const float* rstd, int relu,
+                                const float* coef, void* dy_out, int lddy, void* stream) {
+  IMM_REQUIRE(dout && y && scale && shift && mean && rstd && coef && dy_out && npix > 0, "bn_bwd_apply: null");
+  EW_REQUIRE_VEC(c, lddo, "bn_bwd_apply(dout)");
+  EW_REQUIRE_VEC(c, ldy, "bn_bwd_apply(y)");
+  EW_REQUIRE_VEC(c, lddy, "bn_bwd_apply(dy)");
+  IMM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<ET>), dim3(ew_blocks(npix * (c / 8))),
+                                               dim3(EW_THREADS), 0, (hipStream_t)stream, (const uint16_t*)dout, lddo,
+                                               (const uint16_t*)y, ldy, npix, c / 8, c, scale, shift, mean, rstd, relu,
+                                               coef, (uint16_t*)dy_out, lddy));
+  IMM_CHECK_LAUNCH("imm_bn_bwd_apply");
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// bias gradient: out[n] = sum_p dy[p][n]   (convs without batch norm)
+// ---------------------------------------------------------------------------------------------
+template <typename ET>
+__global__ __launch_bounds__(EW_THREADS) void colsum_kernel(const uint16_t* __restrict__ dy, int ld, int64_t npix,
+                                                            int c, float* __restrict__ partial) {
+  const int tpp = c / 8, rows = EW_THREADS / tpp;
+  const int r = threadIdx.x / tpp, cg = threadIdx.x - r * tpp;
+  const int64_t per_blk = (npix + gridDim.x - 1) / gridDim.x;
+  const int64_t p0 = (int64_t)blockIdx.x * per_blk;
+  const int64_t p1 = p0 + per_blk < npix ? p0 + per_blk : npix;
+  float acc[1][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[0][i] = 0.f;
+  for (int64_t p = p0 + r; p < p1; p += rows) {
+    float d[8];
+    unpack8<ET>(*(const uint4*)(dy + p * ld + cg * 8), d);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[0][i] += d[i];
+  }
+  col_reduce_tail<1>(acc, c, tpp, rows, partial + (int64_t)blockIdx.x * c);
+}
+
+__global__ void colsum_finalize_kernel(const float* __restrict__ partial, int nblk, int c, int c_real, float* out) {
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= c_real) return;
+  double s = 0.0;
+  for (int b = 0; b < nblk; ++b) s += (double)partial[(int64_t)b * c + ch];
+  out[ch] = (float)s;
+}
+
+// c = padded channel count of the buffer rows that are summed (multiple of 8); the first c_out sums are written.
+extern "C" int imm_colsum(const void* dy, int dtype, int64_t npix, int c, int c_out, int ld, float* partial, float* out,
+                          void* stream) {
+  IMM_REQUIRE(dy && partial && out && npix > 0 && c_out > 0 && c_out <= c, "colsum: args");
+  EW_REQUIRE_VEC(c, ld, "colsum");
+  const int nblk = imm_colsum_blocks(npix, c);
+  if (nblk < 0) return imm_fail(IMM_E_UNSUPPORTED, "colsum: C=%d unsupported", c);
+  IMM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((colsum_kernel<ET>), dim3(nblk), dim3(EW_THREADS), 0, (hipStream_t)stream,
+                                               (const uint16_t*)dy, ld, npix, c, partial));
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((c + 63) / 64), dim3(64), 0, (hipStream_t)stream, partial, nblk, c, c_out, out);
+  IMM_CHECK_LAUNCH("imm_colsum");
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// x2 bilinear upsample, TF legacy mapping (src = dst/2): out[2i] = in[i], out[2i+1] = (in[i]+in[min(i+1,n-1)])/2
+// ---------------------------------------------------------------------------------------------
+template <typename ET>
+__global__ void upsample2x_fwd_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y, int batch, int h, int w,
+                                      int c8n, int ldx, int ldy) {
+  const int H = 2 * h, W = 2 * w;
+  const int64_t total = (int64_t)batch * H * W * c8n;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int cg = (int)(idx % c8n);
+    int64_t t = idx / c8n;
+    const int X = (int)(t % W); t /= W;
+    const int Y = (int)(t % H);
+    const int b = (int)(t / H);
+    const int y0 = Y >> 1, x0 = X >> 1;
+    const int y1 = min(y0 + 1, h - 1), x1 = min(x0 + 1, w - 1);
+    const float ly = (Y & 1) ? 0.5f : 0.f, lx = (X & 1) ? 0.5f : 0.f;
+    const uint16_t* base = x + (int64_t)b * h * w * ldx + cg * 8;
+    float tl[8], tr[8], bl[8], br[8], o[8];
+    unpack8<ET>(*(const uint4*)(base + ((int64_t)y0 * w + x0) * ldx), tl);
+    unpack8<ET>(*(const uint4*)(base + ((int64_t)y0 * w + x1) * ldx), tr);
+    unpack8<ET>(*(const uint4*)(base + ((int64_t)y1 * w + x0) * ldx), bl);
+    unpack8<ET>(*(const uint4*)(base + ((int64_t)y1 * w + x1) * ldx), br);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float top = tl[i] + (tr[i] - tl[i]) * lx;
+      const float bot = bl[i] + (br[i] - bl[i]) * lx;
+      o[i] = top + (bot - top) * ly;
+    }
+    *(uint4*)(y + (((int64_t)b * H + Y) * W + X) * ldy + cg * 8) = pack8<ET>(o);
+  }
+}
+
+// adjoint as a gather: dx[i][j] = sum_{Y,X} wy(i,Y)*wx(j,X)*dy[Y][X]
+template <typename ET>
+__global__ void upsample2x_bwd_kernel(const uint16_t* __restrict__ dy, uint16_t* __restrict__ dx, int batch, int h,
+                                      int w, int c8n, int lddy, int lddx) {
+  const int H = 2 * h, W = 2 * w;
+  const int64_t total = (int64_t)batch * h * w * c8n;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int cg = (int)(idx % c8n);
+    int64_t t = idx / c8n;
+    const int j = (int)(t % w); t /= w;
+    const int i = (int)(t % h);
+    const int b = (int)(t / h);
+    // contributing output rows/cols and weights
+    int Ys[3], Xs[3]; float wy[3], wx[3];
+    Ys[0] = 2 * i - 1; wy[0] = (i >= 1) ? 0.5f : 0.f;
+    Ys[1] = 2 * i;     wy[1] = 1.f;
+    Ys[2] = 2 * i + 1; wy[2] = (i == h - 1) ? 1.f : 0.5f;
+    Xs[0] = 2 * j - 1; wx[0] = (j >= 1) ? 0.5f : 0.f;
+    Xs[1] = 2 * j;     wx[1] = 1.f;
+    Xs[2] = 2 * j + 1; wx[2] = (j == w - 1) ? 1.f : 0.5f;
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = 0.f;
+    const uint16_t* base = dy + (int64_t)b * H * W * lddy + cg * 8;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      if (wy[a] == 0.f) continue;
+#pragma unroll
+      for (int bb = 0; bb < 3; ++bb) {
+        if (wx[bb] == 0.f) continue;
+        float d[8];
+        unpack8<ET>(*(const uint4*)(base + ((int64_t)Ys[a] * W + Xs[bb]) * lddy), d);
+        const float wgt = wy[a] * wx[bb];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] += wgt * d[e];
+      }
+    }
+    *(uint4*)(dx + (((int64_t)b * h + i) * w + j) * lddx + cg * 8) = pack8<ET>(o);
+  }
+}
+
+extern "C" int imm_upsample2x_fwd(const void* x, void* y, int dtype, int batch, int h, int w, int c, int ldx, int ldy,
+                                  void* stream) {
+  IMM_REQUIRE(x && y && batch > 0 && h > 0 && w > 0, "upsample2x_fwd: args");
+  EW_REQUIRE_VEC(c, ldx, "upsample2x_fwd(x)");
+  EW_REQUIRE_VEC(c, ldy, "upsample2x_fwd(y)");
+  const int64_t total = (int64_t)batch * 4 * h * w * (c / 8);
+  IMM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((upsample2x_fwd_kernel<ET>), dim3(ew_blocks(total)), dim3(EW_THREADS), 0,
+                                               (hipStream_t)stream, (const uint16_t*)x, (uint16_t*)y, batch, h, w, c / 8,
+                                               ldx, ldy));
+  IMM_CHECK_LAUNCH("imm_upsample2x_fwd");
+  return 0;
+}
+
+extern "C" int imm_upsample2x_bwd(const void* dy, void* dx, int dtype, int batch, int h, int w, int c, int lddy,
+                                  int lddx, void* stream) {
+  IMM_REQUIRE(dy && dx && batch > 0 && h > 0 && w > 0, "upsample2x_bwd: args");
+  EW_REQUIRE_VEC(c, lddy, "upsample2x_bwd(dy)");
+  EW_REQUIRE_VEC(c, lddx, "upsample2x_bwd(dx)");
+  const int64_t total = (int64_t)batch * h * w * (c / 8);
+  IMM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((upsample2x_bwd_kernel<ET>), dim3(ew_blocks(total)), dim3(EW_THREADS), 0,
+                                               (hipStream_t)stream, (const uint16_t*)dy, (uint16_t*)dx, batch, h, w,
+                                               c / 8, lddy, lddx));
+  IMM_CHECK_LAUNCH("imm_upsample2x_bwd");
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// resize_bilinear(align_corners=True): src = dst*(in-1)/(out-1)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void ac_coord(int o, int n_in, int n_out, int& lo, int& hi, float& lerp) {
+  const float scale = (n_out > 1) ? (float)(n_in - 1) / (float)(n_out - 1) : 0.f;
+  const float src = o * scale;
+  lo = (int)floorf(src);
+  hi = min(lo + 1, n_in - 1);
+  lerp = src - (float)lo;
+}
+
+template <typename ET>
+__global__ void resize_ac_fwd_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y, int batch, int hi, int wi,
+                                     int ho, int wo, int c8n, int ldx, int ldy) {
+  const int64_t total = (int64_t)batch * ho * wo * c8n;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int cg = (int)(idx % c8n);
+    int64_t t = idx / c8n;
+    const int X = (int)(t % wo); t /= wo;
+    const int Y = (int)(t % ho);
+    const int b = (int)(t / ho);
+    int y0, y1, x0, x1; float ly, lx;
+    ac_coord(Y, hi, ho, y0, y1, ly);
+    ac_coord(X, wi, wo, x0, x1, lx);
+    const uint16_t* base = x + (int64_t)b * hi * wi * ldx + cg * 8;
+    float tl[8], tr[8], bl[8], br[8], o[8];
+    unpack8<ET>(*(const uint4*)(base + ((int64_t)y0 * wi + x0) * ldx), tl);
+    unpack8<ET>(*(const uint4*)(base + ((int64_t)y0 * wi + x1) * ldx), tr);
+    unpack8<ET>(*(const uint4*)(base + ((int64_t)y1 * wi + x0) * ldx), bl);
+    unpack8<ET>(*(const uint4*)(base + ((int64_t)y1 * wi + x1) * ldx), br);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float top = tl[i] + (tr[i] - tl[i]) * lx;
+      const float bot = bl[i] + (br[i] - bl[i]) * lx;
+      o[i] = top + (bot - top) * ly;
+    }
+    *(uint4*)(y + (((int64_t)b * ho + Y) * wo + X) * ldy + cg * 8) = pack8<ET>(o);
+  }
+}
+
+// adjoint by gather: each input pixel scans the (few) output rows/cols whose stencil touches it
+template <typename ET>
+__global__ void resize_ac_bwd_kernel(const uint16_t* __restrict__ dy, uint16_t* __restrict__ dx, int batch, int hi,
+                                     int wi, int ho, int wo, int c8n, int lddy, int lddx) {
+  const int64_t total = (int64_t)batch * hi * wi * c8n;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int cg = (int)(idx % c8n);
+    int64_t t = idx / c8n;
+    const int j = (int)(t % wi); t /= wi;
+    const int i = (int)(t % hi);
+    const int b = (int)(t / hi);
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = 0.f;
+    const uint16_t* base = dy + (int64_t)b * ho * wo * lddy + cg * 8;
+    for (int Y = 0; Y < ho; ++Y) {
+      int y0, y1; float ly;
+      ac_coord(Y, hi, ho, y0, y1, ly);
+      float wy = 0.f;
+      if (y0 == i) wy += 1.f - ly;
+      if (y1 == i) wy += ly;
+      if (wy == 0.f) continue;
+      for (int X = 0; X < wo; ++X) {
+        int x0, x1; float lx;
+        ac_coord(X, wi, wo, x0, x1, lx);
+        float wx = 0.f;
+        if (x0 == j) wx += 1.f - lx;
+        if (x1 == j) wx += lx;
+        if (wx == 0.f) continue;
+        float d[8];
+        unpack8<ET>(*(const uint4*)(base + ((int64_t)Y * wo + X) * lddy), d);
+        const float wgt = wy * wx;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] += wgt * d[e];
+      }
+    }
+    *(uint4*)(dx + (((int64_t)b * hi + i) * wi + j) * lddx + cg * 8) = pack8<ET>(o);
+  }
+}
+
+extern "C" int imm_resize_ac_fwd(const void* x, void* y, int dtype, int batch, int hi, int wi, int ho, int wo, int c,
+                                 int ldx, int ldy, void* stream) {
+  IMM_REQUIRE(x && y && batch > 0 && hi > 0 && wi > 0 && ho > 0 && wo > 0, "resize_ac_fwd: args");
+  EW_REQUIRE_VEC(c, ldx, "resize_ac_fwd(x)");
+  EW_REQUIRE_VEC(c, ldy, "resize_ac_fwd(y)");
+  const int64_t total = (int64_t)batch * ho * wo * (c / 8);
+  IMM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((resize_ac_fwd_kernel<ET>), dim3(ew_blocks(total)), dim3(EW_THREADS), 0,
+                                               (hipStream_t)stream, (const uint16_t*)x, (uint16_t*)y, batch, hi, wi, ho,
+                                               wo, c / 8, ldx, ldy));
+  IMM_CHECK_LAUNCH("imm_resize_ac_fwd");
+  return 0;
+}
+
+extern "C" int imm_resize_ac_bwd(const void* dy, void* dx, int dtype, int batch, int hi, int wi, int ho, int wo, int c,
+                                 int lddy, int lddx, void* stream) {
+  IMM_REQUIRE(dy && dx && batch > 0 && hi > 0 && wi > 0 && ho > 0 && wo > 0, "resize_ac_bwd: args");
+  EW_REQUIRE_VEC(c, lddy, "resize_ac_bwd(dy)");
+  EW_REQUIRE_VEC(c, lddx, "resize_ac_bwd(dx)");
+  const int64_t total = (int64_t)batch * hi * wi * (c / 8);
+  IMM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((resize_ac_bwd_kernel<ET>), dim3(ew_blocks(total)), dim3(EW_THREADS), 0,
+                                               (hipStream_t)stream, (const uint16_t*)dy, (uint16_t*)dx, batch, hi, wi, ho,
+                                               wo, c / 8, lddy, lddx));
+  IMM_CHECK_LAUNCH("imm_resize_ac_bwd");
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// 2x2/2 max pool (dense NHWC, ld == c)
+// ---------------------------------------------------------------------------------------------
+template <typename ET>
+__global__ void maxpool2_fwd_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y, int batch, int h, int w,
+                                    int c8n) {
+  const int ho = h / 2, wo = w / 2, c = c8n * 8;
+  const int64_t total = (int64_t)batch * ho * wo * c8n;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int cg = (int)(idx % c8n);
+    int64_t t = idx / c8n;
+    const int X = (int)(t % wo); t /= wo;
+    const int Y = (int)(t % ho);
+    const int b = (int)(t / ho);
+    const uint16_t* base = x + (((int64_t)b * h + 2 * Y) * w + 2 * X) * c + cg * 8;
+    float a0[8], a1[8], a2[8], a3[8], o[8];
+    unpack8<ET>(*(const uint4*)(base), a0);
+    unpack8<ET>(*(const uint4*)(base + c), a1);
+    unpack8<ET>(*(const uint4*)(base + (int64_t)w * c), a2);
+    unpack8<ET>(*(const uint4*)(base + (int64_t)w * c + c), a3);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = fmaxf(fmaxf(a0[i], a1[i]), fmaxf(a2[i], a3[i]));
+    *(uint4*)(y + (((int64_t)b * ho + Y) * wo + X) * c + cg * 8) = pack8<ET>(o);
+  }
+}
+
+template <typename ET>
+__global__ void maxpool2_bwd_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy,
+                                    uint16_t* __restrict__ dx, int batch, int h, int w, int c8n, int relu_mask) {
+  const int ho = h / 2, wo = w / 2, c = c8n * 8;
+  const int64_t total = (int64_t)batch * ho * wo * c8n;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int cg = (int)(idx % c8n);
+    int64_t t = idx / c8n;
+    const int X = (int)(t % wo); t /= wo;
+    const int Y = (int)(t % ho);
+    const int b = (int)(t / ho);
+    const int64_t off = (((int64_t)b * h + 2 * Y) * w + 2 * X) * c + cg * 8;
+    float a[4][8], g[8], o[4][8];
+    unpack8<ET>(*(const uint4*)(x + off), a[0]);
+    unpack8<ET>(*(const uint4*)(x + off + c), a[1]);
+    unpack8<ET>(*(const uint4*)(x + off + (int64_t)w * c), a[2]);
+    unpack8<ET>(*(const uint4*)(x + off + (int64_t)w * c + c), a[3]);
+    unpack8<ET>(*(const uint4*)(dy + (((int64_t)b * ho + Y) * wo + X) * c + cg * 8), g);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      int am = 0; float mv = a[0][i];
+#pragma unroll
+      for (int q = 1; q < 4; ++q) if (a[q][i] > mv) { mv = a[q][i]; am = q; }
+      const float gv = (relu_mask && !(mv > 0.f)) ? 0.f : g[i];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) o[q][i] = (q == am) ? gv : 0.f;
+    }
+    *(uint4*)(dx + off) = pack8<ET>(o[0]);
+    *(uint4*)(dx + off + c) = pack8<ET>(o[1]);
+    *(uint4*)(dx + off + (int64_t)w * c) = pack8<ET>(o[2]);
+    *(uint4*)(dx + off + (int64_t)w * c + c) = pack8<ET>(o[3]);
+  }
+}
+
+extern "C" int imm_maxpool2_fwd(const void* x, void* y, int dtype, int batch, int h, int w, int c, void* stream) {
+  IMM_REQUIRE(x && y && batch > 0 && h > 0 && w > 0 && h % 2 == 0 && w % 2 == 0, "maxpool2_fwd: even sides required");
+  EW_REQUIRE_VEC(c, c, "maxpool2_fwd");
+  const int64_t total = (int64_t)batch * (h / 2) * (w / 2) * (c / 8);
+  IMM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((maxpool2_fwd_kernel<ET>), dim3(ew_blocks(total)), dim3(EW_THREADS), 0,
+                                               (hipStream_t)stream, (const uint16_t*)x, (uint16_t*)y, batch, h, w, c / 8));
+  IMM_CHECK_LAUNCH("imm_maxpool2_fwd");
+  return 0;
+}
+
+extern "C" int imm_maxpool2_bwd(const void* x, const void* dy, void* dx, int dtype, int batch, int h, int w, int c,
+                                int relu_mask, void* stream) {
+  IMM_REQUIRE(x && dy && dx && batch > 0 && h > 0 && w > 0 && h % 2 == 0 && w % 2 == 0, "maxpool2_bwd: even sides required");
+  EW_REQUIRE_VEC(c, c, "maxpool2_bwd");
+  const int64_t total = (int64_t)batch * (h / 2) * (w / 2) * (c / 8);
+  IMM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((maxpool2_bwd_kernel<ET>), dim3(ew_blocks(total)), dim3(EW_THREADS), 0,
+                                               (hipStream_t)stream, (const uint16_t*)x, (const uint16_t*)dy,
+                                               (uint16_t*)dx, batch, h, w, c / 8, relu_mask));
+  IMM_CHECK_LAUNCH("imm_maxpool2_bwd");
+  return 0;
+}

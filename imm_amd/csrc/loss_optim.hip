@@ -1,0 +1,303 @@
+// loss_optim.hip — perceptual-loss reductions / gradient injection and the fused clip+Adam optimizer.
+//
+// Reference: imm/models/imm_model.py:111-151 (_colorization_reconstruction_loss: masked squared
+// feature differences, normalised by a DIFFERENTIABLE running average, base_model.py:39-50),
+// :408-410 (_loss_mask = legacy resize of the mask == strided pick), base_model.py:33-37 (_decay),
+// imm/train/cnn_train_multi.py:86-98,231-243 (tower mean -> tf.clip_by_norm per tensor) and
+// scripts/train.py:92-98 (staircase lr, tf.train.AdamOptimizer).
+// Everything the host would otherwise need to read back between launches (loss normalisers,
+// gradient coefficients, step count, learning rate) lives in device memory, so the whole step is a
+// fixed launch sequence that a HIP graph can replay.
+#include "common.h"
+
+#define LO_THREADS 256
+
+// ---------------------------------------------------------------------------------------------
+// masked sum of squared differences (per feature; IMM_SSE_BLOCKS deterministic partials)
+// ---------------------------------------------------------------------------------------------
+template <typename ET>
+__global__ __launch_bounds__(LO_THREADS) void masked_sse_kernel(const uint16_t* __restrict__ a, const uint16_t* __restrict__ b,
+                                                                int batch, int s, int c8n, const float* __restrict__ mask,
+                                                                int S, float* __restrict__ partial) {
+  __shared__ float red[4];
+  const int r = S / s;
+  const int64_t total = (int64_t)batch * s * s * c8n;
+  float acc = 0.f;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p = idx / c8n;
+    float mk = 1.f;
+    if (mask) {
+      const int xx = (int)(p % s);
+      const int64_t t = p / s;
+      const int yy = (int)(t % s);
+      const int64_t bi = t / s;
+      mk = mask[(bi * S + (int64_t)yy * r) * S + (int64_t)xx * r];
+    }
+    float fa[8], fb[8];
+    unpack8<ET>(*(const uint4*)(a + idx * 8), fa);
+    unpack8<ET>(*(const uint4*)(b + idx * 8), fb);
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { const float d = fa[i] - fb[i]; sq += d * d; }
+    acc += mk * sq;
+  }
+  acc = block_sum_256(acc, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = acc;
+}
+
+__global__ __launch_bounds__(LO_THREADS) void masked_sse_f32_kernel(const float* __restrict__ a, int lda,
+                                                                    const float* __restrict__ b, int ldb, int64_t npix,
+                                                                    int c, const float* __restrict__ mask,
+                                                                    float* __restrict__ partial) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (int64_t)gridDim.x * blockDim.x) {
+    float sq = 0.f;
+    for (int ch = 0; ch < c; ++ch) { const float d = a[p * lda + ch] - b[p * ldb + ch]; sq += d * d; }
+    acc += (mask ? mask[p] : 1.f) * sq;
+  }
+  acc = block_sum_256(acc, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = acc;
+}
+
+extern "C" int imm_masked_sse(const void* a, const void* b, int dtype, int batch, int s, int c, const float* mask, int S,
+                              float* partial, void* stream) {
+  IMM_REQUIRE(a && b && partial && batch > 0 && s > 0 && c > 0 && c % 8 == 0, "masked_sse: args");
+  IMM_REQUIRE(mask == nullptr || (S >= s && S % s == 0), "masked_sse: mask side %d not a multiple of feature side %d", S, s);
+  IMM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((masked_sse_kernel<ET>), dim3(IMM_SSE_BLOCKS), dim3(LO_THREADS), 0,
+                                               (hipStream_t)stream, (const uint16_t*)a, (const uint16_t*)b, batch, s, c / 8,
+                                               mask, S, partial));
+  IMM_CHECK_LAUNCH("imm_masked_sse");
+  return 0;
+}
+
+extern "C" int imm_masked_sse_f32(const float* a, int lda, const float* b, int ldb, int batch, int s, int c,
+                                  const float* mask, float* partial, void* stream) {
+  IMM_REQUIRE(a && b && partial && batch > 0 && s > 0 && c > 0 && lda >= c && ldb >= c, "masked_sse_f32: args");
+  hipLaunchKernelGGL(masked_sse_f32_kernel, dim3(IMM_SSE_BLOCKS), dim3(LO_THREADS), 0, (hipStream_t)stream, a, lda, b, ldb,
+                     (int64_t)batch * s * s, c, mask, partial);
+  IMM_CHECK_LAUNCH("imm_masked_sse_f32");
+  return 0;
+}
+
+// m_k = SSE_k / nel_k ; wl_k = a_k + 0.01 (m_k - a_k) ; term_k = m_k / wl_k
+// d(1000*sum term)/d a_pred = c_k * mask * (a_pred - a_gt),  c_k = 1000 * (1/wl - 0.01 m/wl^2) * 2/nel
+__global__ __launch_bounds__(LO_THREADS) void perceptual_finalize_kernel(const float* __restrict__ partial, int nfeat,
+                                                                         const float* __restrict__ nel, float* agg,
+                                                                         int training, const float* __restrict__ wd_loss,
+                                                                         float* __restrict__ out) {
+  __shared__ double dred[LO_THREADS];
+  __shared__ double sse[16];
+  const int tid = threadIdx.x;
+  for (int f = 0; f < nfeat; ++f) {
+    double v = 0.0;
+    for (int i = tid; i < IMM_SSE_BLOCKS; i += LO_THREADS) v += (double)partial[f * IMM_SSE_BLOCKS + i];
+    dred[tid] = v;
+    __syncthreads();
+    for (int o = LO_THREADS / 2; o > 0; o >>= 1) {
+      if (tid < o) dred[tid] += dred[tid + o];
+      __syncthreads();
+    }
+    if (tid == 0) sse[f] = dred[0];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    float rec = 0.f;
+    for (int f = 0; f < nfeat; ++f) {
+      const float m = (float)(sse[f] / (double)nel[f]);
+      const float a = agg[f];
+      const float wl = a + 0.01f * (m - a);
+      const float term = m / wl;
+      out[f] = term;
+      out[nfeat + f] = m;
+      out[2 * nfeat + f] = 1000.f * (1.f / wl - 0.01f * m / (wl * wl)) * 2.f / nel[f];
+      if (training) agg[f] = wl;
+      rec += term;
+    }
+    rec *= 1000.f;
+    const float wd = wd_loss ? wd_loss[0] : 0.f;
+    out[3 * nfeat] = rec;
+    out[3 * nfeat + 1] = wd;
+    out[3 * nfeat + 2] = rec + wd;
+  }
+}
+
+extern "C" int imm_perceptual_finalize(const float* partial, int nfeat, const float* nel, float* agg, int training,
+                                       const float* wd_loss, float* out, void* stream) {
+  IMM_REQUIRE(partial && nel && agg && out && nfeat > 0 && nfeat <= 16, "perceptual_finalize: args");
+  hipLaunchKernelGGL(perceptual_finalize_kernel, dim3(1), dim3(LO_THREADS), 0, (hipStream_t)stream, partial, nfeat, nel,
+                     agg, training, wd_loss, out);
+  IMM_CHECK_LAUNCH("imm_perceptual_finalize");
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// gradient injection at a perceptual tap (+ fused ReLU backward of the tapped activation)
+// ---------------------------------------------------------------------------------------------
+template <typename ET>
+__global__ void tap_grad_kernel(uint16_t* __restrict__ da, int has_in, const uint16_t* __restrict__ ap,
+                                const uint16_t* __restrict__ ag, int batch, int s, int c8n, const float* __restrict__ mask,
+                                int S, const float* __restrict__ coef, int idx_coef, int relu) {
+  const int r = S / s;
+  const float ck = coef[idx_coef];
+  const int64_t total = (int64_t)batch * s * s * c8n;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p = idx / c8n;
+    float mk = 1.f;
+    if (mask) {
+      const int xx = (int)(p % s);
+      const int64_t t = p / s;
+      const int yy = (int)(t % s);
+      const int64_t bi = t / s;
+      mk = mask[(bi * S + (int64_t)yy * r) * S + (int64_t)xx * r];
+    }
+    float fp[8], fg[8], d[8];
+    unpack8<ET>(*(const uint4*)(ap + idx * 8), fp);
+    unpack8<ET>(*(const uint4*)(ag + idx * 8), fg);
+    if (has_in) unpack8<ET>(*(const uint4*)(da + idx * 8), d);
+    const float cm = ck * mk;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float v = (has_in ? d[i] : 0.f) + cm * (fp[i] - fg[i]);
+      if (relu && !(fp[i] > 0.f)) v = 0.f;
+      d[i] = v;
+    }
+    *(uint4*)(da + idx * 8) = pack8<ET>(d);
+  }
+}
+
+extern "C" int imm_tap_grad(void* da, int has_in, const void* a_pred, const void* a_gt, int dtype, int batch, int s, int c,
+                            const float* mask, int S, const float* coef, int idx, int relu, void* stream) {
+  IMM_REQUIRE(da && a_pred && a_gt && coef && batch > 0 && s > 0 && c > 0 && c % 8 == 0 && idx >= 0, "tap_grad: args");
+  IMM_REQUIRE(mask == nullptr || (S >= s && S % s == 0), "tap_grad: mask side");
+  const int64_t total = (int64_t)batch * s * s * (c / 8);
+  int64_t blocks = (total + LO_THREADS - 1) / LO_THREADS;
+  if (blocks > 16384) blocks = 16384;
+  IMM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((tap_grad_kernel<ET>), dim3((int)blocks), dim3(LO_THREADS), 0,
+                                               (hipStream_t)stream, (uint16_t*)da, has_in, (const uint16_t*)a_pred,
+                                               (const uint16_t*)a_gt, batch, s, c / 8, mask, S, coef, idx, relu));
+  IMM_CHECK_LAUNCH("imm_tap_grad");
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// optimizer: flat f32 buffers, block table (one block = one chunk of one tensor)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(LO_THREADS) void wd_partial_kernel(const float* __restrict__ params,
+                                                                const int32_t* __restrict__ blk_seg,
+                                                                const int32_t* __restrict__ blk_begin,
+                                                                const int32_t* __restrict__ blk_end,
+                                                                const float* __restrict__ seg_wd,
+                                                                float* __restrict__ blk_partial) {
+  __shared__ float red[4];
+  const int blk = blockIdx.x;
+  const float wd = seg_wd[blk_seg[blk]];
+  float acc = 0.f;
+  if (wd != 0.f)
+    for (int i = blk_begin[blk] + threadIdx.x; i < blk_end[blk]; i += LO_THREADS) { const float w = params[i]; acc += w * w; }
+  acc = block_sum_256(acc, red);
+  if (threadIdx.x == 0) blk_partial[blk] = 0.5f * wd * acc;
+}
+
+__global__ __launch_bounds__(LO_THREADS) void sum_partials_kernel(const float* __restrict__ partial, int n, float* out) {
+  __shared__ double dred[LO_THREADS];
+  double v = 0.0;
+  for (int i = threadIdx.x; i < n; i += LO_THREADS) v += (double)partial[i];
+  dred[threadIdx.x] = v;
+  __syncthreads();
+  for (int o = LO_THREADS / 2; o > 0; o >>= 1) {
+    if (threadIdx.x < o) dred[threadIdx.x] += dred[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = (float)dred[0];
+}
+
+extern "C" int imm_weight_decay_loss(const float* params, const int32_t* blk_seg, const int32_t* blk_begin,
+                                     const int32_t* blk_end, int nblk, const float* seg_wd, float* blk_partial, float* out,
+                                     void* stream) {
+  IMM_REQUIRE(params && blk_seg && blk_begin && blk_end && seg_wd && blk_partial && out && nblk > 0, "weight_decay_loss: args");
+  hipLaunchKernelGGL(wd_partial_kernel, dim3(nblk), dim3(LO_THREADS), 0, (hipStream_t)stream, params, blk_seg, blk_begin,
+                     blk_end, seg_wd, blk_partial);
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(LO_THREADS), 0, (hipStream_t)stream, blk_partial, nblk, out);
+  IMM_CHECK_LAUNCH("imm_weight_decay_loss");
+  return 0;
+}
+
+__global__ __launch_bounds__(LO_THREADS) void grad_prepare_kernel(const float* __restrict__ params, float* __restrict__ grads,
+                                                                  const int32_t* __restrict__ blk_seg,
+                                                                  const int32_t* __restrict__ blk_begin,
+                                                                  const int32_t* __restrict__ blk_end,
+                                                                  const float* __restrict__ seg_wd, float grad_scale,
+                                                                  float* __restrict__ blk_partial) {
+  __shared__ float red[4];
+  const int blk = blockIdx.x;
+  const float wd = seg_wd[blk_seg[blk]];
+  float acc = 0.f;
+  for (int i = blk_begin[blk] + threadIdx.x; i < blk_end[blk]; i += LO_THREADS) {
+    const float g = grads[i] * grad_scale + wd * params[i];
+    grads[i] = g;
+    acc += g * g;
+  }
+  acc = block_sum_256(acc, red);
+  if (threadIdx.x == 0) blk_partial[blk] = acc;
+}
+
+__global__ void opt_tick_kernel(const float* __restrict__ blk_partial, const int32_t* __restrict__ seg_first_blk, int nseg,
+                                float* __restrict__ seg_norm2, int32_t* step_count, float* lr_state, imm_opt_hparams hp) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < nseg) {
+    double s = 0.0;
+    for (int b = seg_first_blk[t]; b < seg_first_blk[t + 1]; ++b) s += (double)blk_partial[b];
+    seg_norm2[t] = (float)s;
+  }
+  if (t == 0) {
+    const int gs = step_count[0];           // TF global_step before this apply
+    const int tt = gs + 1;                  // Adam's t
+    const double lr = (double)hp.lr_multiple * (double)hp.lr_start * pow((double)hp.lr_decay, (double)(gs / hp.lr_step));
+    const double lr_t = lr * sqrt(1.0 - pow((double)hp.beta2, (double)tt)) / (1.0 - pow((double)hp.beta1, (double)tt));
+    lr_state[0] = (float)lr_t;
+    lr_state[1] = (float)lr;
+    step_count[0] = tt;
+  }
+}
+
+__global__ __launch_bounds__(LO_THREADS) void clip_adam_kernel(float* __restrict__ params, const float* __restrict__ grads,
+                                                               float* __restrict__ m, float* __restrict__ v,
+                                                               const int32_t* __restrict__ blk_seg,
+                                                               const int32_t* __restrict__ blk_begin,
+                                                               const int32_t* __restrict__ blk_end,
+                                                               const float* __restrict__ seg_norm2,
+                                                               const float* __restrict__ lr_state, imm_opt_hparams hp) {
+  const int blk = blockIdx.x;
+  float factor = 1.f;
+  if (hp.clip > 0.f) factor = hp.clip / fmaxf(sqrtf(seg_norm2[blk_seg[blk]]), hp.clip);
+  const float lr_t = lr_state[0];
+  for (int i = blk_begin[blk] + threadIdx.x; i < blk_end[blk]; i += LO_THREADS) {
+    const float g = grads[i] * factor;
+    const float mi = hp.beta1 * m[i] + (1.f - hp.beta1) * g;
+    const float vi = hp.beta2 * v[i] + (1.f - hp.beta2) * g * g;
+    m[i] = mi;
+    v[i] = vi;
+    params[i] -= lr_t * mi / (sqrtf(vi) + hp.eps);
+  }
+}
+
+extern "C" int imm_clip_adam_step(float* params, float* grads, float* m, float* v, const int32_t* blk_seg,
+                                  const int32_t* blk_begin, const int32_t* blk_end, int nblk, int nseg,
+                                  const int32_t* seg_first_blk, const float* seg_wd, float* blk_partial, float* seg_norm2,
+                                  int32_t* step_count, float* lr_state, const imm_opt_hparams* hp, void* stream) {
+  IMM_REQUIRE(params && grads && m && v && blk_seg && blk_begin && blk_end && seg_first_blk && seg_wd && blk_partial &&
+                  seg_norm2 && step_count && lr_state && hp, "clip_adam_step: null");
+  IMM_REQUIRE(nblk > 0 && nseg > 0 && hp->lr_step > 0, "clip_adam_step: dims");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(grad_prepare_kernel, dim3(nblk), dim3(LO_THREADS), 0, s, params, grads, blk_seg, blk_begin, blk_end,
+                     seg_wd, hp->grad_scale, blk_partial);
+  hipLaunchKernelGGL(opt_tick_kernel, dim3((nseg + 63) / 64), dim3(64), 0, s, blk_partial, seg_first_blk, nseg, seg_norm2,
+                     step_count, lr_state, *hp);
+  hipLaunchKernelGGL(clip_adam_kernel, dim3(nblk), dim3(LO_THREADS), 0, s, params, grads, m, v, blk_seg, blk_begin, blk_end,
+                     seg_norm2, lr_state, *hp);
+  IMM_CHECK_LAUNCH("imm_clip_adam_step");
+  return 0;
+}

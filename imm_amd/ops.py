@@ -1,0 +1,260 @@
+"""Thin torch-tensor -> C-ABI wrappers.  Every function launches on torch's CURRENT stream and returns
+immediately; tensors are caller-allocated device buffers (PyTorch is only the allocator here).
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from ._lib import ConvDesc, OptHParams, call  # noqa: F401
+
+
+def _s():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def dtype_enum(dt):
+    if dt == torch.bfloat16:
+        return L.IMM_BF16
+    if dt == torch.float16:
+        return L.IMM_F16
+    raise ValueError('activation dtype must be torch.bfloat16 or torch.float16, got %r' % (dt,))
+
+
+def round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+def same_pad_before(n_in, k, s):
+    """TF SAME: pad_before = max((ceil(in/s)-1)*s + k - in, 0) // 2  (SURVEY.md §8a S1)."""
+    n_out = -(-n_in // s)
+    return max((n_out - 1) * s + k - n_in, 0) // 2, n_out
+
+
+def fwd_desc(batch, hi, wi, ci, ldx, co, ldy, k, stride, flags, ldmask=0):
+    pt, ho = same_pad_before(hi, k, stride)
+    pl, wo = same_pad_before(wi, k, stride)
+    return ConvDesc(batch=batch, hi=hi, wi=wi, ci=ci, ldx=ldx, ho=ho, wo=wo, co=co, ldy=ldy, kh=k, kw=k,
+                    stride=stride, pad_t=pt, pad_l=pl, updiv=1, kpad=round_up(k * k * ci, 32), flags=flags,
+                    ldmask=ldmask)
+
+
+def dgrad_desc(batch, hi, wi, ci_out, lddx, co_pad, lddy, k, stride, flags, ldmask=0):
+    """Data gradient of the forward conv (hi,wi,ci)->(ho,wo,co): a conv of dy [ho,wo,co_pad] producing
+    dx [hi,wi,ci_out] with flipped weights, stride 1, updiv = forward stride, pad = k-1-pad_fwd."""
+    pt, ho = same_pad_before(hi, k, stride)
+    pl, wo = same_pad_before(wi, k, stride)
+    return ConvDesc(batch=batch, hi=ho, wi=wo, ci=co_pad, ldx=lddy, ho=hi, wo=wi, co=ci_out, ldy=lddx, kh=k, kw=k,
+                    stride=1, pad_t=k - 1 - pt, pad_l=k - 1 - pl, updiv=stride, kpad=round_up(k * k * co_pad, 32),
+                    flags=flags, ldmask=ldmask)
+
+
+def device_info():
+    out = (C.c_int32 * 2)()
+    call('imm_device_info', C.cast(out, C.c_void_p))
+    return int(out[0]), int(out[1])
+
+
+# ---- graph capture ---------------------------------------------------------------------------
+class Graph:
+    """A captured launch sequence (HIP graph) on torch's current stream."""
+
+    def __init__(self):
+        self._exec = C.c_void_p()
+
+    def capture_begin(self):
+        call('imm_graph_begin', _s())
+
+    def capture_end(self):
+        call('imm_graph_end', _s(), C.byref(self._exec))
+
+    def launch(self):
+        call('imm_graph_launch', self._exec, _s())
+
+    def __del__(self):
+        try:
+            if self._exec:
+                L.load().imm_graph_destroy(self._exec)
+        except Exception:
+            pass
+
+
+# ---- weights / conv --------------------------------------------------------------------------
+def pack_weights(w, wt, mode, kh, kw, ci_real, co_real, c_pad, rows, kpad):
+    call('imm_pack_weights', _p(w), _p(wt), dtype_enum(wt.dtype), mode, kh, kw, ci_real, co_real, c_pad, rows, kpad, _s())
+
+
+def conv2d(desc, x, wt, bias, y, stats=None, mask=None):
+    call('imm_conv2d', C.byref(desc), dtype_enum(x.dtype), _p(x), _p(wt), _p(bias), _p(y), _p(stats), _p(mask), _s())
+
+
+def conv_stats_blocks(desc):
+    n = L.load().imm_conv_stats_blocks(C.byref(desc))
+    if n <= 0:
+        raise L.ImmHipError('imm_conv_stats_blocks: ' + L.load().imm_last_error().decode())
+    return n
+
+
+def conv2d_wgrad(desc, x, dy, lddy, slab, nsplit):
+    call('imm_conv2d_wgrad', C.byref(desc), dtype_enum(x.dtype), _p(x), _p(dy), lddy, _p(slab), nsplit, _s())
+
+
+def conv2d_wgrad_reduce(slab, nsplit, kh, kw, ci_pad, ci_real, co, kpad, dw):
+    call('imm_conv2d_wgrad_reduce', _p(slab), nsplit, kh, kw, ci_pad, ci_real, co, kpad, _p(dw), _s())
+
+
+def colsum_blocks(npix, c):
+    n = L.load().imm_colsum_blocks(npix, c)
+    if n <= 0:
+        raise L.ImmHipError('imm_colsum_blocks(%d,%d) unsupported' % (npix, c))
+    return n
+
+
+def colsum(dy, npix, c, c_out, ld, partial, out):
+    call('imm_colsum', _p(dy), dtype_enum(dy.dtype), npix, c, c_out, ld, _p(partial), _p(out), _s())
+
+
+# ---- batch norm ------------------------------------------------------------------------------
+def bn_finalize(partial, nblk, c, count, gamma, beta, eps, momentum, training, mm, mv, scale, shift, mean, rstd):
+    call('imm_bn_finalize', _p(partial), nblk, c, count, _p(gamma), _p(beta), eps, momentum, int(training), _p(mm),
+         _p(mv), _p(scale), _p(shift), _p(mean), _p(rstd), _s())
+
+
+def bn_apply_relu(y, npix, c, ldy, scale, shift, relu, x_out, ldx):
+    call('imm_bn_apply_relu', _p(y), dtype_enum(y.dtype), npix, c, ldy, _p(scale), _p(shift), int(relu), _p(x_out), ldx, _s())
+
+
+def bn_bwd_blocks(npix, c):
+    n = L.load().imm_bn_bwd_blocks(npix, c)
+    if n <= 0:
+        raise L.ImmHipError('imm_bn_bwd_blocks(%d,%d) unsupported' % (npix, c))
+    return n
+
+
+def bn_bwd_reduce(dout, lddo, y, ldy, npix, c, scale, shift, mean, rstd, relu, partial):
+    call('imm_bn_bwd_reduce', _p(dout), lddo, _p(y), ldy, dtype_enum(y.dtype), npix, c, _p(scale), _p(shift), _p(mean),
+         _p(rstd), int(relu), _p(partial), _s())
+
+
+def bn_bwd_finalize(partial, nblk, c, count, gamma, rstd, dgamma, dbeta, coef):
+    call('imm_bn_bwd_finalize', _p(partial), nblk, c, count, _p(gamma), _p(rstd), _p(dgamma), _p(dbeta), _p(coef), _s())
+
+
+def bn_bwd_apply(dout, lddo, y, ldy, npix, c, scale, shift, mean, rstd, relu, coef, dy_out, lddy):
+    call('imm_bn_bwd_apply', _p(dout), lddo, _p(y), ldy, dtype_enum(y.dtype), npix, c, _p(scale), _p(shift), _p(mean),
+         _p(rstd), int(relu), _p(coef), _p(dy_out), lddy, _s())
+
+
+# ---- resampling / pooling ---------------------------------------------------------------------
+def upsample2x_fwd(x, y, batch, h, w, c, ldx, ldy):
+    call('imm_upsample2x_fwd', _p(x), _p(y), dtype_enum(x.dtype), batch, h, w, c, ldx, ldy, _s())
+
+
+def upsample2x_bwd(dy, dx, batch, h, w, c, lddy, lddx):
+    call('imm_upsample2x_bwd', _p(dy), _p(dx), dtype_enum(dy.dtype), batch, h, w, c, lddy, lddx, _s())
+
+
+def resize_ac_fwd(x, y, batch, hi, wi, ho, wo, c, ldx, ldy):
+    call('imm_resize_ac_fwd', _p(x), _p(y), dtype_enum(x.dtype), batch, hi, wi, ho, wo, c, ldx, ldy, _s())
+
+
+def resize_ac_bwd(dy, dx, batch, hi, wi, ho, wo, c, lddy, lddx):
+    call('imm_resize_ac_bwd', _p(dy), _p(dx), dtype_enum(dy.dtype), batch, hi, wi, ho, wo, c, lddy, lddx, _s())
+
+
+def maxpool2_fwd(x, y, batch, h, w, c):
+    call('imm_maxpool2_fwd', _p(x), _p(y), dtype_enum(x.dtype), batch, h, w, c, _s())
+
+
+def maxpool2_bwd(x, dy, dx, batch, h, w, c, relu_mask):
+    call('imm_maxpool2_bwd', _p(x), _p(dy), _p(dx), dtype_enum(x.dtype), batch, h, w, c, int(relu_mask), _s())
+
+
+def pack_image(src, dst, npix):
+    call('imm_pack_image', _p(src), _p(dst), dtype_enum(dst.dtype), npix, _s())
+
+
+# ---- bottleneck ------------------------------------------------------------------------------
+def softargmax_gauss_fwd(heat, ldh, batch, h, w, k, inv_std, s, mu, py, px, gauss_out, ldg, dtype):
+    call('imm_softargmax_gauss_fwd', _p(heat), ldh, batch, h, w, k, float(inv_std), s, _p(mu), _p(py), _p(px),
+         _p(gauss_out), ldg, dtype_enum(dtype), _s())
+
+
+def softargmax_gauss_bwd(dgauss, ldg, batch, h, w, k, inv_std, s, mu, py, px, dheat, lddh):
+    call('imm_softargmax_gauss_bwd', _p(dgauss), ldg, dtype_enum(dheat.dtype), batch, h, w, k, float(inv_std), s, _p(mu),
+         _p(py), _p(px), _p(dheat), lddh, _s())
+
+
+def gauss_render_f32(mu, batch, k, inv_std, s, out):
+    call('imm_gauss_render_f32', _p(mu), batch, k, float(inv_std), s, _p(out), _s())
+
+
+# ---- VGG head / loss --------------------------------------------------------------------------
+def vgg_conv1_1_fwd(gt, pred, ldp, batch, s, w, b, out):
+    call('imm_vgg_conv1_1_fwd', _p(gt), _p(pred), ldp, batch, s, _p(w), _p(b), _p(out), dtype_enum(out.dtype), _s())
+
+
+def vgg_conv1_1_bwd(dz, batch, s, w, gt, pred, ldp, mask, coef, dpred, lddp):
+    call('imm_vgg_conv1_1_bwd', _p(dz), dtype_enum(dz.dtype), batch, s, _p(w), _p(gt), _p(pred), ldp, _p(mask), _p(coef),
+         _p(dpred), lddp, _s())
+
+
+def masked_sse(a, b, batch, s, c, mask, S, partial):
+    call('imm_masked_sse', _p(a), _p(b), dtype_enum(a.dtype), batch, s, c, _p(mask), S, _p(partial), _s())
+
+
+def masked_sse_f32(a, lda, b, ldb, batch, s, c, mask, partial):
+    call('imm_masked_sse_f32', _p(a), lda, _p(b), ldb, batch, s, c, _p(mask), _p(partial), _s())
+
+
+def perceptual_finalize(partial, nfeat, nel, agg, training, wd_loss, out):
+    call('imm_perceptual_finalize', _p(partial), nfeat, _p(nel), _p(agg), int(training), _p(wd_loss), _p(out), _s())
+
+
+def tap_grad(da, has_in, a_pred, a_gt, batch, s, c, mask, S, coef, idx, relu):
+    call('imm_tap_grad', _p(da), int(has_in), _p(a_pred), _p(a_gt), dtype_enum(da.dtype), batch, s, c, _p(mask), S,
+         _p(coef), idx, int(relu), _s())
+
+
+# ---- optimizer --------------------------------------------------------------------------------
+def weight_decay_loss(params, tab, blk_partial, out):
+    call('imm_weight_decay_loss', _p(params), _p(tab.blk_seg), _p(tab.blk_begin), _p(tab.blk_end), tab.nblk, _p(tab.seg_wd),
+         _p(blk_partial), _p(out), _s())
+
+
+def clip_adam_step(params, grads, m, v, tab, blk_partial, seg_norm2, step_count, lr_state, hp):
+    call('imm_clip_adam_step', _p(params), _p(grads), _p(m), _p(v), _p(tab.blk_seg), _p(tab.blk_begin), _p(tab.blk_end),
+         tab.nblk, tab.nseg, _p(tab.seg_first_blk), _p(tab.seg_wd), _p(blk_partial), _p(seg_norm2), _p(step_count),
+         _p(lr_state), C.byref(hp), _s())
+
+
+class SegmentTable:
+    """Device-side description of the flat parameter buffer: tensors (segments) and the chunk each
+    optimizer workgroup owns."""
+    CHUNK = 8192
+
+    def __init__(self, sizes, wds, device):
+        offs = [0]
+        for n in sizes:
+            offs.append(offs[-1] + int(n))
+        blk_seg, blk_begin, blk_end, first = [], [], [], [0]
+        for s, n in enumerate(sizes):
+            for b0 in range(0, int(n), self.CHUNK):
+                blk_seg.append(s)
+                blk_begin.append(offs[s] + b0)
+                blk_end.append(offs[s] + min(int(n), b0 + self.CHUNK))
+            first.append(len(blk_seg))
+        self.offsets = offs
+        self.nseg, self.nblk, self.total = len(sizes), len(blk_seg), offs[-1]
+        i32 = dict(dtype=torch.int32, device=device)
+        self.blk_seg = torch.tensor(blk_seg, **i32)
+        self.blk_begin = torch.tensor(blk_begin, **i32)
+        self.blk_end = torch.tensor(blk_end, **i32)
+        self.seg_first_blk = torch.tensor(first, **i32)
+        self.seg_wd = torch.tensor([float(w) for w in wds], dtype=torch.float32, device=device)

@@ -1,0 +1,206 @@
+/* imm_hip.h — C-ABI of libimm_hip.so: the MI355X (gfx950) kernels behind the IMM training step.
+ *
+ * The reference (tomasjakab/imm) has NO native layer and NO FFI: every number on its hot path comes
+ * from stock TensorFlow-1.10 ops called from Python.  This header therefore declares one entry
+ * point per TF op call site on the path (SURVEY.md §2a op table); each declaration cites the
+ * reference call site it replaces (paths relative to /root/reference).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host; nothing allocates, nothing
+ *     synchronises, nothing throws; every launch goes to the caller's hipStream_t (passed as void*).
+ *   - return value: 0 = ok, <0 = error (IMM_E_*); imm_last_error() returns a thread-local message.
+ *   - activations are NHWC with an explicit pixel stride `ld*` (elements), 16-bit storage
+ *     (imm_dtype BF16 or F16) unless a parameter says f32; channel counts that feed a
+ *     convolution are multiples of 8 and padding channels hold zeros.
+ *   - statistics, parameters, gradients of parameters, optimizer state: f32.
+ */
+#ifndef IMM_HIP_H
+#define IMM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IMM_ABI_VERSION 1
+
+enum imm_dtype { IMM_BF16 = 0, IMM_F16 = 1 };
+
+enum imm_error {
+  IMM_OK = 0,
+  IMM_E_INVALID = -1,      /* bad argument (null pointer, misaligned stride, non-positive dim) */
+  IMM_E_UNSUPPORTED = -2,  /* shape / mode not implemented by these kernels */
+  IMM_E_HIP = -3           /* a HIP runtime call failed */
+};
+
+/* convolution epilogue / mode flags */
+#define IMM_CONV_BIAS 1      /* add f32 bias[co]                                               */
+#define IMM_CONV_RELU 2      /* max(.,0)                                                       */
+#define IMM_CONV_STATS 4     /* write per-M-block partial sum / sum-of-squares for batch norm   */
+#define IMM_CONV_MASK 8      /* multiply by (mask_ref[m][n] > 0): ReLU backward fused in dgrad  */
+#define IMM_CONV_OUT_F32 16  /* y is f32 instead of 16-bit                                      */
+
+/* Geometry of one implicit-GEMM convolution launch.  Forward (tf.nn.conv2d SAME,
+ * imm/tf_utils/nn_utils.py:100; imm/models/selfsup/vgg16.py:182) uses stride>=1, updiv=1.
+ * Data-gradient (tf.gradients of the same op) is expressed as a convolution of dy with the
+ * flipped/transposed packed weights: stride=1, updiv=<forward stride>, pad = k-1-pad_fwd. */
+typedef struct imm_conv_desc {
+  int32_t batch, hi, wi, ci;   /* input: ci = channels entering the K loop (multiple of 8)        */
+  int32_t ldx;                 /* input pixel stride (elements, multiple of 8)                    */
+  int32_t ho, wo, co;          /* output: co = real output channels                               */
+  int32_t ldy;                 /* output pixel stride (elements, multiple of 4)                   */
+  int32_t kh, kw, stride, pad_t, pad_l;
+  int32_t updiv;               /* 1, or 2 for the transposed (stride-2 dgrad) gather              */
+  int32_t kpad;                /* packed-weight row length: round_up(kh*kw*ci, 32)                */
+  int32_t flags;               /* IMM_CONV_*                                                      */
+  int32_t ldmask;              /* pixel stride of mask_ref (IMM_CONV_MASK)                        */
+} imm_conv_desc;
+
+/* ---- runtime ------------------------------------------------------------------------------- */
+int imm_abi_version(void);
+const char* imm_last_error(void);
+/* device properties the host needs to size launches: [0]=CU count, [1]=gfx arch number (950) */
+int imm_device_info(int32_t* out2_host);
+/* HIP-graph capture of a launch sequence on `stream` (replaces TF's session.run of a static graph,
+ * imm/train/cnn_train_multi.py:459). */
+int imm_graph_begin(void* stream);
+int imm_graph_end(void* stream, void** graph_exec_out_host);
+int imm_graph_launch(void* graph_exec, void* stream);
+int imm_graph_destroy(void* graph_exec);
+
+/* ---- weights ------------------------------------------------------------------------------- */
+/* f32 HWIO master [kh,kw,ci_real,co_real] -> 16-bit packed Wt[rows][kpad] (k contiguous).
+ * mode 0 (forward): row n = co, k = (ky*kw+kx)*ci_pad + c.
+ * mode 1 (dgrad):   row n = ci, k = (ky'*kw+kx')*co_pad + c', value W[kh-1-ky'][kw-1-kx'][n][c'].
+ * rows >= real count and padded k are written as zeros; `rows` is the allocated row count. */
+int imm_pack_weights(const float* w, void* wt, int dtype, int mode, int kh, int kw, int ci_real, int co_real,
+                     int c_pad, int rows, int kpad, void* stream);
+
+/* ---- convolution (implicit GEMM on MFMA) ----------------------------------------------------- */
+/* y[m][n] = epilogue( sum_k gather(x)[m][k] * wt[n][k] ).  stats_partial: [n_mblocks][2][co] f32
+ * with n_mblocks = imm_conv_stats_blocks(desc).  Replaces tf.nn.conv2d+bias_add (nn_utils.py:100,108),
+ * vgg conv+bias+relu (vgg16.py:182-189,230) and their data gradients. */
+int imm_conv2d(const imm_conv_desc* desc_host, int dtype, const void* x, const void* wt, const float* bias,
+               void* y, float* stats_partial, const void* mask_ref, void* stream);
+int imm_conv_stats_blocks(const imm_conv_desc* desc_host);
+/* Filter gradient: slab[split][kpad][co] f32 partials over `nsplit` pixel ranges, then
+ * imm_conv2d_wgrad_reduce sums the slabs into the HWIO f32 gradient [kh,kw,ci_real,co]
+ * (tf.gradients of nn_utils.py:100 w.r.t. `w`).  desc describes the FORWARD convolution. */
+int imm_conv2d_wgrad(const imm_conv_desc* desc_host, int dtype, const void* x, const void* dy, int lddy,
+                     float* slab, int nsplit, void* stream);
+int imm_conv2d_wgrad_reduce(const float* slab, int nsplit, int kh, int kw, int ci_pad, int ci_real, int co,
+                            int kpad, float* dw, void* stream);
+/* db[n] = sum_m dy[m][n], n < c_out, for convolutions not followed by batch norm (bias_add gradient,
+ * nn_utils.py:108); c = padded channel count summed per row (multiple of 8);
+ * partial: [nblk][c] scratch with nblk = imm_colsum_blocks(npix, c). */
+int imm_colsum(const void* dy, int dtype, int64_t npix, int c, int c_out, int ld, float* partial, float* out,
+               void* stream);
+int imm_colsum_blocks(int64_t npix, int c);
+
+/* ---- batch norm (tf.layers.batch_normalization(fused=True) + relu, nn_utils.py:201-209) ------ */
+/* partial [nblk][2][c] -> scale/shift for the apply pass, saved mean/rstd for backward, moving
+ * averages updated with momentum 0.99 / unbiased variance when training != 0. */
+int imm_bn_finalize(const float* partial, int nblk, int c, int64_t count, const float* gamma, const float* beta,
+                    float eps, float momentum, int training, float* moving_mean, float* moving_var,
+                    float* scale, float* shift, float* mean, float* rstd, void* stream);
+int imm_bn_apply_relu(const void* y, int dtype, int64_t npix, int c, int ldy, const float* scale,
+                      const float* shift, int relu, void* x_out, int ldx, void* stream);
+/* backward: reduce -> finalize (writes dgamma, dbeta, coef[3][c]) -> apply (dy_conv = ...) */
+int imm_bn_bwd_reduce(const void* dout, int lddo, const void* y, int ldy, int dtype, int64_t npix, int c,
+                      const float* scale, const float* shift, const float* mean, const float* rstd, int relu,
+                      float* partial, void* stream);
+int imm_bn_bwd_blocks(int64_t npix, int c);
+int imm_bn_bwd_finalize(const float* partial, int nblk, int c, int64_t count, const float* gamma,
+                        const float* rstd, float* dgamma, float* dbeta, float* coef, void* stream);
+int imm_bn_bwd_apply(const void* dout, int lddo, const void* y, int ldy, int dtype, int64_t npix, int c,
+                     const float* scale, const float* shift, const float* mean, const float* rstd, int relu,
+                     const float* coef, void* dy_out, int lddy, void* stream);
+
+/* ---- resampling / pooling -------------------------------------------------------------------- */
+/* tf.image.resize_images x2, bilinear, legacy align_corners=False (imm_model.py:175) and its adjoint */
+int imm_upsample2x_fwd(const void* x, void* y, int dtype, int batch, int h, int w, int c, int ldx, int ldy,
+                       void* stream);
+int imm_upsample2x_bwd(const void* dy, void* dx, int dtype, int batch, int h, int w, int c, int lddy, int lddx,
+                       void* stream);
+/* tf.image.resize_bilinear(align_corners=True) (imm_model.py:334) and its adjoint (dx must be zeroed
+ * by the kernel itself: it is, via a gather formulation) */
+int imm_resize_ac_fwd(const void* x, void* y, int dtype, int batch, int hi, int wi, int ho, int wo, int c,
+                      int ldx, int ldy, void* stream);
+int imm_resize_ac_bwd(const void* dy, void* dx, int dtype, int batch, int hi, int wi, int ho, int wo, int c,
+                      int lddy, int lddx, void* stream);
+/* tf.nn.max_pool 2x2/2 (selfsup/ops.py:16-26).  bwd routes to the first maximum in scan order and,
+ * with relu_mask != 0, zeroes gradients where x <= 0 (ReLU backward of the producing conv). */
+int imm_maxpool2_fwd(const void* x, void* y, int dtype, int batch, int h, int w, int c, void* stream);
+int imm_maxpool2_bwd(const void* x, const void* dy, void* dx, int dtype, int batch, int h, int w, int c,
+                     int relu_mask, void* stream);
+
+/* ---- inputs ---------------------------------------------------------------------------------- */
+/* f32 NHWC [npix,3] in [0,255] -> 16-bit [npix,8] (channels 3..7 zero): first encoder conv input */
+int imm_pack_image(const float* src, void* dst, int dtype, int64_t npix, void* stream);
+
+/* ---- landmark bottleneck (imm_model.py:252-264 soft-argmax, :34-78 Gaussian maps, mode 'rot') -- */
+/* heat f32 [B,h,w,ldh] (k<K) -> mu [B,K,2] (y,x), py [B,h,K], px [B,w,K];
+ * gauss: 16-bit written at gauss_out[((b*s+y)*s+x)*ldg + k] for k<K. */
+int imm_softargmax_gauss_fwd(const float* heat, int ldh, int batch, int h, int w, int k, float inv_std, int s,
+                             float* mu, float* py, float* px, void* gauss_out, int ldg, int dtype, void* stream);
+/* dgauss 16-bit (same addressing as gauss_out) -> dheat 16-bit [B,h,w,lddh], channels >= K zeroed */
+int imm_softargmax_gauss_bwd(const void* dgauss, int ldg, int dtype, int batch, int h, int w, int k, float inv_std,
+                             int s, const float* mu, const float* py, const float* px, void* dheat, int lddh,
+                             void* stream);
+/* render only (pose_embedding summary maps at other sizes; f32 output [B,s,s,K]) */
+int imm_gauss_render_f32(const float* mu, int batch, int k, float inv_std, int s, float* out, void* stream);
+
+/* ---- frozen VGG16 first layer (build_vgg16.py:22-26 grayscale+normalise, vgg16.py:345 conv1_1) -- */
+/* images: gt f32 [B,S,S,3] and pred f32 [B,S,S,ldp] (first 3 ch) -> out 16-bit [2B,S,S,64] */
+int imm_vgg_conv1_1_fwd(const float* gt, const float* pred, int ldp, int batch, int s, const float* w9x64,
+                        const float* b64, void* out, int dtype, void* stream);
+/* dz 16-bit [B,S,S,64] (pred half, already ReLU-masked) -> dpred 16-bit [B,S,S,lddp]:
+ * ch<3 = dgray/(3*255) + coef[0]*mask[p]*(pred-gt), ch>=3 = 0.  coef is a device scalar table. */
+int imm_vgg_conv1_1_bwd(const void* dz, int dtype, int batch, int s, const float* w9x64, const float* gt,
+                        const float* pred, int ldp, const float* mask, const float* coef, void* dpred, int lddp,
+                        void* stream);
+
+/* ---- perceptual loss (imm_model.py:111-151; base_model.py:39-50) ----------------------------- */
+#define IMM_SSE_BLOCKS 512
+/* partial[IMM_SSE_BLOCKS] of sum mask[pixel/(s*s)...]*(a-b)^2; mask is the full-res f32 [B,S,S] mask,
+ * sampled with stride S/s (legacy resize == strided pick, imm_model.py:408-410). a/b 16-bit [B,s,s,c]. */
+int imm_masked_sse(const void* a, const void* b, int dtype, int batch, int s, int c, const float* mask, int S,
+                   float* partial, void* stream);
+int imm_masked_sse_f32(const float* a, int lda, const float* b, int ldb, int batch, int s, int c, const float* mask,
+                       float* partial, void* stream);
+/* nfeat features: partial [nfeat][IMM_SSE_BLOCKS], nel[nfeat] element counts, agg[nfeat] running
+ * normalisers (updated when training).  Writes out[0..nfeat) loss terms, [nfeat..2nfeat) masked means,
+ * [2nfeat..3nfeat) gradient coefficients c_k (d total / d (a_pred) = c_k*mask*(a_pred-a_gt)),
+ * out[3nfeat] = 1000*sum terms, out[3nfeat+1] = wd_loss, out[3nfeat+2] = total. */
+int imm_perceptual_finalize(const float* partial, int nfeat, const float* nel, float* agg, int training,
+                            const float* wd_loss, float* out, void* stream);
+/* da = (has_in ? da : 0) + coef[idx]*mask*(a_pred-a_gt), then *= (a_pred>0) if relu. 16-bit [B,s,s,c] */
+int imm_tap_grad(void* da, int has_in, const void* a_pred, const void* a_gt, int dtype, int batch, int s, int c,
+                 const float* mask, int S, const float* coef, int idx, int relu, void* stream);
+
+/* ---- optimizer (cnn_train_multi.py:86-98 mean+clip_by_norm; scripts/train.py:92-98 Adam) ------ */
+/* segment table: nseg tensors, seg_off[nseg+1] element offsets into the flat f32 buffers,
+ * seg_wd[nseg] = weight-decay coefficient of that tensor (1e-5 for conv kernels, else 0).
+ * All tables are device int32/f32 arrays built once by the host. */
+typedef struct imm_opt_hparams {
+  float lr_start, lr_decay; int32_t lr_step; float lr_multiple;   /* staircase exponential decay */
+  float beta1, beta2, eps, clip;                                   /* clip <= 0 disables clipping  */
+  float grad_scale;                                                /* 1 / number of towers         */
+} imm_opt_hparams;
+/* wd_loss = sum_seg wd/2 * sum w^2  -> *out  (base_model.py:33-37) */
+int imm_weight_decay_loss(const float* params, const int32_t* blk_seg, const int32_t* blk_begin,
+                          const int32_t* blk_end, int nblk, const float* seg_wd, float* blk_partial, float* out,
+                          void* stream);
+/* g <- g*grad_scale + wd*w (in place), norm2[seg] = sum g^2; then Adam with per-tensor clip.
+ * step_count: device int32 (Adam's t; incremented by this call, lr uses global_step = t-1 before
+ * the increment); lr_state: device f32[2] = {lr_t, lr} written for inspection. */
+int imm_clip_adam_step(float* params, float* grads, float* m, float* v, const int32_t* blk_seg,
+                       const int32_t* blk_begin, const int32_t* blk_end, int nblk, int nseg,
+                       const int32_t* seg_first_blk, const float* seg_wd, float* blk_partial, float* seg_norm2,
+                       int32_t* step_count, float* lr_state, const imm_opt_hparams* hp_host, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IMM_HIP_H */
