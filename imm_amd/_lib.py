@@ -6,6 +6,11 @@ routes through the CPU oracle.
 import ctypes as C
 import os
 
+# torch ships its own libamdhip64; it MUST be in the process before libimm_hip.so is dlopen'ed so that
+# both share one HIP runtime (device context, streams).  Loading ours first binds /opt/rocm's copy and
+# the two runtimes do not see each other's devices.
+import torch  # noqa: F401  (side effect: loads the ROCm runtime libraries bundled with PyTorch)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libimm_hip.so')
 

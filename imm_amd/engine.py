@@ -1,0 +1,707 @@
+"""Static launch program of one IMM training step on one MI355X.
+
+The reference builds a TF1 graph once and replays it with session.run
+(/root/reference/imm/train/cnn_train_multi.py:459).  The MI355X-native counterpart is this engine:
+at construction it allocates every activation / gradient / workspace buffer in HBM once (NHWC,
+16-bit activations, f32 statistics and parameters) and records the step as three ordered lists of
+kernel launches on libimm_hip.so —
+
+    prog_fwd : inputs -> encoders -> landmark bottleneck -> renderer -> VGG16 features -> loss
+    prog_bwd : loss gradient -> VGG dgrad -> renderer / encoders (BN bwd, wgrad, dgrad) -> flat grads
+    prog_opt : (grads already all-reduced) per-tensor clip + Adam -> re-pack 16-bit weights
+
+— which run eagerly or are captured into HIP graphs and replayed.  There is no autograd engine, no
+allocation and no host synchronisation inside a step.
+
+Network definition follows /root/reference/imm/models/imm_model.py (encoder :182-217, pose_encoder
+:233-276, model :279-357, simple_renderer :154-179, _colorization_reconstruction_loss :111-151) and
+imm/models/selfsup/vgg16.py:343-370; TF1 op semantics as listed in SURVEY.md §8a (S1-S12).
+"""
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import ops
+
+BN_EPS = 1e-3          # tf.layers.batch_normalization default (nn_utils.py:201)
+BN_MOMENTUM = 0.99
+WEIGHT_DECAY = 1e-5    # base_model.py:62-69
+INIT_STD = 0.01
+PERCEPTUAL_WS = [100.0, 1.6, 2.3, 1.8, 2.8, 100.0]   # imm_model.py:131
+SUPPORTED_COMP = ['input', 'conv1_2', 'conv2_2', 'conv3_2', 'conv4_2', 'conv5_2']
+VGG_LAYERS = [('conv1_1', 1, 64), ('conv1_2', 64, 64), ('conv2_1', 64, 128), ('conv2_2', 128, 128),
+              ('conv3_1', 128, 256), ('conv3_2', 256, 256), ('conv3_3', 256, 256),
+              ('conv4_1', 256, 512), ('conv4_2', 512, 512), ('conv4_3', 512, 512),
+              ('conv5_1', 512, 512), ('conv5_2', 512, 512)]
+VGG_POOL_AFTER = ('conv1_2', 'conv2_2', 'conv3_3', 'conv4_3')
+VGG_TAPS = {'conv1_2': 1, 'conv2_2': 2, 'conv3_2': 3, 'conv4_2': 4, 'conv5_2': 5}
+
+
+def encoder_spec(n_filters):
+    """(k, cin, cout, stride) of imm_model.py:190-214."""
+    f = n_filters
+    return [(7, 3, f, 1), (3, f, f, 1), (3, f, 2 * f, 2), (3, 2 * f, 2 * f, 1), (3, 2 * f, 4 * f, 2),
+            (3, 4 * f, 4 * f, 1), (3, 4 * f, 8 * f, 2), (3, 8 * f, 8 * f, 1)]
+
+
+def renderer_spec(cfg, image_size, n_out):
+    """(k, cin, cout, batch_norm, upsample_after) of imm_model.py:154-179."""
+    filters = cfg.n_filters_render * 8
+    cin = cfg.n_filters * 8 + cfg.n_maps
+    size, spec = 16, []
+    while size <= image_size:
+        spec.append((3, cin, filters, True, False))
+        if size == image_size:
+            spec.append((3, filters, n_out, False, False))
+            break
+        spec.append((3, filters, filters, True, True))
+        cin = filters
+        size *= 2
+        if filters >= 8:
+            filters //= 2
+    return spec
+
+
+def render_sizes(cfg, max_size):
+    """imm_model.py:295-303."""
+    sizes, size = [], max_size
+    while True:
+        sizes.append(size)
+        if size <= cfg.min_res:
+            break
+        size = size // cfg.renderer_stride
+    return sizes
+
+
+def n_renderer_out(cfg):
+    extra = len(cfg.perceptual.comp) if getattr(cfg, 'channels_bug_fix', False) else 0
+    return 3 + extra
+
+
+def trainable_spec(cfg, image_size):
+    """Ordered (name, shape, weight_decay) of every trainable tensor, TF variable names."""
+    out = []
+
+    def add(scope, k, cin, cout, bn):
+        out.append((scope + '/w', (k, k, cin, cout), WEIGHT_DECAY))
+        out.append((scope + '/b', (cout,), 0.0))
+        if bn:
+            out.append((scope + '/gamma', (cout,), 0.0))
+            out.append((scope + '/beta', (cout,), 0.0))
+
+    for enc in ('image_encoder', 'pose_encoder'):
+        for i, (k, ci, co, _s) in enumerate(encoder_spec(cfg.n_filters)):
+            add('model/%s/encoder/conv_%d' % (enc, i + 1), k, ci, co, True)
+        if enc == 'pose_encoder':
+            add('model/pose_encoder/conv_1', 1, cfg.n_filters * 8, cfg.n_maps, False)
+    for i, (k, ci, co, bn, _u) in enumerate(renderer_spec(cfg, image_size, n_renderer_out(cfg))):
+        add('model/renderer/conv_%d' % (i + 1), k, ci, co, bn)
+    return out
+
+
+def truncated_normal(rng, shape, std):
+    z = rng.standard_normal(shape)
+    bad = np.abs(z) > 2.0
+    while bad.any():
+        z[bad] = rng.standard_normal(int(bad.sum()))
+        bad = np.abs(z) > 2.0
+    return (z * std).astype(np.float32)
+
+
+def synthetic_vgg_weights(seed=2):
+    """Stand-in for vgg16.caffemodel.h5 (not available offline): He-normal kernels, N(0,0.1) biases."""
+    rng = np.random.default_rng(seed)
+    w = OrderedDict()
+    for name, cin, cout in VGG_LAYERS:
+        w['vgg16/%s/weights' % name] = torch.from_numpy(
+            (rng.standard_normal((3, 3, cin, cout)) * math.sqrt(2.0 / (9 * cin))).astype(np.float32))
+        w['vgg16/%s/biases' % name] = torch.from_numpy((rng.standard_normal(cout) * 0.1).astype(np.float32))
+    return w
+
+
+class _Launch:
+    __slots__ = ('fn', 'tag', 'flops', 'bytes')
+
+    def __init__(self, fn, tag, flops=0.0, nbytes=0.0):
+        self.fn, self.tag, self.flops, self.bytes = fn, tag, flops, nbytes
+
+
+class _ConvLayer:
+    """Geometry + buffers of one trainable convolution block (conv+bias [-> BN -> ReLU])."""
+    pass
+
+
+class IMMEngine:
+    def __init__(self, cfg, batch, image_size, device='cuda:0', act_dtype=torch.bfloat16, seed=1, vgg_weights=None,
+                 hparams=None, world_size=1):
+        if cfg.gauss_mode != 'rot':
+            if cfg.gauss_mode in ('flat', 'ankush'):
+                raise NotImplementedError("gauss_mode %r: only 'rot' (the mode of every shipped config) has HIP kernels"
+                                          % cfg.gauss_mode)
+            raise ValueError('Unknown mode: ' + str(cfg.gauss_mode))
+        if cfg.reconstruction_loss not in ('perceptual', 'l2'):
+            raise ValueError('Reconsutruction loss-type: ' + str(cfg.reconstruction_loss) + ' not understood')
+        if cfg.reconstruction_loss != 'perceptual':
+            raise NotImplementedError("reconstruction_loss 'l2' has no HIP path yet; shipped configs use 'perceptual'")
+        if list(cfg.perceptual.comp) != SUPPORTED_COMP or not cfg.perceptual.l2:
+            raise NotImplementedError('perceptual.comp must be %r with l2: True' % (SUPPORTED_COMP,))
+        if image_size % 16 or image_size < 64:
+            raise ValueError('image side must be a multiple of 16 and >= 64')
+        L.load()   # fail loudly, now, if the HIP library is missing
+        self.cfg, self.B, self.S, self.dev, self.dt = cfg, int(batch), int(image_size), torch.device(device), act_dtype
+        self.K = int(cfg.n_maps)
+        self.world_size = world_size
+        self.use_mask = bool(cfg.loss_mask)
+        self.n_cu, self.arch = ops.device_info()
+        self._alloc_bytes = 0
+
+        # ---- flat parameter / gradient / optimizer-state buffers -------------------------------
+        self.spec = trainable_spec(cfg, self.S)
+        sizes = [int(np.prod(s)) for _n, s, _w in self.spec]
+        self.tab = ops.SegmentTable(sizes, [w for _n, _s, w in self.spec], self.dev)
+        self.params = self._zeros(self.tab.total)
+        self.grads = self._zeros(self.tab.total)
+        self.adam_m = self._zeros(self.tab.total)
+        self.adam_v = self._zeros(self.tab.total)
+        self.pview, self.gview = OrderedDict(), OrderedDict()
+        for i, (name, shape, _wd) in enumerate(self.spec):
+            o0, o1 = self.tab.offsets[i], self.tab.offsets[i + 1]
+            self.pview[name] = self.params[o0:o1].view(shape)
+            self.gview[name] = self.grads[o0:o1].view(shape)
+        self.opt_blk_partial = self._zeros(self.tab.nblk)
+        self.seg_norm2 = self._zeros(self.tab.nseg)
+        self.step_count = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        self.lr_state = self._zeros(2)
+        self.wd_loss = self._zeros(1)
+        hp = dict(lr_start=1e-3, lr_decay=0.95, lr_step=100000, lr_multiple=1.0, beta1=0.9, beta2=0.999, eps=1e-8,
+                  clip=1.0, grad_scale=1.0 / world_size)
+        hp.update(hparams or {})
+        self.hp = ops.OptHParams(**hp)
+
+        # ---- non-trainable state ------------------------------------------------------------------
+        self.state = OrderedDict()           # BN moving statistics, loss normalisers
+        self.loss_agg = torch.tensor(PERCEPTUAL_WS, dtype=torch.float32, device=self.dev)
+        self.vgg_w = OrderedDict((k, v.to(self.dev).contiguous()) for k, v in (vgg_weights or synthetic_vgg_weights()).items())
+
+        self.prog_pack, self.prog_fwd, self.prog_bwd, self.prog_opt = [], [], [], []
+        self._training = True
+        self._build_network()
+        self.init_parameters(seed)
+
+    # ------------------------------------------------------------------------------------------
+    # allocation helpers
+    # ------------------------------------------------------------------------------------------
+    def _zeros(self, *shape, dtype=torch.float32):
+        t = torch.zeros(*shape, dtype=dtype, device=self.dev)
+        self._alloc_bytes += t.numel() * t.element_size()
+        return t
+
+    def _act(self, *shape):
+        return self._zeros(*shape, dtype=self.dt)
+
+    # ------------------------------------------------------------------------------------------
+    # parameters
+    # ------------------------------------------------------------------------------------------
+    def init_parameters(self, seed=1):
+        """truncated-normal(0.01) kernels, zero biases, gamma 1 / beta 0; Adam state reset."""
+        rng = np.random.default_rng(seed)
+        for name, shape, _wd in self.spec:
+            if name.endswith('/w'):
+                self.pview[name].copy_(torch.from_numpy(truncated_normal(rng, shape, INIT_STD)))
+            elif name.endswith('/gamma'):
+                self.pview[name].fill_(1.0)
+            else:
+                self.pview[name].zero_()
+        for k, v in self.state.items():
+            v.fill_(1.0 if k.endswith('moving_variance') else 0.0)
+        self.loss_agg.copy_(torch.tensor(PERCEPTUAL_WS))
+        self.adam_m.zero_(); self.adam_v.zero_(); self.grads.zero_(); self.step_count.zero_()
+        self.run(self.prog_pack)
+
+    def load_parameters(self, named, state=None):
+        """named: {tf_variable_name: tensor}.  Missing names raise (no silent partial restore)."""
+        for name in self.pview:
+            self.pview[name].copy_(named[name].to(self.dev))
+        if state:
+            for k, v in state.items():
+                if k in self.state:
+                    self.state[k].copy_(v.to(self.dev))
+                elif k.startswith('loss/') and k.endswith('_agg'):
+                    self.loss_agg[list(self.cfg.perceptual.comp).index(k[5:-4])] = float(v)
+                elif k.startswith('vgg16/'):
+                    self.vgg_w[k].copy_(v.to(self.dev))
+                else:
+                    raise KeyError(k)
+            self._pack_vgg()
+        self.run(self.prog_pack)
+
+    def named_parameters(self):
+        return OrderedDict((k, v.detach().clone()) for k, v in self.pview.items())
+
+    def named_state(self):
+        out = OrderedDict((k, v.detach().clone()) for k, v in self.state.items())
+        for i, name in enumerate(self.cfg.perceptual.comp):
+            out['loss/%s_agg' % name] = self.loss_agg[i].detach().clone()
+        return out
+
+    # ------------------------------------------------------------------------------------------
+    # network construction
+    # ------------------------------------------------------------------------------------------
+    def _add(self, prog, fn, tag, flops=0.0, nbytes=0.0):
+        prog.append(_Launch(fn, tag, flops, nbytes))
+
+    def _conv_block(self, scope, x, H, W, ci_real, ci_pad, ldx, co, k, stride, bn, relu, needs_dgrad,
+                    out=None, ldo=None, out_f32=False):
+        """Registers forward launches now and returns a layer record whose .backward(d_out, dx) registers the
+        backward launches later (in reverse order)."""
+        B, dt, dev = self.B, self.dt, self.dev
+        lay = _ConvLayer()
+        lay.scope, lay.bn, lay.relu, lay.x, lay.ldx = scope, bn, relu, x, ldx
+        lay.ci_real, lay.ci_pad, lay.co, lay.k, lay.stride, lay.H, lay.W = ci_real, ci_pad, co, k, stride, H, W
+        flags = L.CONV_BIAS | (L.CONV_OUT_F32 if out_f32 else 0)
+        ldy = ops.round_up(co, 4) if out_f32 else ops.round_up(co, 8)
+        lay.ldy = ldy
+        fd = ops.fwd_desc(B, H, W, ci_pad, ldx, co, ldy, k, stride, flags | (L.CONV_STATS if bn else 0))
+        fd_eval = ops.fwd_desc(B, H, W, ci_pad, ldx, co, ldy, k, stride, flags)
+        lay.fd, lay.Ho, lay.Wo = fd, fd.ho, fd.wo
+        npix = B * fd.ho * fd.wo
+        lay.npix = npix
+        w, b = self.pview[scope + '/w'], self.pview[scope + '/b']
+        rows = ops.round_up(co, 128)
+        lay.wt = self._zeros(rows, fd.kpad, dtype=dt)
+        self._add(self.prog_pack, lambda: ops.pack_weights(w, lay.wt, 0, k, k, ci_real, co, ci_pad, rows, fd.kpad), 'pack')
+        lay.y = self._zeros(B, fd.ho, fd.wo, ldy, dtype=torch.float32 if out_f32 else dt)
+        flops = 2.0 * npix * k * k * ci_real * co
+        if bn:
+            nblk = ops.conv_stats_blocks(fd)
+            lay.stats = self._zeros(nblk, 2, co)
+            lay.scale, lay.shift, lay.mean, lay.rstd = (self._zeros(co) for _ in range(4))
+            mm, mv = self._zeros(co), self._zeros(co)
+            mv.fill_(1.0)
+            self.state[scope + '/moving_mean'], self.state[scope + '/moving_variance'] = mm, mv
+            gamma, beta = self.pview[scope + '/gamma'], self.pview[scope + '/beta']
+            if out is None:
+                out, ldo = self._act(B, fd.ho, fd.wo, co), co
+            lay.out, lay.ldo = out, ldo
+
+            def f_conv():
+                ops.conv2d(fd if self._training else fd_eval, x, lay.wt, b, lay.y, lay.stats if self._training else None)
+
+            def f_fin():
+                ops.bn_finalize(lay.stats, nblk, co, npix, gamma, beta, BN_EPS, BN_MOMENTUM, self._training, mm, mv,
+                                lay.scale, lay.shift, lay.mean, lay.rstd)
+            self._add(self.prog_fwd, f_conv, 'conv_fwd', flops)
+            self._add(self.prog_fwd, f_fin, 'bn_finalize')
+            self._add(self.prog_fwd, lambda: ops.bn_apply_relu(lay.y, npix, co, ldy, lay.scale, lay.shift, relu, out, ldo),
+                      'bn_apply', 0.0, npix * co * 4.0)
+        else:
+            lay.out, lay.ldo = lay.y, ldy
+            self._add(self.prog_fwd, lambda: ops.conv2d(fd_eval, x, lay.wt, b, lay.y), 'conv_fwd', flops)
+
+        # ---- backward resources -------------------------------------------------------------------
+        lay.needs_dgrad = needs_dgrad
+        if needs_dgrad:
+            lddy = ldy if not out_f32 else ops.round_up(co, 8)
+            lay.lddy = lddy
+            lay.dd = None   # filled in backward()
+            rows_d = ops.round_up(ci_real, 128)
+            kpad_d = ops.round_up(k * k * lddy, 32)
+            lay.wt_d = self._zeros(rows_d, kpad_d, dtype=dt)
+            self._add(self.prog_pack,
+                      lambda: ops.pack_weights(w, lay.wt_d, 1, k, k, ci_real, co, lddy, rows_d, kpad_d), 'pack')
+        else:
+            lay.lddy = ldy if not out_f32 else ops.round_up(co, 8)
+        # wgrad split: enough workgroups to fill the chip, at least 512 pixels per split
+        bn_w = 128 if co > 64 else 64 if co > 32 else 32 if co > 16 else 16
+        tiles = -(-fd.kpad // 128) * -(-co // bn_w)
+        nsplit = max(1, min(-(-2 * self.n_cu // tiles), max(1, npix // 512)))
+        lay.nsplit = nsplit
+        lay.slab = self._zeros(nsplit, fd.kpad, co)
+        if bn:
+            lay.bwd_nblk = ops.bn_bwd_blocks(npix, co)
+            lay.bwd_partial = self._zeros(lay.bwd_nblk, 2, co)
+            lay.coef = self._zeros(3, co)
+            lay.dy = self._act(B, fd.ho, fd.wo, ldy)
+        else:
+            lay.cs_partial = self._zeros(ops.colsum_blocks(npix, lay.lddy), lay.lddy)
+        return lay
+
+    def _conv_backward(self, lay, d_out, ldd, dx, lddx, dx_mask=None):
+        """d_out: gradient w.r.t. the block output (post BN/ReLU for BN blocks; w.r.t. the conv output,
+        16-bit with stride lay.lddy, otherwise).  dx: buffer receiving the input gradient (or None)."""
+        B, co, k = self.B, lay.co, lay.k
+        npix = lay.npix
+        scope = lay.scope
+        gw, gb = self.gview[scope + '/w'], self.gview[scope + '/b']
+        if lay.bn:
+            gg, gbeta = self.gview[scope + '/gamma'], self.gview[scope + '/beta']
+            gamma = self.pview[scope + '/gamma']
+            self._add(self.prog_bwd, lambda: ops.bn_bwd_reduce(d_out, ldd, lay.y, lay.ldy, npix, co, lay.scale, lay.shift,
+                                                               lay.mean, lay.rstd, lay.relu, lay.bwd_partial),
+                      'bn_bwd_reduce', 0.0, npix * co * 4.0)
+            self._add(self.prog_bwd, lambda: ops.bn_bwd_finalize(lay.bwd_partial, lay.bwd_nblk, co, npix, gamma, lay.rstd,
+                                                                 gg, gbeta, lay.coef), 'bn_bwd_finalize')
+            self._add(self.prog_bwd, lambda: ops.bn_bwd_apply(d_out, ldd, lay.y, lay.ldy, npix, co, lay.scale, lay.shift,
+                                                              lay.mean, lay.rstd, lay.relu, lay.coef, lay.dy, lay.ldy),
+                      'bn_bwd_apply', 0.0, npix * co * 6.0)
+            dy, lddy = lay.dy, lay.ldy
+            # conv bias feeds a batch norm: its gradient is analytically zero (sum of dy == 0); the
+            # reference computes rounding noise there.  The flat gradient slice stays 0.
+        else:
+            dy, lddy = d_out, ldd
+            self._add(self.prog_bwd, lambda: ops.colsum(dy, npix, lddy, co, lddy, lay.cs_partial, gb), 'colsum')
+        fd = lay.fd
+        flops = 2.0 * npix * k * k * lay.ci_real * co
+        self._add(self.prog_bwd, lambda: ops.conv2d_wgrad(fd, lay.x, dy, lddy, lay.slab, lay.nsplit), 'conv_wgrad', flops)
+        self._add(self.prog_bwd, lambda: ops.conv2d_wgrad_reduce(lay.slab, lay.nsplit, k, k, lay.ci_pad, lay.ci_real, co,
+                                                                  fd.kpad, gw), 'wgrad_reduce')
+        if lay.needs_dgrad and dx is not None:
+            dd = ops.dgrad_desc(B, lay.H, lay.W, lay.ci_real, lddx, lddy, lddy, k, lay.stride, 0)
+            assert dd.kpad == lay.wt_d.shape[1], (dd.kpad, lay.wt_d.shape)
+            self._add(self.prog_bwd, lambda: ops.conv2d(dd, dy, lay.wt_d, None, dx), 'conv_dgrad', flops)
+
+    def _build_network(self):
+        cfg, B, S, K, dt = self.cfg, self.B, self.S, self.K, self.dt
+        nf = cfg.n_filters
+        self.in_image = self._zeros(B, S, S, 3)
+        self.in_future = self._zeros(B, S, S, 3)
+        self.in_mask = self._zeros(B, S, S) if self.use_mask else None
+        sizes = render_sizes(cfg, S)
+        s16 = sizes[-1]
+        if s16 != 16:
+            raise NotImplementedError('renderer starts at 16x16 (min_res 16, renderer_stride 2): got %d' % s16)
+        He = S // 8                        # encoder output side
+        Cj = ops.round_up(8 * nf + K, 32)  # joint embedding channels (zero padded)
+        self.Cj, self.He = Cj, He
+        self.joint = self._act(B, 16, 16, Cj)
+        self.d_joint = self._act(B, 16, 16, Cj)
+
+        # ---- encoders -------------------------------------------------------------------------------
+        def build_encoder(scope, src):
+            xin = self._act(B, S, S, 8)
+            self._add(self.prog_fwd, lambda: ops.pack_image(src, xin, B * S * S), 'pack_image', 0.0, B * S * S * 28.0)
+            layers, x, H, ci_real, ci_pad, ldx = [], xin, S, 3, 8, 8
+            spec = encoder_spec(nf)
+            for i, (k, ci, co, stride) in enumerate(spec):
+                last = i == len(spec) - 1
+                out, ldo = (None, None)
+                if last and scope == 'model/image_encoder' and He == 16:
+                    out, ldo = self.joint, Cj       # conv_8 writes straight into the concat buffer
+                lay = self._conv_block('%s/encoder/conv_%d' % (scope, i + 1), x, H, H, ci_real, ci_pad, ldx, co, k,
+                                       stride, True, True, needs_dgrad=(i > 0), out=out, ldo=ldo)
+                layers.append(lay)
+                x, H, ci_real, ci_pad, ldx = lay.out, lay.Ho, co, co, lay.ldo
+            return layers
+
+        self.enc_im = build_encoder('model/image_encoder', self.in_image)
+        if He != 16:   # imm_model.py:324-335: align_corners resize of the 8f-channel embedding down to 16x16
+            e = self.enc_im[-1]
+            self._add(self.prog_fwd, lambda: ops.resize_ac_fwd(e.out, self.joint, B, He, He, 16, 16, 8 * nf, e.ldo, Cj),
+                      'resize_ac')
+        self.enc_pose = build_encoder('model/pose_encoder', self.in_future)
+        pe = self.enc_pose[-1]
+        self.pose_head = self._conv_block('model/pose_encoder/conv_1', pe.out, He, He, 8 * nf, 8 * nf, pe.ldo, K, 1, 1,
+                                          False, False, needs_dgrad=True, out_f32=True)
+        ph = self.pose_head
+        self.heat, self.ldh = ph.y, ph.ldy
+        self.mu = self._zeros(B, K, 2)
+        self.py = self._zeros(B, He, K)
+        self.px = self._zeros(B, He, K)
+        self.inv_std = 1.0 / float(cfg.gauss_std)
+        gview = self.joint[..., 8 * nf:]
+        self._add(self.prog_fwd, lambda: ops.softargmax_gauss_fwd(self.heat, self.ldh, B, He, He, K, self.inv_std, 16,
+                                                                  self.mu, self.py, self.px, gview, Cj, dt), 'bottleneck')
+
+        # ---- renderer ---------------------------------------------------------------------------------
+        self.ren, self.ren_up = [], []
+        x, H, ci_real, ci_pad, ldx = self.joint, 16, 8 * nf + K, Cj, Cj
+        rspec = renderer_spec(cfg, S, n_renderer_out(cfg))
+        for i, (k, ci, co, bn, up) in enumerate(rspec):
+            assert ci == ci_real, (ci, ci_real)
+            lay = self._conv_block('model/renderer/conv_%d' % (i + 1), x, H, H, ci_real, ci_pad, ldx, co, k, 1, bn, bn,
+                                   needs_dgrad=True, out_f32=not bn)
+            self.ren.append(lay)
+            x, ci_real, ci_pad, ldx = lay.out, co, co, lay.ldo
+            if up:
+                ub = self._act(B, 2 * H, 2 * H, co)
+                src = lay.out
+                self._add(self.prog_fwd, (lambda src=src, ub=ub, H=H, co=co: ops.upsample2x_fwd(src, ub, B, H, H, co, co, co)),
+                          'upsample', 0.0, B * H * H * co * 10.0)
+                self.ren_up.append((len(self.ren) - 1, ub, H, co))
+                x, H = ub, 2 * H
+        self.pred = self.ren[-1].y              # f32 [B,S,S,ldp]; channels 0..2 = future_im_pred
+        self.ldp = self.ren[-1].ldy
+
+        self.n_fwd_model = len(self.prog_fwd)   # launches up to here produce future_im_pred / gauss_yx
+
+        # ---- frozen VGG16 on concat([gt, pred]) --------------------------------------------------------
+        self.vgg_act, self.vgg_wt, self.vgg_wtd, self.vgg_desc, self.vgg_dd = OrderedDict(), {}, {}, {}, {}
+        self.vgg_pool = {}
+        self.w11 = self._zeros(9, 64); self.b11 = self._zeros(64)
+        a = self._act(2 * B, S, S, 64)
+        self.vgg_act['conv1_1'] = (a, S)
+        self._add(self.prog_fwd, lambda: ops.vgg_conv1_1_fwd(self.in_future, self.pred, self.ldp, B, S, self.w11, self.b11, a),
+                  'vgg_conv1_1', 2.0 * 2 * B * S * S * 9 * 64, 2 * B * S * S * 128.0)
+        x, H = a, S
+        for name, cin, cout in VGG_LAYERS[1:]:
+            fd = ops.fwd_desc(2 * B, H, H, cin, cin, cout, cout, 3, 1, L.CONV_BIAS | L.CONV_RELU)
+            wt = self._zeros(ops.round_up(cout, 128), fd.kpad, dtype=dt)
+            wtd = self._zeros(ops.round_up(cin, 128), ops.round_up(9 * cout, 32), dtype=dt)
+            y = self._act(2 * B, H, H, cout)
+            self.vgg_wt[name], self.vgg_wtd[name], self.vgg_desc[name] = wt, wtd, fd
+            bias = self.vgg_w['vgg16/%s/biases' % name]
+            self._add(self.prog_fwd, (lambda fd=fd, x=x, wt=wt, bias=bias, y=y: ops.conv2d(fd, x, wt, bias, y)), 'vgg_fwd',
+                      2.0 * 2 * B * H * H * 9 * cin * cout)
+            self.vgg_act[name] = (y, H)
+            x = y
+            if name in VGG_POOL_AFTER:
+                p = self._act(2 * B, H // 2, H // 2, cout)
+                self._add(self.prog_fwd, (lambda x=x, p=p, H=H, cout=cout: ops.maxpool2_fwd(x, p, 2 * B, H, H, cout)), 'maxpool',
+                          0.0, 2 * B * H * H * cout * 2.5)
+                self.vgg_pool[name] = p
+                x, H = p, H // 2
+        self._pack_vgg()
+
+        # ---- loss -------------------------------------------------------------------------------------------
+        nfeat = 6
+        self.sse_partial = self._zeros(nfeat, L.SSE_BLOCKS)
+        nel = [float(B * S * S * 3)]
+        for name in SUPPORTED_COMP[1:]:
+            y, H = self.vgg_act[name]
+            nel.append(float(B * H * H * y.shape[-1]))
+        self.nel = torch.tensor(nel, dtype=torch.float32, device=self.dev)
+        self.loss_out = self._zeros(3 * nfeat + 3)
+        mask = self.in_mask
+        self._add(self.prog_fwd, lambda: ops.masked_sse_f32(self.in_future, 3, self.pred, self.ldp, B, S, 3, mask,
+                                                            self.sse_partial[0]), 'sse')
+        for name, idx in VGG_TAPS.items():
+            y, H = self.vgg_act[name]
+            c = y.shape[-1]
+            self._add(self.prog_fwd, (lambda y=y, H=H, c=c, idx=idx: ops.masked_sse(y[:B], y[B:], B, H, c, mask, S,
+                                                                                  self.sse_partial[idx])), 'sse',
+                      0.0, 2 * B * H * H * c * 2.0)
+        self._add(self.prog_fwd, lambda: ops.weight_decay_loss(self.params, self.tab, self.opt_blk_partial, self.wd_loss),
+                  'wd_loss')
+        self._add(self.prog_fwd, lambda: ops.perceptual_finalize(self.sse_partial, nfeat, self.nel, self.loss_agg,
+                                                                 self._training, self.wd_loss, self.loss_out), 'loss_finalize')
+        self.coef = self.loss_out[2 * nfeat:3 * nfeat]
+
+        self._build_backward()
+
+        # ---- optimizer --------------------------------------------------------------------------------------
+        self._add(self.prog_opt, lambda: ops.clip_adam_step(self.params, self.grads, self.adam_m, self.adam_v, self.tab,
+                                                            self.opt_blk_partial, self.seg_norm2, self.step_count,
+                                                            self.lr_state, self.hp), 'clip_adam', 0.0, self.tab.total * 36.0)
+        self.prog_opt.extend(self.prog_pack)
+
+    def _pack_vgg(self):
+        w = self.vgg_w
+        self.w11.copy_(w['vgg16/conv1_1/weights'].reshape(9, 64))
+        self.b11.copy_(w['vgg16/conv1_1/biases'])
+        for name, cin, cout in VGG_LAYERS[1:]:
+            fd = self.vgg_desc[name]
+            wm = w['vgg16/%s/weights' % name]
+            ops.pack_weights(wm, self.vgg_wt[name], 0, 3, 3, cin, cout, cin, self.vgg_wt[name].shape[0], fd.kpad)
+            wtd = self.vgg_wtd[name]
+            ops.pack_weights(wm, wtd, 1, 3, 3, cin, cout, cout, wtd.shape[0], wtd.shape[1])
+
+    def _build_backward(self):
+        B, S, K, dt, Cj = self.B, self.S, self.K, self.dt, self.Cj
+        mask = self.in_mask
+        acts = self.vgg_act
+        names = [n for n, _ci, _co in VGG_LAYERS]
+        # gradient buffers w.r.t. the (pred half of the) VGG activations, reused in place as dz after masking
+        dbuf = {n: self._act(B, acts[n][1], acts[n][1], acts[n][0].shape[-1]) for n in names}
+        dpool = {n: self._act(B, acts[n][1] // 2, acts[n][1] // 2, acts[n][0].shape[-1]) for n in self.vgg_pool if n != 'conv5_3'}
+
+        def pred_half(t):
+            return t[B:]
+
+        def tap(name, has_in):
+            y, H = acts[name]
+            c = y.shape[-1]
+            self._add(self.prog_bwd, lambda: ops.tap_grad(dbuf[name], has_in, y[B:], y[:B], B, H, c, mask, S, self.coef,
+                                                          VGG_TAPS[name], True), 'tap_grad', 0.0, B * H * H * c * 8.0)
+
+        def dgrad(name, dst, mask_ref):
+            """conv `name`: dz(name) -> gradient w.r.t. its input written to dst (masked by mask_ref>0 if given)."""
+            cin, cout = [(ci, co) for n, ci, co in VGG_LAYERS if n == name][0]
+            H = acts[name][1]
+            flags = L.CONV_MASK if mask_ref is not None else 0
+            dd = ops.dgrad_desc(B, H, H, cin, cin, cout, cout, 3, 1, flags, ldmask=cin)
+            wtd = self.vgg_wtd[name]
+            src = dbuf[name]
+            self._add(self.prog_bwd, lambda: ops.conv2d(dd, src, wtd, None, dst, None, mask_ref), 'vgg_dgrad',
+                      2.0 * B * H * H * 9 * cin * cout)
+
+        def unpool(src_name, dy, relu_mask):
+            y, H = acts[src_name]
+            c = y.shape[-1]
+            self._add(self.prog_bwd, lambda: ops.maxpool2_bwd(y[B:], dy, dbuf[src_name], B, H, H, c, relu_mask), 'maxpool_bwd',
+                      0.0, B * H * H * c * 5.0)
+
+        tap('conv5_2', False)
+        dgrad('conv5_2', dbuf['conv5_1'], pred_half(acts['conv5_1'][0]))
+        dgrad('conv5_1', dpool['conv4_3'], None)
+        unpool('conv4_3', dpool['conv4_3'], 1)
+        dgrad('conv4_3', dbuf['conv4_2'], None)
+        tap('conv4_2', True)
+        dgrad('conv4_2', dbuf['conv4_1'], pred_half(acts['conv4_1'][0]))
+        dgrad('conv4_1', dpool['conv3_3'], None)
+        unpool('conv3_3', dpool['conv3_3'], 1)
+        dgrad('conv3_3', dbuf['conv3_2'], None)
+        tap('conv3_2', True)
+        dgrad('conv3_2', dbuf['conv3_1'], pred_half(acts['conv3_1'][0]))
+        dgrad('conv3_1', dpool['conv2_2'], None)
+        unpool('conv2_2', dpool['conv2_2'], 0)
+        tap('conv2_2', True)
+        dgrad('conv2_2', dbuf['conv2_1'], pred_half(acts['conv2_1'][0]))
+        dgrad('conv2_1', dpool['conv1_2'], None)
+        unpool('conv1_2', dpool['conv1_2'], 0)
+        tap('conv1_2', True)
+        dgrad('conv1_2', dbuf['conv1_1'], pred_half(acts['conv1_1'][0]))
+        # first layer + 'input' feature -> gradient of the renderer's last convolution
+        last = self.ren[-1]
+        self.d_pred = self._act(B, S, S, last.lddy)
+        self._add(self.prog_bwd, lambda: ops.vgg_conv1_1_bwd(dbuf['conv1_1'], B, S, self.w11, self.in_future, self.pred,
+                                                             self.ldp, mask, self.coef, self.d_pred, last.lddy),
+                  'vgg_conv1_1_bwd', 2.0 * B * S * S * 9 * 64)
+
+        # ---- renderer backward -----------------------------------------------------------------------------
+        ups = {idx: (ub, H, co) for idx, ub, H, co in self.ren_up}
+        d_out, ldd = self.d_pred, last.lddy
+        for i in range(len(self.ren) - 1, -1, -1):
+            lay = self.ren[i]
+            if i == 0:
+                dx, lddx = self.d_joint, Cj
+            else:
+                prev = self.ren[i - 1]
+                if (i - 1) in ups:     # this conv's input is the upsampled output of conv i-1
+                    _ub, Hp, cp = ups[i - 1]
+                    d_up = self._act(B, 2 * Hp, 2 * Hp, cp)
+                    dx, lddx = d_up, cp
+                else:
+                    dx, lddx = self._act(B, prev.Ho, prev.Wo, prev.co), prev.co
+            self._conv_backward(lay, d_out, ldd, dx, lddx)
+            if i > 0:
+                if (i - 1) in ups:
+                    _ub, Hp, cp = ups[i - 1]
+                    d_prev = self._act(B, Hp, Hp, cp)
+                    self._add(self.prog_bwd, (lambda dx=dx, d_prev=d_prev, Hp=Hp, cp=cp:
+                                              ops.upsample2x_bwd(dx, d_prev, B, Hp, Hp, cp, cp, cp)), 'upsample_bwd',
+                              0.0, B * Hp * Hp * cp * 10.0)
+                    d_out, ldd = d_prev, cp
+                else:
+                    d_out, ldd = dx, lddx
+
+        # ---- bottleneck + pose encoder backward --------------------------------------------------------------
+        nf8 = 8 * self.cfg.n_filters
+        He = self.He
+        ph = self.pose_head
+        self.d_heat = self._act(B, He, He, ph.lddy)
+        dg = self.d_joint[..., nf8:]
+        self._add(self.prog_bwd, lambda: ops.softargmax_gauss_bwd(dg, Cj, B, He, He, K, self.inv_std, 16, self.mu, self.py,
+                                                                  self.px, self.d_heat, ph.lddy), 'bottleneck_bwd')
+        d_feat = self._act(B, He, He, nf8)
+        self._conv_backward(ph, self.d_heat, ph.lddy, d_feat, nf8)
+        self._encoder_backward(self.enc_pose, d_feat, nf8)
+
+        # ---- image encoder backward ----------------------------------------------------------------------------
+        if He == 16:
+            self._encoder_backward(self.enc_im, self.d_joint, Cj)
+        else:
+            e = self.enc_im[-1]
+            d_e = self._act(B, He, He, nf8)
+            self._add(self.prog_bwd, lambda: ops.resize_ac_bwd(self.d_joint, d_e, B, He, He, 16, 16, nf8, Cj, nf8), 'resize_ac_bwd')
+            self._encoder_backward(self.enc_im, d_e, nf8)
+
+    def _encoder_backward(self, layers, d_out, ldd):
+        B = self.B
+        for i in range(len(layers) - 1, -1, -1):
+            lay = layers[i]
+            if i > 0:
+                prev = layers[i - 1]
+                dx, lddx = self._act(B, prev.Ho, prev.Wo, prev.co), prev.co
+            else:
+                dx, lddx = None, 0
+            self._conv_backward(lay, d_out, ldd, dx, lddx)
+            d_out, ldd = dx, lddx
+
+    # ------------------------------------------------------------------------------------------
+    # execution
+    # ------------------------------------------------------------------------------------------
+    def run(self, prog):
+        for l in prog:
+            l.fn()
+
+    def run_timed(self, prog):
+        """Eager run with a HIP event pair around every launch (events on the launch stream).
+        Returns [(tag, ms, flops, bytes)]."""
+        evs = []
+        for l in prog:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            l.fn()
+            e1.record()
+            evs.append((l, e0, e1))
+        torch.cuda.synchronize()
+        return [(l.tag, e0.elapsed_time(e1), l.flops, l.bytes) for l, e0, e1 in evs]
+
+    def set_inputs(self, image, future_image, mask=None):
+        self.in_image.copy_(image.reshape(self.in_image.shape))
+        self.in_future.copy_(future_image.reshape(self.in_future.shape))
+        if self.use_mask:
+            if mask is None:
+                raise RuntimeError('No loss mask recieved but is required.')
+            self.in_mask.copy_(mask.reshape(self.in_mask.shape))
+
+    def forward(self, training=True):
+        self._training = bool(training)
+        self.run(self.prog_fwd)
+
+    def forward_model_only(self, training=False):
+        """IMMModel.build(build_loss=False): encoders, bottleneck, renderer (no VGG, no loss)."""
+        self._training = bool(training)
+        self.run(self.prog_fwd[:self.n_fwd_model])
+
+    def backward(self):
+        self.run(self.prog_bwd)
+
+    def snapshot(self):
+        """Everything a step mutates (used to warm kernels up before graph capture without side effects)."""
+        return {'params': self.params.clone(), 'm': self.adam_m.clone(), 'v': self.adam_v.clone(),
+                'step': self.step_count.clone(), 'agg': self.loss_agg.clone(), 'grads': self.grads.clone(),
+                'state': {k: v.clone() for k, v in self.state.items()}}
+
+    def restore(self, snap):
+        self.params.copy_(snap['params']); self.adam_m.copy_(snap['m']); self.adam_v.copy_(snap['v'])
+        self.step_count.copy_(snap['step']); self.loss_agg.copy_(snap['agg']); self.grads.copy_(snap['grads'])
+        for k, v in snap['state'].items():
+            self.state[k].copy_(v)
+        self.run(self.prog_pack)
+
+    def optimizer_step(self):
+        self.run(self.prog_opt)
+
+    # convenience views -----------------------------------------------------------------------------
+    @property
+    def loss(self):
+        return self.loss_out[3 * 6 + 2]
+
+    @property
+    def loss_terms(self):
+        return self.loss_out[:6]
+
+    @property
+    def future_im_pred(self):
+        return self.pred[..., :3]
+
+    def memory_bytes(self):
+        return self._alloc_bytes
+
+    def step_flops(self):
+        """Algorithmic conv FLOPs of one training step (2 FLOP/MAC), BASELINE.md §4 counting rule."""
+        return sum(l.flops for p in (self.prog_fwd, self.prog_bwd) for l in p)

@@ -1,0 +1,103 @@
+"""IMMModel — drop-in construction/config surface of /root/reference/imm/models/imm_model.py:95-490,
+backed by the MI355X engine (imm_amd/engine.py -> libimm_hip.so).
+
+Same constructor and `build` keywords and return arity as the reference:
+    IMMModel(config, global_step=None, dtype=..., name='IMMModel')
+    build(inputs, training_pl, costs_collection='costs', scope=None, var_device='/cpu:0',
+          output_tensors=False, build_loss=True) -> (None, loss, avg_ops[, tensors])
+Differences forced by leaving TF1: `inputs` holds torch tensors (NHWC float32, image values in
+[0,255], mask in [0,1]), `training_pl` is a Python bool (the reference's notebook already passes
+False), `dtype` is the 16-bit activation storage type (torch.bfloat16 / torch.float16), and `build`
+EXECUTES the forward pass on the GPU instead of adding nodes to a graph.  Errors keep the
+reference's types: ValueError for an unknown gauss mode (:75) / loss type (:389), RuntimeError when
+the loss mask is required but missing (:369), AssertionError for non-square inputs (:292,432).
+"""
+import colorsys
+
+import torch
+
+from ..engine import IMMEngine
+from .base_model import BaseModel
+
+
+def get_n_colors(n):
+    """Deterministic distinct colours for the landmark summary image (the reference draws random
+    distinct colours, imm/utils/utils.py via colorize_landmark_maps imm_model.py:81-92)."""
+    return [colorsys.hsv_to_rgb(i / float(max(n, 1)), 0.9, 1.0) for i in range(n)]
+
+
+def colorize_landmark_maps(maps):
+    """imm_model.py:81-92: [B,H,W,N] -> [B,H,W,3], max over landmarks of map*colour."""
+    n = maps.shape[-1]
+    colors = torch.tensor(get_n_colors(n), dtype=maps.dtype, device=maps.device)      # [N,3]
+    return (maps.unsqueeze(-1) * colors.reshape(1, 1, 1, n, 3)).amax(dim=3)
+
+
+class IMMModel(BaseModel):
+
+    def __init__(self, config, global_step=None, dtype=torch.bfloat16, name='IMMModel', device=None, seed=1,
+                 vgg_weights=None, hparams=None, world_size=1):
+        super(IMMModel, self).__init__(dtype, name)
+        self._config = config
+        self._global_step = global_step
+        self._device = device
+        self._seed = seed
+        self._vgg_weights = vgg_weights
+        self._hparams = hparams
+        self._world_size = world_size
+        self._engines = {}
+        self.engine = None
+
+    # -- engine management ---------------------------------------------------------------------------
+    def _get_engine(self, batch, size):
+        key = (int(batch), int(size))
+        if key not in self._engines:
+            dev = self._device or ('cuda:%d' % torch.cuda.current_device())
+            eng = IMMEngine(self._config, batch, size, device=dev, act_dtype=self.dtype, seed=self._seed,
+                            vgg_weights=self._vgg_weights, hparams=self._hparams, world_size=self._world_size)
+            if self.engine is not None:      # variables are shared between instantiations (reuse_variables)
+                eng.load_parameters(self.engine.named_parameters(), self.engine.named_state())
+                eng.adam_m.copy_(self.engine.adam_m); eng.adam_v.copy_(self.engine.adam_v)
+                eng.step_count.copy_(self.engine.step_count)
+            self._engines[key] = eng
+        self.engine = self._engines[key]
+        return self.engine
+
+    # -- reference surface -----------------------------------------------------------------------------
+    def build(self, inputs, training_pl, costs_collection='costs', scope=None, var_device='/cpu:0',
+              output_tensors=False, build_loss=True):
+        im, future_im = inputs['image'], inputs['future_image']
+        future_im_size = list(future_im.shape[1:3])
+        assert future_im_size[0] == future_im_size[1]
+        assert list(im.shape) == list(future_im.shape)
+        mask = inputs.get('mask')
+        cfg = self._config
+        if build_loss and cfg.loss_mask and mask is None:
+            raise RuntimeError('No loss mask recieved but is required.')
+        eng = self._get_engine(im.shape[0], future_im_size[0])
+        if mask is None and eng.use_mask:
+            mask = torch.ones(im.shape[0], future_im_size[0], future_im_size[0], 1)
+        eng.set_inputs(im.to(eng.dev, torch.float32), future_im.to(eng.dev, torch.float32),
+                       None if mask is None else mask.to(eng.dev, torch.float32))
+        training = bool(training_pl)
+        if build_loss:
+            eng.forward(training)
+            loss = eng.loss
+        else:
+            eng.forward_model_only(training)
+            loss = None
+        if not output_tensors:
+            return None, loss, self._avg_ops
+        tensors = {}
+        tensors.update(inputs)
+        size = future_im_size[0]
+        full_maps = torch.empty(eng.B, size, size, eng.K, device=eng.dev)
+        from .. import ops
+        ops.gauss_render_f32(eng.mu, eng.B, eng.K, eng.inv_std, size, full_maps)
+        tensors.update({'future_im': future_im, 'im': im,
+                        'pose_embedding': colorize_landmark_maps(full_maps),
+                        'future_im_pred': eng.future_im_pred,
+                        'gauss_yx': eng.mu,
+                        # collection 'tensors' extras (imm_model.py:250,266-267)
+                        'heatmaps': eng.heat[..., :eng.K], 'gauss_y_prob': eng.py, 'gauss_x_prob': eng.px})
+        return None, loss, self._avg_ops, tensors

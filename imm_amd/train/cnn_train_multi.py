@@ -1,0 +1,145 @@
+"""Training runtime — counterpart of /root/reference/imm/train/cnn_train_multi.py.
+
+Reference: single process, in-graph towers (`train_multi` :109-192): split the batch evenly
+(:132), one tower per GPU, `average_gradients` (:66-106: per-variable mean over towers THEN
+tf.clip_by_norm per tensor), one `apply_gradients` (:164), BN statistics per tower, variables
+hosted on the CPU and re-broadcast every step.
+MI355X-native: one process per GPU (torchrun), every rank owns full weights + Adam state in HBM;
+the per-tower mean becomes ONE sum all-reduce of the flat f32 gradient buffer over RCCL/xGMI
+(`torch.distributed`, backend "nccl" == RCCL), the 1/N scale is folded into the fused
+clip+Adam kernel (order preserved: average, then clip, then Adam).  Forward+backward and the
+optimizer are HIP graphs replayed each step; nothing synchronises with the host inside a step.
+BN statistics and the loss normalisers stay rank-local exactly like the reference's per-tower
+statistics (:155, S11).
+"""
+import os
+import time
+
+import torch
+import torch.distributed as dist
+
+from .. import ops
+
+
+def split_inputs(inputs, num_splits, index):
+    """imm/utils/utils.py:113-121 split_tensors: even split along the batch axis (cnn_train_multi.py:126,132)."""
+    out = {}
+    for k, v in inputs.items():
+        n = v.shape[0]
+        assert n % num_splits == 0, 'Batch size must be divisible by number of GPUs'
+        per = n // num_splits
+        out[k] = v[index * per:(index + 1) * per]
+    return out
+
+
+def average_gradients(flat_grads, world_size, group=None):
+    """cnn_train_multi.py:66-106.  Sum-all-reduce of the flat gradient buffer; the division by the
+    number of towers happens inside imm_clip_adam_step (grad_scale = 1/world_size), before the
+    per-tensor clip, as in the reference."""
+    if world_size > 1:
+        dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM, group=group)
+    return flat_grads
+
+
+class TrainStep:
+    """One rank's training step: fwd+bwd graph -> gradient all-reduce -> clip+Adam graph."""
+
+    def __init__(self, model, batch_per_rank, image_size, world_size=1, use_graph=True, group=None):
+        self.model = model
+        self.world_size = world_size
+        self.group = group
+        self.engine = model._get_engine(batch_per_rank, image_size)
+        if abs(self.engine.hp.grad_scale - 1.0 / world_size) > 1e-9:
+            raise ValueError('engine was built for world_size %g' % (1.0 / self.engine.hp.grad_scale))
+        self.use_graph = use_graph
+        self.stream = torch.cuda.Stream(device=self.engine.dev)
+        self._graphs = None
+        torch.cuda.synchronize(self.engine.dev)   # engine construction ran on the default stream
+
+    # -- graph capture --------------------------------------------------------------------------------
+    def _capture(self):
+        eng = self.engine
+        with torch.cuda.stream(self.stream):
+            # warm every kernel up once outside capture (code-object loading, LDS attribute calls),
+            # then roll the state back so the warm-up leaves no trace
+            snap = eng.snapshot()
+            eng.forward(True); eng.backward(); eng.optimizer_step()
+            self.stream.synchronize()
+            eng.restore(snap)
+            self.stream.synchronize()
+            eng._training = True
+            if self.world_size == 1:
+                g = ops.Graph()
+                g.capture_begin()
+                eng.run(eng.prog_fwd); eng.run(eng.prog_bwd); eng.run(eng.prog_opt)
+                g.capture_end()
+                self._graphs = (g,)
+            else:
+                g1 = ops.Graph()
+                g1.capture_begin()
+                eng.run(eng.prog_fwd); eng.run(eng.prog_bwd)
+                g1.capture_end()
+                g2 = ops.Graph()
+                g2.capture_begin()
+                eng.run(eng.prog_opt)
+                g2.capture_end()
+                self._graphs = (g1, g2)
+
+    def step(self, inputs=None):
+        """Runs one training step on this rank's shard; returns the (device) scalar loss."""
+        eng = self.engine
+        self.stream.wait_stream(torch.cuda.current_stream(eng.dev))   # producers of `inputs`
+        with torch.cuda.stream(self.stream):
+            if inputs is not None:
+                eng.set_inputs(inputs['image'], inputs['future_image'], inputs.get('mask'))
+            if self.use_graph:
+                if self._graphs is None:
+                    self._capture()
+                self._graphs[0].launch()
+                if self.world_size > 1:
+                    average_gradients(eng.grads, self.world_size, self.group)
+                    self._graphs[1].launch()
+            else:
+                eng.forward(True)
+                eng.backward()
+                average_gradients(eng.grads, self.world_size, self.group)
+                eng.optimizer_step()
+        return eng.loss
+
+    def synchronize(self):
+        self.stream.synchronize()
+
+
+def setup_training(opts, model_factory, clip_value=None, use_graph=True):
+    """cnn_train_multi.py:342-368.  `opts` keeps the reference keys: gpu_ids, batch_size, image_size.
+    The rank/world come from the torchrun environment (one process per GPU)."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    assert opts['batch_size'] % world == 0, 'Batch size must be divisible by number of GPUs'
+    model = model_factory.create()
+    return TrainStep(model, opts['batch_size'] // world, opts['image_size'], world_size=world, use_graph=use_graph)
+
+
+def train_loop(opts, train_step, data_iter, num_steps, log_every=10, checkpoint_fn=None):
+    """cnn_train_multi.py:371-516 (session loop): step, NaN assert (:463), examples/sec (:466-469),
+    periodic checkpoint (:511-513).  The loss is read back only on logging steps."""
+    t_start, n_seen = time.time(), 0
+    rank = int(os.environ.get('RANK', '0'))
+    for step in range(num_steps):
+        t0 = time.time()
+        loss = train_step.step(next(data_iter))
+        n_seen += opts['batch_size']
+        if step % log_every == 0:
+            train_step.synchronize()
+            loss_value = float(loss)
+            assert loss_value == loss_value, 'Model diverged with loss = NaN'
+            if rank == 0:
+                dt = time.time() - t0
+                print('step %d, loss = %.4f (%.1f examples/sec; %.3f sec/batch)' % (step, loss_value,
+                                                                                    opts['batch_size'] / dt, dt))
+        if checkpoint_fn is not None and opts.get('n_checkpoint') and (step + 1) % opts['n_checkpoint'] == 0:
+            train_step.synchronize()
+            if rank == 0:
+                checkpoint_fn(step + 1)
+    train_step.synchronize()
+    if rank == 0:
+        print('Avg. samples per second %.2f' % (n_seen / (time.time() - t_start)))

@@ -1,0 +1,290 @@
+"""End-to-end parity of the MI355X training step against the CPU oracle (same seeds, same inputs).
+
+Two oracles are used:
+  * `emul`  — the oracle fed the same 16-bit-rounded weights and rounding its activations (and, through
+              autograd, their gradients) to bf16 where the engine stores bf16: isolates kernel/wiring
+              errors from storage precision;
+  * `fp32`  — the plain fp32 restatement of the TF1 graph: the parity target of BASELINE.json
+              ("landmarks within 1e-3 of the TF1 reference").
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import imm_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+bf = lambda t: t.to(torch.bfloat16).to(torch.float32)
+
+
+def make(batch, K=10, S=128, seed_in=0):
+    from imm_amd.models.imm_model import IMMModel
+    from imm_amd.utils.box import Box
+    cfg = O.default_model_config(K)
+    model = IMMModel(Box(dict(cfg)), dtype=torch.bfloat16, device=DEV)
+    inputs = O.synthetic_inputs(batch, S, seed=seed_in)
+    eng = model._get_engine(batch, S)
+    P, St = O.init_params(cfg, S)
+    # the engine draws its own parameters with the same seeded generator: they must be identical
+    for k, v in eng.named_parameters().items():
+        assert torch.equal(v.cpu(), P[k]), k
+    for k in St:
+        if k.startswith('vgg16/'):
+            assert torch.equal(eng.vgg_w[k].cpu(), St[k]), k
+    return cfg, model, eng, inputs, P, St
+
+
+def emul_params(P, St):
+    Pe = type(P)((k, bf(v) if k.endswith('/w') else v) for k, v in P.items())
+    Se = type(St)((k, bf(v) if (k.startswith('vgg16/') and k.endswith('/weights') and 'conv1_1' not in k) else v)
+                  for k, v in St.items())
+    return Pe, Se
+
+
+def rel(a, b):
+    a, b = a.detach().float().cpu().double(), b.detach().float().cpu().double()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+@pytest.fixture(scope='module')
+def fwd2():
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    cfg, model, eng, inputs, P, St = make(2)
+    _, loss, avg_ops, tensors = model.build(inputs, True, output_tensors=True)
+    eng.backward()
+    torch.cuda.synchronize()
+    Pe, Se = emul_params(P, St)
+    out_e, g_e = O.loss_and_grads(Pe, Se, inputs, cfg, act_round=bf)
+    out_f, g_f = O.loss_and_grads(P, St, inputs, cfg)
+    return dict(cfg=cfg, model=model, eng=eng, inputs=inputs, P=P, St=St, loss=loss, tensors=tensors,
+                out_e=out_e, g_e=g_e, out_f=out_f, g_f=g_f, avg_ops=avg_ops)
+
+
+def test_forward_parity(fwd2):
+    eng, t = fwd2['eng'], fwd2['tensors']
+    rows = {}
+    for tag, out in (('emul', fwd2['out_e']), ('fp32', fwd2['out_f'])):
+        rows[tag] = dict(
+            mu_maxabs=float((t['gauss_yx'].cpu() - out['gauss_yx'].detach()).abs().max()),
+            pred_rel=rel(t['future_im_pred'], out['future_im_pred']),
+            heat_rel=rel(t['heatmaps'], out['heatmaps']),
+            loss_rel=abs(float(fwd2['loss']) - float(out['loss'])) / abs(float(out['loss'])),
+            terms_rel=max(abs(float(a) - float(b)) / abs(float(b)) for a, b in zip(eng.loss_terms.cpu(), out['loss_terms'])))
+    print('\nFORWARD_PARITY ' + json.dumps(rows))
+    # landmarks: BASELINE.json tolerance 1e-3 on mu in [-1,1] against the fp32 restatement
+    assert rows['fp32']['mu_maxabs'] < 1e-3, rows
+    assert rows['emul']['mu_maxabs'] < 5e-4, rows
+    # reconstruction: bf16 storage noise (~0.4 % relative L2 per layer, drifting smoothly through the
+    # 16 conv+BN blocks in front of `pred`: see test_layerwise_forward_diagnostics) => 8 % measured
+    assert rows['emul']['pred_rel'] < 0.12 and rows['fp32']['pred_rel'] < 0.12, rows
+    assert rows['emul']['heat_rel'] < 0.05 and rows['fp32']['heat_rel'] < 0.05, rows
+    # loss and its six terms (f32 reductions of bf16 features)
+    assert rows['emul']['loss_rel'] < 1e-3 and rows['fp32']['loss_rel'] < 1e-3, rows
+    assert rows['emul']['terms_rel'] < 1e-2 and rows['fp32']['terms_rel'] < 1e-2, rows
+    assert fwd2['avg_ops'] == [] and t['pose_embedding'].shape == (2, 128, 128, 3)
+    assert t['gauss_y_prob'].shape == (2, 16, 10) and t['heatmaps'].shape == (2, 16, 16, 10)
+
+
+def test_layerwise_forward_diagnostics(fwd2):
+    """Prints the relative error of every stored activation against both oracles (no hard limits
+    beyond a coarse sanity bound): a wiring bug shows up as a jump at one layer, storage noise as a
+    slow drift."""
+    eng = fwd2['eng']
+    B = eng.B
+    table = []
+    for tag, out in (('emul', fwd2['out_e']), ('fp32', fwd2['out_f'])):
+        acts = out['acts']
+        for lays in (eng.enc_im, eng.enc_pose, eng.ren):
+            for lay in lays:
+                ref = acts[lay.scope]
+                got = lay.out[..., :lay.co] if lay.bn else lay.y[..., :lay.co]
+                table.append((tag, lay.scope, rel(got, ref)))
+                rc = acts[lay.scope + ':conv']
+                table.append((tag, lay.scope + ':conv', rel(lay.y[..., :lay.co], rc)))
+        for name, (y, H) in eng.vgg_act.items():
+            table.append((tag, 'vgg/' + name, rel(y, acts['vgg'][name])))
+    for row in table:
+        print('ACT_PARITY %-5s %-48s %.4g' % row)
+    assert max(r[2] for r in table if not r[1].startswith('model/renderer/conv_8')) < 0.2
+
+
+def test_gradient_parity(fwd2):
+    """The step's gradient is ill-conditioned at initialisation: the fp32 oracle differs from an fp64
+    run of itself by 2e-3..7e-3 and from its own bf16-storage emulation by up to 0.44 relative L2
+    (encoders), 0.003 at the last conv (numbers in DESIGN.md).  So the bar for the bf16 engine is:
+    (i) tight agreement where the problem is well conditioned (last renderer convs), and
+    (ii) everywhere, no further from the fp32 oracle than the oracle's own bf16 emulation is."""
+    eng = fwd2['eng']
+    g_e, g_f = fwd2['g_e'], fwd2['g_f']
+    fails = []
+    for k, v in g_f.items():
+        if k.endswith('/b') and (k[:-2] + '/gamma') in g_f:
+            # conv bias in front of a batch norm: analytically zero gradient; the oracle (like TF)
+            # produces rounding noise there, the engine writes exact zeros (DESIGN.md numerics)
+            assert float(eng.gview[k].abs().max()) == 0.0
+            if float(v.norm()) > 1e-3 * float(g_f[k[:-2] + '/gamma'].norm()) + 1e-6:
+                fails.append(('bias-not-noise', k, float(v.norm())))
+            continue
+        if float(v.norm()) < 1e-6:
+            continue     # pose 1x1 bias: |g| ~ 3e-8, pure cancellation noise in every implementation
+        e_eng, e_emul = rel(eng.gview[k], v), rel(g_e[k], v)
+        print('GRAD_PARITY %-48s engine-vs-fp32 %.4g   emul-vs-fp32 %.4g   |g|=%.4g' % (k, e_eng, e_emul, float(v.norm())))
+        if e_eng > 1.5 * e_emul + 0.02:
+            fails.append(('worse-than-bf16-emulation', k, e_eng, e_emul))
+    for k, lim in (('model/renderer/conv_8/w', 1e-2), ('model/renderer/conv_8/b', 1e-3), ('model/renderer/conv_7/gamma', 2e-2),
+                   ('model/renderer/conv_7/beta', 2e-2), ('model/renderer/conv_7/w', 8e-2)):
+        if rel(eng.gview[k], g_f[k]) > lim:
+            fails.append(('tight', k, rel(eng.gview[k], g_f[k]), lim))
+    assert not fails, fails
+
+
+def test_f16_storage_scales_the_error_down():
+    """Same engine with f16 storage (3 more mantissa bits than bf16): errors against the fp32 oracle must
+    shrink accordingly where f16's range suffices (renderer / image encoder), which separates storage
+    noise from wiring mistakes in the backward pass."""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    from imm_amd.models.imm_model import IMMModel
+    from imm_amd.utils.box import Box
+    cfg = O.default_model_config(10)
+    inputs = O.synthetic_inputs(2, 128)
+    P, St = O.init_params(cfg, 128)
+    out_f, g_f = O.loss_and_grads(P, St, inputs, cfg)
+    res = {}
+    for dt in (torch.float16, torch.bfloat16):
+        model = IMMModel(Box(dict(cfg)), dtype=dt, device=DEV)
+        _, loss, _, t = model.build(inputs, True, output_tensors=True)
+        model.engine.backward()
+        torch.cuda.synchronize()
+        eng = model.engine
+        res[dt] = dict(pred=rel(t['future_im_pred'], out_f['future_im_pred']),
+                       mu=float((t['gauss_yx'].cpu() - out_f['gauss_yx'].detach()).abs().max()),
+                       ren1=rel(eng.gview['model/renderer/conv_1/w'], g_f['model/renderer/conv_1/w']),
+                       ren5=rel(eng.gview['model/renderer/conv_5/w'], g_f['model/renderer/conv_5/w']),
+                       enc8=rel(eng.gview['model/image_encoder/encoder/conv_8/w'], g_f['model/image_encoder/encoder/conv_8/w']),
+                       enc1=rel(eng.gview['model/image_encoder/encoder/conv_1/w'], g_f['model/image_encoder/encoder/conv_1/w']))
+    print('\nF16_VS_BF16 ' + json.dumps({str(k): v for k, v in res.items()}))
+    f, b = res[torch.float16], res[torch.bfloat16]
+    assert f['pred'] < 0.4 * b['pred'] and f['pred'] < 0.03, res
+    assert f['mu'] < 1e-3, res
+    for k in ('ren1', 'ren5', 'enc8', 'enc1'):
+        assert f[k] < 0.5 * b[k], (k, res)
+
+
+def test_one_step_matches_oracle(fwd2):
+    cfg, eng, inputs = fwd2['cfg'], fwd2['eng'], fwd2['inputs']
+    eng.optimizer_step()
+    torch.cuda.synchronize()
+    Pe, Se = emul_params(fwd2['P'], fwd2['St'])
+    opt = O.new_adam_state(Pe)
+    newP, newS, info = O.train_step(Pe, Se, opt, [inputs], cfg, clip=1.0, lr=O.learning_rate(0), act_round=bf)
+    got = eng.named_parameters()
+    bad = []
+    for k, v in newP.items():
+        if k.endswith('/b'):
+            continue   # gradient is cancellation noise in the oracle (see test_gradient_parity)
+        # the first Adam step moves every element by ~lr*sign(g): compare update DIRECTIONS.  With the
+        # bf16-limited gradient agreement measured above the sign vectors agree on >= ~80 % of elements.
+        du_ref = (v - Pe[k]).detach().flatten().double()
+        du_got = (got[k].cpu() - fwd2['P'][k]).flatten().double()
+        cos = float((du_ref * du_got).sum() / (du_ref.norm() * du_got.norm() + 1e-30))
+        lim = 0.97 if k in ('model/renderer/conv_8/w', 'model/renderer/conv_7/gamma', 'model/renderer/conv_7/beta') else 0.5
+        print('STEP_PARITY %-48s cos(update) %.4f' % (k, cos))
+        if cos < lim:
+            bad.append((k, cos))
+        mag = float(du_got.abs().max())
+        if not (mag <= 1.05e-3):
+            bad.append((k, 'update magnitude', mag))      # |lr_t * m/(sqrt(v)+eps)| <= lr at t=1
+    assert not bad, bad
+    st = eng.named_state()
+    for k, v in newS.items():
+        if k.startswith('vgg16/'):
+            continue
+        tol = 2e-2 if 'moving' in k else 5e-3
+        assert rel(st[k], v) < tol, (k, rel(st[k], v))
+    assert int(eng.step_count) == 1
+
+
+def test_eval_mode_and_model_only(fwd2):
+    model, inputs, cfg = fwd2['model'], fwd2['inputs'], fwd2['cfg']
+    eng = fwd2['eng']
+    agg0, mm0 = eng.loss_agg.clone(), {k: v.clone() for k, v in eng.state.items()}
+    _, loss, _, t = model.build(inputs, False, output_tensors=True)
+    torch.cuda.synchronize()
+    assert torch.equal(agg0, eng.loss_agg) and all(torch.equal(mm0[k], eng.state[k]) for k in mm0)   # S12
+    P, St = eng.named_parameters(), eng.named_state()
+    Sfull = dict(fwd2['St']); Sfull.update({k: v.cpu() for k, v in St.items()})
+    Pe, Se = emul_params(type(fwd2['P'])((k, v.cpu()) for k, v in P.items()), type(fwd2['St'])(Sfull))
+    out = O.forward(Pe, Se, inputs, cfg, training=False, act_round=bf)
+    assert float((t['gauss_yx'].cpu() - out['gauss_yx']).abs().max()) < 1e-3
+    assert abs(float(loss) - float(out['loss'])) / abs(float(out['loss'])) < 2e-2
+    _, loss2, _ = model.build(inputs, False, build_loss=False)
+    assert loss2 is None
+
+
+def test_reference_error_types():
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    from imm_amd.models.imm_model import IMMModel
+    from imm_amd.utils.box import Box
+    cfg = Box(dict(O.default_model_config()))
+    inp = O.synthetic_inputs(1, 128)
+    del inp['mask']
+    with pytest.raises(RuntimeError):
+        IMMModel(cfg, device=DEV).build(inp, True)
+    c2 = Box(dict(O.default_model_config())); c2.reconstruction_loss = 'huber'
+    with pytest.raises(ValueError):
+        IMMModel(c2, device=DEV).build(O.synthetic_inputs(1, 128), True)
+    c3 = Box(dict(O.default_model_config())); c3.gauss_mode = 'nope'
+    with pytest.raises(ValueError):
+        IMMModel(c3, device=DEV).build(O.synthetic_inputs(1, 128), True)
+    bad = O.synthetic_inputs(1, 128); bad['future_image'] = bad['future_image'][:, :, :64]; bad['image'] = bad['image'][:, :, :64]
+    with pytest.raises(AssertionError):
+        IMMModel(cfg, device=DEV).build(bad, True)
+
+
+def test_graph_replay_equals_eager_and_is_deterministic():
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    from imm_amd.train.cnn_train_multi import TrainStep
+    res = []
+    for use_graph in (False, True, True):
+        cfg, model, eng, inputs, P, St = make(4)
+        ts = TrainStep(model, 4, 128, world_size=1, use_graph=use_graph)
+        for it in range(3):
+            loss = ts.step(inputs)
+        ts.synchronize()
+        res.append((float(loss), eng.params.clone(), eng.loss_agg.clone(), int(eng.step_count)))
+    assert res[1][0] == res[2][0] and torch.equal(res[1][1], res[2][1])          # replay is deterministic
+    assert res[0][0] == res[1][0] and torch.equal(res[0][1], res[1][1])          # graph == eager, bitwise
+    assert res[0][3] == 3 and torch.equal(res[0][2], res[1][2])
+    assert np.isfinite(res[0][0])
+
+
+def test_full_size_step_properties():
+    """BASELINE.json configs[1]: batch 32, 128x128, K=10 — size-independent properties."""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    from imm_amd.train.cnn_train_multi import TrainStep
+    cfg, model, eng, inputs, P, St = make(32)
+    ts = TrainStep(model, 32, 128, world_size=1, use_graph=True)
+    losses = []
+    for it in range(6):
+        losses.append(ts.step(inputs).clone())
+    ts.synchronize()
+    losses = [float(l) for l in losses]
+    assert all(np.isfinite(losses)), losses
+    assert losses[-1] < losses[0], losses                      # same batch: the loss must go down
+    assert bool(torch.isfinite(eng.params).all()) and bool(torch.isfinite(eng.grads).all())
+    mu = eng.mu.cpu()
+    assert float(mu.abs().max()) <= 1.0                        # expectation of linspace(-1,1)
+    # per-tensor clip: every clipped gradient has norm <= 1 (+ fp slack)
+    n2 = eng.seg_norm2.cpu()
+    assert bool((n2 >= 0).all())
+    # the 6 bug-fix channels of the last conv get no loss gradient (S10): their bias gradient is exactly 0
+    assert float(eng.gview['model/renderer/conv_8/b'][3:].abs().max()) == 0.0
