@@ -9,6 +9,12 @@
 
 #define IMM_WAVE 64
 
+// debug-only ablation bits in imm_conv_desc.flags (tools/bench_conv.py); never set by the product path
+#define IMM_DBG_NO_GLOAD 0x100
+#define IMM_DBG_NO_LDS_STORE 0x200
+#define IMM_DBG_NO_MFMA 0x400
+#define IMM_DBG_NO_EPILOGUE 0x800
+
 // ---------------------------------------------------------------------------------------------
 // error plumbing (thread-local message; no exceptions cross the C boundary)
 // ---------------------------------------------------------------------------------------------

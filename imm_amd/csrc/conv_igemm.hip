@@ -26,7 +26,8 @@ struct ConvArgs {
   int kh, kw, stride, pad_t, pad_l, updiv;
   int kpad, KT, ntaps;
   int flags, ldmask;
-  int n_nblk;
+  int n_nblk, n_blocks;
+  uint32_t x_bytes, wt_bytes;   // buffer-descriptor extents (fast path: out-of-range lanes read zeros)
 };
 
 __device__ __forceinline__ int lds_chunk_idx(int row, int chunk) {
@@ -34,7 +35,10 @@ __device__ __forceinline__ int lds_chunk_idx(int row, int chunk) {
   return row * 4 + (chunk ^ (((row >> 3) & 1) * 3));
 }
 
-template <typename ET, int BM, int BN, int WGM, int WGN>
+// FAST: ci % 32 == 0, so a K tile is ONE filter tap x 32 channels: the tap walk is wave-uniform (SGPRs),
+// per-lane gather offsets are recomputed once per tap and the channel slice rides in the buffer
+// instruction's scalar offset -> a handful of VALU instructions per K step instead of ~150.
+template <typename ET, int BM, int BN, int WGM, int WGN, bool FAST>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
   constexpr int TM = BM / WGM, TN = BN / WGN;
   constexpr int MT = TM / 16, NT = TN / 16;
@@ -49,7 +53,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WGN, wn = wid % WGN;
-  const int nblk = blockIdx.x % a.n_nblk, mblk = blockIdx.x / a.n_nblk;
+  // XCD-aware remap (workgroup id -> XCD id%8 is the observed dispatch rule; speed only): give every
+  // XCD a contiguous run of logical tiles so the N-blocks of one pixel tile and its halo neighbours
+  // share that XCD's L2.  Bijective for any grid size.
+  int bid = blockIdx.x;
+  {
+    const int q = a.n_blocks >> 3, r = a.n_blocks & 7, xcd = bid & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int nblk = bid % a.n_nblk, mblk = bid / a.n_nblk;
   const int m0 = mblk * BM, n0 = nblk * BN;
 
   // ---- per-thread loader state ---------------------------------------------------------------
@@ -70,37 +82,91 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
       by[i] = -(1 << 28); bx[i] = -(1 << 28); pbase[i] = 0;
     }
   }
-  // K-chunk cursor of this thread: k8 = kt*4 + chunk -> (tap=(ky,kx), c8)
-  int c8 = chunk, tap = 0, ky = 0, kx = 0;
-  while (c8 >= a.ci8) { c8 -= a.ci8; ++tap; if (++kx == a.kw) { kx = 0; ++ky; } }
-
   uint4 ra[A_PASSES], rb[B_PASSES];
   const uint4 zero4 = make_uint4(0, 0, 0, 0);
+  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 
-  auto load_tile = [&](int kt) {
+  // ---- generic cursor (ci = 8 or 16): k8 = kt*4 + chunk -> (tap=(ky,kx), c8), per lane ----------------
+  int c8 = chunk, tap = 0, ky = 0, kx = 0;
+  // ---- fast path state --------------------------------------------------------------------------------
+  constexpr uint32_t OOB = 0x80000000u;
+  uint32_t a_voff[A_PASSES], b_voff[B_PASSES];
+  int cs = 0;                               // channel slice of the current tap (uniform)
+  const int ncs = a.ci8 >> 2;
+  __amdgpu_buffer_rsrc_t xr, wr;
+  auto tap_offsets = [&]() {
 #pragma unroll
     for (int i = 0; i < A_PASSES; ++i) {
       int iy = by[i] + ky, ix = bx[i] + kx;
-      bool ok = tap < a.ntaps;
-      if (a.updiv == 2) { ok = ok && (((iy | ix) & 1) == 0); iy >>= 1; ix >>= 1; }
+      bool ok = true;
+      if (a.updiv == 2) { ok = (((iy | ix) & 1) == 0); iy >>= 1; ix >>= 1; }
       ok = ok && ((unsigned)iy < (unsigned)a.hi) && ((unsigned)ix < (unsigned)a.wi);
-      ra[i] = zero4;
-      if (ok) ra[i] = *(const uint4*)(a.x + ((pbase[i] + (int64_t)iy * a.wi + ix) * a.ldx + c8 * 8));
+      a_voff[i] = ok ? (uint32_t)((((int)pbase[i] + iy * a.wi + ix) * a.ldx + chunk * 8) * 2) : OOB;
     }
+  };
+  if constexpr (FAST) {
+    xr = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
+    wr = __builtin_amdgcn_make_buffer_rsrc((void*)a.wt, 0, a.wt_bytes, 0x00020000);
 #pragma unroll
     for (int j = 0; j < B_PASSES; ++j) {
       const int cidx = j * 256 + tid;
-      rb[j] = zero4;
-      if (cidx < B_CHUNKS) {
-        const int n = n0 + (cidx >> 2);
-        if (n < a.co) rb[j] = *(const uint4*)(a.wt + ((int64_t)n * a.kpad + kt * 32 + chunk * 8));
-      }
+      const int n = n0 + (cidx >> 2);
+      b_voff[j] = (cidx < B_CHUNKS && n < a.co) ? (uint32_t)((n * a.kpad + chunk * 8) * 2) : OOB;
     }
-    // advance the cursor by one K tile (4 chunks)
-    c8 += 4;
+    if (a.flags & IMM_DBG_NO_GLOAD) {
+#pragma unroll
+      for (int j = 0; j < B_PASSES; ++j) b_voff[j] = OOB;
+    }
+    tap_offsets();
+  } else {
     while (c8 >= a.ci8) { c8 -= a.ci8; ++tap; if (++kx == a.kw) { kx = 0; ++ky; } }
+  }
+
+  auto load_tile = [&](int kt) {
+    if constexpr (FAST) {
+      const int a_soff = cs * 64, b_soff = kt * 64;
+#pragma unroll
+      for (int i = 0; i < A_PASSES; ++i) {
+        const uint32_t vo = (a.flags & IMM_DBG_NO_GLOAD) ? OOB : a_voff[i];
+        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(xr, vo, a_soff, 0);
+        ra[i] = make_uint4(v.x, v.y, v.z, v.w);
+      }
+#pragma unroll
+      for (int j = 0; j < B_PASSES; ++j) {
+        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(wr, b_voff[j], b_soff, 0);
+        rb[j] = make_uint4(v.x, v.y, v.z, v.w);
+      }
+      if (++cs == ncs) {          // next filter tap (uniform branch)
+        cs = 0;
+        if (++kx == a.kw) { kx = 0; ++ky; }
+        tap_offsets();
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < A_PASSES; ++i) {
+        int iy = by[i] + ky, ix = bx[i] + kx;
+        bool ok = tap < a.ntaps;
+        if (a.updiv == 2) { ok = ok && (((iy | ix) & 1) == 0); iy >>= 1; ix >>= 1; }
+        ok = ok && ((unsigned)iy < (unsigned)a.hi) && ((unsigned)ix < (unsigned)a.wi);
+        ra[i] = zero4;
+        if (ok && !(a.flags & IMM_DBG_NO_GLOAD)) ra[i] = *(const uint4*)(a.x + ((pbase[i] + (int64_t)iy * a.wi + ix) * a.ldx + c8 * 8));
+      }
+#pragma unroll
+      for (int j = 0; j < B_PASSES; ++j) {
+        const int cidx = j * 256 + tid;
+        rb[j] = zero4;
+        if (cidx < B_CHUNKS) {
+          const int n = n0 + (cidx >> 2);
+          if (n < a.co && !(a.flags & IMM_DBG_NO_GLOAD)) rb[j] = *(const uint4*)(a.wt + ((int64_t)n * a.kpad + kt * 32 + chunk * 8));
+        }
+      }
+      // advance the cursor by one K tile (4 chunks)
+      c8 += 4;
+      while (c8 >= a.ci8) { c8 -= a.ci8; ++tap; if (++kx == a.kw) { kx = 0; ++ky; } }
+    }
   };
   auto store_tile = [&](int buf) {
+    if (a.flags & IMM_DBG_NO_LDS_STORE) return;
     uint4* Ab = smem + buf * BUF;
     uint4* Bb = Ab + BM * 4;
 #pragma unroll
@@ -128,6 +194,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     const bool more = (kt + 1) < a.KT;
     if (more) load_tile(kt + 1);
     uint4 af[MT], bf[NT];
+    if (a.flags & IMM_DBG_NO_MFMA) { if (more) store_tile(buf ^ 1); __syncthreads(); continue; }
     const uint4* Ab = smem + buf * BUF;
     const uint4* Bb = Ab + BM * 4;
 #pragma unroll
@@ -143,6 +210,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
   }
 
   // ---- epilogue ------------------------------------------------------------------------------
+  if (a.flags & IMM_DBG_NO_EPILOGUE) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (t == 123456.789f) ((float*)a.y)[0] = t;   // keeps the accumulators live
+    return;
+  }
   // lane holds D[n = 4*(lane>>4)+r][m = lane&15] of each 16x16 tile
   const bool f_bias = a.flags & IMM_CONV_BIAS, f_relu = a.flags & IMM_CONV_RELU;
   const bool f_stats = a.flags & IMM_CONV_STATS, f_mask = a.flags & IMM_CONV_MASK;
@@ -296,9 +372,11 @@ extern "C" int imm_conv_stats_blocks(const imm_conv_desc* d) {
 }
 
 template <typename ET, int BM, int BN, int WGM, int WGN>
-static void launch_cfg(const ConvArgs& a, hipStream_t s) {
+static void launch_cfg(ConvArgs& a, bool fast, hipStream_t s) {
   const int mblk = (a.M + BM - 1) / BM;
-  hipLaunchKernelGGL((conv_igemm_kernel<ET, BM, BN, WGM, WGN>), dim3(mblk * a.n_nblk), dim3(256), 0, s, a);
+  a.n_blocks = mblk * a.n_nblk;
+  if (fast) hipLaunchKernelGGL((conv_igemm_kernel<ET, BM, BN, WGM, WGN, true>), dim3(a.n_blocks), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((conv_igemm_kernel<ET, BM, BN, WGM, WGN, false>), dim3(a.n_blocks), dim3(256), 0, s, a);
 }
 
 template <typename ET>
@@ -315,11 +393,15 @@ static int conv_launch(const imm_conv_desc* d, const void* x, const void* wt, co
   a.flags = d->flags; a.ldmask = d->ldmask;
   const TileCfg t = pick_tile(a.M, a.co);
   a.n_nblk = (a.co + t.bn - 1) / t.bn;
-  if (t.bm == 128 && t.bn == 128) launch_cfg<ET, 128, 128, 2, 2>(a, s);
-  else if (t.bm == 128 && t.bn == 64) launch_cfg<ET, 128, 64, 2, 2>(a, s);
-  else if (t.bm == 64 && t.bn == 64) launch_cfg<ET, 64, 64, 2, 2>(a, s);
-  else if (t.bm == 128 && t.bn == 32) launch_cfg<ET, 128, 32, 4, 1>(a, s);
-  else launch_cfg<ET, 128, 16, 4, 1>(a, s);
+  const int64_t xb = (int64_t)d->batch * d->hi * d->wi * d->ldx * 2, wb = (int64_t)d->co * d->kpad * 2;
+  const bool fast = (d->ci % 32 == 0) && xb < (1LL << 31) && wb < (1LL << 31);
+  a.x_bytes = (uint32_t)(fast ? xb : 0);
+  a.wt_bytes = (uint32_t)(fast ? wb : 0);
+  if (t.bm == 128 && t.bn == 128) launch_cfg<ET, 128, 128, 2, 2>(a, fast, s);
+  else if (t.bm == 128 && t.bn == 64) launch_cfg<ET, 128, 64, 2, 2>(a, fast, s);
+  else if (t.bm == 64 && t.bn == 64) launch_cfg<ET, 64, 64, 2, 2>(a, fast, s);
+  else if (t.bm == 128 && t.bn == 32) launch_cfg<ET, 128, 32, 4, 1>(a, fast, s);
+  else launch_cfg<ET, 128, 16, 4, 1>(a, fast, s);
   IMM_CHECK_LAUNCH("imm_conv2d");
   return 0;
 }

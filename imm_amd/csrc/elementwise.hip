@@ -42,21 +42,45 @@ extern "C" int imm_pack_image(const float* src, void* dst, int dtype, int64_t np
 // ---------------------------------------------------------------------------------------------
 // batch norm forward
 // ---------------------------------------------------------------------------------------------
-__global__ void bn_finalize_kernel(const float* __restrict__ partial, int nblk, int c, double count,
+// Sums the per-M-block partials of one 32-channel group with a 32x32 thread block (32 row lanes, f64
+// accumulation, fixed order => deterministic), then lane row 0 finalises its channel.
+template <int NS>
+__device__ __forceinline__ void reduce_partials_32x32(const float* __restrict__ partial, int nblk, int c, int ch,
+                                                      double (&out)[NS]) {
+  __shared__ double red[NS][32][33];
+  double acc[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) acc[s] = 0.0;
+  if (ch < c)
+    for (int b = threadIdx.y; b < nblk; b += 32) {
+#pragma unroll
+      for (int s = 0; s < NS; ++s) acc[s] += (double)partial[((int64_t)b * NS + s) * c + ch];
+    }
+#pragma unroll
+  for (int s = 0; s < NS; ++s) red[s][threadIdx.y][threadIdx.x] = acc[s];
+  __syncthreads();
+  if (threadIdx.y == 0) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      double t = 0.0;
+      for (int r = 0; r < 32; ++r) t += red[s][r][threadIdx.x];
+      out[s] = t;
+    }
+  }
+}
+
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ partial, int nblk, int c, double count,
                                    const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                    float momentum, int training, float* moving_mean, float* moving_var,
                                    float* scale, float* shift, float* mean_out, float* rstd_out) {
-  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-  if (ch >= c) return;
+  const int ch = blockIdx.x * 32 + threadIdx.x;
+  double s[2] = {0.0, 0.0};
+  if (training) reduce_partials_32x32<2>(partial, nblk, c, ch, s);
+  if (threadIdx.y != 0 || ch >= c) return;
   float mean, var;
   if (training) {
-    double s1 = 0.0, s2 = 0.0;
-    for (int b = 0; b < nblk; ++b) {
-      s1 += (double)partial[((int64_t)b * 2 + 0) * c + ch];
-      s2 += (double)partial[((int64_t)b * 2 + 1) * c + ch];
-    }
-    const double m = s1 / count;
-    double v = s2 / count - m * m;
+    const double m = s[0] / count;
+    double v = s[1] / count - m * m;
     if (v < 0.0) v = 0.0;
     mean = (float)m; var = (float)v;
     const double unbiased = count > 1.0 ? v * count / (count - 1.0) : v;
@@ -79,7 +103,7 @@ extern "C" int imm_bn_finalize(const float* partial, int nblk, int c, int64_t co
   IMM_REQUIRE(gamma && beta && moving_mean && moving_var && scale && shift && mean && rstd, "bn_finalize: null");
   IMM_REQUIRE(!training || (partial && nblk > 0), "bn_finalize: training needs partial sums");
   IMM_REQUIRE(c > 0 && count > 0, "bn_finalize: dims");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + 63) / 64), dim3(64), 0, (hipStream_t)stream, partial, nblk, c,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + 31) / 32), dim3(32, 32), 0, (hipStream_t)stream, partial, nblk, c,
                      (double)count, gamma, beta, eps, momentum, training, moving_mean, moving_var, scale, shift, mean, rstd);
   IMM_CHECK_LAUNCH("imm_bn_finalize");
   return 0;
@@ -208,27 +232,24 @@ extern "C" int imm_bn_bwd_reduce(const void* dout, int lddo, const void* y, int 
   return 0;
 }
 
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int c, double count,
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int c, double count,
                                        const float* __restrict__ gamma, const float* __restrict__ rstd,
                                        float* dgamma, float* dbeta, float* coef) {
-  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-  if (ch >= c) return;
-  double s1 = 0.0, s2 = 0.0;
-  for (int b = 0; b < nblk; ++b) {
-    s1 += (double)partial[((int64_t)b * 2 + 0) * c + ch];
-    s2 += (double)partial[((int64_t)b * 2 + 1) * c + ch];
-  }
-  dbeta[ch] = (float)s1;
-  dgamma[ch] = (float)s2;
+  const int ch = blockIdx.x * 32 + threadIdx.x;
+  double s[2] = {0.0, 0.0};
+  reduce_partials_32x32<2>(partial, nblk, c, ch, s);
+  if (threadIdx.y != 0 || ch >= c) return;
+  dbeta[ch] = (float)s[0];
+  dgamma[ch] = (float)s[1];
   coef[ch] = gamma[ch] * rstd[ch];
-  coef[c + ch] = (float)(s1 / count);
-  coef[2 * c + ch] = (float)(s2 / count);
+  coef[c + ch] = (float)(s[0] / count);
+  coef[2 * c + ch] = (float)(s[1] / count);
 }
 
 extern "C" int imm_bn_bwd_finalize(const float* partial, int nblk, int c, int64_t count, const float* gamma,
                                    const float* rstd, float* dgamma, float* dbeta, float* coef, void* stream) {
   IMM_REQUIRE(partial && gamma && rstd && dgamma && dbeta && coef && nblk > 0 && c > 0 && count > 0, "bn_bwd_finalize: args");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 63) / 64), dim3(64), 0, (hipStream_t)stream, partial, nblk, c,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 31) / 32), dim3(32, 32), 0, (hipStream_t)stream, partial, nblk, c,
                      (double)count, gamma, rstd, dgamma, dbeta, coef);
   IMM_CHECK_LAUNCH("imm_bn_bwd_finalize");
   return 0;
@@ -298,12 +319,12 @@ __global__ __launch_bounds__(EW_THREADS) void colsum_kernel(const uint16_t* __re
   col_reduce_tail<1>(acc, c, tpp, rows, partial + (int64_t)blockIdx.x * c);
 }
 
-__global__ void colsum_finalize_kernel(const float* __restrict__ partial, int nblk, int c, int c_real, float* out) {
-  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-  if (ch >= c_real) return;
-  double s = 0.0;
-  for (int b = 0; b < nblk; ++b) s += (double)partial[(int64_t)b * c + ch];
-  out[ch] = (float)s;
+__global__ __launch_bounds__(1024) void colsum_finalize_kernel(const float* __restrict__ partial, int nblk, int c, int c_real, float* out) {
+  const int ch = blockIdx.x * 32 + threadIdx.x;
+  double s[1] = {0.0};
+  reduce_partials_32x32<1>(partial, nblk, c, ch, s);
+  if (threadIdx.y != 0 || ch >= c_real) return;
+  out[ch] = (float)s[0];
 }
 
 // c = padded channel count of the buffer rows that are summed (multiple of 8); the first c_out sums are written.
@@ -315,7 +336,7 @@ extern "C" int imm_colsum(const void* dy, int dtype, int64_t npix, int c, int c_
   if (nblk < 0) return imm_fail(IMM_E_UNSUPPORTED, "colsum: C=%d unsupported", c);
   IMM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((colsum_kernel<ET>), dim3(nblk), dim3(EW_THREADS), 0, (hipStream_t)stream,
                                                (const uint16_t*)dy, ld, npix, c, partial));
-  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((c + 63) / 64), dim3(64), 0, (hipStream_t)stream, partial, nblk, c, c_out, out);
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((c + 31) / 32), dim3(32, 32), 0, (hipStream_t)stream, partial, nblk, c, c_out, out);
   IMM_CHECK_LAUNCH("imm_colsum");
   return 0;
 }
