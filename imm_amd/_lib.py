@@ -45,6 +45,8 @@ _SIGS = {
     'imm_graph_launch': [_P, _P],
     'imm_graph_destroy': [_P],
     'imm_pack_weights': [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    'imm_pack_weights_multi': [_P, _P, _I, _I, _I, _P],
+    'imm_wgrad_reduce_multi': [_P, _P, _I, _I, _P],
     'imm_conv2d': [C.POINTER(ConvDesc), _I, _P, _P, _P, _P, _P, _P, _P],
     'imm_conv_stats_blocks': [C.POINTER(ConvDesc)],
     'imm_conv2d_wgrad': [C.POINTER(ConvDesc), _I, _P, _P, _I, _P, _I, _P],

@@ -22,6 +22,7 @@ struct WgradArgs {
   int kh, kw, stride, pad_t, pad_l;
   int kpad, ntaps;
   int n_kblk, n_nblk, nsplit, p_per_split;
+  uint32_t x_bytes, dy_bytes;
 };
 
 __device__ __forceinline__ int wg_dword_idx(int row, int pp) {
@@ -32,7 +33,10 @@ __device__ __forceinline__ int wg_chunk_idx(int row, int chunk) {
   return row * 4 + (chunk ^ (((row >> 3) & 1) * 3));
 }
 
-template <typename ET, int BK, int BN, int WGK, int WGN>
+// FAST (ho*wo % 32 == 0 and wo | 32 or 32 | wo): a 32-pixel step never crosses an image, so the image
+// index and the step's top-left (y0,x0) are wave-uniform; each lane adds compile-time-constant pixel
+// offsets and the image / pixel-block base rides in the buffer instruction's scalar offset.
+template <typename ET, int BK, int BN, int WGK, int WGN, bool FAST>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
   constexpr int TK = BK / WGK, TN = BN / WGN;
   constexpr int KT_ = TK / 16, NT = TN / 16;
@@ -68,18 +72,70 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
     a_ok[i] = tap < a.ntaps;
   }
   const bool b_ok = (g < BN / 8) && (n0 + g * 8 < a.lddy);   // dY channel group inside the row
-  // pixel cursor for this thread's first pixel (p_begin + 2*pp); second pixel is +1
+  uint4 ra[A_PASSES][2], rb[2];
+  const uint4 zero4 = make_uint4(0, 0, 0, 0);
+  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+  constexpr uint32_t OOB = 0x80000000u;
+
+  // ---- generic pixel cursor (per lane) ---------------------------------------------------------------
   int pcur = p_begin + 2 * pp;
   int img, oy, ox;
   {
     const int hw = a.ho * a.wo;
     img = pcur / hw; const int rem = pcur - img * hw; oy = rem / a.wo; ox = rem - oy * a.wo;
   }
-
-  uint4 ra[A_PASSES][2], rb[2];
-  const uint4 zero4 = make_uint4(0, 0, 0, 0);
+  // ---- fast path state: uniform step origin + per-lane constant offsets -------------------------------
+  int s_img = 0, s_y0 = 0, s_x0 = 0, s_p0 = p_begin;      // wave-uniform
+  int cy[A_PASSES][2], cx[A_PASSES][2];
+  uint32_t b_voff[2];
+  __amdgpu_buffer_rsrc_t xr, dr;
+  if constexpr (FAST) {
+    const int hw = a.ho * a.wo;
+    s_img = p_begin / hw;
+    const int rem0 = p_begin - s_img * hw;
+    s_y0 = rem0 / a.wo;
+    s_x0 = rem0 - s_y0 * a.wo;
+    xr = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
+    dr = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, a.dy_bytes, 0x00020000);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int j = 2 * pp + q;
+      const int jy = (a.wo >= 32) ? 0 : j / a.wo;
+      const int jx = (a.wo >= 32) ? j : j - jy * a.wo;
+#pragma unroll
+      for (int i = 0; i < A_PASSES; ++i) {
+        cy[i][q] = jy * a.stride - a.pad_t + a_ky[i];
+        cx[i][q] = jx * a.stride - a.pad_l + a_kx[i];
+      }
+      b_voff[q] = b_ok ? (uint32_t)((j * a.lddy + n0 + g * 8) * 2) : OOB;
+    }
+  }
 
   auto load_tile = [&]() {
+    if constexpr (FAST) {
+      const uint32_t a_soff = (uint32_t)(s_img * a.hi * a.wi) * (uint32_t)(a.ldx * 2);
+      const uint32_t b_soff = (uint32_t)s_p0 * (uint32_t)(a.lddy * 2);
+      const int ys = s_y0 * a.stride, xs = s_x0 * a.stride;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+#pragma unroll
+        for (int i = 0; i < A_PASSES; ++i) {
+          const int iy = ys + cy[i][q], ix = xs + cx[i][q];
+          const bool ok = a_ok[i] && ((unsigned)iy < (unsigned)a.hi) && ((unsigned)ix < (unsigned)a.wi);
+          const uint32_t vo = ok ? (uint32_t)(((iy * a.wi + ix) * a.ldx + a_c8[i] * 8) * 2) : OOB;
+          const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(xr, vo, a_soff, 0);
+          ra[i][q] = make_uint4(v.x, v.y, v.z, v.w);
+        }
+        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(dr, b_voff[q], b_soff, 0);
+        rb[q] = make_uint4(v.x, v.y, v.z, v.w);
+      }
+      // advance the uniform origin by 32 pixels
+      s_p0 += 32;
+      if (a.wo >= 32) { s_x0 += 32; if (s_x0 == a.wo) { s_x0 = 0; ++s_y0; } }
+      else s_y0 += 32 / a.wo;
+      if (s_y0 == a.ho) { s_y0 = 0; ++s_img; }
+      return;
+    }
     // the two pixels of the pair (ox even start, wo even => same row; handled generally below)
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -180,8 +236,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
 }
 
 template <typename ET, int BK, int BN, int WGK, int WGN>
-static void wg_launch_cfg(const WgradArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL((conv_wgrad_kernel<ET, BK, BN, WGK, WGN>), dim3(a.n_kblk * a.n_nblk * a.nsplit), dim3(256), 0, s, a);
+static void wg_launch_cfg(const WgradArgs& a, bool fast, hipStream_t s) {
+  const dim3 grid(a.n_kblk * a.n_nblk * a.nsplit);
+  if (fast) hipLaunchKernelGGL((conv_wgrad_kernel<ET, BK, BN, WGK, WGN, true>), grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((conv_wgrad_kernel<ET, BK, BN, WGK, WGN, false>), grid, dim3(256), 0, s, a);
 }
 
 static int wgrad_bn(int co) { return co > 64 ? 128 : co > 32 ? 64 : co > 16 ? 32 : 16; }
@@ -203,10 +261,15 @@ static int wgrad_launch(const imm_conv_desc* d, const void* x, const void* dy, i
   int pps = (a.P + nsplit - 1) / nsplit;
   pps = (pps + 31) / 32 * 32;
   a.p_per_split = pps;
-  if (bn == 128) wg_launch_cfg<ET, 128, 128, 2, 2>(a, s);
-  else if (bn == 64) wg_launch_cfg<ET, 128, 64, 2, 2>(a, s);
-  else if (bn == 32) wg_launch_cfg<ET, 128, 32, 4, 1>(a, s);
-  else wg_launch_cfg<ET, 128, 16, 4, 1>(a, s);
+  const int hw = d->ho * d->wo;
+  const int64_t xb = (int64_t)d->batch * d->hi * d->wi * d->ldx * 2, db = (int64_t)a.P * lddy * 2;
+  const bool fast = (hw % 32 == 0) && (d->wo % 32 == 0 || 32 % d->wo == 0) && xb < (1LL << 31) && db < (1LL << 31);
+  a.x_bytes = (uint32_t)(fast ? xb : 0);
+  a.dy_bytes = (uint32_t)(fast ? db : 0);
+  if (bn == 128) wg_launch_cfg<ET, 128, 128, 2, 2>(a, fast, s);
+  else if (bn == 64) wg_launch_cfg<ET, 128, 64, 2, 2>(a, fast, s);
+  else if (bn == 32) wg_launch_cfg<ET, 128, 32, 4, 1>(a, fast, s);
+  else wg_launch_cfg<ET, 128, 16, 4, 1>(a, fast, s);
   IMM_CHECK_LAUNCH("imm_conv2d_wgrad");
   return 0;
 }

@@ -255,27 +255,32 @@ extern "C" int imm_bn_bwd_finalize(const float* partial, int nblk, int c, int64_
   return 0;
 }
 
+// Channel-stationary mapping (same as the reduce pass): a thread owns ONE 8-channel group, keeps its 7x8
+// per-channel constants in registers and streams pixels -> 2 loads + 1 store + ~50 VALU per 16 bytes.
 template <typename ET>
-__global__ void bn_bwd_apply_kernel(const uint16_t* __restrict__ dout, int lddo, const uint16_t* __restrict__ y,
-                                    int ldy, int64_t npix, int c8n, int c, const float* __restrict__ scale,
-                                    const float* __restrict__ shift, const float* __restrict__ mean,
-                                    const float* __restrict__ rstd, int relu, const float* __restrict__ coef,
-                                    uint16_t* __restrict__ dy, int lddy) {
-  const int64_t total = npix * c8n;
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t p = idx / c8n;
-    const int cg = (int)(idx - p * c8n);
+__global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(
+    const uint16_t* __restrict__ dout, int lddo, const uint16_t* __restrict__ y, int ldy, int64_t npix, int c8n, int c,
+    const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
+    const float* __restrict__ rstd, int relu, const float* __restrict__ coef, uint16_t* __restrict__ dy, int lddy) {
+  const int tpp = c8n, rows = EW_THREADS / tpp;
+  const int r = threadIdx.x / tpp, cg = threadIdx.x - r * tpp;
+  float sc[8], sh[8], mu[8], rs[8], k0[8], k1[8], k2[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int ch = cg * 8 + i;
+    sc[i] = scale[ch]; sh[i] = shift[ch]; mu[i] = mean[ch]; rs[i] = rstd[ch];
+    k0[i] = coef[ch]; k1[i] = coef[c + ch]; k2[i] = coef[2 * c + ch];
+  }
+  for (int64_t p = (int64_t)blockIdx.x * rows + r; p < npix; p += (int64_t)gridDim.x * rows) {
     float d[8], v[8], o[8];
     unpack8<ET>(*(const uint4*)(dout + p * lddo + cg * 8), d);
     unpack8<ET>(*(const uint4*)(y + p * ldy + cg * 8), v);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const int ch = cg * 8 + i;
       float dz = d[i];
-      if (relu && !(v[i] * scale[ch] + shift[ch] > 0.f)) dz = 0.f;
-      const float xhat = (v[i] - mean[ch]) * rstd[ch];
-      o[i] = coef[ch] * (dz - coef[c + ch] - xhat * coef[2 * c + ch]);
+      if (relu && !(v[i] * sc[i] + sh[i] > 0.f)) dz = 0.f;
+      const float xhat = (v[i] - mu[i]) * rs[i];
+      o[i] = k0[i] * (dz - k1[i] - xhat * k2[i]);
     }
     *(uint4*)(dy + p * lddy + cg * 8) = pack8<ET>(o);
   }
@@ -288,7 +293,9 @@ extern "C" int imm_bn_bwd_apply(const void* dout, int lddo, const void* y, int l
   EW_REQUIRE_VEC(c, lddo, "bn_bwd_apply(dout)");
   EW_REQUIRE_VEC(c, ldy, "bn_bwd_apply(y)");
   EW_REQUIRE_VEC(c, lddy, "bn_bwd_apply(dy)");
-  IMM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<ET>), dim3(ew_blocks(npix * (c / 8))),
+  if (imm_bn_bwd_blocks(npix, c) < 0) return imm_fail(IMM_E_UNSUPPORTED, "bn_bwd_apply: C=%d unsupported (C/8 must divide 256)", c);
+  const int rows_per_blk = EW_THREADS / (c / 8);
+  IMM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<ET>), dim3(ew_blocks((npix + rows_per_blk - 1) / rows_per_blk * EW_THREADS / 4, 4096)),
                                                dim3(EW_THREADS), 0, (hipStream_t)stream, (const uint16_t*)dout, lddo,
                                                (const uint16_t*)y, ldy, npix, c / 8, c, scale, shift, mean, rstd, relu,
                                                coef, (uint16_t*)dy_out, lddy));

@@ -187,6 +187,7 @@ class IMMEngine:
         self.vgg_w = OrderedDict((k, v.to(self.dev).contiguous()) for k, v in (vgg_weights or synthetic_vgg_weights()).items())
 
         self.prog_pack, self.prog_fwd, self.prog_bwd, self.prog_opt = [], [], [], []
+        self._pack_jobs, self._reduce_jobs = [], []
         self._training = True
         self._build_network()
         self.init_parameters(seed)
@@ -272,7 +273,7 @@ class IMMEngine:
         w, b = self.pview[scope + '/w'], self.pview[scope + '/b']
         rows = ops.round_up(co, 128)
         lay.wt = self._zeros(rows, fd.kpad, dtype=dt)
-        self._add(self.prog_pack, lambda: ops.pack_weights(w, lay.wt, 0, k, k, ci_real, co, ci_pad, rows, fd.kpad), 'pack')
+        self._pack_jobs.append(((w.data_ptr(), lay.wt.data_ptr(), 0, k, k, ci_real, co, ci_pad, rows, fd.kpad), rows * fd.kpad))
         lay.y = self._zeros(B, fd.ho, fd.wo, ldy, dtype=torch.float32 if out_f32 else dt)
         flops = 2.0 * npix * k * k * ci_real * co
         if bn:
@@ -310,8 +311,8 @@ class IMMEngine:
             rows_d = ops.round_up(ci_real, 128)
             kpad_d = ops.round_up(k * k * lddy, 32)
             lay.wt_d = self._zeros(rows_d, kpad_d, dtype=dt)
-            self._add(self.prog_pack,
-                      lambda: ops.pack_weights(w, lay.wt_d, 1, k, k, ci_real, co, lddy, rows_d, kpad_d), 'pack')
+            self._pack_jobs.append(((w.data_ptr(), lay.wt_d.data_ptr(), 1, k, k, ci_real, co, lddy, rows_d, kpad_d),
+                                    rows_d * kpad_d))
         else:
             lay.lddy = ldy if not out_f32 else ops.round_up(co, 8)
         # wgrad split: enough workgroups to fill the chip, at least 512 pixels per split
@@ -356,8 +357,8 @@ class IMMEngine:
         fd = lay.fd
         flops = 2.0 * npix * k * k * lay.ci_real * co
         self._add(self.prog_bwd, lambda: ops.conv2d_wgrad(fd, lay.x, dy, lddy, lay.slab, lay.nsplit), 'conv_wgrad', flops)
-        self._add(self.prog_bwd, lambda: ops.conv2d_wgrad_reduce(lay.slab, lay.nsplit, k, k, lay.ci_pad, lay.ci_real, co,
-                                                                  fd.kpad, gw), 'wgrad_reduce')
+        self._reduce_jobs.append(((lay.slab.data_ptr(), gw.data_ptr(), lay.nsplit, k * k, lay.ci_pad, lay.ci_real, co, fd.kpad),
+                                  k * k * lay.ci_real * co))
         if lay.needs_dgrad and dx is not None:
             dd = ops.dgrad_desc(B, lay.H, lay.W, lay.ci_real, lddx, lddy, lddy, k, lay.stride, 0)
             assert dd.kpad == lay.wt_d.shape[1], (dd.kpad, lay.wt_d.shape)
@@ -490,6 +491,9 @@ class IMMEngine:
         self.coef = self.loss_out[2 * nfeat:3 * nfeat]
 
         self._build_backward()
+        # one table-driven launch re-packs every trainable kernel (forward + dgrad layouts) after an update
+        self.pack_tab = ops.JobTable([j for j, _n in self._pack_jobs], [n for _j, n in self._pack_jobs], 2048, self.dev)
+        self._add(self.prog_pack, lambda: ops.pack_weights_multi(self.pack_tab, dt), 'pack')
 
         # ---- optimizer --------------------------------------------------------------------------------------
         self._add(self.prog_opt, lambda: ops.clip_adam_step(self.params, self.grads, self.adam_m, self.adam_v, self.tab,
@@ -617,6 +621,9 @@ class IMMEngine:
             d_e = self._act(B, He, He, nf8)
             self._add(self.prog_bwd, lambda: ops.resize_ac_bwd(self.d_joint, d_e, B, He, He, 16, 16, nf8, Cj, nf8), 'resize_ac_bwd')
             self._encoder_backward(self.enc_im, d_e, nf8)
+        # one table-driven launch sums every layer's split-K slabs into the flat gradient buffer
+        self.reduce_tab = ops.JobTable([j for j, _n in self._reduce_jobs], [n for _j, n in self._reduce_jobs], 256, self.dev)
+        self._add(self.prog_bwd, lambda: ops.wgrad_reduce_multi(self.reduce_tab), 'wgrad_reduce')
 
     def _encoder_backward(self, layers, d_out, ldd):
         B = self.B

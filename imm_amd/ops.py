@@ -90,6 +90,27 @@ def pack_weights(w, wt, mode, kh, kw, ci_real, co_real, c_pad, rows, kpad):
     call('imm_pack_weights', _p(w), _p(wt), dtype_enum(wt.dtype), mode, kh, kw, ci_real, co_real, c_pad, rows, kpad, _s())
 
 
+class JobTable:
+    """Device job table for the table-driven launches (imm_pack_weights_multi / imm_wgrad_reduce_multi)."""
+
+    def __init__(self, jobs, items_per_job, items_per_block, device):
+        first = [0]
+        for n in items_per_job:
+            first.append(first[-1] + max(1, -(-int(n) // items_per_block)))
+        rows = [list(j) + [0] * (12 - len(j)) for j in jobs]
+        self.jobs = torch.tensor(rows, dtype=torch.int64, device=device)
+        self.blk_first = torch.tensor(first, dtype=torch.int32, device=device)
+        self.n_jobs, self.n_blocks = len(jobs), first[-1]
+
+
+def pack_weights_multi(tab, dtype):
+    call('imm_pack_weights_multi', _p(tab.jobs), _p(tab.blk_first), tab.n_jobs, tab.n_blocks, dtype_enum(dtype), _s())
+
+
+def wgrad_reduce_multi(tab):
+    call('imm_wgrad_reduce_multi', _p(tab.jobs), _p(tab.blk_first), tab.n_jobs, tab.n_blocks, _s())
+
+
 def conv2d(desc, x, wt, bias, y, stats=None, mask=None):
     call('imm_conv2d', C.byref(desc), dtype_enum(x.dtype), _p(x), _p(wt), _p(bias), _p(y), _p(stats), _p(mask), _s())
 

@@ -184,6 +184,42 @@ def test_conv_wgrad(ops, case):
     close(dw, gw, 2e-3, 5e-4, 'wgrad/' + tag)     # f32 accumulate of exact bf16 products
 
 
+def test_table_driven_pack_and_reduce(ops):
+    """imm_pack_weights_multi / imm_wgrad_reduce_multi must equal their single-tensor counterparts bit for bit."""
+    dt = torch.bfloat16
+    layers = [(3, 3, 8, 32, 0), (3, 32, 32, 64, 0), (3, 266, 288, 256, 0), (3, 32, 16, 9, 1), (1, 256, 16, 10, 1)]
+    jobs, items, refs = [], [], []
+    for k, ci_real, c_pad, co, mode in layers:
+        w = rnd((k, k, ci_real, co), 100 + ci_real, 0.1, torch.float32).to(DEV).contiguous()
+        if mode == 0:
+            rows, kpad = ops.round_up(co, 128), ops.round_up(k * k * c_pad, 32)
+        else:
+            rows, kpad = ops.round_up(ci_real, 128), ops.round_up(k * k * c_pad, 32)
+        wt_ref = torch.zeros(rows, kpad, dtype=dt, device=DEV)
+        wt = torch.full((rows, kpad), float('nan'), dtype=dt, device=DEV)
+        ops.pack_weights(w, wt_ref, mode, k, k, ci_real, co, c_pad, rows, kpad)
+        jobs.append((w.data_ptr(), wt.data_ptr(), mode, k, k, ci_real, co, c_pad, rows, kpad)); items.append(rows * kpad)
+        refs.append((w, wt, wt_ref))
+    tab = ops.JobTable(jobs, items, 2048, DEV)
+    ops.pack_weights_multi(tab, dt)
+    torch.cuda.synchronize()
+    for _w, wt, wt_ref in refs:
+        assert torch.equal(wt.view(torch.int16), wt_ref.view(torch.int16))
+    jobs, items, refs = [], [], []
+    for k, ci_real, ci_pad, co, nsplit in [(3, 32, 32, 32, 5), (7, 3, 8, 32, 3), (3, 266, 288, 256, 2), (1, 256, 256, 10, 1)]:
+        kpad = ops.round_up(k * k * ci_pad, 32)
+        slab = rnd((nsplit, kpad, co), 200 + co, 1.0, torch.float32).to(DEV).contiguous()
+        dw_ref = torch.empty(k, k, ci_real, co, device=DEV); dw = torch.full((k, k, ci_real, co), float('nan'), device=DEV)
+        ops.conv2d_wgrad_reduce(slab, nsplit, k, k, ci_pad, ci_real, co, kpad, dw_ref)
+        jobs.append((slab.data_ptr(), dw.data_ptr(), nsplit, k * k, ci_pad, ci_real, co, kpad)); items.append(k * k * ci_real * co)
+        refs.append((slab, dw, dw_ref))
+    tab = ops.JobTable(jobs, items, 256, DEV)
+    ops.wgrad_reduce_multi(tab)
+    torch.cuda.synchronize()
+    for _s, dw, dw_ref in refs:
+        assert torch.equal(dw, dw_ref)
+
+
 def test_colsum(ops):
     dy = rnd((3000, 10), 31)
     dd = padded(dy, 16)
