@@ -136,7 +136,10 @@ def main():
             for _ in range(3):
                 rows = eng.run_timed(eng.prog_fwd) + eng.run_timed(eng.prog_bwd) + eng.run_timed(eng.prog_opt)
         by_tag = {}
-        for tag, ms, fl, nb in rows:
+        if os.environ.get('IMM_BENCH_DUMP'):
+            for tag, ms, fl, nb, name in rows:
+                sys.stderr.write('LAUNCH %-16s %-44s %9.1f us %8.1f TF\n' % (tag, name, ms * 1e3, fl / (ms * 1e-3) / 1e12 if fl else 0.0))
+        for tag, ms, fl, nb, _name in rows:
             d = by_tag.setdefault(tag, [0, 0.0, 0.0, 0.0])
             d[0] += 1; d[1] += ms; d[2] += fl; d[3] += nb
         ig = [by_tag[t] for t in IGEMM_TAGS if t in by_tag]

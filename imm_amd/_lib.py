@@ -66,6 +66,7 @@ _SIGS = {
     'imm_maxpool2_fwd': [_P, _P, _I, _I, _I, _I, _I, _P],
     'imm_maxpool2_bwd': [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     'imm_pack_image': [_P, _P, _I, _L, _P],
+    'imm_pack_image_taps': [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     'imm_softargmax_gauss_fwd': [_P, _I, _I, _I, _I, _I, _F, _I, _P, _P, _P, _P, _I, _I, _P],
     'imm_softargmax_gauss_bwd': [_P, _I, _I, _I, _I, _I, _I, _F, _I, _P, _P, _P, _P, _I, _P],
     'imm_gauss_render_f32': [_P, _I, _I, _F, _I, _P, _P],

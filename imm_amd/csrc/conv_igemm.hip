@@ -248,12 +248,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
         if (f_relu) v[r] = fmaxf(v[r], 0.f);
       }
       if (f_mask && mok) {
+        const uint16_t* mp = a.mask + (int64_t)m * a.ldmask + n;
+        if (n + 3 < a.co && (a.ldmask & 3) == 0) {
+          const uint2 mw = *(const uint2*)mp;
+          const uint16_t mh[4] = {(uint16_t)(mw.x & 0xffffu), (uint16_t)(mw.x >> 16), (uint16_t)(mw.y & 0xffffu), (uint16_t)(mw.y >> 16)};
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (n + r < a.co) {
-            const float ref = ET::to_f32(a.mask[(int64_t)m * a.ldmask + n + r]);
-            if (!(ref > 0.f)) v[r] = 0.f;
-          }
+          for (int r = 0; r < 4; ++r) if (!(ET::to_f32(mh[r]) > 0.f)) v[r] = 0.f;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (n + r < a.co && !(ET::to_f32(mp[r]) > 0.f)) v[r] = 0.f;
+        }
       }
       if (f_stats && mok) {
 #pragma unroll

@@ -39,6 +39,43 @@ extern "C" int imm_pack_image(const float* src, void* dst, int dtype, int64_t np
   return 0;
 }
 
+// First encoder convolution (7x7x3, imm/models/imm_model.py:190): a 3-channel NHWC image gives the
+// matrix cores a K-chunk of 3.  Unroll the kw horizontal taps into the channel axis instead:
+// dst[b,y,x, kx*3+ch] = src[b,y,x+kx-pad_l,ch] (zero outside, channels kw*3..ld-1 zero), so the
+// layer becomes a (kh x 1) convolution over ld=32 channels whose K tile is one vertical tap.
+template <typename ET>
+__global__ void pack_image_taps_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, int batch, int h, int w,
+                                       int kw, int pad_l, int ld) {
+  const int c8n = ld / 8;
+  const int64_t total = (int64_t)batch * h * w * c8n;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int cg = (int)(idx % c8n);
+    const int64_t p = idx / c8n;
+    const int x = (int)(p % w);
+    const int64_t row = p - x;          // pixel index of (b, y, 0)
+    float f[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = cg * 8 + e;
+      const int kx = c / 3, ch = c - kx * 3;
+      const int xx = x + kx - pad_l;
+      f[e] = (kx < kw && xx >= 0 && xx < w) ? src[(row + xx) * 3 + ch] : 0.f;
+    }
+    *(uint4*)(dst + p * ld + cg * 8) = pack8<ET>(f);
+  }
+}
+
+extern "C" int imm_pack_image_taps(const float* src, void* dst, int dtype, int batch, int h, int w, int kw, int pad_l,
+                                   int ld, void* stream) {
+  IMM_REQUIRE(src && dst && batch > 0 && h > 0 && w > 0 && kw > 0 && ld % 8 == 0 && ld >= 3 * kw, "pack_image_taps: args");
+  const int64_t total = (int64_t)batch * h * w * (ld / 8);
+  IMM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((pack_image_taps_kernel<ET>), dim3(ew_blocks(total)), dim3(EW_THREADS), 0,
+                                               (hipStream_t)stream, src, (uint16_t*)dst, batch, h, w, kw, pad_l, ld));
+  IMM_CHECK_LAUNCH("imm_pack_image_taps");
+  return 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // batch norm forward
 // ---------------------------------------------------------------------------------------------

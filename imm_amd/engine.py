@@ -123,10 +123,10 @@ def synthetic_vgg_weights(seed=2):
 
 
 class _Launch:
-    __slots__ = ('fn', 'tag', 'flops', 'bytes')
+    __slots__ = ('fn', 'tag', 'flops', 'bytes', 'name')
 
-    def __init__(self, fn, tag, flops=0.0, nbytes=0.0):
-        self.fn, self.tag, self.flops, self.bytes = fn, tag, flops, nbytes
+    def __init__(self, fn, tag, flops=0.0, nbytes=0.0, name=''):
+        self.fn, self.tag, self.flops, self.bytes, self.name = fn, tag, flops, nbytes, name
 
 
 class _ConvLayer:
@@ -251,31 +251,33 @@ class IMMEngine:
     # ------------------------------------------------------------------------------------------
     # network construction
     # ------------------------------------------------------------------------------------------
-    def _add(self, prog, fn, tag, flops=0.0, nbytes=0.0):
-        prog.append(_Launch(fn, tag, flops, nbytes))
+    def _add(self, prog, fn, tag, flops=0.0, nbytes=0.0, name=''):
+        prog.append(_Launch(fn, tag, flops, nbytes, name or getattr(self, '_cur_scope', '')))
 
     def _conv_block(self, scope, x, H, W, ci_real, ci_pad, ldx, co, k, stride, bn, relu, needs_dgrad,
-                    out=None, ldo=None, out_f32=False):
+                    out=None, ldo=None, out_f32=False, kw=None):
         """Registers forward launches now and returns a layer record whose .backward(d_out, dx) registers the
         backward launches later (in reverse order)."""
         B, dt, dev = self.B, self.dt, self.dev
+        self._cur_scope = scope
         lay = _ConvLayer()
         lay.scope, lay.bn, lay.relu, lay.x, lay.ldx = scope, bn, relu, x, ldx
-        lay.ci_real, lay.ci_pad, lay.co, lay.k, lay.stride, lay.H, lay.W = ci_real, ci_pad, co, k, stride, H, W
+        kw = k if kw is None else kw      # kw != k only for the tap-unrolled first encoder conv (7x1 over 21 channels)
+        lay.ci_real, lay.ci_pad, lay.co, lay.k, lay.stride, lay.H, lay.W, lay.kw = ci_real, ci_pad, co, k, stride, H, W, kw
         flags = L.CONV_BIAS | (L.CONV_OUT_F32 if out_f32 else 0)
         ldy = ops.round_up(co, 4) if out_f32 else ops.round_up(co, 8)
         lay.ldy = ldy
-        fd = ops.fwd_desc(B, H, W, ci_pad, ldx, co, ldy, k, stride, flags | (L.CONV_STATS if bn else 0))
-        fd_eval = ops.fwd_desc(B, H, W, ci_pad, ldx, co, ldy, k, stride, flags)
+        fd = ops.fwd_desc(B, H, W, ci_pad, ldx, co, ldy, k, stride, flags | (L.CONV_STATS if bn else 0), kw=kw)
+        fd_eval = ops.fwd_desc(B, H, W, ci_pad, ldx, co, ldy, k, stride, flags, kw=kw)
         lay.fd, lay.Ho, lay.Wo = fd, fd.ho, fd.wo
         npix = B * fd.ho * fd.wo
         lay.npix = npix
         w, b = self.pview[scope + '/w'], self.pview[scope + '/b']
         rows = ops.round_up(co, 128)
         lay.wt = self._zeros(rows, fd.kpad, dtype=dt)
-        self._pack_jobs.append(((w.data_ptr(), lay.wt.data_ptr(), 0, k, k, ci_real, co, ci_pad, rows, fd.kpad), rows * fd.kpad))
+        self._pack_jobs.append(((w.data_ptr(), lay.wt.data_ptr(), 0, k, kw, ci_real, co, ci_pad, rows, fd.kpad), rows * fd.kpad))
         lay.y = self._zeros(B, fd.ho, fd.wo, ldy, dtype=torch.float32 if out_f32 else dt)
-        flops = 2.0 * npix * k * k * ci_real * co
+        flops = 2.0 * npix * k * kw * ci_real * co
         if bn:
             nblk = ops.conv_stats_blocks(fd)
             lay.stats = self._zeros(nblk, 2, co)
@@ -305,7 +307,10 @@ class IMMEngine:
         # ---- backward resources -------------------------------------------------------------------
         lay.needs_dgrad = needs_dgrad
         if needs_dgrad:
-            lddy = ldy if not out_f32 else ops.round_up(co, 8)
+            assert kw == k
+            # 16-bit gradient of an f32 head is stored with 32 channels so that its dgrad takes the fast
+            # (one tap x 32 channels per K tile) path; the extra channels are zeros
+            lddy = ldy if not out_f32 else ops.round_up(co, 32)
             lay.lddy = lddy
             lay.dd = None   # filled in backward()
             rows_d = ops.round_up(ci_real, 128)
@@ -314,7 +319,7 @@ class IMMEngine:
             self._pack_jobs.append(((w.data_ptr(), lay.wt_d.data_ptr(), 1, k, k, ci_real, co, lddy, rows_d, kpad_d),
                                     rows_d * kpad_d))
         else:
-            lay.lddy = ldy if not out_f32 else ops.round_up(co, 8)
+            lay.lddy = ldy if not out_f32 else ops.round_up(co, 32)
         # wgrad split: enough workgroups to fill the chip, at least 512 pixels per split
         bn_w = 128 if co > 64 else 64 if co > 32 else 32 if co > 16 else 16
         tiles = -(-fd.kpad // 128) * -(-co // bn_w)
@@ -336,6 +341,7 @@ class IMMEngine:
         B, co, k = self.B, lay.co, lay.k
         npix = lay.npix
         scope = lay.scope
+        self._cur_scope = scope
         gw, gb = self.gview[scope + '/w'], self.gview[scope + '/b']
         if lay.bn:
             gg, gbeta = self.gview[scope + '/gamma'], self.gview[scope + '/beta']
@@ -355,10 +361,10 @@ class IMMEngine:
             dy, lddy = d_out, ldd
             self._add(self.prog_bwd, lambda: ops.colsum(dy, npix, lddy, co, lddy, lay.cs_partial, gb), 'colsum')
         fd = lay.fd
-        flops = 2.0 * npix * k * k * lay.ci_real * co
+        flops = 2.0 * npix * k * lay.kw * lay.ci_real * co
         self._add(self.prog_bwd, lambda: ops.conv2d_wgrad(fd, lay.x, dy, lddy, lay.slab, lay.nsplit), 'conv_wgrad', flops)
-        self._reduce_jobs.append(((lay.slab.data_ptr(), gw.data_ptr(), lay.nsplit, k * k, lay.ci_pad, lay.ci_real, co, fd.kpad),
-                                  k * k * lay.ci_real * co))
+        self._reduce_jobs.append(((lay.slab.data_ptr(), gw.data_ptr(), lay.nsplit, k * lay.kw, lay.ci_pad, lay.ci_real, co, fd.kpad),
+                                  k * lay.kw * lay.ci_real * co))
         if lay.needs_dgrad and dx is not None:
             dd = ops.dgrad_desc(B, lay.H, lay.W, lay.ci_real, lddx, lddy, lddy, k, lay.stride, 0)
             assert dd.kpad == lay.wt_d.shape[1], (dd.kpad, lay.wt_d.shape)
@@ -382,9 +388,15 @@ class IMMEngine:
 
         # ---- encoders -------------------------------------------------------------------------------
         def build_encoder(scope, src):
-            xin = self._act(B, S, S, 8)
-            self._add(self.prog_fwd, lambda: ops.pack_image(src, xin, B * S * S), 'pack_image', 0.0, B * S * S * 28.0)
-            layers, x, H, ci_real, ci_pad, ldx = [], xin, S, 3, 8, 8
+            # conv_1 is 7x7 over 3 channels: feed it the image with the 7 horizontal taps unrolled into 21(+11
+            # zero) channels, i.e. run it as a 7x1 convolution over 32 channels (same arithmetic, HWIO weights
+            # [7,7,3,co] are bit-identical to [7,1,21,co])
+            k1 = encoder_spec(nf)[0][0]
+            ld1 = ops.round_up(3 * k1, 32)
+            xin = self._act(B, S, S, ld1)
+            self._add(self.prog_fwd, lambda: ops.pack_image_taps(src, xin, B, S, S, k1, (k1 - 1) // 2, ld1), 'pack_image',
+                      0.0, B * S * S * (12.0 + 2.0 * ld1), name=scope + '/pack')
+            layers, x, H, ci_real, ci_pad, ldx = [], xin, S, 3 * k1, ld1, ld1
             spec = encoder_spec(nf)
             for i, (k, ci, co, stride) in enumerate(spec):
                 last = i == len(spec) - 1
@@ -392,7 +404,7 @@ class IMMEngine:
                 if last and scope == 'model/image_encoder' and He == 16:
                     out, ldo = self.joint, Cj       # conv_8 writes straight into the concat buffer
                 lay = self._conv_block('%s/encoder/conv_%d' % (scope, i + 1), x, H, H, ci_real, ci_pad, ldx, co, k,
-                                       stride, True, True, needs_dgrad=(i > 0), out=out, ldo=ldo)
+                                       stride, True, True, needs_dgrad=(i > 0), out=out, ldo=ldo, kw=(1 if i == 0 else None))
                 layers.append(lay)
                 x, H, ci_real, ci_pad, ldx = lay.out, lay.Ho, co, co, lay.ldo
             return layers
@@ -455,7 +467,7 @@ class IMMEngine:
             self.vgg_wt[name], self.vgg_wtd[name], self.vgg_desc[name] = wt, wtd, fd
             bias = self.vgg_w['vgg16/%s/biases' % name]
             self._add(self.prog_fwd, (lambda fd=fd, x=x, wt=wt, bias=bias, y=y: ops.conv2d(fd, x, wt, bias, y)), 'vgg_fwd',
-                      2.0 * 2 * B * H * H * 9 * cin * cout)
+                      2.0 * 2 * B * H * H * 9 * cin * cout, name='vgg16/' + name)
             self.vgg_act[name] = (y, H)
             x = y
             if name in VGG_POOL_AFTER:
@@ -539,7 +551,7 @@ class IMMEngine:
             wtd = self.vgg_wtd[name]
             src = dbuf[name]
             self._add(self.prog_bwd, lambda: ops.conv2d(dd, src, wtd, None, dst, None, mask_ref), 'vgg_dgrad',
-                      2.0 * B * H * H * 9 * cin * cout)
+                      2.0 * B * H * H * 9 * cin * cout, name='vgg16/' + name)
 
         def unpool(src_name, dy, relu_mask):
             y, H = acts[src_name]
@@ -655,7 +667,7 @@ class IMMEngine:
             e1.record()
             evs.append((l, e0, e1))
         torch.cuda.synchronize()
-        return [(l.tag, e0.elapsed_time(e1), l.flops, l.bytes) for l, e0, e1 in evs]
+        return [(l.tag, e0.elapsed_time(e1), l.flops, l.bytes, l.name) for l, e0, e1 in evs]
 
     def set_inputs(self, image, future_image, mask=None):
         self.in_image.copy_(image.reshape(self.in_image.shape))

@@ -37,11 +37,13 @@ def same_pad_before(n_in, k, s):
     return max((n_out - 1) * s + k - n_in, 0) // 2, n_out
 
 
-def fwd_desc(batch, hi, wi, ci, ldx, co, ldy, k, stride, flags, ldmask=0):
+def fwd_desc(batch, hi, wi, ci, ldx, co, ldy, k, stride, flags, ldmask=0, kw=None):
+    """k x k SAME convolution; kw (e.g. 1) gives a k x kw kernel (SAME along both axes)."""
+    kw = k if kw is None else kw
     pt, ho = same_pad_before(hi, k, stride)
-    pl, wo = same_pad_before(wi, k, stride)
-    return ConvDesc(batch=batch, hi=hi, wi=wi, ci=ci, ldx=ldx, ho=ho, wo=wo, co=co, ldy=ldy, kh=k, kw=k,
-                    stride=stride, pad_t=pt, pad_l=pl, updiv=1, kpad=round_up(k * k * ci, 32), flags=flags,
+    pl, wo = same_pad_before(wi, kw, stride)
+    return ConvDesc(batch=batch, hi=hi, wi=wi, ci=ci, ldx=ldx, ho=ho, wo=wo, co=co, ldy=ldy, kh=k, kw=kw,
+                    stride=stride, pad_t=pt, pad_l=pl, updiv=1, kpad=round_up(k * kw * ci, 32), flags=flags,
                     ldmask=ldmask)
 
 
@@ -195,6 +197,10 @@ def maxpool2_fwd(x, y, batch, h, w, c):
 
 def maxpool2_bwd(x, dy, dx, batch, h, w, c, relu_mask):
     call('imm_maxpool2_bwd', _p(x), _p(dy), _p(dx), dtype_enum(x.dtype), batch, h, w, c, int(relu_mask), _s())
+
+
+def pack_image_taps(src, dst, batch, h, w, kw, pad_l, ld):
+    call('imm_pack_image_taps', _p(src), _p(dst), dtype_enum(dst.dtype), batch, h, w, kw, pad_l, ld, _s())
 
 
 def pack_image(src, dst, npix):

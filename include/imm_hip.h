@@ -146,6 +146,11 @@ int imm_maxpool2_bwd(const void* x, const void* dy, void* dx, int dtype, int bat
 /* ---- inputs ---------------------------------------------------------------------------------- */
 /* f32 NHWC [npix,3] in [0,255] -> 16-bit [npix,8] (channels 3..7 zero): first encoder conv input */
 int imm_pack_image(const float* src, void* dst, int dtype, int64_t npix, void* stream);
+/* same source, horizontal taps unrolled into channels: dst[b,y,x,kx*3+ch] = src[b,y,x+kx-pad_l,ch] (zero outside
+ * the image; channels >= 3*kw zero; pixel stride ld).  Turns the 7x7x3 first encoder convolution
+ * (imm_model.py:190) into a 7x1 convolution over 32 channels with identical arithmetic. */
+int imm_pack_image_taps(const float* src, void* dst, int dtype, int batch, int h, int w, int kw, int pad_l, int ld,
+                        void* stream);
 
 /* ---- landmark bottleneck (imm_model.py:252-264 soft-argmax, :34-78 Gaussian maps, mode 'rot') -- */
 /* heat f32 [B,h,w,ldh] (k<K) -> mu [B,K,2] (y,x), py [B,h,K], px [B,w,K];

@@ -339,6 +339,38 @@ def test_maxpool(ops):
             np.testing.assert_allclose(float(dx.float().sum()), float(dy.float().sum()), rtol=1e-3)
 
 
+def test_first_conv_as_tap_unrolled_7x1(ops):
+    """conv 7x7x3 == pack_image_taps (7 horizontal taps -> 21 channels) + 7x1 conv over 32 channels."""
+    from imm_amd import _lib as L
+    B, S, co, dt = 2, 32, 32, torch.bfloat16
+    src = torch.rand(B, S, S, 3) * 255
+    w = rnd((7, 7, 3, co), 57, 0.01, torch.float32)
+    xin = torch.full((B, S, S, 32), float('nan'), dtype=dt, device=DEV)
+    ops.pack_image_taps(src.to(DEV), xin, B, S, S, 7, 3, 32)
+    torch.cuda.synchronize()
+    xp = torch.nn.functional.pad(src.to(dt), (0, 0, 3, 3))
+    for kx in range(7):
+        assert torch.equal(xin[..., kx * 3:kx * 3 + 3].cpu(), xp[:, :, kx:kx + S]), kx
+    assert float(xin[..., 21:].float().abs().max()) == 0.0
+    desc = ops.fwd_desc(B, S, S, 32, 32, co, co, 7, 1, 0, kw=1)
+    assert (desc.kh, desc.kw, desc.pad_t, desc.pad_l, desc.kpad) == (7, 1, 3, 0, 224)
+    wt = torch.zeros(128, desc.kpad, dtype=dt, device=DEV)
+    ops.pack_weights(w.to(DEV).contiguous(), wt, 0, 7, 1, 21, co, 32, 128, desc.kpad)
+    y = torch.empty(B, S, S, co, dtype=dt, device=DEV)
+    ops.conv2d(desc, xin, wt, None, y)
+    ref = O.conv2d_same(src.to(dt).float(), w.to(dt).float(), None, 1)
+    dy = rnd((B, S, S, co), 58)
+    slab = torch.empty(3, desc.kpad, co, device=DEV)
+    ops.conv2d_wgrad(desc, xin, dy.to(DEV), co, slab, 3)
+    dw = torch.empty(7, 7, 3, co, device=DEV)
+    ops.conv2d_wgrad_reduce(slab, 3, 7, 1, 32, 21, co, desc.kpad, dw)
+    torch.cuda.synchronize()
+    close(y, ref, 1e-2, 2e-3, 'conv7x1')
+    wr = torch.zeros(7, 7, 3, co, requires_grad=True)
+    (gw,) = torch.autograd.grad(O.conv2d_same(src.to(dt).float(), wr, None, 1), wr, dy.float())
+    close(dw, gw, 2e-3, 5e-4, 'wgrad7x1')
+
+
 def test_pack_image(ops):
     src = torch.rand(5, 7, 7, 3) * 255
     dst = torch.empty(5, 7, 7, 8, dtype=torch.bfloat16, device=DEV)
