@@ -12,23 +12,8 @@
 // The MFMA is issued as D[n][m] (weights as the row operand) so every lane ends up holding 4
 // CONSECUTIVE channels of one pixel -> 8-byte (16-bit out) / 16-byte (f32 out) NHWC stores.
 // Epilogue: bias, ReLU, ReLU-backward mask, and deterministic per-M-block batch-norm partial sums.
-#include "common.h"
-
-struct ConvArgs {
-  const uint16_t* x;
-  const uint16_t* wt;
-  const float* bias;
-  void* y;
-  float* stats;
-  const uint16_t* mask;
-  int M, hi, wi, ci8, ldx;
-  int ho, wo, co, ldy;
-  int kh, kw, stride, pad_t, pad_l, updiv;
-  int kpad, KT, ntaps;
-  int flags, ldmask;
-  int n_nblk, n_blocks;
-  uint32_t x_bytes, wt_bytes;   // buffer-descriptor extents (fast path: out-of-range lanes read zeros)
-};
+#include "conv_common.h"
+#include <stdlib.h>
 
 __device__ __forceinline__ int lds_chunk_idx(int row, int chunk) {
   // 64-byte rows; swizzle so the four 16-lane service groups of ds_read_b128 hit 16 distinct slots
@@ -209,118 +194,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     __syncthreads();
   }
 
-  // ---- epilogue ------------------------------------------------------------------------------
-  if (a.flags & IMM_DBG_NO_EPILOGUE) {
-    float t = 0.f;
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-      for (int j = 0; j < NT; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
-    if (t == 123456.789f) ((float*)a.y)[0] = t;   // keeps the accumulators live
-    return;
-  }
-  // lane holds D[n = 4*(lane>>4)+r][m = lane&15] of each 16x16 tile
-  const bool f_bias = a.flags & IMM_CONV_BIAS, f_relu = a.flags & IMM_CONV_RELU;
-  const bool f_stats = a.flags & IMM_CONV_STATS, f_mask = a.flags & IMM_CONV_MASK;
-  const bool f_f32 = a.flags & IMM_CONV_OUT_F32;
-  float s1[NT][4], s2[NT][4];
-#pragma unroll
-  for (int j = 0; j < NT; ++j)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { s1[j][r] = 0.f; s2[j][r] = 0.f; }
-
-#pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int n = n0 + wn * TN + j * 16 + 4 * (lane >> 4);
-    float bv[4] = {0.f, 0.f, 0.f, 0.f};
-    if (f_bias) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) if (n + r < a.co) bv[r] = a.bias[n + r];
-    }
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      const int m = m0 + wm * TM + i * 16 + (lane & 15);
-      const bool mok = m < a.M;
-      float v[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        v[r] = acc[i][j][r] + bv[r];
-        if (f_relu) v[r] = fmaxf(v[r], 0.f);
-      }
-      if (f_mask && mok) {
-        const uint16_t* mp = a.mask + (int64_t)m * a.ldmask + n;
-        if (n + 3 < a.co && (a.ldmask & 3) == 0) {
-          const uint2 mw = *(const uint2*)mp;
-          const uint16_t mh[4] = {(uint16_t)(mw.x & 0xffffu), (uint16_t)(mw.x >> 16), (uint16_t)(mw.y & 0xffffu), (uint16_t)(mw.y >> 16)};
-#pragma unroll
-          for (int r = 0; r < 4; ++r) if (!(ET::to_f32(mh[r]) > 0.f)) v[r] = 0.f;
-        } else {
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (n + r < a.co && !(ET::to_f32(mp[r]) > 0.f)) v[r] = 0.f;
-        }
-      }
-      if (f_stats && mok) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { s1[j][r] += v[r]; s2[j][r] += v[r] * v[r]; }
-      }
-      if (mok) {
-        if (f_f32) {
-          float* yp = (float*)a.y + (int64_t)m * a.ldy + n;
-          if (n + 3 < a.co) {
-            *(float4*)yp = make_float4(v[0], v[1], v[2], v[3]);
-          } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) if (n + r < a.co) yp[r] = v[r];
-          }
-        } else {
-          uint16_t* yp = (uint16_t*)a.y + (int64_t)m * a.ldy + n;
-          uint16_t h[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) h[r] = ET::from_f32(v[r]);
-          if (n + 3 < a.co) {
-            *(uint2*)yp = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
-          } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) if (n + r < a.co) yp[r] = h[r];
-          }
-        }
-      }
-    }
-  }
-
-  if (f_stats) {
-    // reduce over the 16 pixel-lanes of each channel quad, then over the WGM wave rows through LDS
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {
-          s1[j][r] += __shfl_xor(s1[j][r], o, 64);
-          s2[j][r] += __shfl_xor(s2[j][r], o, 64);
-        }
-      }
-    float* red = (float*)smem;  // [WGM][2][BN]; the main loop ended with a barrier
-    if ((lane & 15) == 0) {
-#pragma unroll
-      for (int j = 0; j < NT; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int nl = wn * TN + j * 16 + 4 * (lane >> 4) + r;
-          red[(wm * 2 + 0) * BN + nl] = s1[j][r];
-          red[(wm * 2 + 1) * BN + nl] = s2[j][r];
-        }
-    }
-    __syncthreads();
-    if (tid < BN && n0 + tid < a.co) {
-      float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-      for (int w = 0; w < WGM; ++w) { t1 += red[(w * 2 + 0) * BN + tid]; t2 += red[(w * 2 + 1) * BN + tid]; }
-      a.stats[((int64_t)mblk * 2 + 0) * a.co + n0 + tid] = t1;
-      a.stats[((int64_t)mblk * 2 + 1) * a.co + n0 + tid] = t2;
-    }
-  }
+  conv_epilogue<ET, BM, BN, WGM, WGN, MT, NT>(a, acc, tid, wm, wn, m0, n0, mblk, (float*)smem);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -384,6 +258,8 @@ static void launch_cfg(ConvArgs& a, bool fast, hipStream_t s) {
   else hipLaunchKernelGGL((conv_igemm_kernel<ET, BM, BN, WGM, WGN, false>), dim3(a.n_blocks), dim3(256), 0, s, a);
 }
 
+void imm_conv64_launch(int dtype, ConvArgs& a, int bm, int bn, hipStream_t s);   // conv_igemm64.hip
+
 template <typename ET>
 static int conv_launch(const imm_conv_desc* d, const void* x, const void* wt, const float* bias, void* y,
                        float* stats, const void* mask, hipStream_t s) {
@@ -402,7 +278,9 @@ static int conv_launch(const imm_conv_desc* d, const void* x, const void* wt, co
   const bool fast = (d->ci % 32 == 0) && xb < (1LL << 31) && wb < (1LL << 31);
   a.x_bytes = (uint32_t)(fast ? xb : 0);
   a.wt_bytes = (uint32_t)(fast ? wb : 0);
-  if (t.bm == 128 && t.bn == 128) launch_cfg<ET, 128, 128, 2, 2>(a, fast, s);
+  const bool deep = fast && (d->ci % 64 == 0) && t.bn >= 64 && !(d->flags & 0xf00) && !getenv("IMM_NO_DEEPK");
+  if (deep) imm_conv64_launch(ET::kEnum, a, t.bm, t.bn, s);
+  else if (t.bm == 128 && t.bn == 128) launch_cfg<ET, 128, 128, 2, 2>(a, fast, s);
   else if (t.bm == 128 && t.bn == 64) launch_cfg<ET, 128, 64, 2, 2>(a, fast, s);
   else if (t.bm == 64 && t.bn == 64) launch_cfg<ET, 64, 64, 2, 2>(a, fast, s);
   else if (t.bm == 128 && t.bn == 32) launch_cfg<ET, 128, 32, 4, 1>(a, fast, s);
