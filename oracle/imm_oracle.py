@@ -541,7 +541,7 @@ def train_step(P, S, opt, tower_inputs, cfg, clip=1.0, lr=1e-3, act_round=None):
     newP = adam_apply(P, gclip, opt, lr)
     newS = OrderedDict(S)
     newS.update({k: v.detach() for k, v in outs[-1]['new_state'].items()})
-    info = {'loss': sum(float(o['loss']) for o in outs) / n, 'outs': outs, 'grads': gmean, 'clipped': gclip}
+    info = {'loss': sum(float(o['loss'].detach()) for o in outs) / n, 'outs': outs, 'grads': gmean, 'clipped': gclip}
     return newP, newS, info
 
 

@@ -1,0 +1,130 @@
+"""Training entry point — counterpart of /root/reference/scripts/train.py (same flags, same YAML files).
+
+    python scripts/train.py --configs configs/paths/default.yaml configs/experiments/celeba-10pts.yaml [--ngpus N]
+    torchrun --nnodes=1 --nproc-per-node N scripts/train.py --configs ... --ngpus N      (one process per GPU)
+
+The accelerated part is the training step itself (imm_amd/engine.py -> libimm_hip.so).  The reference's
+tf.data input pipelines (CelebA / AFLW decode + thin-plate-spline warps, imm/datasets/*) are outside this
+build's scope: batches are synthetic unless --data-npz points at pre-rendered pairs
+{image, future_image, mask} stored as float32 NHWC arrays.
+"""
+from __future__ import print_function
+
+import argparse
+import os
+import os.path as osp
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, osp.dirname(osp.dirname(osp.abspath(__file__))))
+from imm_amd.models.imm_model import IMMModel          # noqa: E402
+from imm_amd.train import cnn_train_multi as tru        # noqa: E402
+from imm_amd.utils.config import load_configs           # noqa: E402
+
+
+class model_factory():
+    """scripts/train.py:30-40."""
+
+    def __init__(self, network, **kwargs):
+        self.network = network
+        self.net_args = kwargs
+
+    def create(self):
+        return self.network(**self.net_args)
+
+
+def smooth_mask(h, w, margin=10, step=20, b=0.4):
+    """imm/datasets/tps_dataset.py:47-67."""
+    def sstep(n, bb):
+        return 0.5 + 0.5 * torch.tanh(torch.linspace(-1.0, 1.0, n) / bb)
+
+    def strip(size):
+        return torch.cat([torch.zeros(margin), sstep(step, b), torch.ones(size - 2 * margin - 2 * step), sstep(step, -b),
+                          torch.zeros(margin)])
+    return strip(h)[:, None] * strip(w)[None]
+
+
+def synthetic_iter(batch, size, device, seed):
+    g = torch.Generator().manual_seed(seed)
+    mask = smooth_mask(size, size).reshape(1, size, size, 1).repeat(batch, 1, 1, 1).to(device)
+    while True:
+        yield {'image': (torch.rand(batch, size, size, 3, generator=g) * 255).to(device),
+               'future_image': (torch.rand(batch, size, size, 3, generator=g) * 255).to(device), 'mask': mask}
+
+
+def npz_iter(path, batch, device, rank, world):
+    d = np.load(path)
+    n = d['image'].shape[0]
+    i = rank * batch
+    while True:
+        idx = [(i + j) % n for j in range(batch)]
+        yield {k: torch.from_numpy(d[k][idx]).float().to(device) for k in ('image', 'future_image', 'mask')}
+        i += batch * world
+
+
+def main(args):
+    config = load_configs(args.configs)
+    train_config = config.training
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != max(args.ngpus, 1):
+        raise SystemExit('--ngpus %d needs `torchrun --nproc-per-node %d` (one process per GPU)' % (args.ngpus, args.ngpus))
+    if args.ngpus == 0:
+        raise SystemExit('CPU training (train_single_cpu, cnn_train_multi.py:252-301) is not provided: the product path '
+                         'has no CPU fallback; oracle/imm_oracle.py is the CPU restatement used for checking')
+    torch.cuda.set_device(local_rank)
+    dev = 'cuda:%d' % local_rank
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.distributed.init_process_group('nccl', device_id=torch.device(dev))
+
+    if train_config.optim.lower() != 'adam':
+        if train_config.optim.lower() in ('adadelta', 'adagrad'):
+            raise NotImplementedError('optimizer %s: only Adam (every shipped config) has a fused HIP kernel' % train_config.optim)
+        raise ValueError('Optimizer = %s not suppoerted' % train_config.optim)
+    hparams = dict(lr_start=float(train_config.lr.start_val), lr_decay=float(train_config.lr.decay),
+                   lr_step=int(train_config.lr.step), lr_multiple=float(args.lr_multiple), clip=float(train_config.gradclip))
+    batch_size = int(train_config.batch)
+    size = int(args.image_size)
+    factory = model_factory(IMMModel, config=config.model, global_step=None, device=dev, hparams=hparams, world_size=world)
+    opts = {'gpu_ids': list(range(args.ngpus)), 'batch_size': batch_size, 'image_size': size,
+            'log_dir': train_config.logdir, 'n_checkpoint': int(train_config.ncheckpoint)}
+    step = tru.setup_training(opts, factory, clip_value=train_config.gradclip)
+    eng = step.engine
+    if args.checkpoint is not None and osp.exists(args.checkpoint):
+        ck = torch.load(args.checkpoint, map_location='cpu')
+        eng.load_parameters(ck['params'], ck.get('state'))
+        if args.restore_optim and 'adam_m' in ck:
+            eng.adam_m.copy_(ck['adam_m']); eng.adam_v.copy_(ck['adam_v']); eng.step_count.fill_(int(ck['step']))
+    if args.reset_global_step >= 0:
+        eng.step_count.fill_(args.reset_global_step)
+    per_rank = batch_size // world
+    data = npz_iter(args.data_npz, per_rank, dev, rank, world) if args.data_npz else synthetic_iter(per_rank, size, dev, rank)
+
+    def save(n):
+        os.makedirs(train_config.logdir, exist_ok=True)
+        path = osp.join(train_config.logdir, 'model.ckpt-%d.pt' % n)
+        torch.save({'params': eng.named_parameters(), 'state': eng.named_state(), 'adam_m': eng.adam_m.cpu(),
+                    'adam_v': eng.adam_v.cpu(), 'step': int(eng.step_count)}, path)
+        print('saved', path)
+
+    tru.train_loop(opts, step, data, args.num_steps, log_every=10, checkpoint_fn=save)
+
+
+if __name__ == '__main__':
+    parser = argparse.ArgumentParser(description='Train Unsupervised Sequence Model')
+    parser.add_argument('--configs', nargs='+', default=[], help='Paths to the config files.')
+    parser.add_argument('--ngpus', type=int, default=1, required=False, help='Number of GPUs to use for training.')
+    parser.add_argument('--lr-multiple', type=float, default=1, help='multiplier on the learning rate.')
+    parser.add_argument('--checkpoint', type=str, default=None, help='checkpoint file-name of the *FULL* model to restore.')
+    parser.add_argument('--restore-optim', action='store_true', help='Restore the optimizer variables.')
+    parser.add_argument('--reset-global-step', type=int, default=-1, help='Force the value of global step.')
+    parser.add_argument('--ignore-missing-vars', action='store_true', help='Skip re-storing vars not in the checkpoint file.')
+    # additions of this build
+    parser.add_argument('--num-steps', type=int, default=30000000)
+    parser.add_argument('--image-size', type=int, default=128)
+    parser.add_argument('--data-npz', type=str, default=None, help='optional .npz with image/future_image/mask float32 NHWC arrays')
+    main(parser.parse_args())

@@ -1,0 +1,124 @@
+"""CPU-only checks of the host side: the C-ABI library loads and exports every declared symbol (no compute
+calls without a GPU), config/attr-dict behaviour, network specs against the oracle, launch-table helpers."""
+import os
+import re
+
+import pytest
+import torch
+
+from oracle import imm_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_builds_loads_and_exports_every_declared_symbol():
+    from imm_amd import build as B
+    from imm_amd import _lib as L
+    B.build()
+    lib = L.load()
+    header = open(os.path.join(ROOT, 'include', 'imm_hip.h')).read()
+    declared = sorted(set(re.findall(r'^(?:int|const char\*)\s+(imm_[a-z0-9_]+)\s*\(', header, flags=re.M)))
+    assert declared == L.declared_symbols(), set(declared) ^ set(L.declared_symbols())
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.imm_abi_version() == L.ABI_VERSION
+    # argument validation happens before any HIP call: exercisable without a device
+    assert lib.imm_pack_image(None, None, 0, 10, None) == -1
+    assert b'pack_image' in lib.imm_last_error()
+    assert lib.imm_bn_bwd_blocks(1000, 24) == -2 and lib.imm_bn_bwd_blocks(1 << 20, 32) > 0
+    d = L.ConvDesc(batch=1, hi=8, wi=8, ci=12, ldx=16, ho=8, wo=8, co=8, ldy=8, kh=3, kw=3, stride=1, pad_t=1, pad_l=1,
+                   updiv=1, kpad=128, flags=0, ldmask=0)
+    assert lib.imm_conv_stats_blocks(d) == -1 and b'multiple of 8' in lib.imm_last_error()
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from imm_amd import _lib as L
+    monkeypatch.setattr(L, '_lib', None)
+    monkeypatch.setattr(L, 'LIB_PATH', str(tmp_path / 'nope.so'))
+    with pytest.raises(L.ImmHipError):
+        L.load()
+
+
+def test_product_package_never_imports_the_oracle():
+    for dirpath, _d, files in os.walk(os.path.join(ROOT, 'imm_amd')):
+        for f in files:
+            if f.endswith('.py'):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r'^\s*(import|from)\s+oracle', src, flags=re.M), os.path.join(dirpath, f)
+                assert 'imm_oracle' not in src and 'np_ref' not in src, os.path.join(dirpath, f)
+    src = open(os.path.join(ROOT, 'scripts', 'train.py')).read() if os.path.exists(os.path.join(ROOT, 'scripts', 'train.py')) else ''
+    assert 'import oracle' not in src and 'from oracle' not in src
+
+
+def test_box_and_config_loader(tmp_path):
+    from imm_amd.utils.box import Box
+    from imm_amd.utils.config import load_configs
+    b = Box({'a': {'b': 1}, 'l': [{'c': 2}]})
+    assert b.a.b == 1 and b.l[0].c == 2 and hasattr(b, 'a') and not hasattr(b, 'zzz')
+    b.x = {'y': 3}
+    assert b.x.y == 3 and b.to_dict()['x'] == {'y': 3}
+    p1, p2 = tmp_path / 'paths.yaml', tmp_path / 'exp.yaml'
+    p1.write_text('logdir: data/logs\nvgg16_path: data/models/vgg16.caffemodel.h5\nnum: 7\n')
+    p2.write_text('name: e1\ntraining:\n  logdir: ${logdir}/${name}\n  n: ${num}\nmodel:\n  perceptual:\n    net_file: ${vgg16_path}\n')
+    c = load_configs([str(p1), str(p2)])
+    assert c.training.logdir == 'data/logs/e1' and c.training.n == 7 and c.model.perceptual.net_file.endswith('.h5')
+
+
+def test_shipped_reference_configs_parse_if_present():
+    ref = '/root/reference/configs'
+    if not os.path.isdir(ref):
+        pytest.skip('reference not mounted (GPU box)')
+    from imm_amd.utils.config import load_configs
+    for exp in sorted(os.listdir(os.path.join(ref, 'experiments'))):
+        c = load_configs([os.path.join(ref, 'paths', 'default.yaml'), os.path.join(ref, 'experiments', exp)])
+        assert c.model.gauss_mode == 'rot' and c.model.n_filters == 32 and c.training.batch == 50
+        assert c.training.logdir.startswith('data/logs/') and '${' not in str(c.to_dict())
+
+
+def test_network_specs_match_oracle():
+    from imm_amd import engine as E
+    from imm_amd.utils.box import Box
+    for K, S, total in ((10, 128, 4138067), (30, 128, 4189287), (50, 128, 4240507), (30, 256, 4201959)):
+        cfg = O.default_model_config(K)
+        spec = E.trainable_spec(Box(dict(cfg)), S)
+        P, _ = O.init_params(cfg, S)
+        assert [n for n, _s, _w in spec] == list(P.keys())
+        assert all(tuple(P[n].shape) == tuple(s) for n, s, _w in spec)
+        assert sum(int(torch.tensor(s).prod()) for _n, s, _w in spec) == total
+        assert all((w == 1e-5) == n.endswith('/w') for n, _s, w in spec)
+        assert E.render_sizes(Box(dict(cfg)), S) == O.render_sizes(cfg, S)
+        assert E.renderer_spec(Box(dict(cfg)), S, 9) == O.renderer_spec(cfg, S, 9)
+    # seeded initialisation is bit-identical to the oracle's (same generator, same draw order)
+    import numpy as np
+    rng = np.random.default_rng(1)
+    P, _ = O.init_params(O.default_model_config(10), 128)
+    first = E.truncated_normal(rng, (7, 7, 3, 32), 0.01)
+    assert np.array_equal(first, P['model/image_encoder/encoder/conv_1/w'].numpy())
+    w = E.synthetic_vgg_weights(2)
+    _, St = O.init_params(O.default_model_config(10), 128)
+    assert all(torch.equal(w[k], St[k]) for k in w)
+
+
+def test_segment_and_job_tables_on_cpu():
+    from imm_amd import ops
+    tab = ops.SegmentTable([10, 20000, 3], [1e-5, 0.0, 0.0], 'cpu')
+    assert tab.nseg == 3 and tab.total == 20013 and tab.offsets == [0, 10, 20010, 20013]
+    assert tab.seg_first_blk.tolist() == [0, 1, 4, 5] and tab.blk_begin.tolist() == [0, 10, 8202, 16394, 20010]
+    assert tab.blk_end.tolist() == [10, 8202, 16394, 20010, 20013] and tab.blk_seg.tolist() == [0, 1, 1, 1, 2]
+    jt = ops.JobTable([(1, 2, 3), (4, 5, 6)], [5000, 10], 2048, 'cpu')
+    assert jt.blk_first.tolist() == [0, 3, 4] and jt.n_blocks == 4 and jt.jobs.shape == (2, 12)
+    assert ops.same_pad_before(128, 3, 2) == (0, 64) and ops.same_pad_before(128, 7, 1) == (3, 128)
+    d = ops.dgrad_desc(2, 128, 128, 32, 32, 64, 64, 3, 2, 0)
+    assert (d.hi, d.ho, d.updiv, d.stride, d.pad_t, d.ci, d.co, d.kpad) == (64, 128, 2, 1, 2, 64, 32, 576)
+    d = ops.fwd_desc(2, 128, 128, 32, 32, 32, 32, 7, 1, 0, kw=1)
+    assert (d.kh, d.kw, d.pad_t, d.pad_l, d.kpad) == (7, 1, 3, 0, 224)
+
+
+def test_split_inputs_is_an_even_batch_split():
+    from imm_amd.train.cnn_train_multi import split_inputs
+    inp = O.synthetic_inputs(4, 64)
+    parts = [split_inputs(inp, 2, i) for i in range(2)]
+    assert all(p['image'].shape[0] == 2 for p in parts)
+    assert torch.equal(torch.cat([p['future_image'] for p in parts]), inp['future_image'])
+    with pytest.raises(AssertionError):
+        split_inputs(O.synthetic_inputs(3, 64), 2, 0)
