@@ -9,18 +9,38 @@
 // covers row (l>>3) of an 8-row group and fetches source chunk (l&7) ^ swz(row).  Out-of-image taps and
 // rows beyond M / channels beyond co use an out-of-range buffer offset, for which the DMA writes zeros.
 #include "conv_common.h"
+#include <stdlib.h>
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+
 __device__ __forceinline__ int lds64_idx(int row, int chunk) { return row * 8 + (chunk ^ ((row >> 1) & 7)); }
 
-template <typename ET, int BM, int BN>
+// One LDS-DMA instruction: 64 lanes x 16 B from buffer `rsrc` (+ per-lane voff + scalar soff; out-of-range lanes
+// deliver zeros) to LDS bytes [lds_addr, lds_addr + 1024).  Inline asm on purpose: hipcc models the builtin form
+// as an LDS write and drains vmcnt(0) in front of the next ds_read, which serialises the ring; an asm statement is
+// invisible to that bookkeeping, so the counted s_waitcnt below is the only wait.  M0 (LDS base of the DMA) is
+// written in the same statement that uses it (the compiler does not preserve M0 across statements).
+__device__ __forceinline__ void lds_dma16(u32x4_t rsrc, uint32_t lds_addr, uint32_t voff, uint32_t soff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+               :: "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+
+// NS-stage LDS ring: tile kt+NS-1 is DMA'd while tile kt feeds the MFMAs.  Ordering per K step (raw
+// s_barrier, counted vmcnt -- a __syncthreads() would drain the DMA queue to zero):
+//   s_waitcnt vmcnt((NS-2)*LPT)   this wave's share of tile kt has landed (LPT = DMA instructions per tile per wave)
+//   s_barrier                     => every wave's share has landed, and every wave finished reading tile kt-1
+//   issue tile kt+NS-1            into the stage tile kt-1 occupied
+//   ds_read + MFMA on tile kt
+template <typename ET, int BM, int BN, int NS>
 __global__ __launch_bounds__(256) void conv_igemm64_kernel(const ConvArgs a) {
   constexpr int WGM = 2, WGN = 2;
   constexpr int TM = BM / WGM, TN = BN / WGN, MT = TM / 16, NT = TN / 16;
   constexpr int A_INSTR = BM / 32, B_INSTR = BN / 32;   // 8-row wave instructions per wave per tile
   constexpr int BUF = (BM + BN) * 8;                    // uint4 per stage
-  __shared__ uint4 smem[2 * BUF];
+  extern __shared__ __attribute__((aligned(16))) uint4 smem[];   // NS * BUF
+  constexpr int LPT = A_INSTR + B_INSTR;
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WGN, wn = wid % WGN;
@@ -33,8 +53,10 @@ __global__ __launch_bounds__(256) void conv_igemm64_kernel(const ConvArgs a) {
   const int m0 = mblk * BM, n0 = nblk * BN;
 
   constexpr uint32_t OOB = 0x80000000u;
-  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)a.wt, 0, a.wt_bytes, 0x00020000);
+  const uint64_t xa = (uint64_t)a.x, wa = (uint64_t)a.wt;
+  const u32x4_t xr = {(uint32_t)xa, (uint32_t)(xa >> 32) & 0xffffu, a.x_bytes, 0x00020000u};
+  const u32x4_t wr = {(uint32_t)wa, (uint32_t)(wa >> 32) & 0xffffu, a.wt_bytes, 0x00020000u};
+  const uint32_t lds_base = (uint32_t)(size_t)(lds_void_t*)smem;
 
   // ---- loader state: this lane's rows and source chunk --------------------------------------------------
   const int lrow = lane >> 3, lchunk = lane & 7;
@@ -77,19 +99,13 @@ __global__ __launch_bounds__(256) void conv_igemm64_kernel(const ConvArgs a) {
   tap_offsets();
 
   auto issue_tile = [&](int kt, int buf) {
-    const int a_base = buf * BUF + (wid * A_INSTR) * 64;
-    const int b_base = buf * BUF + BM * 8 + (wid * B_INSTR) * 64;
-    const int a_soff = cs * 128, b_soff = kt * 128;
+    const uint32_t a_lds = __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)((buf * BUF + (wid * A_INSTR) * 64) * 16));
+    const uint32_t b_lds = __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)((buf * BUF + BM * 8 + (wid * B_INSTR) * 64) * 16));
+    const uint32_t a_soff = (uint32_t)(cs * 128), b_soff = (uint32_t)(kt * 128);
 #pragma unroll
-    for (int i = 0; i < A_INSTR; ++i) {
-      const uint32_t vo = a_voff[i];
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_t*)(smem + a_base + i * 64), 16, vo, a_soff, 0, 0);
-    }
+    for (int i = 0; i < A_INSTR; ++i) lds_dma16(xr, a_lds + i * 1024, a_voff[i], a_soff);
 #pragma unroll
-    for (int j = 0; j < B_INSTR; ++j) {
-      const uint32_t vo = b_voff[j];
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void_t*)(smem + b_base + j * 64), 16, vo, b_soff, 0, 0);
-    }
+    for (int j = 0; j < B_INSTR; ++j) lds_dma16(wr, b_lds + j * 1024, b_voff[j], b_soff);
     if (++cs == ncs) {
       cs = 0;
       if (++kx == a.kw) { kx = 0; ++ky; }
@@ -103,14 +119,23 @@ __global__ __launch_bounds__(256) void conv_igemm64_kernel(const ConvArgs a) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  issue_tile(0, 0);
-  __syncthreads();          // (an LDS-DMA in flight makes this wait vmcnt(0) first)
+#pragma unroll
+  for (int t = 0; t < NS - 1; ++t)
+    if (t < a.KT) issue_tile(t, t);
 
   const int frow = lane & 15, fchunk = lane >> 4;
+  int stage = 0;
   for (int kt = 0; kt < a.KT; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < a.KT) issue_tile(kt + 1, buf ^ 1);
-    const uint4* Ab = smem + buf * BUF;
+    // tiles kt .. min(kt+NS-2, KT-1) are in flight; tile kt must have landed
+    if (kt + NS - 2 < a.KT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * LPT) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    {
+      const int nt = kt + NS - 1;
+      int ns = stage + NS - 1; if (ns >= NS) ns -= NS;
+      if (nt < a.KT) issue_tile(nt, ns);
+    }
+    const uint4* Ab = smem + stage * BUF;
     const uint4* Bb = Ab + BM * 8;
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh) {
@@ -124,9 +149,21 @@ __global__ __launch_bounds__(256) void conv_igemm64_kernel(const ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = ET::mfma(bf[j], af[i], acc[i][j]);
     }
-    __syncthreads();
+    if (++stage == NS) stage = 0;
   }
+  __syncthreads();   // all waves done with LDS before the epilogue reuses it for the BN partial sums
   conv_epilogue<ET, BM, BN, WGM, WGN, MT, NT>(a, acc, tid, wm, wn, m0, n0, mblk, (float*)smem);
+}
+
+template <typename ET, int BM, int BN, int NS>
+static void launch64_cfg(const ConvArgs& a, hipStream_t s) {
+  constexpr int lds = NS * (BM + BN) * 128;
+  static bool attr_set = false;   // per instantiation; > 64 KB of dynamic LDS needs the opt-in once
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)conv_igemm64_kernel<ET, BM, BN, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_igemm64_kernel<ET, BM, BN, NS>), dim3(a.n_blocks), dim3(256), lds, s, a);
 }
 
 template <typename ET>
@@ -134,9 +171,14 @@ static void launch64(ConvArgs& a, int bm, int bn, hipStream_t s) {
   const int mblk = (a.M + bm - 1) / bm;
   a.n_blocks = mblk * a.n_nblk;
   a.KT = a.kpad / 64;
-  if (bm == 128 && bn == 128) hipLaunchKernelGGL((conv_igemm64_kernel<ET, 128, 128>), dim3(a.n_blocks), dim3(256), 0, s, a);
-  else if (bm == 128 && bn == 64) hipLaunchKernelGGL((conv_igemm64_kernel<ET, 128, 64>), dim3(a.n_blocks), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((conv_igemm64_kernel<ET, 64, 64>), dim3(a.n_blocks), dim3(256), 0, s, a);
+  // stage count: big tiles are throughput-bound and want 2-3 co-resident workgroups per CU (2 stages = 64 / 48 KB);
+  // the 64x64 tile is used when the grid is small (deep layers), is latency-bound and wants a deeper ring instead
+  static const int ns64 = getenv("IMM_NS64") ? atoi(getenv("IMM_NS64")) : 4;
+  if (bm == 128 && bn == 128) launch64_cfg<ET, 128, 128, 2>(a, s);
+  else if (bm == 128 && bn == 64) launch64_cfg<ET, 128, 64, 2>(a, s);
+  else if (ns64 == 3) launch64_cfg<ET, 64, 64, 3>(a, s);
+  else if (ns64 == 6) launch64_cfg<ET, 64, 64, 6>(a, s);
+  else launch64_cfg<ET, 64, 64, 4>(a, s);
 }
 
 // called from conv_igemm.hip's dispatcher
