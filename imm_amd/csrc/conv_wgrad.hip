@@ -11,6 +11,7 @@
 // The pixel range is split over `nsplit` blocks per tile; each writes its f32 partial tile to
 // slab[split][kpad][co]; imm_conv2d_wgrad_reduce sums slabs in a fixed order (deterministic).
 #include "common.h"
+#include <stdlib.h>
 
 struct WgradArgs {
   const uint16_t* x;
@@ -25,27 +26,33 @@ struct WgradArgs {
   uint32_t x_bytes, dy_bytes;
 };
 
-__device__ __forceinline__ int wg_dword_idx(int row, int pp) {
-  // LDS image: 64-byte rows = 16 dwords (32 pixels); chunk = pp>>2 swizzled like the forward kernel
-  return row * 16 + ((((pp >> 2) ^ (((row >> 3) & 1) * 3))) << 2) + (pp & 3);
+// LDS image: row = kk (or n), 32*PSUB pixels = 16*PSUB dwords = 4*PSUB 16-byte chunks per row.
+// chunk c of row r is stored at c ^ swz(r); swz makes the 16-row x 4-chunk ds_read_b128 fragments conflict-free
+// (PSUB=1: 64-byte rows, the forward kernel's pattern; PSUB=4: 256-byte rows, every row starts on bank 0, so the
+// 16 rows of a fragment must land on 16 different chunks: swz = r & 15).
+template <int PSUB>
+__device__ __forceinline__ int wg_swz(int row) { return PSUB == 1 ? (((row >> 3) & 1) * 3) : (row & (4 * PSUB - 1)); }
+template <int PSUB>
+__device__ __forceinline__ int wg_dword_idx(int row, int u, int pp) {   // pixel pair pp of sub-step u
+  return row * (16 * PSUB) + (((u * 4 + (pp >> 2)) ^ wg_swz<PSUB>(row)) << 2) + (pp & 3);
 }
-__device__ __forceinline__ int wg_chunk_idx(int row, int chunk) {
-  return row * 4 + (chunk ^ (((row >> 3) & 1) * 3));
-}
+template <int PSUB>
+__device__ __forceinline__ int wg_chunk_idx(int row, int chunk) { return row * (4 * PSUB) + (chunk ^ wg_swz<PSUB>(row)); }
 
-// FAST (ho*wo % 32 == 0 and wo | 32 or 32 | wo): a 32-pixel step never crosses an image, so the image
-// index and the step's top-left (y0,x0) are wave-uniform; each lane adds compile-time-constant pixel
-// offsets and the image / pixel-block base rides in the buffer instruction's scalar offset.
-template <typename ET, int BK, int BN, int WGK, int WGN, bool FAST>
+// FAST (ho*wo % 32 == 0 and wo | 32 or 32 | wo): a 32-pixel sub-step never crosses an image, so the image
+// index and the sub-step's top-left (y0,x0) are wave-uniform; each lane adds constant pixel offsets and the
+// image / pixel-block base rides in the buffer instruction's scalar offset.  PSUB sub-steps (32 pixels each) are
+// staged per barrier: 4*PSUB MFMA k-steps of work and 2*PSUB independent 16-byte loads per lane in flight.
+template <typename ET, int BK, int BN, int WGK, int WGN, bool FAST, int PSUB>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
   constexpr int TK = BK / WGK, TN = BN / WGN;
   constexpr int KT_ = TK / 16, NT = TN / 16;
-  constexpr int A_PASSES = BK / 128;              // 16 k8-groups x 16 pixel pairs per pass
-  static_assert(BK % 128 == 0, "BK multiple of 128");
+  static_assert(BK == 128, "one pass of 16 k8-groups x 16 pixel pairs");
   static_assert(WGK * WGN == 4, "4 waves");
-  constexpr int BUF = (BK + BN) * 4;              // uint4 per stage
+  static_assert(FAST || PSUB == 1, "multi-sub-step staging needs the uniform pixel walk");
+  constexpr int BUF = (BK + BN) * 4 * PSUB;       // uint4 per stage
 
-  __shared__ uint4 smem[2 * BUF];
+  extern __shared__ __attribute__((aligned(16))) uint4 smem[];   // 2 * BUF
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wk = wid / WGN, wn = wid % WGN;
@@ -59,20 +66,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
 
   // ---- loader state ---------------------------------------------------------------------------
   const int pp = tid & 15, g = tid >> 4;          // pixel pair / 8-channel group
-  // A: group g of pass i covers kk = k0 + (i*16+g)*8 .. +7 -> fixed (tap, c8) per thread
-  int a_ky[A_PASSES], a_kx[A_PASSES], a_c8[A_PASSES];
-  bool a_ok[A_PASSES];
-#pragma unroll
-  for (int i = 0; i < A_PASSES; ++i) {
-    const int k8 = (k0 >> 3) + i * 16 + g;
+  // A: group g covers kk = k0 + g*8 .. +7 -> fixed (tap, c8) per thread
+  int a_ky, a_kx, a_c8;
+  bool a_ok;
+  {
+    const int k8 = (k0 >> 3) + g;
     const int tap = k8 / a.ci8;
-    a_c8[i] = k8 - tap * a.ci8;
-    a_ky[i] = tap / a.kw;
-    a_kx[i] = tap - a_ky[i] * a.kw;
-    a_ok[i] = tap < a.ntaps;
+    a_c8 = k8 - tap * a.ci8;
+    a_ky = tap / a.kw;
+    a_kx = tap - a_ky * a.kw;
+    a_ok = tap < a.ntaps;
   }
   const bool b_ok = (g < BN / 8) && (n0 + g * 8 < a.lddy);   // dY channel group inside the row
-  uint4 ra[A_PASSES][2], rb[2];
+  uint4 ra[PSUB][2], rb[PSUB][2];
   const uint4 zero4 = make_uint4(0, 0, 0, 0);
   typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
   constexpr uint32_t OOB = 0x80000000u;
@@ -84,9 +90,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
     const int hw = a.ho * a.wo;
     img = pcur / hw; const int rem = pcur - img * hw; oy = rem / a.wo; ox = rem - oy * a.wo;
   }
-  // ---- fast path state: uniform step origin + per-lane constant offsets -------------------------------
+  // ---- fast path state: uniform sub-step origin + per-lane constant offsets ---------------------------
   int s_img = 0, s_y0 = 0, s_x0 = 0, s_p0 = p_begin;      // wave-uniform
-  int cy[A_PASSES][2], cx[A_PASSES][2];
+  int cy[2], cx[2];
   uint32_t b_voff[2];
   __amdgpu_buffer_rsrc_t xr, dr;
   if constexpr (FAST) {
@@ -102,83 +108,78 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
       const int j = 2 * pp + q;
       const int jy = (a.wo >= 32) ? 0 : j / a.wo;
       const int jx = (a.wo >= 32) ? j : j - jy * a.wo;
-#pragma unroll
-      for (int i = 0; i < A_PASSES; ++i) {
-        cy[i][q] = jy * a.stride - a.pad_t + a_ky[i];
-        cx[i][q] = jx * a.stride - a.pad_l + a_kx[i];
-      }
+      cy[q] = jy * a.stride - a.pad_t + a_ky;
+      cx[q] = jx * a.stride - a.pad_l + a_kx;
       b_voff[q] = b_ok ? (uint32_t)((j * a.lddy + n0 + g * 8) * 2) : OOB;
     }
   }
 
-  auto load_tile = [&]() {
+  auto load_sub = [&](int u) {       // one 32-pixel sub-step into ra[u], rb[u]
     if constexpr (FAST) {
       const uint32_t a_soff = (uint32_t)(s_img * a.hi * a.wi) * (uint32_t)(a.ldx * 2);
       const uint32_t b_soff = (uint32_t)s_p0 * (uint32_t)(a.lddy * 2);
       const int ys = s_y0 * a.stride, xs = s_x0 * a.stride;
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
-#pragma unroll
-        for (int i = 0; i < A_PASSES; ++i) {
-          const int iy = ys + cy[i][q], ix = xs + cx[i][q];
-          const bool ok = a_ok[i] && ((unsigned)iy < (unsigned)a.hi) && ((unsigned)ix < (unsigned)a.wi);
-          const uint32_t vo = ok ? (uint32_t)(((iy * a.wi + ix) * a.ldx + a_c8[i] * 8) * 2) : OOB;
-          const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(xr, vo, a_soff, 0);
-          ra[i][q] = make_uint4(v.x, v.y, v.z, v.w);
-        }
-        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(dr, b_voff[q], b_soff, 0);
-        rb[q] = make_uint4(v.x, v.y, v.z, v.w);
+        const int iy = ys + cy[q], ix = xs + cx[q];
+        const bool ok = a_ok && ((unsigned)iy < (unsigned)a.hi) && ((unsigned)ix < (unsigned)a.wi);
+        const uint32_t vo = ok ? (uint32_t)(((iy * a.wi + ix) * a.ldx + a_c8 * 8) * 2) : OOB;
+        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(xr, vo, a_soff, 0);
+        ra[u][q] = make_uint4(v.x, v.y, v.z, v.w);
+        const u32x4_t w = __builtin_amdgcn_raw_buffer_load_b128(dr, b_voff[q], b_soff, 0);
+        rb[u][q] = make_uint4(w.x, w.y, w.z, w.w);
       }
       // advance the uniform origin by 32 pixels
       s_p0 += 32;
       if (a.wo >= 32) { s_x0 += 32; if (s_x0 == a.wo) { s_x0 = 0; ++s_y0; } }
       else s_y0 += 32 / a.wo;
       if (s_y0 == a.ho) { s_y0 = 0; ++s_img; }
-      return;
-    }
-    // the two pixels of the pair (ox even start, wo even => same row; handled generally below)
+    } else {
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      int qi = img, qy = oy, qx = ox + q;
-      if (qx >= a.wo) { qx -= a.wo; if (++qy == a.ho) { qy = 0; ++qi; } }
-      const bool pok = (pcur + q) < p_end;
-#pragma unroll
-      for (int i = 0; i < A_PASSES; ++i) {
-        const int iy = qy * a.stride - a.pad_t + a_ky[i], ix = qx * a.stride - a.pad_l + a_kx[i];
-        const bool ok = pok && a_ok[i] && ((unsigned)iy < (unsigned)a.hi) && ((unsigned)ix < (unsigned)a.wi);
-        ra[i][q] = zero4;
-        if (ok) ra[i][q] = *(const uint4*)(a.x + ((((int64_t)qi * a.hi + iy) * a.wi + ix) * a.ldx + a_c8[i] * 8));
+      for (int q = 0; q < 2; ++q) {
+        int qi = img, qy = oy, qx = ox + q;
+        if (qx >= a.wo) { qx -= a.wo; if (++qy == a.ho) { qy = 0; ++qi; } }
+        const bool pok = (pcur + q) < p_end;
+        const int iy = qy * a.stride - a.pad_t + a_ky, ix = qx * a.stride - a.pad_l + a_kx;
+        const bool ok = pok && a_ok && ((unsigned)iy < (unsigned)a.hi) && ((unsigned)ix < (unsigned)a.wi);
+        ra[u][q] = zero4;
+        if (ok) ra[u][q] = *(const uint4*)(a.x + ((((int64_t)qi * a.hi + iy) * a.wi + ix) * a.ldx + a_c8 * 8));
+        rb[u][q] = zero4;
+        if (pok && b_ok) rb[u][q] = *(const uint4*)(a.dy + ((int64_t)(pcur + q) * a.lddy + n0 + g * 8));
       }
-      rb[q] = zero4;
-      if (pok && b_ok) rb[q] = *(const uint4*)(a.dy + ((int64_t)(pcur + q) * a.lddy + n0 + g * 8));
+      pcur += 32;
+      ox += 32;
+      while (ox >= a.wo) { ox -= a.wo; if (++oy == a.ho) { oy = 0; ++img; } }
     }
-    // advance 32 pixels
-    pcur += 32;
-    ox += 32;
-    while (ox >= a.wo) { ox -= a.wo; if (++oy == a.ho) { oy = 0; ++img; } }
+  };
+  auto load_tile = [&]() {
+#pragma unroll
+    for (int u = 0; u < PSUB; ++u) load_sub(u);
   };
   auto store_tile = [&](int buf) {
     uint32_t* Ab = (uint32_t*)(smem + buf * BUF);
-    uint32_t* Bb = Ab + BK * 16;
+    uint32_t* Bb = Ab + BK * 16 * PSUB;
 #pragma unroll
-    for (int i = 0; i < A_PASSES; ++i) {
-      const uint32_t lo[4] = {ra[i][0].x, ra[i][0].y, ra[i][0].z, ra[i][0].w};
-      const uint32_t hi[4] = {ra[i][1].x, ra[i][1].y, ra[i][1].z, ra[i][1].w};
+    for (int u = 0; u < PSUB; ++u) {
+      {
+        const uint32_t lo[4] = {ra[u][0].x, ra[u][0].y, ra[u][0].z, ra[u][0].w};
+        const uint32_t hi[4] = {ra[u][1].x, ra[u][1].y, ra[u][1].z, ra[u][1].w};
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int row = (i * 16 + g) * 8 + 2 * j;
-        Ab[wg_dword_idx(row, pp)] = (lo[j] & 0xffffu) | (hi[j] << 16);
-        Ab[wg_dword_idx(row + 1, pp)] = (lo[j] >> 16) | (hi[j] & 0xffff0000u);
+        for (int j = 0; j < 4; ++j) {
+          const int row = g * 8 + 2 * j;
+          Ab[wg_dword_idx<PSUB>(row, u, pp)] = (lo[j] & 0xffffu) | (hi[j] << 16);
+          Ab[wg_dword_idx<PSUB>(row + 1, u, pp)] = (lo[j] >> 16) | (hi[j] & 0xffff0000u);
+        }
       }
-    }
-    if (g < BN / 8) {
-      const uint32_t lo[4] = {rb[0].x, rb[0].y, rb[0].z, rb[0].w};
-      const uint32_t hi[4] = {rb[1].x, rb[1].y, rb[1].z, rb[1].w};
+      if (g < BN / 8) {
+        const uint32_t lo[4] = {rb[u][0].x, rb[u][0].y, rb[u][0].z, rb[u][0].w};
+        const uint32_t hi[4] = {rb[u][1].x, rb[u][1].y, rb[u][1].z, rb[u][1].w};
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int row = g * 8 + 2 * j;
-        Bb[wg_dword_idx(row, pp)] = (lo[j] & 0xffffu) | (hi[j] << 16);
-        Bb[wg_dword_idx(row + 1, pp)] = (lo[j] >> 16) | (hi[j] & 0xffff0000u);
+        for (int j = 0; j < 4; ++j) {
+          const int row = g * 8 + 2 * j;
+          Bb[wg_dword_idx<PSUB>(row, u, pp)] = (lo[j] & 0xffffu) | (hi[j] << 16);
+          Bb[wg_dword_idx<PSUB>(row + 1, u, pp)] = (lo[j] >> 16) | (hi[j] & 0xffff0000u);
+        }
       }
     }
   };
@@ -189,7 +190,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  const int nsteps = (p_end - p_begin + 31) / 32;
+  const int nsteps = (p_end - p_begin + 32 * PSUB - 1) / (32 * PSUB);
   if (nsteps > 0) {
     load_tile();
     store_tile(0);
@@ -201,16 +202,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
     const bool more = (st + 1) < nsteps;
     if (more) load_tile();
     const uint4* Ab = smem + buf * BUF;
-    const uint4* Bb = Ab + BK * 4;
-    uint4 af[KT_], bf[NT];
+    const uint4* Bb = Ab + BK * 4 * PSUB;
 #pragma unroll
-    for (int i = 0; i < KT_; ++i) af[i] = Ab[wg_chunk_idx(wk * TK + i * 16 + frow, fchunk)];
+    for (int u = 0; u < PSUB; ++u) {
+      uint4 af[KT_], bf[NT];
 #pragma unroll
-    for (int j = 0; j < NT; ++j) bf[j] = Bb[wg_chunk_idx(wn * TN + j * 16 + frow, fchunk)];
+      for (int i = 0; i < KT_; ++i) af[i] = Ab[wg_chunk_idx<PSUB>(wk * TK + i * 16 + frow, u * 4 + fchunk)];
 #pragma unroll
-    for (int i = 0; i < KT_; ++i)
+      for (int j = 0; j < NT; ++j) bf[j] = Bb[wg_chunk_idx<PSUB>(wn * TN + j * 16 + frow, u * 4 + fchunk)];
 #pragma unroll
-      for (int j = 0; j < NT; ++j) acc[i][j] = ET::mfma(bf[j], af[i], acc[i][j]);   // D[n][kk]
+      for (int i = 0; i < KT_; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = ET::mfma(bf[j], af[i], acc[i][j]);   // D[n][kk]
+    }
     if (more) store_tile(buf ^ 1);
     __syncthreads();
   }
@@ -235,11 +239,24 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
   }
 }
 
+template <typename ET, int BK, int BN, int WGK, int WGN, bool FAST, int PSUB>
+static void wg_launch_one(const WgradArgs& a, hipStream_t s) {
+  constexpr int lds = 2 * (BK + BN) * 64 * PSUB;
+  static bool attr_set = false;
+  if (!attr_set && lds > 64 * 1024) {
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<ET, BK, BN, WGK, WGN, FAST, PSUB>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_wgrad_kernel<ET, BK, BN, WGK, WGN, FAST, PSUB>), dim3(a.n_kblk * a.n_nblk * a.nsplit),
+                     dim3(256), lds, s, a);
+}
+
 template <typename ET, int BK, int BN, int WGK, int WGN>
-static void wg_launch_cfg(const WgradArgs& a, bool fast, hipStream_t s) {
-  const dim3 grid(a.n_kblk * a.n_nblk * a.nsplit);
-  if (fast) hipLaunchKernelGGL((conv_wgrad_kernel<ET, BK, BN, WGK, WGN, true>), grid, dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((conv_wgrad_kernel<ET, BK, BN, WGK, WGN, false>), grid, dim3(256), 0, s, a);
+static void wg_launch_cfg(const WgradArgs& a, bool fast, int psub, hipStream_t s) {
+  if (fast && psub == 4) wg_launch_one<ET, BK, BN, WGK, WGN, true, 4>(a, s);
+  else if (fast) wg_launch_one<ET, BK, BN, WGK, WGN, true, 1>(a, s);
+  else wg_launch_one<ET, BK, BN, WGK, WGN, false, 1>(a, s);
 }
 
 static int wgrad_bn(int co) { return co > 64 ? 128 : co > 32 ? 64 : co > 16 ? 32 : 16; }
@@ -258,18 +275,21 @@ static int wgrad_launch(const imm_conv_desc* d, const void* x, const void* dy, i
   a.n_kblk = (d->kpad + 127) / 128;
   a.n_nblk = (d->co + bn - 1) / bn;
   a.nsplit = nsplit;
-  int pps = (a.P + nsplit - 1) / nsplit;
-  pps = (pps + 31) / 32 * 32;
-  a.p_per_split = pps;
   const int hw = d->ho * d->wo;
   const int64_t xb = (int64_t)d->batch * d->hi * d->wi * d->ldx * 2, db = (int64_t)a.P * lddy * 2;
   const bool fast = (hw % 32 == 0) && (d->wo % 32 == 0 || 32 % d->wo == 0) && xb < (1LL << 31) && db < (1LL << 31);
+  static const int psub_env = getenv("IMM_WGRAD_PSUB") ? atoi(getenv("IMM_WGRAD_PSUB")) : 1;
+  // 128 pixels per barrier when the pixel count allows it and each split still gets >= 4 steps
+  int pps = (a.P + nsplit - 1) / nsplit;
+  const int psub = (fast && psub_env == 4 && a.P % 128 == 0 && pps >= 512 && bn <= 64) ? 4 : 1;
+  pps = (pps + 32 * psub - 1) / (32 * psub) * (32 * psub);
+  a.p_per_split = pps;
   a.x_bytes = (uint32_t)(fast ? xb : 0);
   a.dy_bytes = (uint32_t)(fast ? db : 0);
-  if (bn == 128) wg_launch_cfg<ET, 128, 128, 2, 2>(a, fast, s);
-  else if (bn == 64) wg_launch_cfg<ET, 128, 64, 2, 2>(a, fast, s);
-  else if (bn == 32) wg_launch_cfg<ET, 128, 32, 4, 1>(a, fast, s);
-  else wg_launch_cfg<ET, 128, 16, 4, 1>(a, fast, s);
+  if (bn == 128) wg_launch_cfg<ET, 128, 128, 2, 2>(a, fast, psub, s);
+  else if (bn == 64) wg_launch_cfg<ET, 128, 64, 2, 2>(a, fast, psub, s);
+  else if (bn == 32) wg_launch_cfg<ET, 128, 32, 4, 1>(a, fast, psub, s);
+  else wg_launch_cfg<ET, 128, 16, 4, 1>(a, fast, psub, s);
   IMM_CHECK_LAUNCH("imm_conv2d_wgrad");
   return 0;
 }

@@ -88,11 +88,27 @@ __device__ __forceinline__ void reduce_partials_32x32(const float* __restrict__ 
   double acc[NS];
 #pragma unroll
   for (int s = 0; s < NS; ++s) acc[s] = 0.0;
-  if (ch < c)
-    for (int b = threadIdx.y; b < nblk; b += 32) {
+  if (ch < c) {
+    // 4 independent row chains per lane keep 4*NS loads in flight (the loop is latency-, not bandwidth-bound)
+    double a1[NS], a2[NS], a3[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) { a1[s] = 0.0; a2[s] = 0.0; a3[s] = 0.0; }
+    int b = threadIdx.y;
+    for (; b + 96 < nblk; b += 128) {
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const float v0 = partial[((int64_t)b * NS + s) * c + ch], v1 = partial[((int64_t)(b + 32) * NS + s) * c + ch];
+        const float v2 = partial[((int64_t)(b + 64) * NS + s) * c + ch], v3 = partial[((int64_t)(b + 96) * NS + s) * c + ch];
+        acc[s] += (double)v0; a1[s] += (double)v1; a2[s] += (double)v2; a3[s] += (double)v3;
+      }
+    }
+    for (; b < nblk; b += 32) {
 #pragma unroll
       for (int s = 0; s < NS; ++s) acc[s] += (double)partial[((int64_t)b * NS + s) * c + ch];
     }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) acc[s] = (acc[s] + a1[s]) + (a2[s] + a3[s]);
+  }
 #pragma unroll
   for (int s = 0; s < NS; ++s) red[s][threadIdx.y][threadIdx.x] = acc[s];
   __syncthreads();

@@ -58,7 +58,7 @@ extern "C" int imm_pack_weights_multi(const int64_t* jobs, const int32_t* blk_fi
   return 0;
 }
 
-// job: {slab, dw, nsplit, ntaps, ci_pad, ci_real, co, kpad, 0...}; 256 outputs per workgroup
+// job: {slab, dw, nsplit, ntaps, ci_pad, ci_real, co, kpad, 0...}; 1024 outputs per workgroup (4 per lane)
 __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const int64_t* __restrict__ jobs,
                                                                 const int32_t* __restrict__ blk_first, int n_jobs) {
   const int j = find_job(blk_first, n_jobs, blockIdx.x);
@@ -68,16 +68,46 @@ __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const int64_t* 
   const int nsplit = (int)jb[2], ntaps = (int)jb[3], ci_pad = (int)jb[4], ci_real = (int)jb[5], co = (int)jb[6];
   const int kpad = (int)jb[7];
   const int64_t total = (int64_t)ntaps * ci_real * co;
-  const int64_t idx = (int64_t)(blockIdx.x - blk_first[j]) * 256 + threadIdx.x;
-  if (idx >= total) return;
-  const int n = (int)(idx % co);
-  const int64_t tc = idx / co;
-  const int c = (int)(tc % ci_real), tap = (int)(tc / ci_real);
-  const float* sp = slab + ((int64_t)tap * ci_pad + c) * co + n;
   const int64_t sstride = (int64_t)kpad * co;
-  float acc = 0.f;
-  for (int s = 0; s < nsplit; ++s) acc += sp[s * sstride];
-  dw[idx] = acc;
+  if ((co & 3) == 0) {
+    // 4 consecutive output channels per lane: 16-byte slab loads, 4 independent splits in flight
+    const int64_t idx = ((int64_t)(blockIdx.x - blk_first[j]) * 256 + threadIdx.x) * 4;
+    if (idx >= total) return;
+    const int n = (int)(idx % co);
+    const int64_t tc = idx / co;
+    const int c = (int)(tc % ci_real), tap = (int)(tc / ci_real);
+    const float* sp = slab + ((int64_t)tap * ci_pad + c) * co + n;
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+    int s = 0;
+    for (; s + 3 < nsplit; s += 4) {
+      const float4 v0 = *(const float4*)(sp + (int64_t)s * sstride), v1 = *(const float4*)(sp + (int64_t)(s + 1) * sstride);
+      const float4 v2 = *(const float4*)(sp + (int64_t)(s + 2) * sstride), v3 = *(const float4*)(sp + (int64_t)(s + 3) * sstride);
+      a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+      a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+      a2.x += v2.x; a2.y += v2.y; a2.z += v2.z; a2.w += v2.w;
+      a3.x += v3.x; a3.y += v3.y; a3.z += v3.z; a3.w += v3.w;
+    }
+    for (; s < nsplit; ++s) {
+      const float4 v0 = *(const float4*)(sp + (int64_t)s * sstride);
+      a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+    }
+    dw[idx] = (a0.x + a1.x) + (a2.x + a3.x);
+    dw[idx + 1] = (a0.y + a1.y) + (a2.y + a3.y);
+    dw[idx + 2] = (a0.z + a1.z) + (a2.z + a3.z);
+    dw[idx + 3] = (a0.w + a1.w) + (a2.w + a3.w);
+    return;
+  }
+  for (int e = 0; e < 4; ++e) {
+    const int64_t idx = ((int64_t)(blockIdx.x - blk_first[j]) * 256 + threadIdx.x) * 4 + e;
+    if (idx >= total) return;
+    const int n = (int)(idx % co);
+    const int64_t tc = idx / co;
+    const int c = (int)(tc % ci_real), tap = (int)(tc / ci_real);
+    const float* sp = slab + ((int64_t)tap * ci_pad + c) * co + n;
+    float acc = 0.f;
+    for (int s = 0; s < nsplit; ++s) acc += sp[s * sstride];
+    dw[idx] = acc;
+  }
 }
 
 extern "C" int imm_wgrad_reduce_multi(const int64_t* jobs, const int32_t* blk_first, int n_jobs, int n_blocks, void* stream) {

@@ -11,18 +11,19 @@
 
 #define VF_TILE 16
 
+// Thread mapping (both kernels): a workgroup owns a 16x16 pixel tile; 8 lanes share a pixel, each owning 8 of the 64
+// channels, so a wave touches 8 neighbouring pixels x 128 contiguous bytes (fully coalesced 16-byte stores/loads) and
+// every lane keeps its 9x8 filter taps in registers.
 template <typename ET>
 __global__ __launch_bounds__(256) void vgg_conv1_1_fwd_kernel(const float* __restrict__ gt, const float* __restrict__ pred,
                                                               int ldp, int batch, int s, const float* __restrict__ w,
                                                               const float* __restrict__ bias, uint16_t* __restrict__ out) {
   __shared__ float gray[(VF_TILE + 2) * (VF_TILE + 2)];
-  __shared__ float sw[9 * 64 + 64];
   const int tid = threadIdx.x;
   const int img = blockIdx.z;
   const int ty0 = blockIdx.y * VF_TILE, tx0 = blockIdx.x * VF_TILE;
   const float* src = img < batch ? gt + (int64_t)img * s * s * 3 : pred + (int64_t)(img - batch) * s * s * ldp;
   const int ld = img < batch ? 3 : ldp;
-  for (int i = tid; i < 9 * 64 + 64; i += 256) sw[i] = i < 576 ? w[i] : bias[i - 576];
   for (int i = tid; i < (VF_TILE + 2) * (VF_TILE + 2); i += 256) {
     const int yy = ty0 + i / (VF_TILE + 2) - 1, xx = tx0 + i % (VF_TILE + 2) - 1;
     float g = 0.f;   // SAME zero padding applies to the NORMALISED gray image
@@ -32,26 +33,33 @@ __global__ __launch_bounds__(256) void vgg_conv1_1_fwd_kernel(const float* __res
     }
     gray[i] = g;
   }
+  const int cg = tid & 7, pl = tid >> 3;      // channel group, pixel slot (32 pixels per pass)
+  float wr[9][8], br[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    br[e] = bias[cg * 8 + e];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wr[t][e] = w[t * 64 + cg * 8 + e];
+  }
   __syncthreads();
-  const int ly = tid / VF_TILE, lx = tid % VF_TILE;
-  const int yy = ty0 + ly, xx = tx0 + lx;
-  if (yy >= s || xx >= s) return;
-  float g[9];
+#pragma unroll 2
+  for (int pass = 0; pass < 8; ++pass) {
+    const int pix = pass * 32 + pl;
+    const int ly = pix / VF_TILE, lx = pix % VF_TILE;
+    const int yy = ty0 + ly, xx = tx0 + lx;
+    if (yy >= s || xx >= s) continue;
+    float g[9];
 #pragma unroll
-  for (int t = 0; t < 9; ++t) g[t] = gray[(ly + t / 3) * (VF_TILE + 2) + lx + t % 3];
-  uint16_t* op = out + (((int64_t)img * s + yy) * s + xx) * 64;
-#pragma unroll
-  for (int cg = 0; cg < 8; ++cg) {
+    for (int t = 0; t < 9; ++t) g[t] = gray[(ly + t / 3) * (VF_TILE + 2) + lx + t % 3];
     float o[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const int c = cg * 8 + e;
       float acc = 0.f;
 #pragma unroll
-      for (int t = 0; t < 9; ++t) acc += g[t] * sw[t * 64 + c];
-      o[e] = fmaxf(acc + sw[576 + c], 0.f);
+      for (int t = 0; t < 9; ++t) acc += g[t] * wr[t][e];
+      o[e] = fmaxf(acc + br[e], 0.f);
     }
-    *(uint4*)(op + cg * 8) = pack8<ET>(o);
+    *(uint4*)(out + (((int64_t)img * s + yy) * s + xx) * 64 + cg * 8) = pack8<ET>(o);
   }
 }
 
@@ -61,38 +69,58 @@ __global__ __launch_bounds__(256) void vgg_conv1_1_bwd_kernel(const uint16_t* __
                                                               const float* __restrict__ pred, int ldp,
                                                               const float* __restrict__ mask, const float* __restrict__ coef,
                                                               uint16_t* __restrict__ dpred, int lddp) {
-  __shared__ float sw[9 * 64];
+  constexpr int HT = VF_TILE + 2;
+  __shared__ uint4 sdz[HT * HT * 8];          // dz tile + halo, 64 channels = 8 x 16 B per pixel (41 KB)
   const int tid = threadIdx.x;
-  for (int i = tid; i < 576; i += 256) sw[i] = w[i];
-  __syncthreads();
   const int img = blockIdx.z;
-  const int yy = blockIdx.y * VF_TILE + tid / VF_TILE, xx = blockIdx.x * VF_TILE + tid % VF_TILE;
-  if (yy >= s || xx >= s) return;
-  // z[q][c] = sum_t gray[q + (ky-1,kx-1)] w[t][c]  =>  dgray[p] = sum_t sum_c dz[p - (ky-1,kx-1)][c] w[t][c]
-  float dgray = 0.f;
+  const int ty0 = blockIdx.y * VF_TILE, tx0 = blockIdx.x * VF_TILE;
+  for (int i = tid; i < HT * HT * 8; i += 256) {
+    const int hp = i >> 3, c = i & 7;
+    const int yy = ty0 + hp / HT - 1, xx = tx0 + hp % HT - 1;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (yy >= 0 && yy < s && xx >= 0 && xx < s) v = *(const uint4*)(dz + (((int64_t)img * s + yy) * s + xx) * 64 + c * 8);
+    sdz[i] = v;
+  }
+  const int cg = tid & 7, pl = tid >> 3;
+  float wr[9][8];
 #pragma unroll
-  for (int t = 0; t < 9; ++t) {
-    const int qy = yy - (t / 3 - 1), qx = xx - (t % 3 - 1);
-    if (qy < 0 || qy >= s || qx < 0 || qx >= s) continue;
-    const uint16_t* q = dz + (((int64_t)img * s + qy) * s + qx) * 64;
+  for (int e = 0; e < 8; ++e)
 #pragma unroll
-    for (int cg = 0; cg < 8; ++cg) {
+    for (int t = 0; t < 9; ++t) wr[t][e] = w[t * 64 + cg * 8 + e];
+  const float c0 = coef[0];
+  __syncthreads();
+#pragma unroll 2
+  for (int pass = 0; pass < 8; ++pass) {
+    const int pix = pass * 32 + pl;
+    const int ly = pix / VF_TILE, lx = pix % VF_TILE;
+    const int yy = ty0 + ly, xx = tx0 + lx;
+    // z[q][c] = sum_t gray[q + (ky-1,kx-1)] w[t][c]  =>  dgray[p] = sum_t sum_c dz[p - (ky-1,kx-1)][c] w[t][c]
+    float part = 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int hy = ly + 1 - (t / 3 - 1), hx = lx + 1 - (t % 3 - 1);     // halo coordinates of q
       float d[8];
-      unpack8<ET>(*(const uint4*)(q + cg * 8), d);
+      unpack8<ET>(sdz[(hy * HT + hx) * 8 + cg], d);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) dgray += d[e] * sw[t * 64 + cg * 8 + e];
+      for (int e = 0; e < 8; ++e) part += d[e] * wr[t][e];
+    }
+    part += __shfl_xor(part, 1, 64);
+    part += __shfl_xor(part, 2, 64);
+    part += __shfl_xor(part, 4, 64);
+    if (yy >= s || xx >= s) continue;
+    const int nvec = lddp / 8;
+    if (cg < nvec) {
+      float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      const int64_t p = ((int64_t)img * s + yy) * s + xx;
+      if (cg == 0) {
+        const float cm = c0 * (mask ? mask[p] : 1.f);
+        const float dg = part / (3.0f * 255.0f);
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) o[ch] = dg + cm * (pred[p * ldp + ch] - gt[p * 3 + ch]);
+      }
+      *(uint4*)(dpred + p * lddp + cg * 8) = pack8<ET>(o);
     }
   }
-  const int64_t p = ((int64_t)img * s + yy) * s + xx;
-  const float c0 = coef[0] * (mask ? mask[p] : 1.f);
-  const float dg = dgray / (3.0f * 255.0f);
-  float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int ch = 0; ch < 3; ++ch) o[ch] = dg + c0 * (pred[p * ldp + ch] - gt[p * 3 + ch]);
-  uint16_t* op = dpred + p * lddp;
-  *(uint4*)op = pack8<ET>(o);
-  const uint4 z = make_uint4(0, 0, 0, 0);
-  for (int cg = 1; cg < lddp / 8; ++cg) *(uint4*)(op + cg * 8) = z;
 }
 
 extern "C" int imm_vgg_conv1_1_fwd(const float* gt, const float* pred, int ldp, int batch, int s, const float* w9x64,
@@ -110,7 +138,7 @@ extern "C" int imm_vgg_conv1_1_bwd(const void* dz, int dtype, int batch, int s, 
                                    const float* pred, int ldp, const float* mask, const float* coef, void* dpred,
                                    int lddp, void* stream) {
   IMM_REQUIRE(dz && w9x64 && gt && pred && coef && dpred, "vgg_conv1_1_bwd: null");
-  IMM_REQUIRE(batch > 0 && s > 0 && ldp >= 3 && lddp >= 8 && lddp % 8 == 0, "vgg_conv1_1_bwd: dims");
+  IMM_REQUIRE(batch > 0 && s > 0 && ldp >= 3 && lddp >= 8 && lddp % 8 == 0 && lddp <= 64, "vgg_conv1_1_bwd: dims");
   const dim3 grid((s + VF_TILE - 1) / VF_TILE, (s + VF_TILE - 1) / VF_TILE, batch);
   IMM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((vgg_conv1_1_bwd_kernel<ET>), grid, dim3(256), 0, (hipStream_t)stream,
                                                (const uint16_t*)dz, batch, s, w9x64, gt, pred, ldp, mask, coef,

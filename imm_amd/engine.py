@@ -18,6 +18,7 @@ Network definition follows /root/reference/imm/models/imm_model.py (encoder :182
 imm/models/selfsup/vgg16.py:343-370; TF1 op semantics as listed in SURVEY.md §8a (S1-S12).
 """
 import math
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -323,7 +324,10 @@ class IMMEngine:
         # wgrad split: enough workgroups to fill the chip, at least 512 pixels per split
         bn_w = 128 if co > 64 else 64 if co > 32 else 32 if co > 16 else 16
         tiles = -(-fd.kpad // 128) * -(-co // bn_w)
-        nsplit = max(1, min(-(-2 * self.n_cu // tiles), max(1, npix // 512)))
+        # 2 workgroups per CU for small filters; 1 per CU once a slab copy exceeds 512 KB (slab traffic = nsplit x filter)
+        big = fd.kpad * co * 4 > (1 << 19)
+        target = int(os.environ.get('IMM_WGRAD_TARGET_BIG', '1' if big else '2')) if big else 2
+        nsplit = max(1, min(-(-target * self.n_cu // tiles), max(1, npix // 512)))
         lay.nsplit = nsplit
         lay.slab = self._zeros(nsplit, fd.kpad, co)
         if bn:
@@ -634,7 +638,7 @@ class IMMEngine:
             self._add(self.prog_bwd, lambda: ops.resize_ac_bwd(self.d_joint, d_e, B, He, He, 16, 16, nf8, Cj, nf8), 'resize_ac_bwd')
             self._encoder_backward(self.enc_im, d_e, nf8)
         # one table-driven launch sums every layer's split-K slabs into the flat gradient buffer
-        self.reduce_tab = ops.JobTable([j for j, _n in self._reduce_jobs], [n for _j, n in self._reduce_jobs], 256, self.dev)
+        self.reduce_tab = ops.JobTable([j for j, _n in self._reduce_jobs], [n for _j, n in self._reduce_jobs], 1024, self.dev)
         self._add(self.prog_bwd, lambda: ops.wgrad_reduce_multi(self.reduce_tab), 'wgrad_reduce')
 
     def _encoder_backward(self, layers, d_out, ldd):

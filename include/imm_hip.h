@@ -79,7 +79,7 @@ int imm_pack_weights(const float* w, void* wt, int dtype, int mode, int kh, int 
 
 /* Table-driven variants: ONE launch re-packs / reduces every tensor of a step.  jobs: device int64[n_jobs][12];
  * pack job  = {w, wt, mode, kh, kw, ci_real, co_real, c_pad, rows, kpad, 0, 0}  (256*8 elements per workgroup)
- * reduce job = {slab, dw, nsplit, kh*kw, ci_pad, ci_real, co, kpad, 0, 0, 0, 0}   (256 outputs per workgroup)
+ * reduce job = {slab, dw, nsplit, kh*kw, ci_pad, ci_real, co, kpad, 0, 0, 0, 0}   (1024 outputs per workgroup)
  * blk_first: device int32[n_jobs+1] prefix sums of workgroups per job; n_blocks = blk_first[n_jobs]. */
 int imm_pack_weights_multi(const int64_t* jobs, const int32_t* blk_first, int n_jobs, int n_blocks, int dtype,
                            void* stream);

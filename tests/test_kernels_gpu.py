@@ -185,7 +185,7 @@ def test_conv_wgrad(ops, case):
 
 
 def test_table_driven_pack_and_reduce(ops):
-    """imm_pack_weights_multi / imm_wgrad_reduce_multi must equal their single-tensor counterparts bit for bit."""
+    """imm_pack_weights_multi (bit for bit) / imm_wgrad_reduce_multi (to f32 rounding) vs their single-tensor counterparts."""
     dt = torch.bfloat16
     layers = [(3, 3, 8, 32, 0), (3, 32, 32, 64, 0), (3, 266, 288, 256, 0), (3, 32, 16, 9, 1), (1, 256, 16, 10, 1)]
     jobs, items, refs = [], [], []
@@ -213,11 +213,11 @@ def test_table_driven_pack_and_reduce(ops):
         ops.conv2d_wgrad_reduce(slab, nsplit, k, k, ci_pad, ci_real, co, kpad, dw_ref)
         jobs.append((slab.data_ptr(), dw.data_ptr(), nsplit, k * k, ci_pad, ci_real, co, kpad)); items.append(k * k * ci_real * co)
         refs.append((slab, dw, dw_ref))
-    tab = ops.JobTable(jobs, items, 256, DEV)
+    tab = ops.JobTable(jobs, items, 1024, DEV)
     ops.wgrad_reduce_multi(tab)
     torch.cuda.synchronize()
     for _s, dw, dw_ref in refs:
-        assert torch.equal(dw, dw_ref)
+        close(dw, dw_ref, 1e-6, 1e-6, 'wgrad_reduce_multi')      # 4 interleaved partial sums vs a serial sum
 
 
 def test_colsum(ops):
