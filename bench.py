@@ -56,6 +56,22 @@ def synthetic_batch(batch, size, seed, device):
     return {'image': im.to(device), 'future_image': fut.to(device), 'mask': mask.to(device).contiguous()}
 
 
+def pmc_traffic_per_launch():
+    """HBM MB per launch of the conv_igemm kernels from the committed PMC profile (separate rocprofv3 --pmc passes,
+    profiles/r*_pmc_hbm_bytes.csv: newest round wins); None when no profile is present."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_hbm_bytes.csv')))
+    if not files:
+        return None
+    n = mb = 0.0
+    with open(files[-1]) as f:
+        for row in csv.reader(f):
+            if len(row) == 7 and 'conv_igemm' in row[0]:
+                n += float(row[1]); mb += float(row[1]) * (float(row[4]) + float(row[5]))
+    return round(mb / n, 2) if n else None
+
+
 def cpu_baseline(sample_batch=8, steps=2):
     """CPU restatement of the TF1 graph (oracle/imm_oracle.py) timed on this node's host cores: the same
     algorithmic work per image as the GPU step (forward + backward + clip + Adam)."""
@@ -143,11 +159,13 @@ def main():
             d = by_tag.setdefault(tag, [0, 0.0, 0.0, 0.0])
             d[0] += 1; d[1] += ms; d[2] += fl; d[3] += nb
         ig = [by_tag[t] for t in IGEMM_TAGS if t in by_tag]
-        n_l, ms_l, fl_l = sum(d[0] for d in ig), sum(d[1] for d in ig), sum(d[2] for d in ig)
+        n_l, ms_l, fl_l, nb_l = sum(d[0] for d in ig), sum(d[1] for d in ig), sum(d[2] for d in ig), sum(d[3] for d in ig)
         achieved = fl_l / (ms_l * 1e-3) / 1e12
-        roof = {'bound': 'mfma', 'kernel': 'conv_igemm_kernel (implicit-GEMM conv fwd/dgrad, %d launches/step)' % n_l,
+        roof = {'bound': 'mfma', 'kernel': 'conv_igemm*_kernel (implicit-GEMM conv fwd/dgrad, %d launches/step)' % n_l,
                 'achieved': round(achieved, 2), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': round(achieved / PEAK_BF16_TFLOPS, 4), 'traffic': None,
+                'frac': round(achieved / PEAK_BF16_TFLOPS, 4), 'traffic': pmc_traffic_per_launch(),
+                'traffic_unit': 'MB HBM per launch (rocprofv3 PMC FETCH_SIZE x2 [gfx950 correction] + WRITE_SIZE, profiles/)',
+                'algorithmic_mb_per_launch': round(nb_l / n_l / 1e6, 2),
                 'avg_launch_us': round(ms_l * 1e3 / n_l, 2), 'gflop_per_launch': round(fl_l / n_l / 1e9, 3)}
         breakdown = {t: {'launches': d[0], 'ms': round(d[1], 3), 'tflops': (round(d[2] / (d[1] * 1e-3) / 1e12, 1) if d[2] else None)}
                      for t, d in sorted(by_tag.items(), key=lambda kv: -kv[1][1])}

@@ -297,13 +297,15 @@ class IMMEngine:
             def f_fin():
                 ops.bn_finalize(lay.stats, nblk, co, npix, gamma, beta, BN_EPS, BN_MOMENTUM, self._training, mm, mv,
                                 lay.scale, lay.shift, lay.mean, lay.rstd)
-            self._add(self.prog_fwd, f_conv, 'conv_fwd', flops)
+            cbytes = 2.0 * (B * H * W * ci_pad + npix * co + fd.kpad * co)
+            self._add(self.prog_fwd, f_conv, 'conv_fwd', flops, cbytes)
             self._add(self.prog_fwd, f_fin, 'bn_finalize')
             self._add(self.prog_fwd, lambda: ops.bn_apply_relu(lay.y, npix, co, ldy, lay.scale, lay.shift, relu, out, ldo),
                       'bn_apply', 0.0, npix * co * 4.0)
         else:
             lay.out, lay.ldo = lay.y, ldy
-            self._add(self.prog_fwd, lambda: ops.conv2d(fd_eval, x, lay.wt, b, lay.y), 'conv_fwd', flops)
+            self._add(self.prog_fwd, lambda: ops.conv2d(fd_eval, x, lay.wt, b, lay.y), 'conv_fwd', flops,
+                      2.0 * (B * H * W * ci_pad + fd.kpad * co) + npix * co * (4.0 if out_f32 else 2.0))
 
         # ---- backward resources -------------------------------------------------------------------
         lay.needs_dgrad = needs_dgrad
@@ -372,7 +374,8 @@ class IMMEngine:
         if lay.needs_dgrad and dx is not None:
             dd = ops.dgrad_desc(B, lay.H, lay.W, lay.ci_real, lddx, lddy, lddy, k, lay.stride, 0)
             assert dd.kpad == lay.wt_d.shape[1], (dd.kpad, lay.wt_d.shape)
-            self._add(self.prog_bwd, lambda: ops.conv2d(dd, dy, lay.wt_d, None, dx), 'conv_dgrad', flops)
+            self._add(self.prog_bwd, lambda: ops.conv2d(dd, dy, lay.wt_d, None, dx), 'conv_dgrad', flops,
+                      2.0 * (npix * lddy + B * lay.H * lay.W * lay.ci_real + dd.kpad * lay.ci_real))
 
     def _build_network(self):
         cfg, B, S, K, dt = self.cfg, self.B, self.S, self.K, self.dt
@@ -471,7 +474,8 @@ class IMMEngine:
             self.vgg_wt[name], self.vgg_wtd[name], self.vgg_desc[name] = wt, wtd, fd
             bias = self.vgg_w['vgg16/%s/biases' % name]
             self._add(self.prog_fwd, (lambda fd=fd, x=x, wt=wt, bias=bias, y=y: ops.conv2d(fd, x, wt, bias, y)), 'vgg_fwd',
-                      2.0 * 2 * B * H * H * 9 * cin * cout, name='vgg16/' + name)
+                      2.0 * 2 * B * H * H * 9 * cin * cout, 2.0 * (2 * B * H * H * (cin + cout) + 9 * cin * cout),
+                      name='vgg16/' + name)
             self.vgg_act[name] = (y, H)
             x = y
             if name in VGG_POOL_AFTER:
@@ -555,7 +559,8 @@ class IMMEngine:
             wtd = self.vgg_wtd[name]
             src = dbuf[name]
             self._add(self.prog_bwd, lambda: ops.conv2d(dd, src, wtd, None, dst, None, mask_ref), 'vgg_dgrad',
-                      2.0 * B * H * H * 9 * cin * cout, name='vgg16/' + name)
+                      2.0 * B * H * H * 9 * cin * cout,
+                      2.0 * (B * H * H * (cin + cout + (cin if mask_ref is not None else 0)) + 9 * cin * cout), name='vgg16/' + name)
 
         def unpool(src_name, dy, relu_mask):
             y, H = acts[src_name]

@@ -288,3 +288,52 @@ def test_full_size_step_properties():
     assert bool((n2 >= 0).all())
     # the 6 bug-fix channels of the last conv get no loss gradient (S10): their bias gradient is exactly 0
     assert float(eng.gview['model/renderer/conv_8/b'][3:].abs().max()) == 0.0
+
+
+def test_config4_256px_k30_forward_and_step():
+    """BASELINE.json configs[3]: K=30 at 256x256 — exercises the align-corners 32->16 embedding resize
+    (imm_model.py:324-335), the 32x32 heat-map bottleneck and the 10-conv renderer."""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    from imm_amd.train.cnn_train_multi import TrainStep
+    cfg, model, eng, inputs, P, St = make(1, K=30, S=256)
+    _, loss, _, t = model.build(inputs, True, output_tensors=True)
+    torch.cuda.synchronize()
+    out = O.forward(P, St, inputs, cfg, training=True)
+    mu_err = float((t['gauss_yx'].cpu() - out['gauss_yx']).abs().max())
+    loss_rel = abs(float(loss) - float(out['loss'])) / abs(float(out['loss']))
+    print('\nCONFIG4 mu_maxabs %.3g loss_rel %.3g pred_rel %.3g' % (mu_err, loss_rel, rel(t['future_im_pred'], out['future_im_pred'])))
+    assert t['future_im_pred'].shape == (1, 256, 256, 3) and t['heatmaps'].shape == (1, 32, 32, 30)
+    assert mu_err < 1e-3 and loss_rel < 1e-3
+    assert rel(t['future_im_pred'], out['future_im_pred']) < 0.15
+    ts = TrainStep(model, 1, 256, world_size=1, use_graph=True)
+    l0 = float(ts.step(inputs).clone()); ts.synchronize()
+    for _ in range(4):
+        l1 = ts.step(inputs)
+    ts.synchronize()
+    assert np.isfinite(float(l1)) and float(l1) < l0 and bool(torch.isfinite(eng.params).all())
+
+
+def test_config5_k50_f16_step():
+    """BASELINE.json configs[4] shape per GPU: K=50, f16 storage / f16 MFMA."""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    from imm_amd.models.imm_model import IMMModel
+    from imm_amd.train.cnn_train_multi import TrainStep
+    from imm_amd.utils.box import Box
+    cfg = O.default_model_config(50)
+    model = IMMModel(Box(dict(cfg)), dtype=torch.float16, device=DEV)
+    inputs = O.synthetic_inputs(2, 128)
+    _, loss, _, t = model.build(inputs, True, output_tensors=True)
+    torch.cuda.synchronize()
+    P, St = O.init_params(cfg, 128)
+    out = O.forward(P, St, inputs, cfg, training=True)
+    mu_err = float((t['gauss_yx'].cpu() - out['gauss_yx']).abs().max())
+    loss_rel = abs(float(loss) - float(out['loss'])) / abs(float(out['loss']))
+    print('\nCONFIG5 mu_maxabs %.3g loss_rel %.3g pred_rel %.3g' % (mu_err, loss_rel, rel(t['future_im_pred'], out['future_im_pred'])))
+    assert t['gauss_yx'].shape == (2, 50, 2) and mu_err < 1e-3 and loss_rel < 1e-3
+    assert rel(t['future_im_pred'], out['future_im_pred']) < 0.03      # f16: 3 more mantissa bits than bf16
+    ts = TrainStep(model, 2, 128, world_size=1, use_graph=True)
+    losses = [float(ts.step(inputs).clone()) for _ in range(4)]
+    ts.synchronize()
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
