@@ -38,15 +38,18 @@ int imm_fail(int code, const char* fmt, ...);
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
 
 struct BF16 {
   static constexpr int kEnum = IMM_BF16;
   __device__ static __forceinline__ float to_f32(uint16_t u) { return __uint_as_float(((uint32_t)u) << 16); }
-  __device__ static __forceinline__ uint16_t from_f32(float f) {  // round to nearest even
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // quiet NaN
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
+  // round to nearest even in hardware (v_cvt_pk_bf16_f32 on gfx950)
+  __device__ static __forceinline__ uint16_t from_f32(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
+  __device__ static __forceinline__ uint32_t pack2(float lo, float hi) {
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
   }
   __device__ static __forceinline__ f32x4_t mfma(uint4 a, uint4 b, f32x4_t c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b),
@@ -58,6 +61,10 @@ struct F16 {
   static constexpr int kEnum = IMM_F16;
   __device__ static __forceinline__ float to_f32(uint16_t u) { return (float)__builtin_bit_cast(_Float16, u); }
   __device__ static __forceinline__ uint16_t from_f32(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
+  __device__ static __forceinline__ uint32_t pack2(float lo, float hi) {
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_t));
+  }
   __device__ static __forceinline__ f32x4_t mfma(uint4 a, uint4 b, f32x4_t c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b),
                                                   c, 0, 0, 0);
@@ -78,8 +85,7 @@ template <typename ET>
 __device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
   uint32_t w[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
-    w[i] = (uint32_t)ET::from_f32(f[2 * i]) | ((uint32_t)ET::from_f32(f[2 * i + 1]) << 16);
+  for (int i = 0; i < 4; ++i) w[i] = ET::pack2(f[2 * i], f[2 * i + 1]);
   return make_uint4(w[0], w[1], w[2], w[3]);
 }
 

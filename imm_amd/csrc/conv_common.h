@@ -93,14 +93,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4_t (&acc)[
           }
         } else {
           uint16_t* yp = (uint16_t*)a.y + (int64_t)m * a.ldy + n;
-          uint16_t h[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) h[r] = ET::from_f32(v[r]);
           if (n + 3 < a.co) {
-            *(uint2*)yp = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
+            *(uint2*)yp = make_uint2(ET::pack2(v[0], v[1]), ET::pack2(v[2], v[3]));
           } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) if (n + r < a.co) yp[r] = h[r];
+            for (int r = 0; r < 4; ++r) if (n + r < a.co) yp[r] = ET::from_f32(v[r]);
           }
         }
       }

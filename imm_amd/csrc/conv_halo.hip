@@ -1,0 +1,331 @@
+// conv_halo.hip — 3x3 stride-1 convolution for the high-resolution, low-channel layers (ci in {32,64}, co <= 64):
+// encoder conv_2 / conv_4, renderer conv_6..8, VGG conv1_2, and the data gradients of the same layers.
+//
+// Why a second convolution kernel: in the im2col formulation every input pixel is gathered once per filter tap
+// (9x) through L2; at 128x128 / 64x64 with 32-64 channels that re-gather traffic, not the matrix cores, sets the
+// time (rocprofv3 PMC: 3.5x the algorithmic HBM bytes; tools/bench_conv.py ablation).  Here a persistent
+// workgroup keeps ALL nine taps of the filter resident in LDS (<= 72 KB) and walks 8x16-pixel output patches:
+// the 10x18-pixel input halo of a patch is DMA'd once (buffer_load ... lds, double buffered, zero fill outside
+// the image through the out-of-range buffer offset) and the nine taps are just nine different LDS base
+// addresses of the same tile.  HBM/L2 sees each input pixel 1.4x (halo overlap) instead of 9x.
+//
+// MFMA mapping: one 16-pixel patch row = one 16-row MFMA operand; lane (l&15) = pixel x, (l>>4) = 8-channel chunk.
+// LDS images are [pixel or filter row][ci/8 chunks of 16 B], chunk XOR-swizzled on the DMA source side.
+// Epilogue = bias / ReLU / ReLU-backward mask / 16-bit or f32 NHWC store; BN partial sums are accumulated in
+// registers over all patches of the workgroup and written once (one partial row per workgroup).
+#include "conv_common.h"
+#include <stdlib.h>
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+
+#define HALO_PH 8                 // patch rows
+#define HALO_PW 16                // patch cols (= MFMA operand rows)
+#define HALO_HW (HALO_PW + 2)     // halo width 18
+#define HALO_HP 192               // halo pixels (10*18 = 180) padded to a whole number of DMA instructions
+
+__device__ __forceinline__ void halo_dma16(u32x4_t rsrc, uint32_t lds_addr, uint32_t voff, uint32_t soff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+               :: "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+
+// Chunk swizzle that keeps a ds_read_b128 of 16 CONSECUTIVE rows (any start offset: the nine taps shift the pixel
+// index by 0/1/2 and by the halo pitch) x 4 chunks conflict-free.  16-byte slot of (row r, stored chunk c') is
+// (r*C8 + c') mod 16; the instruction is served in 16-lane groups {rows 0-3,12-15 @ chunk c, rows 4-11 @ chunk c^1}.
+//   C8 = 8 (128-B rows): rows of equal parity share 8 slots; XOR bits 1-2 of the chunk with (r>>1)&3: the four
+//     rows {0,1,6,7}+q of one parity/chunk get 4 different values, bit 0 separates chunk c from c^1.
+//   C8 = 4 (64-B rows): rows equal mod 4 share 4 slots; XOR bit 1 with (r>>2)&1: the two rows (r, r+12) resp.
+//     (r+4, r+8) of a class differ, bit 0 again separates the two chunks.
+template <int C8>
+__device__ __forceinline__ int halo_swz(int row) { return C8 == 8 ? (((row >> 1) & 3) << 1) : (((row >> 2) & 1) << 1); }
+
+struct HaloArgs {
+  ConvArgs c;
+  int n_patches, patches_x, patches_y;    // per image: patches_x * patches_y
+};
+
+template <typename ET, int CI, int BN>
+__global__ __launch_bounds__(256) void conv_halo_kernel(const HaloArgs ha) {
+  const ConvArgs& a = ha.c;
+  constexpr int C8 = CI / 8;                       // 16-byte chunks per pixel / filter row
+  constexpr int KS = CI / 32;                      // MFMA k-steps per tap
+  constexpr int WGM = (BN == 64) ? 2 : 4, WGN = 4 / WGM;
+  constexpr int TM = 128 / WGM, TN = BN / WGN, MT = TM / 16, NT = TN / 16;
+  constexpr int PIX_PER_DMA = 64 / C8;             // pixels (or filter rows) per 1-KB DMA instruction
+  constexpr int HALO_DMA = HALO_HP / PIX_PER_DMA;  // instructions per halo tile (24 / 12)
+  constexpr int W_DMA = 9 * BN / PIX_PER_DMA;      // instructions for the whole filter
+  constexpr int W_U4 = 9 * BN * C8;                // uint4 of the filter image
+  constexpr int H_U4 = HALO_HP * C8;               // uint4 per halo stage
+  extern __shared__ __attribute__((aligned(16))) uint4 smem[];   // [W_U4] filter | [2][H_U4] halo tiles
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WGN, wn = wid % WGN;
+  constexpr uint32_t OOB = 0x80000000u;
+  const uint64_t xa = (uint64_t)a.x, wa = (uint64_t)a.wt;
+  const u32x4_t xr = {(uint32_t)xa, (uint32_t)(xa >> 32) & 0xffffu, a.x_bytes, 0x00020000u};
+  const u32x4_t wr = {(uint32_t)wa, (uint32_t)(wa >> 32) & 0xffffu, a.wt_bytes, 0x00020000u};
+  const uint32_t lds_base = (uint32_t)(size_t)(lds_void_t*)smem;
+
+  // ---- filter: all nine taps resident for the lifetime of the workgroup -----------------------------------
+  // LDS row (tap*BN + n) holds Wt[n][tap*CI .. +CI) ; one DMA instruction = PIX_PER_DMA consecutive rows
+  for (int i = wid; i < W_DMA; i += 4) {
+    const int row = i * PIX_PER_DMA + lane / C8;          // tap*BN + n
+    const int tap = row / BN, n = row - tap * BN;
+    const int sc = (lane % C8) ^ halo_swz<C8>(row);
+    const uint32_t vo = (n < a.co) ? (uint32_t)((n * a.kpad + tap * CI) * 2 + sc * 16) : OOB;
+    halo_dma16(wr, __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)(i * 1024)), vo, 0u);
+  }
+
+  // ---- halo loader ----------------------------------------------------------------------------------------
+  const int per_img = ha.patches_x * ha.patches_y;
+  auto issue_halo = [&](int patch, int stage) {
+    const int img = patch / per_img, pr = patch - img * per_img;
+    const int y0 = (pr / ha.patches_x) * HALO_PH, x0 = (pr % ha.patches_x) * HALO_PW;
+    const uint32_t soff = (uint32_t)(img * a.hi * a.wi) * (uint32_t)(a.ldx * 2);
+    for (int i = wid; i < HALO_DMA; i += 4) {
+      const int hp = i * PIX_PER_DMA + lane / C8;        // halo pixel index 0..191
+      const int hy = hp / HALO_HW, hx = hp - hy * HALO_HW;
+      const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+      const bool ok = (hp < (HALO_PH + 2) * HALO_HW) && ((unsigned)iy < (unsigned)a.hi) && ((unsigned)ix < (unsigned)a.wi);
+      const int sc = (lane % C8) ^ halo_swz<C8>(hp);
+      const uint32_t vo = ok ? (uint32_t)((iy * a.wi + ix) * a.ldx * 2 + sc * 16) : OOB;
+      halo_dma16(xr, __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)((W_U4 + stage * H_U4) * 16 + i * 1024)), vo, soff);
+    }
+  };
+
+  // ---- epilogue state -------------------------------------------------------------------------------------
+  const bool f_bias = a.flags & IMM_CONV_BIAS, f_relu = a.flags & IMM_CONV_RELU;
+  const bool f_stats = a.flags & IMM_CONV_STATS, f_mask = a.flags & IMM_CONV_MASK;
+  const bool f_f32 = a.flags & IMM_CONV_OUT_F32;
+  float s1[NT][4], s2[NT][4], bv[NT][4];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      s1[j][r] = 0.f; s2[j][r] = 0.f;
+      const int n = wn * TN + j * 16 + 4 * (lane >> 4) + r;
+      bv[j][r] = (f_bias && n < a.co) ? a.bias[n] : 0.f;
+    }
+
+  int patch = blockIdx.x, stage = 0;
+  if (patch < ha.n_patches) issue_halo(patch, 0);
+  const int frow = lane & 15, fchunk = lane >> 4;
+  const uint4* Wl = smem;
+  // Each wave issues, in order: [halo DMA of the next patch] ... [MT*NT output stores of this patch].  vmcnt retires
+  // in order, so at the top of the next iteration "at most MT*NT operations outstanding" means the DMA has landed
+  // while the stores (HBM write latency) are still allowed in flight.  Only valid when every tile is ONE store
+  // instruction (all 4 channels in range, no mask loads in between); otherwise drain completely.
+  const bool counted = (a.co % 4 == 0) && (a.co == BN) && !f_mask;
+  bool first = true;
+  for (; patch < ha.n_patches; patch += gridDim.x) {
+    if (counted && !first) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MT * NT) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the filter / this patch's halo landed
+    first = false;
+    __builtin_amdgcn_s_barrier();                          // => everyone's share; everyone is done with the other stage
+    if (patch + (int)gridDim.x < ha.n_patches && !(a.flags & IMM_DBG_NO_GLOAD)) issue_halo(patch + gridDim.x, stage ^ 1);
+    const uint4* Hl = smem + W_U4 + stage * H_U4;
+
+    f32x4_t acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    if (!(a.flags & IMM_DBG_NO_MFMA))
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int ky = tap / 3, kx = tap % 3;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        uint4 af[MT], bf[NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const int hp = (wm * MT + i + ky) * HALO_HW + frow + kx;
+          af[i] = Hl[hp * C8 + ((ks * 4 + fchunk) ^ halo_swz<C8>(hp))];
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int row = tap * BN + wn * TN + j * 16 + frow;
+          bf[j] = Wl[row * C8 + ((ks * 4 + fchunk) ^ halo_swz<C8>(row))];
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] = ET::mfma(bf[j], af[i], acc[i][j]);   // D[n][pixel]
+      }
+    }
+
+    if (a.flags & IMM_DBG_NO_EPILOGUE) {
+      float t = 0.f;
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+      if (t == 123456.789f) ((float*)a.y)[0] = t;
+      stage ^= 1;
+      continue;
+    }
+    // ---- store this patch: lane = pixel (wm*MT+i, lane&15), 4 consecutive channels -------------------------
+    const int img = patch / per_img, pr = patch - img * per_img;
+    const int y0 = (pr / ha.patches_x) * HALO_PH, x0 = (pr % ha.patches_x) * HALO_PW;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int yy = y0 + wm * MT + i, xx = x0 + (lane & 15);
+      const bool mok = yy < a.ho && xx < a.wo;
+      const int64_t m = ((int64_t)img * a.ho + yy) * a.wo + xx;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int n = wn * TN + j * 16 + 4 * (lane >> 4);
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[r] = acc[i][j][r] + bv[j][r];
+          if (f_relu) v[r] = fmaxf(v[r], 0.f);
+        }
+        if (!mok) continue;
+        if (f_mask) {
+          const uint16_t* mp = a.mask + m * a.ldmask + n;
+          if (n + 3 < a.co && (a.ldmask & 3) == 0) {
+            const uint2 mw = *(const uint2*)mp;
+            const uint16_t mh[4] = {(uint16_t)(mw.x & 0xffffu), (uint16_t)(mw.x >> 16), (uint16_t)(mw.y & 0xffffu), (uint16_t)(mw.y >> 16)};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (!(ET::to_f32(mh[r]) > 0.f)) v[r] = 0.f;
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (n + r < a.co && !(ET::to_f32(mp[r]) > 0.f)) v[r] = 0.f;
+          }
+        }
+        if (f_stats) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { s1[j][r] += v[r]; s2[j][r] += v[r] * v[r]; }
+        }
+        if (f_f32) {
+          float* yp = (float*)a.y + m * a.ldy + n;
+          if (n + 3 < a.co) *(float4*)yp = make_float4(v[0], v[1], v[2], v[3]);
+          else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (n + r < a.co) yp[r] = v[r];
+          }
+        } else {
+          uint16_t* yp = (uint16_t*)a.y + m * a.ldy + n;
+          if (n + 3 < a.co) *(uint2*)yp = make_uint2(ET::pack2(v[0], v[1]), ET::pack2(v[2], v[3]));
+          else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (n + r < a.co) yp[r] = ET::from_f32(v[r]);
+          }
+        }
+      }
+    }
+    stage ^= 1;
+  }
+
+  if (f_stats) {
+    // per-workgroup partial sums: 16 pixel lanes -> wave rows -> one row of stats per workgroup
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    float* red = (float*)(smem + W_U4);     // halo stages are free now: [WGM][2][BN]
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+          s1[j][r] += __shfl_xor(s1[j][r], o, 64);
+          s2[j][r] += __shfl_xor(s2[j][r], o, 64);
+        }
+      }
+    if ((lane & 15) == 0) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int nl = wn * TN + j * 16 + 4 * (lane >> 4) + r;
+          red[(wm * 2 + 0) * BN + nl] = s1[j][r];
+          red[(wm * 2 + 1) * BN + nl] = s2[j][r];
+        }
+    }
+    __syncthreads();
+    if (tid < BN && tid < a.co) {
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < WGM; ++w) { t1 += red[(w * 2 + 0) * BN + tid]; t2 += red[(w * 2 + 1) * BN + tid]; }
+      a.stats[((int64_t)blockIdx.x * 2 + 0) * a.co + tid] = t1;
+      a.stats[((int64_t)blockIdx.x * 2 + 1) * a.co + tid] = t2;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+static int g_halo_cu = 0;
+static int halo_num_cu() {
+  if (g_halo_cu == 0) {
+    hipDeviceProp_t p; int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) g_halo_cu = p.multiProcessorCount;
+    if (g_halo_cu <= 0) g_halo_cu = 256;
+  }
+  return g_halo_cu;
+}
+
+bool imm_halo_applicable(const imm_conv_desc* d) {
+  static const bool off = getenv("IMM_NO_HALO") != nullptr;
+  if (off) return false;
+  if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->updiv != 1 || d->pad_t != 1 || d->pad_l != 1) return false;
+  if (d->ci != 32 && d->ci != 64) return false;
+  if (d->co > 64) return false;
+  if (d->hi != d->ho || d->wi != d->wo || d->ho % HALO_PH || d->wo % HALO_PW) return false;
+  if (d->ho * d->wo < 64 * 64) return false;      // deep layers: the im2col kernels have more parallelism
+  static const bool abl = getenv("IMM_HALO_ABL") != nullptr;
+  if ((d->flags & 0xf00) && !abl) return false;   // debug ablation bits normally select the im2col kernel
+  const int64_t xb = (int64_t)d->batch * d->hi * d->wi * d->ldx * 2;
+  return xb < (1LL << 31);
+}
+
+static int halo_bn(int co) { return co > 32 ? 64 : co > 16 ? 32 : 16; }
+static size_t halo_lds(int ci, int bn) { return (size_t)(9 * bn * (ci / 8) + 2 * HALO_HP * (ci / 8)) * 16; }
+
+int imm_halo_grid(const imm_conv_desc* d) {
+  const int n_patches = d->batch * (d->ho / HALO_PH) * (d->wo / HALO_PW);
+  const size_t lds = halo_lds(d->ci, halo_bn(d->co));
+  int per_cu = (int)((160 * 1024) / lds);
+  if (per_cu > 4) per_cu = 4;
+  if (per_cu < 1) per_cu = 1;
+  const int grid = halo_num_cu() * per_cu;
+  return n_patches < grid ? n_patches : grid;
+}
+
+template <typename ET, int CI, int BN>
+static void halo_launch_cfg(const HaloArgs& ha, int grid, hipStream_t s) {
+  const size_t lds = halo_lds(CI, BN);
+  static bool attr_set = false;
+  if (!attr_set && lds > 64 * 1024) {
+    (void)hipFuncSetAttribute((const void*)conv_halo_kernel<ET, CI, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_halo_kernel<ET, CI, BN>), dim3(grid), dim3(256), lds, s, ha);
+}
+
+template <typename ET>
+static void halo_launch(const imm_conv_desc* d, const ConvArgs& a, hipStream_t s) {
+  HaloArgs ha;
+  ha.c = a;
+  ha.patches_x = d->wo / HALO_PW; ha.patches_y = d->ho / HALO_PH;
+  ha.n_patches = d->batch * ha.patches_x * ha.patches_y;
+  ha.c.x_bytes = (uint32_t)((int64_t)d->batch * d->hi * d->wi * d->ldx * 2);
+  ha.c.wt_bytes = (uint32_t)((int64_t)d->co * d->kpad * 2);
+  const int grid = imm_halo_grid(d), bn = halo_bn(d->co);
+  if (d->ci == 64) {
+    if (bn == 64) halo_launch_cfg<ET, 64, 64>(ha, grid, s);
+    else if (bn == 32) halo_launch_cfg<ET, 64, 32>(ha, grid, s);
+    else halo_launch_cfg<ET, 64, 16>(ha, grid, s);
+  } else {
+    if (bn == 64) halo_launch_cfg<ET, 32, 64>(ha, grid, s);
+    else if (bn == 32) halo_launch_cfg<ET, 32, 32>(ha, grid, s);
+    else halo_launch_cfg<ET, 32, 16>(ha, grid, s);
+  }
+}
+
+void imm_conv_halo_launch(int dtype, const imm_conv_desc* d, const ConvArgs& a, hipStream_t s) {
+  if (dtype == IMM_BF16) halo_launch<BF16>(d, a, s);
+  else halo_launch<F16>(d, a, s);
+}

@@ -15,6 +15,10 @@
 #include "conv_common.h"
 #include <stdlib.h>
 
+bool imm_halo_applicable(const imm_conv_desc* d);                                  // conv_halo.hip
+int imm_halo_grid(const imm_conv_desc* d);
+void imm_conv_halo_launch(int dtype, const imm_conv_desc* d, const ConvArgs& a, hipStream_t s);
+
 __device__ __forceinline__ int lds_chunk_idx(int row, int chunk) {
   // 64-byte rows; swizzle so the four 16-lane service groups of ds_read_b128 hit 16 distinct slots
   return row * 4 + (chunk ^ (((row >> 3) & 1) * 3));
@@ -245,6 +249,7 @@ static int validate_desc(const imm_conv_desc* d) {
 
 extern "C" int imm_conv_stats_blocks(const imm_conv_desc* d) {
   if (validate_desc(d)) return IMM_E_INVALID;
+  if (imm_halo_applicable(d)) return imm_halo_grid(d);
   const int64_t M = (int64_t)d->batch * d->ho * d->wo;
   const TileCfg t = pick_tile(M, d->co);
   return (int)((M + t.bm - 1) / t.bm);
@@ -272,6 +277,11 @@ static int conv_launch(const imm_conv_desc* d, const void* x, const void* wt, co
   a.kh = d->kh; a.kw = d->kw; a.stride = d->stride; a.pad_t = d->pad_t; a.pad_l = d->pad_l; a.updiv = d->updiv;
   a.kpad = d->kpad; a.KT = d->kpad / 32; a.ntaps = d->kh * d->kw;
   a.flags = d->flags; a.ldmask = d->ldmask;
+  if (imm_halo_applicable(d)) {
+    imm_conv_halo_launch(ET::kEnum, d, a, s);
+    IMM_CHECK_LAUNCH("imm_conv2d(halo)");
+    return 0;
+  }
   const TileCfg t = pick_tile(a.M, a.co);
   a.n_nblk = (a.co + t.bn - 1) / t.bn;
   const int64_t xb = (int64_t)d->batch * d->hi * d->wi * d->ldx * 2, wb = (int64_t)d->co * d->kpad * 2;

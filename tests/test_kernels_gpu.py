@@ -67,6 +67,12 @@ CONV_CASES = [
     (4, 128, 32, 32, 64, 3, 1, False, 'tile128x64'),
     (2, 8, 512, 512, 512, 3, 1, False, 'vgg5'),
     (2, 16, 256, 256, 30, 1, 1, True, 'pose1x1_k30'),
+    # 3x3 s1, ci in {32,64}, co<=64, >=64x64: served by the LDS-resident-filter halo kernel (conv_halo.hip)
+    (2, 64, 64, 64, 64, 3, 1, False, 'halo_64_64'),
+    (1, 128, 32, 32, 32, 3, 1, False, 'halo_32_32'),
+    (3, 64, 32, 32, 9, 3, 1, True, 'halo_32_9_f32'),
+    (2, 64, 64, 64, 32, 3, 1, False, 'halo_64_32'),
+    (70, 64, 32, 32, 64, 3, 1, False, 'halo_32_64_many_patches'),
 ]
 
 
@@ -111,9 +117,10 @@ def test_conv_forward(ops, case, dt):
         pass  # padding channels are not written by the kernel (caller owns them)
 
 
-def test_conv_relu_stats_mask(ops):
+@pytest.mark.parametrize('H,ci,co', [(32, 32, 64), (64, 64, 64), (64, 32, 32)], ids=['igemm', 'halo64', 'halo32'])
+def test_conv_relu_stats_mask(ops, H, ci, co):
     from imm_amd import _lib as L
-    B, H, ci, co = 2, 32, 32, 64
+    B = 2
     x = rnd((B, H, H, ci), 4)
     w = rnd((3, 3, ci, co), 5, 0.1)
     b = rnd((co,), 6, 0.5, torch.float32)
