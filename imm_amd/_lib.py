@@ -50,6 +50,7 @@ _SIGS = {
     'imm_conv2d': [C.POINTER(ConvDesc), _I, _P, _P, _P, _P, _P, _P, _P],
     'imm_conv_stats_blocks': [C.POINTER(ConvDesc)],
     'imm_conv2d_wgrad': [C.POINTER(ConvDesc), _I, _P, _P, _I, _P, _I, _P],
+    'imm_conv2d_wgrad_splits': [C.POINTER(ConvDesc), _I],
     'imm_conv2d_wgrad_reduce': [_P, _I, _I, _I, _I, _I, _I, _I, _P, _P],
     'imm_colsum': [_P, _I, _L, _I, _I, _I, _P, _P, _P],
     'imm_colsum_blocks': [_L, _I],

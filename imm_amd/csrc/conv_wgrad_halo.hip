@@ -1,0 +1,231 @@
+// conv_wgrad_halo.hip — filter gradient of 3x3 stride-1 convolutions on high-resolution, low-channel layers
+// (ci in {32,64}, co <= 64, >= 64x64): encoder conv_2/conv_4, renderer conv_6..8.
+//
+//     dW[tap][c][n] = sum_p X[p + off(tap)][c] * dY[p][n]
+//
+// The contraction index (pixels) is the STRIDED index of both NHWC operands.  The general kernel
+// (conv_wgrad.hip) transposes while staging and re-gathers X once per tap through L2 (rocprofv3 PMC: 3.5x the
+// algorithmic HBM bytes at 128x128).  Here, like conv_halo.hip, a persistent workgroup DMA's the 10x18-pixel X halo
+// and the 8x16-pixel dY patch ONCE in their natural [pixel][channel] layout (double buffered), the nine taps are
+// nine LDS base addresses, and the transposition is done by the LDS hardware: ds_read_b64_tr_b16 hands each lane
+// four CONSECUTIVE PIXELS of one channel (probe: tools/probes/tr_read_probe.hip -- within a 16-lane group lane i
+// supplies the 8-byte piece {row i>>2, columns 4(i&3)..+3} of a 4x16 block and receives column i, rows 0..3).
+// Two such reads = the 8 k-values of a v_mfma_f32_16x16x32 operand; X^T and dY^T use the same pixel order, so the
+// contraction is consistent.  All 9*ci*co accumulators of the workgroup stay in registers over its patches and
+// are written once as one f32 slab per workgroup (summed by imm_wgrad_reduce_multi, fixed order).
+#include "conv_common.h"
+#include <stdlib.h>
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
+
+#define WH_PH 8
+#define WH_PW 16
+#define WH_HW (WH_PW + 2)
+#define WH_HP 192               // 10*18 = 180 halo pixels, padded to whole DMA instructions
+
+__device__ __forceinline__ void wh_dma16(u32x4_t rsrc, uint32_t lds_addr, uint32_t voff, uint32_t soff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+               :: "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+// same offset-robust chunk swizzle as conv_halo.hip (also conflict-free for the 8-byte transpose reads: the 8
+// pixels x 32 bytes a 32-lane half touches land on 8 distinct 32-byte bank windows)
+template <int C8>
+__device__ __forceinline__ int wh_swz(int row) { return C8 == 8 ? (((row >> 1) & 3) << 1) : (((row >> 2) & 1) << 1); }
+
+// byte offset inside an LDS image [row][C8 chunks of 16 B] of the 8-byte piece holding channels ch..ch+3 (ch % 4 == 0)
+template <int C8>
+__device__ __forceinline__ uint32_t wh_piece(int row, int ch) {
+  return (uint32_t)((row * C8 + ((ch >> 3) ^ wh_swz<C8>(row))) * 16 + (ch & 4) * 2);
+}
+
+struct WgradHaloArgs {
+  const uint16_t* x; const uint16_t* dy; float* slab;
+  int batch, h, w, ldx, lddy, co, kpad;
+  int n_patches, patches_x, patches_y;
+  uint32_t x_bytes, dy_bytes;
+};
+
+// CI input channels, CO = channels of the dY rows that are staged (32 or 64; co <= CO real ones)
+template <typename ET, int CI, int CO>
+__global__ __launch_bounds__(256) void conv_wgrad_halo_kernel(const WgradHaloArgs a) {
+  constexpr int XC8 = CI / 8, YC8 = CO / 8;
+  constexpr int NCT = CI / 16, NNT = CO / 16;          // 16-channel tiles
+  constexpr int WC = NCT, WN = 4 / WC;                 // wave grid: wc = ci tile, wn = slice of the co tiles
+  constexpr int TNT = NNT / WN;                        // co tiles per wave
+  static_assert(WC * WN == 4 && TNT >= 1, "tile split");
+  constexpr int X_PIX_PER_DMA = 64 / XC8, Y_PIX_PER_DMA = 64 / YC8;
+  constexpr int X_DMA = WH_HP / X_PIX_PER_DMA, Y_DMA = 128 / Y_PIX_PER_DMA;
+  constexpr int X_BYTES = WH_HP * CI * 2, Y_BYTES = 128 * CO * 2, STAGE = X_BYTES + Y_BYTES;
+  extern __shared__ __attribute__((aligned(16))) uint4 smem[];   // 2 stages of [X halo | dY patch]
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wc = wid % WC, wn = wid / WC;
+  constexpr uint32_t OOB = 0x80000000u;
+  const uint64_t xa = (uint64_t)a.x, ya = (uint64_t)a.dy;
+  const u32x4_t xr = {(uint32_t)xa, (uint32_t)(xa >> 32) & 0xffffu, a.x_bytes, 0x00020000u};
+  const u32x4_t yr = {(uint32_t)ya, (uint32_t)(ya >> 32) & 0xffffu, a.dy_bytes, 0x00020000u};
+  const uint32_t lds_base = (uint32_t)(size_t)(lds_void_t*)smem;
+  const int per_img = a.patches_x * a.patches_y;
+
+  auto issue = [&](int patch, int stage) {
+    const int img = patch / per_img, pr = patch - img * per_img;
+    const int y0 = (pr / a.patches_x) * WH_PH, x0 = (pr % a.patches_x) * WH_PW;
+    const uint32_t xs = (uint32_t)(img * a.h * a.w) * (uint32_t)(a.ldx * 2);
+    const uint32_t ys = (uint32_t)(img * a.h * a.w) * (uint32_t)(a.lddy * 2);
+    for (int i = wid; i < X_DMA; i += 4) {
+      const int hp = i * X_PIX_PER_DMA + lane / XC8;
+      const int hy = hp / WH_HW, hx = hp - hy * WH_HW;
+      const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+      const bool ok = (hp < (WH_PH + 2) * WH_HW) && ((unsigned)iy < (unsigned)a.h) && ((unsigned)ix < (unsigned)a.w);
+      const int sc = (lane % XC8) ^ wh_swz<XC8>(hp);
+      const uint32_t vo = ok ? (uint32_t)((iy * a.w + ix) * a.ldx * 2 + sc * 16) : OOB;
+      wh_dma16(xr, __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)(stage * STAGE + i * 1024)), vo, xs);
+    }
+    for (int i = wid; i < Y_DMA; i += 4) {
+      const int p = i * Y_PIX_PER_DMA + lane / YC8;       // patch pixel 0..127
+      const int ty = p >> 4, tx = p & 15;
+      const int sc = (lane % YC8) ^ wh_swz<YC8>(p);
+      const uint32_t vo = (uint32_t)(((y0 + ty) * a.w + x0 + tx) * a.lddy * 2 + sc * 16);
+      wh_dma16(yr, __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)(stage * STAGE + X_BYTES + i * 1024)), vo, ys);
+    }
+  };
+
+  f32x4_t acc[9][TNT];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int j = 0; j < TNT; ++j) acc[t][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  // transpose-read geometry of this lane: 16-lane group g covers k = 8g..8g+7 of a 32-pixel k-step
+  // (= 2 patch rows x 16 px): row g>>1, x = (g&1)*8 + (i>>2) (+4 for the second read); lane i <-> channel i
+  const int i16 = lane & 15, g = lane >> 4;
+  const int k_row = g >> 1, k_x = (g & 1) * 8 + (i16 >> 2), ch4 = (i16 & 3) * 4;
+  const char* lds_c = (const char*)smem;
+
+  int patch = blockIdx.x, stage = 0;
+  if (patch < a.n_patches) issue(patch, 0);
+  for (; patch < a.n_patches; patch += gridDim.x) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (patch + (int)gridDim.x < a.n_patches) issue(patch + gridDim.x, stage ^ 1);
+    const char* Xl = lds_c + stage * STAGE;
+    const char* Yl = Xl + X_BYTES;
+
+    // dY^T fragments of this wave's co tiles for the 4 k-steps of the patch: reused by all nine taps
+    uint4 bfr[4][TNT];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int j = 0; j < TNT; ++j) {
+        const int n0 = (wn * TNT + j) * 16;
+        const int p0 = (ks * 2 + k_row) * 16 + k_x;
+        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(Yl + wh_piece<YC8>(p0, n0 + ch4)));
+        const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(Yl + wh_piece<YC8>(p0 + 4, n0 + ch4)));
+        const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+        bfr[ks][j] = make_uint4(l2.x, l2.y, h2.x, h2.y);
+      }
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int ky = tap / 3, kx = tap % 3;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int hp = (ks * 2 + k_row + ky) * WH_HW + k_x + kx;
+        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(Xl + wh_piece<XC8>(hp, wc * 16 + ch4)));
+        const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(Xl + wh_piece<XC8>(hp + 4, wc * 16 + ch4)));
+        const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+        const uint4 af = make_uint4(l2.x, l2.y, h2.x, h2.y);
+#pragma unroll
+        for (int j = 0; j < TNT; ++j) acc[tap][j] = ET::mfma(bfr[ks][j], af, acc[tap][j]);   // D[n][c]
+      }
+    }
+    stage ^= 1;
+  }
+
+  // lane holds D[n = 4*(lane>>4)+r][c = lane&15] -> slab[block][kk = tap*CI + wc*16 + c][n..n+3]
+  float* out = a.slab + (int64_t)blockIdx.x * a.kpad * a.co;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    const int kk = tap * CI + wc * 16 + (lane & 15);
+#pragma unroll
+    for (int j = 0; j < TNT; ++j) {
+      const int n = (wn * TNT + j) * 16 + 4 * (lane >> 4);
+      float* op = out + (int64_t)kk * a.co + n;
+      if (n + 3 < a.co && (a.co & 3) == 0) {
+        *(float4*)op = make_float4(acc[tap][j][0], acc[tap][j][1], acc[tap][j][2], acc[tap][j][3]);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (n + r < a.co) op[r] = acc[tap][j][r];
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+static int wh_num_cu() {
+  static int n = 0;
+  if (n == 0) {
+    hipDeviceProp_t p; int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
+
+bool imm_wgrad_halo_applicable(const imm_conv_desc* d, int lddy) {
+  static const bool off = getenv("IMM_NO_WGRAD_HALO") != nullptr;
+  if (off) return false;
+  if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->updiv != 1 || d->pad_t != 1 || d->pad_l != 1) return false;
+  if (d->ci != 32 && d->ci != 64) return false;
+  if (d->co > 64 || (lddy != 32 && lddy != 64) || d->co > lddy) return false;
+  if (d->hi != d->ho || d->wi != d->wo || d->ho % WH_PH || d->wo % WH_PW) return false;
+  if (d->ho * d->wo < 64 * 64) return false;
+  if (d->kpad != 9 * d->ci) return false;
+  const int64_t xb = (int64_t)d->batch * d->hi * d->wi * d->ldx * 2, yb = (int64_t)d->batch * d->ho * d->wo * lddy * 2;
+  return xb < (1LL << 31) && yb < (1LL << 31);
+}
+
+// number of workgroups == number of slab splits the caller must allocate / reduce
+int imm_wgrad_halo_splits(const imm_conv_desc* d) {
+  const int n_patches = d->batch * (d->ho / WH_PH) * (d->wo / WH_PW);
+  int grid = 2 * wh_num_cu();
+  if (grid > n_patches / 4) grid = n_patches / 4;     // >= 4 patches per workgroup: the slab write is amortised
+  if (grid < 1) grid = 1;
+  return grid;
+}
+
+template <typename ET, int CI, int CO>
+static void wh_launch_cfg(const WgradHaloArgs& a, int grid, hipStream_t s) {
+  constexpr int lds = 2 * (WH_HP * CI * 2 + 128 * CO * 2);
+  static bool attr_set = false;
+  if (!attr_set && lds > 64 * 1024) {
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_halo_kernel<ET, CI, CO>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_wgrad_halo_kernel<ET, CI, CO>), dim3(grid), dim3(256), lds, s, a);
+}
+
+void imm_wgrad_halo_launch(int dtype, const imm_conv_desc* d, const void* x, const void* dy, int lddy, float* slab,
+                           int nsplit, hipStream_t s) {
+  WgradHaloArgs a;
+  a.x = (const uint16_t*)x; a.dy = (const uint16_t*)dy; a.slab = slab;
+  a.batch = d->batch; a.h = d->ho; a.w = d->wo; a.ldx = d->ldx; a.lddy = lddy; a.co = d->co; a.kpad = d->kpad;
+  a.patches_x = d->wo / WH_PW; a.patches_y = d->ho / WH_PH;
+  a.n_patches = d->batch * a.patches_x * a.patches_y;
+  a.x_bytes = (uint32_t)((int64_t)d->batch * d->hi * d->wi * d->ldx * 2);
+  a.dy_bytes = (uint32_t)((int64_t)d->batch * d->ho * d->wo * lddy * 2);
+  const int grid = nsplit;
+#define WH_GO(ET_) \
+  do { \
+    if (d->ci == 64 && lddy == 64) wh_launch_cfg<ET_, 64, 64>(a, grid, s); \
+    else if (d->ci == 64) wh_launch_cfg<ET_, 64, 32>(a, grid, s); \
+    else if (lddy == 64) wh_launch_cfg<ET_, 32, 64>(a, grid, s); \
+    else wh_launch_cfg<ET_, 32, 32>(a, grid, s); \
+  } while (0)
+  if (dtype == IMM_BF16) WH_GO(BF16); else WH_GO(F16);
+#undef WH_GO
+}

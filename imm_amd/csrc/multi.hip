@@ -58,9 +58,13 @@ extern "C" int imm_pack_weights_multi(const int64_t* jobs, const int32_t* blk_fi
   return 0;
 }
 
-// job: {slab, dw, nsplit, ntaps, ci_pad, ci_real, co, kpad, 0...}; 1024 outputs per workgroup (4 per lane)
+// job: {slab, dw, nsplit, ntaps, ci_pad, ci_real, co, kpad, 0...}; 64 outputs per workgroup: 16 lanes of 4 consecutive
+// outputs x 16 split lanes (each sums every 16th slab, 16-byte loads), then a fixed-order LDS reduction over the
+// split lanes -> the per-lane dependent chain is nsplit/16 loads instead of nsplit (the kernel is latency-, not
+// bandwidth-bound: up to 512 slabs per tensor).
 __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const int64_t* __restrict__ jobs,
                                                                 const int32_t* __restrict__ blk_first, int n_jobs) {
+  __shared__ float4 red[16][17];
   const int j = find_job(blk_first, n_jobs, blockIdx.x);
   const int64_t* jb = jobs + (int64_t)j * MULTI_FIELDS;
   const float* __restrict__ slab = (const float*)jb[0];
@@ -69,44 +73,53 @@ __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const int64_t* 
   const int kpad = (int)jb[7];
   const int64_t total = (int64_t)ntaps * ci_real * co;
   const int64_t sstride = (int64_t)kpad * co;
-  if ((co & 3) == 0) {
-    // 4 consecutive output channels per lane: 16-byte slab loads, 4 independent splits in flight
-    const int64_t idx = ((int64_t)(blockIdx.x - blk_first[j]) * 256 + threadIdx.x) * 4;
-    if (idx >= total) return;
-    const int n = (int)(idx % co);
-    const int64_t tc = idx / co;
-    const int c = (int)(tc % ci_real), tap = (int)(tc / ci_real);
-    const float* sp = slab + ((int64_t)tap * ci_pad + c) * co + n;
-    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
-    int s = 0;
-    for (; s + 3 < nsplit; s += 4) {
-      const float4 v0 = *(const float4*)(sp + (int64_t)s * sstride), v1 = *(const float4*)(sp + (int64_t)(s + 1) * sstride);
-      const float4 v2 = *(const float4*)(sp + (int64_t)(s + 2) * sstride), v3 = *(const float4*)(sp + (int64_t)(s + 3) * sstride);
-      a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
-      a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
-      a2.x += v2.x; a2.y += v2.y; a2.z += v2.z; a2.w += v2.w;
-      a3.x += v3.x; a3.y += v3.y; a3.z += v3.z; a3.w += v3.w;
+  const int ql = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int64_t idx = ((int64_t)(blockIdx.x - blk_first[j]) * 16 + ql) * 4;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const bool vec = (co & 3) == 0;
+  if (idx < total) {
+    if (vec) {
+      const int n = (int)(idx % co);
+      const int64_t tc = idx / co;
+      const int c = (int)(tc % ci_real), tap = (int)(tc / ci_real);
+      const float* sp = slab + ((int64_t)tap * ci_pad + c) * co + n;
+      float4 a1 = make_float4(0.f, 0.f, 0.f, 0.f);
+      int s = sl;
+      for (; s + 16 < nsplit; s += 32) {
+        const float4 v0 = *(const float4*)(sp + (int64_t)s * sstride), v1 = *(const float4*)(sp + (int64_t)(s + 16) * sstride);
+        acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
+        a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+      }
+      if (s < nsplit) {
+        const float4 v0 = *(const float4*)(sp + (int64_t)s * sstride);
+        acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
+      }
+      acc.x += a1.x; acc.y += a1.y; acc.z += a1.z; acc.w += a1.w;
+    } else {
+      float* ap = &acc.x;
+      for (int e = 0; e < 4; ++e) {
+        const int64_t id = idx + e;
+        if (id >= total) break;
+        const int n = (int)(id % co);
+        const int64_t tc = id / co;
+        const int c = (int)(tc % ci_real), tap = (int)(tc / ci_real);
+        const float* sp = slab + ((int64_t)tap * ci_pad + c) * co + n;
+        float t = 0.f;
+        for (int s = sl; s < nsplit; s += 16) t += sp[s * sstride];
+        ap[e] = t;
+      }
     }
-    for (; s < nsplit; ++s) {
-      const float4 v0 = *(const float4*)(sp + (int64_t)s * sstride);
-      a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
-    }
-    dw[idx] = (a0.x + a1.x) + (a2.x + a3.x);
-    dw[idx + 1] = (a0.y + a1.y) + (a2.y + a3.y);
-    dw[idx + 2] = (a0.z + a1.z) + (a2.z + a3.z);
-    dw[idx + 3] = (a0.w + a1.w) + (a2.w + a3.w);
-    return;
   }
-  for (int e = 0; e < 4; ++e) {
-    const int64_t idx = ((int64_t)(blockIdx.x - blk_first[j]) * 256 + threadIdx.x) * 4 + e;
-    if (idx >= total) return;
-    const int n = (int)(idx % co);
-    const int64_t tc = idx / co;
-    const int c = (int)(tc % ci_real), tap = (int)(tc / ci_real);
-    const float* sp = slab + ((int64_t)tap * ci_pad + c) * co + n;
-    float acc = 0.f;
-    for (int s = 0; s < nsplit; ++s) acc += sp[s * sstride];
-    dw[idx] = acc;
+  red[sl][ql] = acc;
+  __syncthreads();
+  if (sl == 0 && idx < total) {
+    float4 t = red[0][ql];
+#pragma unroll
+    for (int s = 1; s < 16; ++s) { const float4 v = red[s][ql]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+    dw[idx] = t.x;
+    if (idx + 1 < total) dw[idx + 1] = t.y;
+    if (idx + 2 < total) dw[idx + 2] = t.z;
+    if (idx + 3 < total) dw[idx + 3] = t.w;
   }
 }
 

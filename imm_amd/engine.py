@@ -330,6 +330,9 @@ class IMMEngine:
         big = fd.kpad * co * 4 > (1 << 19)
         target = int(os.environ.get('IMM_WGRAD_TARGET_BIG', '1' if big else '2')) if big else 2
         nsplit = max(1, min(-(-target * self.n_cu // tiles), max(1, npix // 512)))
+        forced = ops.conv2d_wgrad_splits(fd, lay.lddy)     # LDS-resident-tile wgrad kernel: one slab per workgroup
+        if forced > 0:
+            nsplit = forced
         lay.nsplit = nsplit
         lay.slab = self._zeros(nsplit, fd.kpad, co)
         if bn:
@@ -643,7 +646,7 @@ class IMMEngine:
             self._add(self.prog_bwd, lambda: ops.resize_ac_bwd(self.d_joint, d_e, B, He, He, 16, 16, nf8, Cj, nf8), 'resize_ac_bwd')
             self._encoder_backward(self.enc_im, d_e, nf8)
         # one table-driven launch sums every layer's split-K slabs into the flat gradient buffer
-        self.reduce_tab = ops.JobTable([j for j, _n in self._reduce_jobs], [n for _j, n in self._reduce_jobs], 1024, self.dev)
+        self.reduce_tab = ops.JobTable([j for j, _n in self._reduce_jobs], [n for _j, n in self._reduce_jobs], 64, self.dev)
         self._add(self.prog_bwd, lambda: ops.wgrad_reduce_multi(self.reduce_tab), 'wgrad_reduce')
 
     def _encoder_backward(self, layers, d_out, ldd):

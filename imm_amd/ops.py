@@ -128,6 +128,13 @@ def conv2d_wgrad(desc, x, dy, lddy, slab, nsplit):
     call('imm_conv2d_wgrad', C.byref(desc), dtype_enum(x.dtype), _p(x), _p(dy), lddy, _p(slab), nsplit, _s())
 
 
+def conv2d_wgrad_splits(desc, lddy):
+    n = L.load().imm_conv2d_wgrad_splits(C.byref(desc), lddy)
+    if n < 0:
+        raise L.ImmHipError('imm_conv2d_wgrad_splits failed')
+    return n
+
+
 def conv2d_wgrad_reduce(slab, nsplit, kh, kw, ci_pad, ci_real, co, kpad, dw):
     call('imm_conv2d_wgrad_reduce', _p(slab), nsplit, kh, kw, ci_pad, ci_real, co, kpad, _p(dw), _s())
 

@@ -79,7 +79,7 @@ int imm_pack_weights(const float* w, void* wt, int dtype, int mode, int kh, int 
 
 /* Table-driven variants: ONE launch re-packs / reduces every tensor of a step.  jobs: device int64[n_jobs][12];
  * pack job  = {w, wt, mode, kh, kw, ci_real, co_real, c_pad, rows, kpad, 0, 0}  (256*8 elements per workgroup)
- * reduce job = {slab, dw, nsplit, kh*kw, ci_pad, ci_real, co, kpad, 0, 0, 0, 0}   (1024 outputs per workgroup)
+ * reduce job = {slab, dw, nsplit, kh*kw, ci_pad, ci_real, co, kpad, 0, 0, 0, 0}   (64 outputs per workgroup)
  * blk_first: device int32[n_jobs+1] prefix sums of workgroups per job; n_blocks = blk_first[n_jobs]. */
 int imm_pack_weights_multi(const int64_t* jobs, const int32_t* blk_first, int n_jobs, int n_blocks, int dtype,
                            void* stream);
@@ -97,6 +97,9 @@ int imm_conv_stats_blocks(const imm_conv_desc* desc_host);
  * (tf.gradients of nn_utils.py:100 w.r.t. `w`).  desc describes the FORWARD convolution. */
 int imm_conv2d_wgrad(const imm_conv_desc* desc_host, int dtype, const void* x, const void* dy, int lddy,
                      float* slab, int nsplit, void* stream);
+/* > 0: the split count at which the LDS-resident-tile variant (3x3 s1, ci in {32,64}, co<=64, >=64x64) runs --
+ * allocate that many slabs and pass it as nsplit; 0: any nsplit >= 1 (general kernel). */
+int imm_conv2d_wgrad_splits(const imm_conv_desc* desc_host, int lddy);
 int imm_conv2d_wgrad_reduce(const float* slab, int nsplit, int kh, int kw, int ci_pad, int ci_real, int co,
                             int kpad, float* dw, void* stream);
 /* db[n] = sum_m dy[m][n], n < c_out, for convolutions not followed by batch norm (bias_add gradient,

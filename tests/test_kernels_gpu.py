@@ -191,6 +191,38 @@ def test_conv_wgrad(ops, case):
     close(dw, gw, 2e-3, 5e-4, 'wgrad/' + tag)     # f32 accumulate of exact bf16 products
 
 
+WGRAD_HALO_CASES = [(1, 128, 32, 32, 32, 'h32_32'), (2, 64, 64, 64, 64, 'h64_64'), (2, 64, 64, 32, 32, 'h64_32'),
+                    (3, 64, 32, 9, 32, 'h32_9'), (40, 64, 32, 64, 64, 'h32_64_many')]
+
+
+@pytest.mark.parametrize('case', WGRAD_HALO_CASES, ids=[c[-1] for c in WGRAD_HALO_CASES])
+def test_conv_wgrad_halo(ops, case):
+    """3x3 s1 filter gradient through the LDS-resident / transpose-read kernel (conv_wgrad_halo.hip)."""
+    B, H, ci, co, lddy, tag = case
+    dt = torch.bfloat16
+    x = rnd((B, H, H, ci), 121)
+    wr = torch.zeros(3, 3, ci, co, requires_grad=True)
+    yref = O.conv2d_same(x.float(), wr, None, 1)
+    dy = rnd(tuple(yref.shape), 122)
+    (gw,) = torch.autograd.grad(yref, wr, dy.float())
+    desc = ops.fwd_desc(B, H, H, ci, ci, co, lddy, 3, 1, 0)
+    nsplit = ops.conv2d_wgrad_splits(desc, lddy)
+    assert nsplit > 0, 'case should select the halo kernel'
+    slab = torch.full((nsplit, desc.kpad, co), float('nan'), dtype=torch.float32, device=DEV)
+    ops.conv2d_wgrad(desc, x.to(DEV), padded(dy, lddy), lddy, slab, nsplit)
+    dw = torch.full((3, 3, ci, co), float('nan'), dtype=torch.float32, device=DEV)
+    ops.conv2d_wgrad_reduce(slab, nsplit, 3, 3, ci, ci, co, desc.kpad, dw)
+    torch.cuda.synchronize()
+    close(dw, gw, 2e-3, 5e-4, 'wgrad_halo/' + tag)
+    # the general kernel (any other split count) must agree
+    slab2 = torch.empty(3, desc.kpad, co, dtype=torch.float32, device=DEV)
+    ops.conv2d_wgrad(desc, x.to(DEV), padded(dy, lddy), lddy, slab2, 3)
+    dw2 = torch.empty(3, 3, ci, co, dtype=torch.float32, device=DEV)
+    ops.conv2d_wgrad_reduce(slab2, 3, 3, 3, ci, ci, co, desc.kpad, dw2)
+    torch.cuda.synchronize()
+    close(dw, dw2, 1e-3, 2e-4, 'wgrad_halo_vs_general/' + tag)
+
+
 def test_table_driven_pack_and_reduce(ops):
     """imm_pack_weights_multi (bit for bit) / imm_wgrad_reduce_multi (to f32 rounding) vs their single-tensor counterparts."""
     dt = torch.bfloat16
@@ -220,7 +252,7 @@ def test_table_driven_pack_and_reduce(ops):
         ops.conv2d_wgrad_reduce(slab, nsplit, k, k, ci_pad, ci_real, co, kpad, dw_ref)
         jobs.append((slab.data_ptr(), dw.data_ptr(), nsplit, k * k, ci_pad, ci_real, co, kpad)); items.append(k * k * ci_real * co)
         refs.append((slab, dw, dw_ref))
-    tab = ops.JobTable(jobs, items, 1024, DEV)
+    tab = ops.JobTable(jobs, items, 64, DEV)
     ops.wgrad_reduce_multi(tab)
     torch.cuda.synchronize()
     for _s, dw, dw_ref in refs:
