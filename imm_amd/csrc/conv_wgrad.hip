@@ -294,6 +294,9 @@ static int wgrad_launch(const imm_conv_desc* d, const void* x, const void* dy, i
   return 0;
 }
 
+bool imm_wgrad_tr_applicable(const imm_conv_desc* d, int lddy);            // conv_wgrad_tr.hip
+void imm_wgrad_tr_launch(int dtype, const imm_conv_desc* d, const void* x, const void* dy, int lddy, float* slab, int nsplit,
+                         hipStream_t s);
 bool imm_wgrad_halo_applicable(const imm_conv_desc* d, int lddy);          // conv_wgrad_halo.hip
 int imm_wgrad_halo_splits(const imm_conv_desc* d);
 void imm_wgrad_halo_launch(int dtype, const imm_conv_desc* d, const void* x, const void* dy, int lddy, float* slab,
@@ -317,6 +320,11 @@ extern "C" int imm_conv2d_wgrad(const imm_conv_desc* d, int dtype, const void* x
   if (imm_wgrad_halo_applicable(d, lddy) && nsplit == imm_wgrad_halo_splits(d) && (dtype == IMM_BF16 || dtype == IMM_F16)) {
     imm_wgrad_halo_launch(dtype, d, x, dy, lddy, slab, nsplit, (hipStream_t)stream);
     IMM_CHECK_LAUNCH("imm_conv2d_wgrad(halo)");
+    return 0;
+  }
+  if (imm_wgrad_tr_applicable(d, lddy) && (dtype == IMM_BF16 || dtype == IMM_F16)) {
+    imm_wgrad_tr_launch(dtype, d, x, dy, lddy, slab, nsplit, (hipStream_t)stream);
+    IMM_CHECK_LAUNCH("imm_conv2d_wgrad(tr)");
     return 0;
   }
   IMM_DISPATCH_DTYPE(dtype, return wgrad_launch<ET>(d, x, dy, lddy, slab, nsplit, (hipStream_t)stream));
