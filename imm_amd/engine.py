@@ -124,10 +124,10 @@ def synthetic_vgg_weights(seed=2):
 
 
 class _Launch:
-    __slots__ = ('fn', 'tag', 'flops', 'bytes', 'name')
+    __slots__ = ('fn', 'tag', 'flops', 'bytes', 'name', 'lane')
 
-    def __init__(self, fn, tag, flops=0.0, nbytes=0.0, name=''):
-        self.fn, self.tag, self.flops, self.bytes, self.name = fn, tag, flops, nbytes, name
+    def __init__(self, fn, tag, flops=0.0, nbytes=0.0, name='', lane=0):
+        self.fn, self.tag, self.flops, self.bytes, self.name, self.lane = fn, tag, flops, nbytes, name, lane
 
 
 class _ConvLayer:
@@ -188,6 +188,8 @@ class IMMEngine:
         self.vgg_w = OrderedDict((k, v.to(self.dev).contiguous()) for k, v in (vgg_weights or synthetic_vgg_weights()).items())
 
         self.prog_pack, self.prog_fwd, self.prog_bwd, self.prog_opt = [], [], [], []
+        self.two_streams = os.environ.get('IMM_TWO_STREAMS', '1') != '0'
+        self._side = None
         self._pack_jobs, self._reduce_jobs = [], []
         self._training = True
         self._build_network()
@@ -253,7 +255,13 @@ class IMMEngine:
     # network construction
     # ------------------------------------------------------------------------------------------
     def _add(self, prog, fn, tag, flops=0.0, nbytes=0.0, name=''):
-        prog.append(_Launch(fn, tag, flops, nbytes, name or getattr(self, '_cur_scope', '')))
+        prog.append(_Launch(fn, tag, flops, nbytes, name or getattr(self, '_cur_scope', ''), getattr(self, '_cur_lane', 0)))
+
+    def _mark(self, prog, what):
+        """'fork': the side stream may start once everything issued so far has finished; 'join': the main stream waits
+        for the side stream.  Launches registered with lane 1 in between run on the side stream: the two encoders
+        (and their backward passes) are independent chains of small kernels that do not fill 256 CUs on their own."""
+        prog.append(_Launch(None, what))
 
     def _conv_block(self, scope, x, H, W, ci_real, ci_pad, ldx, co, k, stride, bn, relu, needs_dgrad,
                     out=None, ldo=None, out_f32=False, kw=None):
@@ -419,11 +427,14 @@ class IMMEngine:
                 x, H, ci_real, ci_pad, ldx = lay.out, lay.Ho, co, co, lay.ldo
             return layers
 
+        self._mark(self.prog_fwd, 'fork')
+        self._cur_lane = 1                      # image encoder: side stream, concurrent with the pose encoder
         self.enc_im = build_encoder('model/image_encoder', self.in_image)
         if He != 16:   # imm_model.py:324-335: align_corners resize of the 8f-channel embedding down to 16x16
             e = self.enc_im[-1]
             self._add(self.prog_fwd, lambda: ops.resize_ac_fwd(e.out, self.joint, B, He, He, 16, 16, 8 * nf, e.ldo, Cj),
                       'resize_ac')
+        self._cur_lane = 0
         self.enc_pose = build_encoder('model/pose_encoder', self.in_future)
         pe = self.enc_pose[-1]
         self.pose_head = self._conv_block('model/pose_encoder/conv_1', pe.out, He, He, 8 * nf, 8 * nf, pe.ldo, K, 1, 1,
@@ -438,6 +449,7 @@ class IMMEngine:
         self._add(self.prog_fwd, lambda: ops.softargmax_gauss_fwd(self.heat, self.ldh, B, He, He, K, self.inv_std, 16,
                                                                   self.mu, self.py, self.px, gview, Cj, dt), 'bottleneck')
 
+        self._mark(self.prog_fwd, 'join')
         # ---- renderer ---------------------------------------------------------------------------------
         self.ren, self.ren_up = [], []
         x, H, ci_real, ci_pad, ldx = self.joint, 16, 8 * nf + K, Cj, Cj
@@ -625,7 +637,8 @@ class IMMEngine:
                 else:
                     d_out, ldd = dx, lddx
 
-        # ---- bottleneck + pose encoder backward --------------------------------------------------------------
+        # ---- bottleneck + pose encoder backward (main stream) || image encoder backward (side stream) --------------
+        self._mark(self.prog_bwd, 'fork')       # d_joint is complete here
         nf8 = 8 * self.cfg.n_filters
         He = self.He
         ph = self.pose_head
@@ -638,6 +651,7 @@ class IMMEngine:
         self._encoder_backward(self.enc_pose, d_feat, nf8)
 
         # ---- image encoder backward ----------------------------------------------------------------------------
+        self._cur_lane = 1
         if He == 16:
             self._encoder_backward(self.enc_im, self.d_joint, Cj)
         else:
@@ -645,6 +659,8 @@ class IMMEngine:
             d_e = self._act(B, He, He, nf8)
             self._add(self.prog_bwd, lambda: ops.resize_ac_bwd(self.d_joint, d_e, B, He, He, 16, 16, nf8, Cj, nf8), 'resize_ac_bwd')
             self._encoder_backward(self.enc_im, d_e, nf8)
+        self._cur_lane = 0
+        self._mark(self.prog_bwd, 'join')
         # one table-driven launch sums every layer's split-K slabs into the flat gradient buffer
         self.reduce_tab = ops.JobTable([j for j, _n in self._reduce_jobs], [n for _j, n in self._reduce_jobs], 64, self.dev)
         self._add(self.prog_bwd, lambda: ops.wgrad_reduce_multi(self.reduce_tab), 'wgrad_reduce')
@@ -665,14 +681,37 @@ class IMMEngine:
     # execution
     # ------------------------------------------------------------------------------------------
     def run(self, prog):
+        main, side = torch.cuda.current_stream(self.dev), None
+        use_side = self.two_streams
         for l in prog:
-            l.fn()
+            if l.fn is None:
+                if not use_side:
+                    continue
+                if side is None:
+                    side = self._side_stream()
+                ev = torch.cuda.Event()
+                if l.tag == 'fork':
+                    ev.record(main); side.wait_event(ev)
+                else:
+                    ev.record(side); main.wait_event(ev)
+            elif l.lane == 1 and use_side:
+                with torch.cuda.stream(side):
+                    l.fn()
+            else:
+                l.fn()
+
+    def _side_stream(self):
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.dev)
+        return self._side
 
     def run_timed(self, prog):
         """Eager run with a HIP event pair around every launch (events on the launch stream).
         Returns [(tag, ms, flops, bytes)]."""
         evs = []
         for l in prog:
+            if l.fn is None:
+                continue
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             l.fn()
@@ -735,4 +774,4 @@ class IMMEngine:
 
     def step_flops(self):
         """Algorithmic conv FLOPs of one training step (2 FLOP/MAC), BASELINE.md §4 counting rule."""
-        return sum(l.flops for p in (self.prog_fwd, self.prog_bwd) for l in p)
+        return sum(l.flops for p in (self.prog_fwd, self.prog_bwd) for l in p if l.fn is not None)
