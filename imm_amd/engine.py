@@ -189,6 +189,7 @@ class IMMEngine:
 
         self.prog_pack, self.prog_fwd, self.prog_bwd, self.prog_opt = [], [], [], []
         self.two_streams = os.environ.get('IMM_TWO_STREAMS', '1') != '0'
+        self.wgrad_lane = int(os.environ.get('IMM_WGRAD_LANE', '0')) if self.two_streams else 0
         self._side = None
         self._pack_jobs, self._reduce_jobs = [], []
         self._training = True
@@ -256,6 +257,13 @@ class IMMEngine:
     # ------------------------------------------------------------------------------------------
     def _add(self, prog, fn, tag, flops=0.0, nbytes=0.0, name=''):
         prog.append(_Launch(fn, tag, flops, nbytes, name or getattr(self, '_cur_scope', ''), getattr(self, '_cur_lane', 0)))
+
+    def _signal(self, prog, key, lane=None):
+        """Record an event on `lane` (default: the current lane) that other lanes can wait for."""
+        prog.append(_Launch(None, 'record:' + key, lane=self._cur_lane if lane is None else lane))
+
+    def _wait(self, prog, key, lane):
+        prog.append(_Launch(None, 'wait:' + key, lane=lane))
 
     def _mark(self, prog, what):
         """'fork': the side stream may start once everything issued so far has finished; 'join': the main stream waits
@@ -379,7 +387,17 @@ class IMMEngine:
             self._add(self.prog_bwd, lambda: ops.colsum(dy, npix, lddy, co, lddy, lay.cs_partial, gb), 'colsum')
         fd = lay.fd
         flops = 2.0 * npix * k * lay.kw * lay.ci_real * co
+        # Filter gradients are off the critical path (nobody reads them before the final slab reduction).  Moving them
+        # to a third stream was MEASURED SLOWER (4.49 -> 5.02 ms/step: the MFMA/LDS-heavy wgrad workgroups take CU
+        # resources from the critical BN-backward/dgrad chain), so it stays an experiment switch.
+        if self.wgrad_lane:
+            self._signal(self.prog_bwd, 'dy:' + scope)
+            self._wait(self.prog_bwd, 'dy:' + scope, lane=self.wgrad_lane)
+        lane_save = getattr(self, '_cur_lane', 0)
+        if self.wgrad_lane:
+            self._cur_lane = self.wgrad_lane
         self._add(self.prog_bwd, lambda: ops.conv2d_wgrad(fd, lay.x, dy, lddy, lay.slab, lay.nsplit), 'conv_wgrad', flops)
+        self._cur_lane = lane_save
         self._reduce_jobs.append(((lay.slab.data_ptr(), gw.data_ptr(), lay.nsplit, k * lay.kw, lay.ci_pad, lay.ci_real, co, fd.kpad),
                                   k * lay.kw * lay.ci_real * co))
         if lay.needs_dgrad and dx is not None:
@@ -661,6 +679,9 @@ class IMMEngine:
             self._encoder_backward(self.enc_im, d_e, nf8)
         self._cur_lane = 0
         self._mark(self.prog_bwd, 'join')
+        if self.wgrad_lane:
+            self._signal(self.prog_bwd, 'wgrad_done', lane=self.wgrad_lane)
+            self._wait(self.prog_bwd, 'wgrad_done', lane=0)
         # one table-driven launch sums every layer's split-K slabs into the flat gradient buffer
         self.reduce_tab = ops.JobTable([j for j, _n in self._reduce_jobs], [n for _j, n in self._reduce_jobs], 64, self.dev)
         self._add(self.prog_bwd, lambda: ops.wgrad_reduce_multi(self.reduce_tab), 'wgrad_reduce')
@@ -681,29 +702,45 @@ class IMMEngine:
     # execution
     # ------------------------------------------------------------------------------------------
     def run(self, prog):
-        main, side = torch.cuda.current_stream(self.dev), None
-        use_side = self.two_streams
-        for l in prog:
-            if l.fn is None:
-                if not use_side:
-                    continue
-                if side is None:
-                    side = self._side_stream()
-                ev = torch.cuda.Event()
-                if l.tag == 'fork':
-                    ev.record(main); side.wait_event(ev)
-                else:
-                    ev.record(side); main.wait_event(ev)
-            elif l.lane == 1 and use_side:
-                with torch.cuda.stream(side):
+        """Issue a launch program.  Lane 0 = the caller's current stream; lanes 1, 2 = side streams (encoder branch,
+        filter gradients) tied to it with events, so the same code serves eager execution and HIP-graph capture
+        (a side stream joins the capture when it waits on an event recorded in the capturing stream)."""
+        if not self.two_streams:
+            for l in prog:
+                if l.fn is not None:
                     l.fn()
-            else:
-                l.fn()
+            return
+        main = torch.cuda.current_stream(self.dev)
+        streams = {0: main}
+        events = {}
+        joined = {0}        # lanes that have (transitively) received work ordered after the main stream
 
-    def _side_stream(self):
+        def lane_stream(i):
+            if i not in streams:
+                streams[i] = self._side_stream(i)
+            return streams[i]
+        for l in prog:
+            if l.fn is not None:
+                if l.lane == 0:
+                    l.fn()
+                else:
+                    with torch.cuda.stream(lane_stream(l.lane)):
+                        l.fn()
+            elif l.tag == 'fork':
+                ev = torch.cuda.Event(); ev.record(main); lane_stream(1).wait_event(ev)
+            elif l.tag == 'join':
+                ev = torch.cuda.Event(); ev.record(lane_stream(1)); main.wait_event(ev)
+            elif l.tag.startswith('record:'):
+                ev = torch.cuda.Event(); ev.record(lane_stream(l.lane)); events[l.tag[7:]] = ev
+            elif l.tag.startswith('wait:'):
+                lane_stream(l.lane).wait_event(events[l.tag[5:]])
+
+    def _side_stream(self, i=1):
         if self._side is None:
-            self._side = torch.cuda.Stream(device=self.dev)
-        return self._side
+            self._side = {}
+        if i not in self._side:
+            self._side[i] = torch.cuda.Stream(device=self.dev)
+        return self._side[i]
 
     def run_timed(self, prog):
         """Eager run with a HIP event pair around every launch (events on the launch stream).
