@@ -97,7 +97,14 @@ def main():
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--force-dist', action='store_true', help='initialise RCCL and run the split-graph + all-reduce path even at 1 GPU')
     args = ap.parse_args()
+
+    # stdout carries exactly ONE JSON line: route everything else written to fd 1 (RCCL's version banner, library
+    # chatter from any rank) to stderr and keep a private handle on the real stdout for the result
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -107,15 +114,17 @@ def main():
             raise SystemExit('launch with torch.distributed.run --nproc-per-node %d' % args.gpus)
     torch.cuda.set_device(local_rank)
     dev = 'cuda:%d' % local_rank
-    if world > 1:
+    if world > 1 or args.force_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
+        os.environ.setdefault('RANK', '0'); os.environ.setdefault('WORLD_SIZE', '1')
         dist.init_process_group('nccl', device_id=torch.device(dev))
 
     from imm_amd.models.imm_model import IMMModel
     from imm_amd.train.cnn_train_multi import TrainStep
 
     model = IMMModel(model_config(N_MAPS), dtype=torch.bfloat16, device=dev, world_size=world)
-    ts = TrainStep(model, BATCH_PER_GPU, IMAGE_SIZE, world_size=world, use_graph=not args.no_graph)
+    ts = TrainStep(model, BATCH_PER_GPU, IMAGE_SIZE, world_size=world, use_graph=not args.no_graph, split_graphs=args.force_dist)
     eng = ts.engine
     inputs = synthetic_batch(BATCH_PER_GPU, IMAGE_SIZE, seed=rank, device=dev)
     eng.set_inputs(inputs['image'], inputs['future_image'], inputs['mask'])     # resident in HBM from here on
@@ -192,8 +201,9 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline()
-        print(json.dumps(out))
-    if world > 1:
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + '\n').encode())
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

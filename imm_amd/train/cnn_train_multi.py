@@ -32,11 +32,11 @@ def split_inputs(inputs, num_splits, index):
     return out
 
 
-def average_gradients(flat_grads, world_size, group=None):
+def average_gradients(flat_grads, world_size, group=None, force=False):
     """cnn_train_multi.py:66-106.  Sum-all-reduce of the flat gradient buffer; the division by the
     number of towers happens inside imm_clip_adam_step (grad_scale = 1/world_size), before the
     per-tensor clip, as in the reference."""
-    if world_size > 1:
+    if world_size > 1 or (force and dist.is_initialized()):
         dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM, group=group)
     return flat_grads
 
@@ -44,9 +44,11 @@ def average_gradients(flat_grads, world_size, group=None):
 class TrainStep:
     """One rank's training step: fwd+bwd graph -> gradient all-reduce -> clip+Adam graph."""
 
-    def __init__(self, model, batch_per_rank, image_size, world_size=1, use_graph=True, group=None):
+    def __init__(self, model, batch_per_rank, image_size, world_size=1, use_graph=True, group=None, split_graphs=False):
         self.model = model
         self.world_size = world_size
+        # two graphs with the all-reduce in between (always for world_size > 1; selectable at 1 to test that path)
+        self.split = split_graphs or world_size > 1
         self.group = group
         self.engine = model._get_engine(batch_per_rank, image_size)
         if abs(self.engine.hp.grad_scale - 1.0 / world_size) > 1e-9:
@@ -68,7 +70,7 @@ class TrainStep:
             eng.restore(snap)
             self.stream.synchronize()
             eng._training = True
-            if self.world_size == 1:
+            if not self.split:
                 g = ops.Graph()
                 g.capture_begin()
                 eng.run(eng.prog_fwd); eng.run(eng.prog_bwd); eng.run(eng.prog_opt)
@@ -96,8 +98,8 @@ class TrainStep:
                 if self._graphs is None:
                     self._capture()
                 self._graphs[0].launch()
-                if self.world_size > 1:
-                    average_gradients(eng.grads, self.world_size, self.group)
+                if self.split:
+                    average_gradients(eng.grads, self.world_size, self.group, force=True)
                     self._graphs[1].launch()
             else:
                 eng.forward(True)

@@ -253,9 +253,9 @@ def test_graph_replay_equals_eager_and_is_deterministic():
         pytest.skip('no GPU')
     from imm_amd.train.cnn_train_multi import TrainStep
     res = []
-    for use_graph in (False, True, True):
+    for use_graph, split in ((False, False), (True, False), (True, False), (True, True)):
         cfg, model, eng, inputs, P, St = make(4)
-        ts = TrainStep(model, 4, 128, world_size=1, use_graph=use_graph)
+        ts = TrainStep(model, 4, 128, world_size=1, use_graph=use_graph, split_graphs=split)
         for it in range(3):
             loss = ts.step(inputs)
         ts.synchronize()
@@ -263,6 +263,8 @@ def test_graph_replay_equals_eager_and_is_deterministic():
     assert res[1][0] == res[2][0] and torch.equal(res[1][1], res[2][1])          # replay is deterministic
     assert res[0][0] == res[1][0] and torch.equal(res[0][1], res[1][1])          # graph == eager, bitwise
     assert res[0][3] == 3 and torch.equal(res[0][2], res[1][2])
+    # the multi-GPU structure (graph(fwd+bwd) | all-reduce | graph(optimizer)) computes the same thing
+    assert res[3][0] == res[1][0] and torch.equal(res[3][1], res[1][1])
     assert np.isfinite(res[0][0])
 
 
