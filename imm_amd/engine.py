@@ -655,6 +655,13 @@ class IMMEngine:
                 else:
                     d_out, ldd = dx, lddx
 
+        # renderer gradients are complete: reduce their slabs now so that a data-parallel run can all-reduce this
+        # bucket (the tail of the flat gradient buffer) while the encoders' backward is still running
+        self.reduce_tab_ren = ops.JobTable([j for j, _n in self._reduce_jobs], [n for _j, n in self._reduce_jobs], 64, self.dev)
+        self._add(self.prog_bwd, lambda: ops.wgrad_reduce_multi(self.reduce_tab_ren), 'wgrad_reduce', name='renderer')
+        self._reduce_jobs = []
+        self.n_bwd_bucket0 = len(self.prog_bwd)
+        self.bucket0_offset = self.tab.offsets[[n for n, _s, _w in self.spec].index('model/renderer/conv_1/w')]
         # ---- bottleneck + pose encoder backward (main stream) || image encoder backward (side stream) --------------
         self._mark(self.prog_bwd, 'fork')       # d_joint is complete here
         nf8 = 8 * self.cfg.n_filters
@@ -684,7 +691,7 @@ class IMMEngine:
             self._wait(self.prog_bwd, 'wgrad_done', lane=0)
         # one table-driven launch sums every layer's split-K slabs into the flat gradient buffer
         self.reduce_tab = ops.JobTable([j for j, _n in self._reduce_jobs], [n for _j, n in self._reduce_jobs], 64, self.dev)
-        self._add(self.prog_bwd, lambda: ops.wgrad_reduce_multi(self.reduce_tab), 'wgrad_reduce')
+        self._add(self.prog_bwd, lambda: ops.wgrad_reduce_multi(self.reduce_tab), 'wgrad_reduce', name='encoders')
 
     def _encoder_backward(self, layers, d_out, ldd):
         B = self.B

@@ -32,13 +32,14 @@ def split_inputs(inputs, num_splits, index):
     return out
 
 
-def average_gradients(flat_grads, world_size, group=None, force=False):
-    """cnn_train_multi.py:66-106.  Sum-all-reduce of the flat gradient buffer; the division by the
+def average_gradients(flat_grads, world_size, group=None, force=False, async_op=False):
+    """cnn_train_multi.py:66-106.  Sum-all-reduce of (a bucket of) the flat gradient buffer; the division by the
     number of towers happens inside imm_clip_adam_step (grad_scale = 1/world_size), before the
-    per-tensor clip, as in the reference."""
+    per-tensor clip, as in the reference.  With async_op the RCCL work handle is returned (the collective runs
+    on RCCL's stream, ordered after everything already enqueued on the current stream)."""
     if world_size > 1 or (force and dist.is_initialized()):
-        dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM, group=group)
-    return flat_grads
+        return dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+    return None
 
 
 class TrainStep:
@@ -49,6 +50,10 @@ class TrainStep:
         self.world_size = world_size
         # two graphs with the all-reduce in between (always for world_size > 1; selectable at 1 to test that path)
         self.split = split_graphs or world_size > 1
+        # IMM_DP_BUCKETS=2: renderer gradients are all-reduced while the encoders' backward still runs.  Measured at
+        # 1 GPU (RCCL single rank) the extra graph + collective launch costs 0.25 ms/step and cannot be validated on
+        # 8 GPUs from the build box, so the default is ONE all-reduce of the whole 16.6 MB buffer per step.
+        self.buckets = int(os.environ.get('IMM_DP_BUCKETS', '1'))
         self.group = group
         self.engine = model._get_engine(batch_per_rank, image_size)
         if abs(self.engine.hp.grad_scale - 1.0 / world_size) > 1e-9:
@@ -76,7 +81,7 @@ class TrainStep:
                 eng.run(eng.prog_fwd); eng.run(eng.prog_bwd); eng.run(eng.prog_opt)
                 g.capture_end()
                 self._graphs = (g,)
-            else:
+            elif self.buckets < 2:
                 g1 = ops.Graph()
                 g1.capture_begin()
                 eng.run(eng.prog_fwd); eng.run(eng.prog_bwd)
@@ -86,6 +91,23 @@ class TrainStep:
                 eng.run(eng.prog_opt)
                 g2.capture_end()
                 self._graphs = (g1, g2)
+            else:
+                # bucketed: [fwd + VGG/renderer backward] | all-reduce(renderer grads) overlapped with
+                # [encoder backward] | all-reduce(encoder grads) | [clip + Adam + re-pack]
+                n0 = eng.n_bwd_bucket0
+                g1 = ops.Graph()
+                g1.capture_begin()
+                eng.run(eng.prog_fwd); eng.run(eng.prog_bwd[:n0])
+                g1.capture_end()
+                g1b = ops.Graph()
+                g1b.capture_begin()
+                eng.run(eng.prog_bwd[n0:])
+                g1b.capture_end()
+                g2 = ops.Graph()
+                g2.capture_begin()
+                eng.run(eng.prog_opt)
+                g2.capture_end()
+                self._graphs = (g1, g1b, g2)
 
     def step(self, inputs=None):
         """Runs one training step on this rank's shard; returns the (device) scalar loss."""
@@ -98,9 +120,18 @@ class TrainStep:
                 if self._graphs is None:
                     self._capture()
                 self._graphs[0].launch()
-                if self.split:
+                if self.split and self.buckets < 2:
                     average_gradients(eng.grads, self.world_size, self.group, force=True)
                     self._graphs[1].launch()
+                elif self.split:
+                    off = eng.bucket0_offset
+                    w0 = average_gradients(eng.grads[off:], self.world_size, self.group, force=True, async_op=True)
+                    self._graphs[1].launch()          # encoder backward overlaps the first bucket's all-reduce
+                    w1 = average_gradients(eng.grads[:off], self.world_size, self.group, force=True, async_op=True)
+                    for w in (w0, w1):
+                        if w is not None:
+                            w.wait()                  # stream-level wait (RCCL stream -> this stream), not a host sync
+                    self._graphs[2].launch()
             else:
                 eng.forward(True)
                 eng.backward()
