@@ -27,7 +27,7 @@ class ImmHipError(RuntimeError):
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         'batch', 'hi', 'wi', 'ci', 'ldx', 'ho', 'wo', 'co', 'ldy', 'kh', 'kw', 'stride', 'pad_t', 'pad_l',
-        'updiv', 'kpad', 'flags', 'ldmask')]
+        'updiv', 'kpad', 'flags', 'ldmask', 'out_scale', 'out_off_y', 'out_off_x')]
 
 
 class OptHParams(C.Structure):

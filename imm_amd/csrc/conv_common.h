@@ -15,6 +15,7 @@ struct ConvArgs {
   int kpad, KT, ntaps;
   int flags, ldmask;
   int n_nblk, n_blocks;
+  int oscale, ooff_y, ooff_x;   // output scatter (oscale 1 = dense)
   uint32_t x_bytes, wt_bytes;   // buffer-descriptor extents (fast path: out-of-range lanes read zeros)
 };
 
@@ -57,8 +58,15 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4_t (&acc)[
     }
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-      const int m = m0 + wm * TM + i * 16 + (lane & 15);
-      const bool mok = m < a.M;
+      const int mi = m0 + wm * TM + i * 16 + (lane & 15);    // pixel index of this launch (drives validity, stats)
+      int64_t m = mi;                                         // pixel index in the output tensor
+      if (a.oscale != 1 && mi < a.M) {
+        const int hw = a.ho * a.wo;
+        const int img = mi / hw, rem = mi - img * hw;
+        const int oy = rem / a.wo, ox = rem - oy * a.wo;
+        m = ((int64_t)img * a.ho * a.oscale + oy * a.oscale + a.ooff_y) * (a.wo * a.oscale) + ox * a.oscale + a.ooff_x;
+      }
+      const bool mok = mi < a.M;
       float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {

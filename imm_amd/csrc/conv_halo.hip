@@ -272,6 +272,7 @@ bool imm_halo_applicable(const imm_conv_desc* d) {
   if (off) return false;
   if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->updiv != 1 || d->pad_t != 1 || d->pad_l != 1) return false;
   if (d->ci != 32 && d->ci != 64) return false;
+  if (d->out_scale > 1) return false;
   if (d->co > 64) return false;
   if (d->hi != d->ho || d->wi != d->wo || d->ho % HALO_PH || d->wo % HALO_PW) return false;
   if (d->ho * d->wo < 64 * 64) return false;      // deep layers: the im2col kernels have more parallelism

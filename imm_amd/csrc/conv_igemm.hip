@@ -244,6 +244,10 @@ static int validate_desc(const imm_conv_desc* d) {
   IMM_REQUIRE(d->updiv == 1 || d->updiv == 2, "conv: updiv must be 1 or 2");
   IMM_REQUIRE(d->kpad % 32 == 0 && d->kpad >= d->kh * d->kw * d->ci, "conv: kpad=%d too small / unaligned", d->kpad);
   IMM_REQUIRE((int64_t)d->batch * d->ho * d->wo < (1LL << 31), "conv: M overflow");
+  IMM_REQUIRE(d->out_scale >= 0 && d->out_scale <= 2 && d->out_off_y >= 0 && d->out_off_x >= 0 &&
+                  d->out_off_y < (d->out_scale > 1 ? d->out_scale : 1) && d->out_off_x < (d->out_scale > 1 ? d->out_scale : 1),
+              "conv: output scatter");
+  IMM_REQUIRE(d->out_scale <= 1 || !(d->flags & (IMM_CONV_STATS | IMM_CONV_MASK)), "conv: scatter excludes stats/mask");
   return 0;
 }
 
@@ -277,6 +281,7 @@ static int conv_launch(const imm_conv_desc* d, const void* x, const void* wt, co
   a.kh = d->kh; a.kw = d->kw; a.stride = d->stride; a.pad_t = d->pad_t; a.pad_l = d->pad_l; a.updiv = d->updiv;
   a.kpad = d->kpad; a.KT = d->kpad / 32; a.ntaps = d->kh * d->kw;
   a.flags = d->flags; a.ldmask = d->ldmask;
+  a.oscale = d->out_scale > 1 ? d->out_scale : 1; a.ooff_y = d->out_off_y; a.ooff_x = d->out_off_x;
   if (imm_halo_applicable(d)) {
     imm_conv_halo_launch(ET::kEnum, d, a, s);
     IMM_CHECK_LAUNCH("imm_conv2d(halo)");
@@ -326,9 +331,17 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, uint16_t* __res
     if (tap < kh * kw) {
       if (mode == 0) {
         if (n < co_real && c < ci_real) v = w[((int64_t)tap * ci_real + c) * co_real + n];
-      } else {
+      } else if (mode == 1) {
         const int kyf = kh - 1 - tap / kw, kxf = kw - 1 - tap % kw;
         if (n < ci_real && c < co_real) v = w[(((int64_t)kyf * kw + kxf) * ci_real + n) * co_real + c];
+      } else {      // parity class (py,px) of the stride-2 data gradient
+        const int py = ((mode - 4) >> 1) & 1, px = (mode - 4) & 1;
+        const int ny = (kh - py + 1) / 2, nx = (kw - px + 1) / 2;
+        if (tap < ny * nx) {
+          const int jy = tap / nx, jx = tap - jy * nx;
+          const int kyf = py + 2 * (ny - 1 - jy), kxf = px + 2 * (nx - 1 - jx);
+          if (n < ci_real && c < co_real) v = w[(((int64_t)kyf * kw + kxf) * ci_real + n) * co_real + c];
+        }
       }
     }
     wt[idx] = ET::from_f32(v);
@@ -338,8 +351,13 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, uint16_t* __res
 extern "C" int imm_pack_weights(const float* w, void* wt, int dtype, int mode, int kh, int kw, int ci_real,
                                 int co_real, int c_pad, int rows, int kpad, void* stream) {
   IMM_REQUIRE(w && wt, "pack_weights: null");
-  IMM_REQUIRE(mode == 0 || mode == 1, "pack_weights: mode");
-  IMM_REQUIRE(c_pad % 8 == 0 && kpad % 32 == 0 && kpad >= kh * kw * c_pad, "pack_weights: padding");
+  IMM_REQUIRE(mode == 0 || mode == 1 || (mode >= 4 && mode <= 7), "pack_weights: mode");
+  IMM_REQUIRE(c_pad % 8 == 0 && kpad % 32 == 0, "pack_weights: padding");
+  if (mode < 4) IMM_REQUIRE(kpad >= kh * kw * c_pad, "pack_weights: kpad too small");
+  else {
+    const int py = ((mode - 4) >> 1) & 1, px = (mode - 4) & 1;
+    IMM_REQUIRE(kpad >= ((kh - py + 1) / 2) * ((kw - px + 1) / 2) * c_pad, "pack_weights: kpad too small for the parity class");
+  }
   IMM_REQUIRE(c_pad >= (mode == 0 ? ci_real : co_real), "pack_weights: c_pad too small");
   IMM_REQUIRE(rows >= (mode == 0 ? co_real : ci_real), "pack_weights: rows too small");
   const int64_t total = (int64_t)rows * kpad;

@@ -206,7 +206,9 @@ extern "C" int imm_bn_apply_relu(const void* y, int dtype, int64_t npix, int c, 
 static int col_reduce_blocks(int64_t npix, int c) {
   const int tpp = c / 8;
   const int rows = EW_THREADS / tpp;
-  int64_t b = (npix + (int64_t)rows * 16 - 1) / ((int64_t)rows * 16);   // >= 16 pixels per thread
+  // 4 pixels per lane for small tensors (the pass is latency-bound: more workgroups, shorter dependent chains),
+  // capped at 1024 workgroups (= partial rows the finalize kernel has to sum)
+  int64_t b = (npix + (int64_t)rows * 4 - 1) / ((int64_t)rows * 4);
   if (b < 1) b = 1;
   if (b > 1024) b = 1024;
   return (int)b;

@@ -39,9 +39,17 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const int64_t* 
     if (tap < kh * kw) {
       if (mode == 0) {
         if (n < co_real && c < ci_real) v = w[((int64_t)tap * ci_real + c) * co_real + n];
-      } else {
+      } else if (mode == 1) {
         const int kyf = kh - 1 - tap / kw, kxf = kw - 1 - tap % kw;
         if (n < ci_real && c < co_real) v = w[(((int64_t)kyf * kw + kxf) * ci_real + n) * co_real + c];
+      } else {      // parity class (py,px) of the stride-2 data gradient
+        const int py = ((mode - 4) >> 1) & 1, px = (mode - 4) & 1;
+        const int ny = (kh - py + 1) / 2, nx = (kw - px + 1) / 2;
+        if (tap < ny * nx) {
+          const int jy = tap / nx, jx = tap - jy * nx;
+          const int kyf = py + 2 * (ny - 1 - jy), kxf = px + 2 * (nx - 1 - jx);
+          if (n < ci_real && c < co_real) v = w[(((int64_t)kyf * kw + kxf) * ci_real + n) * co_real + c];
+        }
       }
     }
     f[e] = v;

@@ -333,10 +333,22 @@ class IMMEngine:
             lay.lddy = lddy
             lay.dd = None   # filled in backward()
             rows_d = ops.round_up(ci_real, 128)
-            kpad_d = ops.round_up(k * k * lddy, 32)
-            lay.wt_d = self._zeros(rows_d, kpad_d, dtype=dt)
-            self._pack_jobs.append(((w.data_ptr(), lay.wt_d.data_ptr(), 1, k, k, ci_real, co, lddy, rows_d, kpad_d),
-                                    rows_d * kpad_d))
+            lay.s2 = ops.dgrad_s2_class_descs(B, H, W, ci_real, 0, lddy, lddy, k) if stride == 2 else None
+            if lay.s2 is not None:
+                # parity-class decomposition: 4 sub-filters (2x2, 2x1, 1x2, 1x1 taps) instead of a 4x-redundant
+                # transposed gather over all 9 taps
+                lay.wt_s2 = []
+                for dd, mode in lay.s2:
+                    wt_c = self._zeros(rows_d, dd.kpad, dtype=dt)
+                    lay.wt_s2.append(wt_c)
+                    self._pack_jobs.append(((w.data_ptr(), wt_c.data_ptr(), mode, k, k, ci_real, co, lddy, rows_d, dd.kpad),
+                                            rows_d * dd.kpad))
+                lay.wt_d = None
+            else:
+                kpad_d = ops.round_up(k * k * lddy, 32)
+                lay.wt_d = self._zeros(rows_d, kpad_d, dtype=dt)
+                self._pack_jobs.append(((w.data_ptr(), lay.wt_d.data_ptr(), 1, k, k, ci_real, co, lddy, rows_d, kpad_d),
+                                        rows_d * kpad_d))
         else:
             lay.lddy = ldy if not out_f32 else ops.round_up(co, 32)
         # wgrad split: enough workgroups to fill the chip, at least 512 pixels per split
@@ -400,7 +412,13 @@ class IMMEngine:
         self._cur_lane = lane_save
         self._reduce_jobs.append(((lay.slab.data_ptr(), gw.data_ptr(), lay.nsplit, k * lay.kw, lay.ci_pad, lay.ci_real, co, fd.kpad),
                                   k * lay.kw * lay.ci_real * co))
-        if lay.needs_dgrad and dx is not None:
+        if lay.needs_dgrad and dx is not None and getattr(lay, 's2', None) is not None:
+            for (dd0, _mode), wt_c in zip(ops.dgrad_s2_class_descs(B, lay.H, lay.W, lay.ci_real, lddx, lddy, lddy, k), lay.wt_s2):
+                ntap = dd0.kh * dd0.kw
+                self._add(self.prog_bwd, (lambda dd0=dd0, wt_c=wt_c: ops.conv2d(dd0, dy, wt_c, None, dx)), 'conv_dgrad',
+                          2.0 * npix * ntap * lay.ci_real * co,
+                          2.0 * (npix * lddy + npix * lay.ci_real + dd0.kpad * lay.ci_real))
+        elif lay.needs_dgrad and dx is not None:
             dd = ops.dgrad_desc(B, lay.H, lay.W, lay.ci_real, lddx, lddy, lddy, k, lay.stride, 0)
             assert dd.kpad == lay.wt_d.shape[1], (dd.kpad, lay.wt_d.shape)
             self._add(self.prog_bwd, lambda: ops.conv2d(dd, dy, lay.wt_d, None, dx), 'conv_dgrad', flops,

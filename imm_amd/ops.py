@@ -57,6 +57,26 @@ def dgrad_desc(batch, hi, wi, ci_out, lddx, co_pad, lddy, k, stride, flags, ldma
                     flags=flags, ldmask=ldmask)
 
 
+def dgrad_s2_class_descs(batch, hi, wi, ci_out, lddx, co_pad, lddy, k, flags=0):
+    """Stride-2 data gradient as 4 dense stride-1 convolutions, one per input-pixel parity class (py,px):
+        dx[2a+py][2b+px] = sum_{ty,tx} dy[a-ty][b-tx] * W[py+2ty][px+2tx]
+    (TF SAME on an even side with k=3 pads 0 before, so ky = iy - 2*oy has the parity of iy).  Returns
+    [(desc, pack_mode)], or None when the geometry does not fit (odd side / pad_before != 0)."""
+    pt, ho = same_pad_before(hi, k, 2)
+    pl, wo = same_pad_before(wi, k, 2)
+    if pt != 0 or pl != 0 or hi != 2 * ho or wi != 2 * wo:
+        return None
+    out = []
+    for py in (0, 1):
+        for px in (0, 1):
+            ny, nx = (k - py + 1) // 2, (k - px + 1) // 2
+            d = ConvDesc(batch=batch, hi=ho, wi=wo, ci=co_pad, ldx=lddy, ho=ho, wo=wo, co=ci_out, ldy=lddx, kh=ny, kw=nx,
+                         stride=1, pad_t=ny - 1, pad_l=nx - 1, updiv=1, kpad=round_up(ny * nx * co_pad, 32), flags=flags,
+                         ldmask=0, out_scale=2, out_off_y=py, out_off_x=px)
+            out.append((d, 4 + 2 * py + px))
+    return out
+
+
 def device_info():
     out = (C.c_int32 * 2)()
     call('imm_device_info', C.cast(out, C.c_void_p))

@@ -55,6 +55,10 @@ typedef struct imm_conv_desc {
   int32_t kpad;                /* packed-weight row length: round_up(kh*kw*ci, 32)                */
   int32_t flags;               /* IMM_CONV_*                                                      */
   int32_t ldmask;              /* pixel stride of mask_ref (IMM_CONV_MASK)                        */
+  /* output scatter (0/0/0 = dense): output pixel (y,x) of this launch is written to pixel
+   * (y*out_scale + out_off_y, x*out_scale + out_off_x) of a [batch, ho*out_scale, wo*out_scale] tensor.
+   * Used by the parity-class decomposition of the stride-2 data gradient (4 launches, out_scale = 2). */
+  int32_t out_scale, out_off_y, out_off_x;
 } imm_conv_desc;
 
 /* ---- runtime ------------------------------------------------------------------------------- */
@@ -73,6 +77,9 @@ int imm_graph_destroy(void* graph_exec);
 /* f32 HWIO master [kh,kw,ci_real,co_real] -> 16-bit packed Wt[rows][kpad] (k contiguous).
  * mode 0 (forward): row n = co, k = (ky*kw+kx)*ci_pad + c.
  * mode 1 (dgrad):   row n = ci, k = (ky'*kw+kx')*co_pad + c', value W[kh-1-ky'][kw-1-kx'][n][c'].
+ * mode 4+2*py+px (stride-2 dgrad, input-pixel parity class (py,px); kh,kw = size of the FULL filter):
+ *                   sub-filter of ny x nx taps, ny = (kh-py+1)/2, nx = (kw-px+1)/2; row n = ci,
+ *                   k = (jy*nx+jx)*co_pad + c', value W[py+2(ny-1-jy)][px+2(nx-1-jx)][n][c'].
  * rows >= real count and padded k are written as zeros; `rows` is the allocated row count. */
 int imm_pack_weights(const float* w, void* wt, int dtype, int mode, int kh, int kw, int ci_real, int co_real,
                      int c_pad, int rows, int kpad, void* stream);

@@ -164,6 +164,28 @@ def test_conv_dgrad(ops, case):
     close(dx[..., :ci_real], gx, 1e-2, 2e-3, 'dgrad/' + tag)
 
 
+@pytest.mark.parametrize('H,ci,co', [(16, 32, 64), (32, 64, 128), (64, 128, 256)])
+def test_conv_dgrad_stride2_parity_classes(ops, H, ci, co):
+    """Stride-2 data gradient as four dense sub-convolutions (one per input-pixel parity class) scattered into dx."""
+    B, k, dt = 2, 3, torch.bfloat16
+    w = rnd((k, k, ci, co), 13, 0.05)
+    xr = torch.zeros(B, H, H, ci, requires_grad=True)
+    yref = O.conv2d_same(xr, w.float(), None, 2)
+    dy = rnd(tuple(yref.shape), 14)
+    (gx,) = torch.autograd.grad(yref, xr, dy.float())
+    descs = ops.dgrad_s2_class_descs(B, H, H, ci, ci, co, co, k)
+    assert descs is not None and len(descs) == 4 and sorted(d.kh * d.kw for d, _ in descs) == [1, 2, 2, 4]
+    dx = torch.full((B, H, H, ci), float('nan'), dtype=dt, device=DEV)
+    dyd = dy.to(DEV).contiguous()
+    rows = ops.round_up(ci, 128)
+    for d, mode in descs:
+        wt = torch.zeros(rows, d.kpad, dtype=dt, device=DEV)
+        ops.pack_weights(w.float().to(DEV).contiguous(), wt, mode, k, k, ci, co, co, rows, d.kpad)
+        ops.conv2d(d, dyd, wt, None, dx)
+    torch.cuda.synchronize()
+    close(dx, gx, 1e-2, 2e-3, 'dgrad_s2_classes')       # every pixel written exactly once (no NaN left)
+
+
 # ----------------------------------------------------------------------------------------------
 # filter gradient
 # ----------------------------------------------------------------------------------------------
