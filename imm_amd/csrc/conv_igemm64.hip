@@ -33,11 +33,14 @@ __device__ __forceinline__ void lds_dma16(u32x4_t rsrc, uint32_t lds_addr, uint3
 //   s_barrier                     => every wave's share has landed, and every wave finished reading tile kt-1
 //   issue tile kt+NS-1            into the stage tile kt-1 occupied
 //   ds_read + MFMA on tile kt
-template <typename ET, int BM, int BN, int NS>
-__global__ __launch_bounds__(256) void conv_igemm64_kernel(const ConvArgs a) {
-  constexpr int WGM = 2, WGN = 2;
+// NW waves per workgroup (4 or 8): 8 waves halve each wave's tile (more waves per SIMD to hide DMA / LDS latency, at
+// 1.5x the LDS bytes per MFMA).
+template <typename ET, int BM, int BN, int NS, int NW>
+__global__ __launch_bounds__(NW * 64) void conv_igemm64_kernel(const ConvArgs a) {
+  constexpr int WGM = NW / 2, WGN = 2;
   constexpr int TM = BM / WGM, TN = BN / WGN, MT = TM / 16, NT = TN / 16;
-  constexpr int A_INSTR = BM / 32, B_INSTR = BN / 32;   // 8-row wave instructions per wave per tile
+  constexpr int A_INSTR = BM / (8 * NW), B_INSTR = BN / (8 * NW);   // 8-row wave instructions per wave per tile
+  static_assert(A_INSTR >= 1 && B_INSTR >= 1 && MT >= 1 && NT >= 1, "tile too small for the wave count");
   constexpr int BUF = (BM + BN) * 8;                    // uint4 per stage
   extern __shared__ __attribute__((aligned(16))) uint4 smem[];   // NS * BUF
   constexpr int LPT = A_INSTR + B_INSTR;
@@ -155,15 +158,15 @@ __global__ __launch_bounds__(256) void conv_igemm64_kernel(const ConvArgs a) {
   conv_epilogue<ET, BM, BN, WGM, WGN, MT, NT>(a, acc, tid, wm, wn, m0, n0, mblk, (float*)smem);
 }
 
-template <typename ET, int BM, int BN, int NS>
+template <typename ET, int BM, int BN, int NS, int NW = 4>
 static void launch64_cfg(const ConvArgs& a, hipStream_t s) {
   constexpr int lds = NS * (BM + BN) * 128;
   static bool attr_set = false;   // per instantiation; > 64 KB of dynamic LDS needs the opt-in once
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)conv_igemm64_kernel<ET, BM, BN, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)conv_igemm64_kernel<ET, BM, BN, NS, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_igemm64_kernel<ET, BM, BN, NS>), dim3(a.n_blocks), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((conv_igemm64_kernel<ET, BM, BN, NS, NW>), dim3(a.n_blocks), dim3(NW * 64), lds, s, a);
 }
 
 template <typename ET>
@@ -174,7 +177,11 @@ static void launch64(ConvArgs& a, int bm, int bn, hipStream_t s) {
   // stage count: big tiles are throughput-bound and want 2-3 co-resident workgroups per CU (2 stages = 64 / 48 KB);
   // the 64x64 tile is used when the grid is small (deep layers), is latency-bound and wants a deeper ring instead
   static const int ns64 = getenv("IMM_NS64") ? atoi(getenv("IMM_NS64")) : 4;
-  if (bm == 128 && bn == 128) launch64_cfg<ET, 128, 128, 2>(a, s);
+  static const int nw8 = getenv("IMM_IGEMM_NW8") ? atoi(getenv("IMM_IGEMM_NW8")) : 0;   // experiment: 1 = 2 stages, 2 = 3 stages
+  if (bm == 128 && bn == 128 && nw8 == 1) launch64_cfg<ET, 128, 128, 2, 8>(a, s);
+  else if (bm == 128 && bn == 128 && nw8 == 2) launch64_cfg<ET, 128, 128, 3, 8>(a, s);
+  else if (bm == 128 && bn == 128) launch64_cfg<ET, 128, 128, 2>(a, s);
+  else if (bm == 128 && bn == 64 && nw8) launch64_cfg<ET, 128, 64, 2, 8>(a, s);
   else if (bm == 128 && bn == 64) launch64_cfg<ET, 128, 64, 2>(a, s);
   else if (ns64 == 3) launch64_cfg<ET, 64, 64, 3>(a, s);
   else if (ns64 == 6) launch64_cfg<ET, 64, 64, 6>(a, s);
