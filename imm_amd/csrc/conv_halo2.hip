@@ -1,0 +1,516 @@
+// conv_halo2.hip — second-generation 3x3 stride-1 convolution for the high-resolution, low-channel layers
+// (ci in {32,64}, co in {32,64}): encoder conv_2 / conv_4, renderer conv_6 / conv_7, VGG conv1_2 and the data
+// gradients of the same layers (reference call sites: imm/models/imm_model.py:213-241 encoder, :258-300 renderer,
+// imm/models/selfsup/vgg16.py:346 conv1_2).  conv_halo.hip (v1) stays for co < 32, f32 output and the ablation bits.
+//
+// What the v1 ablation showed (tools/bench_conv.py --ablate, VGG conv1_2, 129 us): LDS reads + MFMA alone 67 us,
+// epilogue +40 us, halo DMA +20 us — the three phases of a patch ran back to back because one workgroup per CU
+// (72 KB of LDS-resident filter) walks them in lock step, and the LDS pipe (A and B fragments for every wave)
+// was 1.6x busier than the matrix pipe.  This kernel changes the three things that follow from that:
+//   * the filter lives in REGISTERS: a wave owns 32 output channels, so its nine taps are 9 x (ci/32) x 2 MFMA B
+//     operands = 72/144 VGPRs loaded once per workgroup; LDS only carries the input halo (A operand), which
+//     halves the LDS traffic per MFMA;
+//   * the epilogue of patch p-1 (bias / ReLU / ReLU-backward mask / BN partial sums / 16-byte stores) is
+//     interleaved tile row by tile row into the MFMA loop of patch p (two accumulator sets, loop unrolled by two so
+//     the sets are addressed statically) — VALU and store issue ride in the shadow of the matrix pipe;
+//   * the halo ring is NS deep (prefetch distance NS-1 patches instead of 1), and every global access of the loop
+//     — halo DMA, mask DMA, output stores — is issued from inline asm so that ONE counted s_waitcnt vmcnt(N) per
+//     patch is exact: each iteration issues the same number of VMEM instructions (out-of-range buffer offsets turn
+//     the ones without a patch into no-ops), so "at most N outstanding" always means "the DMA of this patch landed".
+// Output channel order inside a wave is permuted (MFMA row 4q+r of tile j <-> channel 8q+4j+r) so that a lane owns 8
+// consecutive channels of its pixel: one 16-byte store (and one 16-byte mask read) per pixel and tile row.
+// Results are bit-identical to v1 except for the order of the BN partial sums (deterministic either way).
+#include "conv_common.h"
+#include <stdlib.h>
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+
+#define H2_PH 8                 // patch rows
+#define H2_PW 16                // patch cols (= MFMA operand rows)
+#define H2_HW (H2_PW + 2)       // halo width 18
+#define H2_HP 192               // halo pixels (10*18 = 180) padded to a whole number of DMA instructions
+#define H2_OOB 0x80000000u      // buffer offset beyond every extent: loads return zero, stores are dropped
+
+struct Halo2Args {
+  ConvArgs c;
+  int n_patches, patches_x, patches_y;
+  uint32_t y_bytes, mask_bytes;
+  int lg_px, lg_pi;                       // log2(patches_x), log2(patches per image), or -1 when not powers of two
+};
+
+__device__ __forceinline__ void h2_dma16(u32x4_t rsrc, uint32_t lds_addr, uint32_t voff, uint32_t soff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+               :: "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+__device__ __forceinline__ void h2_store16(u32x4_t rsrc, u32x4_t data, uint32_t voff, uint32_t soff) {
+  asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen" :: "v"(data), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+
+// same chunk swizzle as conv_halo.hip: a ds_read_b128 of 16 consecutive halo pixels (any start) is conflict-free
+template <int C8>
+__device__ __forceinline__ int h2_swz(int row) { return C8 == 8 ? (((row >> 1) & 3) << 1) : (((row >> 2) & 1) << 1); }
+
+template <int V> struct H2Int { static constexpr int value = V; };
+
+// sched_group_barrier masks (LLVM AMDGPU): the MFMA loop of a halo row is laid out as "1 MFMA + up to 3 other issues"
+#define H2_SG_VALU 0x002
+#define H2_SG_SALU 0x004
+#define H2_SG_MFMA 0x008
+#define H2_SG_DSREAD 0x100
+
+template <typename ET, int CI, int BN, bool MASK, bool STATS, int NS>
+__global__ __launch_bounds__(256) void conv_halo2_kernel(const Halo2Args ha) {
+  const ConvArgs& a = ha.c;
+  constexpr int C8 = CI / 8;                       // 16-byte chunks per input pixel
+  constexpr int KS = CI / 32;                      // MFMA k-steps per tap
+  constexpr int WGN = BN / 32, WGM = 4 / WGN;      // a wave owns 32 channels x MT patch rows
+  constexpr int MT = H2_PH / WGM, NT = 2, NR = MT + 2;   // NR halo rows per wave
+  constexpr int PIXB = CI * 2, ROWB = H2_HW * PIXB;      // bytes per halo pixel / halo row in LDS
+  constexpr int PIX_PER_DMA = 64 / C8;             // halo pixels per 1-KB DMA instruction
+  constexpr int HALO_DMA = H2_HP / PIX_PER_DMA;    // 24 / 12
+  constexpr int DH = HALO_DMA / 4;                 // per wave
+  constexpr int H_U4 = H2_HP * C8;                 // uint4 per halo stage
+  constexpr int O8 = BN / 8;                       // 16-byte chunks per output (= mask) pixel
+  constexpr int M_U4 = MASK ? H2_PH * H2_PW * O8 : 0;
+  constexpr int MASK_DMA = M_U4 / 64, DM = MASK_DMA / 4;
+  // VMEM instructions per wave and iteration: DH + DM DMA pieces and MT stores, spread over the halo rows.  "At most
+  // (NS-2) whole iterations outstanding" => everything issued NS-1 iterations ago (halo of this patch, mask of the
+  // previous one) has landed, whatever the order inside an iteration.
+  constexpr int WAITN = (NS - 2) * (DH + DM + MT);
+  static_assert(HALO_DMA % 4 == 0 && MASK_DMA % 4 == 0 && WAITN < 64, "per-wave VMEM schedule");
+  extern __shared__ __attribute__((aligned(16))) uint4 smem[];   // [NS][H_U4] halo ring | [NS][M_U4] mask ring
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: LDS-DMA destinations are wave-uniform
+  const int wm = wid / WGN, wn = wid % WGN;
+  const int frow = lane & 15, q = lane >> 4;
+  const uint64_t xa = (uint64_t)a.x, ya = (uint64_t)a.y, ma = (uint64_t)a.mask;
+  const u32x4_t xr = {(uint32_t)xa, (uint32_t)(xa >> 32) & 0xffffu, a.x_bytes, 0x00020000u};
+  const u32x4_t yr = {(uint32_t)ya, (uint32_t)(ya >> 32) & 0xffffu, ha.y_bytes, 0x00020000u};
+  const u32x4_t mr = {(uint32_t)ma, (uint32_t)(ma >> 32) & 0xffffu, ha.mask_bytes, 0x00020000u};
+  const uint32_t lds_base = (uint32_t)(size_t)(lds_void_t*)smem;
+  const int G = gridDim.x, per_img = ha.patches_x * ha.patches_y;
+  // Patch order.  Workgroups are dealt round-robin to the 8 XCDs (private L2 each): give every XCD one contiguous
+  // band of patches and let its workgroups walk the band side by side, so the halo rows that neighbouring patches
+  // share are fetched once per L2 instead of once per XCD.  seq = this workgroup's sequence index; -1 = no patch.
+  const bool xcd_mode = (G & 7) == 0;
+  const int xq = ha.n_patches >> 3, xrem = ha.n_patches & 7, xid = blockIdx.x & 7;
+  const int band0 = xid * xq + (xid < xrem ? xid : xrem), band_n = xq + (xid < xrem ? 1 : 0);
+  auto seq_patch = [&](int seq) -> int {
+    if (xcd_mode) {
+      const int local = (int)(blockIdx.x >> 3) + seq * (G >> 3);
+      return local < band_n ? band0 + local : -1;
+    }
+    const int pt = blockIdx.x + seq * G;
+    return pt < ha.n_patches ? pt : -1;
+  };
+  // decoded patch: image and pixel origin (scalars).  Invalid patches get an origin far outside every image, which
+  // turns all their DMA / store offsets into out-of-range no-ops.
+  struct Pd { int img, y0, x0; };
+  const bool pow2 = ha.lg_px >= 0;
+  auto decode = [&](int patch) -> Pd {
+    Pd d;
+    if (patch < 0) { d.img = 0; d.y0 = 0x4000; d.x0 = 0; return d; }
+    int pr, py;
+    if (pow2) { d.img = patch >> ha.lg_pi; pr = patch & (per_img - 1); py = pr >> ha.lg_px; d.x0 = (pr & (ha.patches_x - 1)) * H2_PW; }
+    else { d.img = patch / per_img; pr = patch - d.img * per_img; py = pr / ha.patches_x; d.x0 = (pr - py * ha.patches_x) * H2_PW; }
+    d.y0 = py * H2_PH;
+    return d;
+  };
+
+  // ---- filter -> registers (MFMA B operand layout; channel permutation described in the header) ---------------
+  u32x4_t bw[9][KS][NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int n = wn * 32 + (frow >> 2) * 8 + j * 4 + (frow & 3);
+    const uint16_t* wrow = a.wt + (size_t)n * a.kpad + q * 8;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) bw[tap][ks][j] = *(const u32x4_t*)(wrow + tap * CI + ks * 32);
+  }
+  const bool f_bias = a.flags & IMM_CONV_BIAS;
+  const float relu_floor = (a.flags & IMM_CONV_RELU) ? 0.f : -__builtin_huge_valf();
+  float bv[NT][4], s1[NT][4], s2[NT][4];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      s1[j][r] = 0.f; s2[j][r] = 0.f;
+      bv[j][r] = f_bias ? a.bias[wn * 32 + q * 8 + j * 4 + r] : 0.f;
+    }
+  // Every compiler-visible global load ends here: pass the values through empty asm statements so the compiler's
+  // own s_waitcnt for them is placed before the loop, not (conservatively, as vmcnt(0)) inside it.
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) asm volatile("" : "+v"(bw[tap][ks][j]));
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(bv[j][r]));
+
+  // ---- DMA pieces (piece k of a wave = instruction wid + 4k of the workgroup's batch) ---------------------------
+  // patch-invariant part of a lane's halo addresses: halo pixel (hy, hx), byte offset relative to the halo origin;
+  // the 12 padding slots get a row far outside every image.  LDS image: [halo row][pixel][chunk ^ swz(pixel)].
+  int hyx[DH];
+  uint32_t hrel[DH];
+#pragma unroll
+  for (int k = 0; k < DH; ++k) {
+    const int hp = (wid + 4 * k) * PIX_PER_DMA + lane / C8;        // halo slot 0..191
+    const int hy = hp / H2_HW, hx = hp - hy * H2_HW;
+    const int sc = (lane % C8) ^ h2_swz<C8>(hx);
+    hyx[k] = ((hp < (H2_PH + 2) * H2_HW ? hy : 0x4000) << 16) | hx;
+    hrel[k] = (uint32_t)((hy * a.wi + hx) * a.ldx * 2 + sc * 16);
+  }
+  auto halo_piece = [&](const Pd& d, int stage, int k) {
+    const int y0 = d.y0 - 1, x0 = d.x0 - 1;
+    const uint32_t soff = (uint32_t)(d.img * a.hi * a.wi) * (uint32_t)(a.ldx * 2);
+    const uint32_t base = (uint32_t)((y0 * a.wi + x0) * a.ldx * 2);     // may be "negative": only used when in range
+    const int iy = y0 + (hyx[k] >> 16), ix = x0 + (hyx[k] & 0xffff);
+    const bool ok = ((unsigned)iy < (unsigned)a.hi) & ((unsigned)ix < (unsigned)a.wi);
+    uint32_t in_range = base + hrel[k];
+    asm volatile("" : "+v"(in_range));        // keep the add unconditional: a select, not an exec-masked block
+    const uint32_t vo = ok ? in_range : H2_OOB;
+    h2_dma16(xr, lds_base + (uint32_t)((stage * H_U4) * 16 + (wid + 4 * k) * 1024), vo, soff);
+  };
+  uint32_t mrel[DM > 0 ? DM : 1];
+  if constexpr (MASK) {
+#pragma unroll
+    for (int k = 0; k < DM; ++k) {
+      const int px = (wid + 4 * k) * (64 / O8) + lane / O8;          // patch pixel 0..127
+      const int row = px >> 4, x = px & 15;
+      const int c = (lane % O8) ^ (x & (O8 - 1));                    // stored slot (lane % O8) holds source chunk c
+      mrel[k] = (uint32_t)((row * a.wo + x) * a.ldmask * 2 + c * 16);
+    }
+  }
+  auto mask_piece = [&](const Pd& d, int stage, int k) {
+    if constexpr (MASK) {
+      const uint32_t soff = (uint32_t)(d.img * a.ho * a.wo) * (uint32_t)(a.ldmask * 2);
+      const uint32_t vo = d.y0 < 0x4000 ? (uint32_t)((d.y0 * a.wo + d.x0) * a.ldmask * 2) + mrel[k] : H2_OOB;
+      h2_dma16(mr, lds_base + (uint32_t)((NS * H_U4 + stage * M_U4) * 16 + (wid + 4 * k) * 1024), vo, soff);
+    }
+  };
+
+  // per-lane byte offset of the A fragments inside a halo stage, for the three horizontal taps (k-step 1 = XOR 64;
+  // halo row rr = + rr * ROWB, an immediate of the ds_read)
+  int lrel[3];
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx) lrel[kx] = wm * MT * ROWB + (frow + kx) * PIXB + (q ^ h2_swz<C8>(frow + kx)) * 16;
+  const int moff = frow * O8 + ((wn * 4 + q) ^ (frow & (O8 - 1)));   // + patch row * 16 * O8
+  const uint32_t ovoff = (uint32_t)((frow * a.ldy + wn * 32 + q * 8) * 2);   // lane part of the output address
+
+  // ---- prologue: NS-1 batches in flight; dummy stores keep the per-iteration VMEM count uniform ----------------
+  const u32x4_t zero4 = {0u, 0u, 0u, 0u};
+  Pd dq[NS];                                   // decoded patches it .. it+NS-1 (shift register)
+#pragma unroll
+  for (int s = 0; s < NS; ++s) dq[s] = decode(seq_patch(s));
+  const Pd none = decode(-1);
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s) {
+#pragma unroll
+    for (int k = 0; k < DH; ++k) halo_piece(dq[s], s, k);
+#pragma unroll
+    for (int k = 0; k < DM; ++k) mask_piece(s >= 1 ? dq[s - 1] : none, s >= 1 ? s - 1 : NS - 1, k);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) h2_store16(yr, zero4, H2_OOB, 0u);
+  }
+
+  f32x4_t acc[2][MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[1][i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  int it = 0, hs = 0;                        // sequence index of this workgroup's patch, its halo stage (it % NS)
+  uint32_t prev_voff = H2_OOB, prev_soff = 0u;
+  float prev_w = 0.f;                        // 1 when the previous patch exists (BN partial sums)
+
+  // One patch: MFMA loop of patch `it` into acc[PH] with the epilogue of patch it-1 (acc[PH^1]) interleaved.
+  // MMA = 0 is the pass after the last patch: only the deferred epilogue runs.
+  auto step = [&](auto phase, auto mma) {
+    constexpr int PH = decltype(phase)::value;
+    constexpr bool MMA = decltype(mma)::value;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAITN) : "memory");   // this wave's share of halo(it) and mask(it-1) landed
+    __builtin_amdgcn_s_barrier();                                  // => everyone's; stage it-1 is free for reuse
+    __builtin_amdgcn_sched_barrier(0);
+    const int hprev = hs == 0 ? NS - 1 : hs - 1;                   // (it-1) % NS
+    const int hprev2 = hprev == 0 ? NS - 1 : hprev - 1;            // (it-2) % NS
+    const uint4* Ml = smem + NS * H_U4 + hprev * M_U4 + moff;
+    const uint4* rowp[3][KS];                                      // lane's fragment address in halo row 0 of this stage
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+        rowp[kx][ks] = (const uint4*)((const char*)smem + hs * (H_U4 * 16) + (lrel[kx] ^ (ks * 64)));
+    uint4 fa[2][3][KS];
+    if constexpr (MMA) {
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) fa[0][kx][ks] = rowp[kx][ks][0];
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[PH][i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    __builtin_amdgcn_sched_barrier(0);
+
+    // Halo-row major: the A fragments of halo row rr (3 horizontal shifts x KS k-steps) are read ONCE and feed the
+    // output rows rr, rr-1, rr-2 (vertical taps 0, 1, 2) — NR*3*KS ds_read_b128 per patch instead of 9*MT*KS.  One
+    // wave per SIMD means nothing else hides this wave's non-MFMA issues, so each row region is laid out as: next
+    // row's fragments first, then 1 MFMA : <= 3 other issues — the epilogue of the previous patch (tile row rr-1),
+    // this row's share of the next halo / mask DMA and the scalar bookkeeping ride in the matrix pipe's shadow.
+#pragma unroll
+    for (int rr = 0; rr < NR; ++rr) {
+      int n_mfma = 0;
+      if constexpr (MMA) {
+        if (rr + 1 < NR) {
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) fa[(rr + 1) & 1][kx][ks] = rowp[kx][ks][(rr + 1) * (ROWB / 16)];
+        }
+#pragma unroll
+        for (int k = rr; k < DH; k += NR) halo_piece(dq[NS - 1], hprev, k);
+#pragma unroll
+        for (int k = rr; k < DM; k += NR) mask_piece(dq[NS - 2], hprev2, k);
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+              const int i = rr - ky;
+              if (i >= 0 && i < MT) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                  acc[PH][i][j] = ET::mfma(__builtin_bit_cast(uint4, bw[ky * 3 + kx][ks][j]), fa[rr & 1][kx][ks], acc[PH][i][j]);   // D[n][pixel]
+                n_mfma += NT;
+              }
+            }
+      }
+      // ---- epilogue of the previous patch, tile row (rr - 1) ----------------------------------------------------
+      if (rr >= 1 && rr <= MT) {
+        const int i = rr - 1;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[j * 4 + r] = fmaxf(acc[PH ^ 1][i][j][r] + bv[j][r], relu_floor);
+        if constexpr (MASK) {
+          const uint4 mk = Ml[(wm * MT + i) * 16 * O8];
+          float mf[8];
+          unpack8<ET>(mk, mf);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = (mf[e] > 0.f) ? v[e] : 0.f;
+        }
+        if constexpr (STATS) {
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float t = v[j * 4 + r] * prev_w;
+              s1[j][r] += t; s2[j][r] += t * t;
+            }
+        }
+        const uint4 o = pack8<ET>(v);
+        const u32x4_t od = {o.x, o.y, o.z, o.w};
+        h2_store16(yr, od, prev_voff + (uint32_t)((wm * MT + i) * a.wo * a.ldy * 2), prev_soff);
+      }
+      if (rr == NR - 1) {
+        // bookkeeping for the next iteration (scalar): hand this patch to the next epilogue, shift the decode queue
+        if constexpr (MMA) {
+          prev_voff = (uint32_t)((dq[0].y0 * a.wo + dq[0].x0) * a.ldy * 2) + ovoff;
+          prev_soff = (uint32_t)(dq[0].img * a.ho * a.wo) * (uint32_t)(a.ldy * 2);
+          prev_w = 1.f;
+#pragma unroll
+          for (int s = 0; s + 1 < NS; ++s) dq[s] = dq[s + 1];
+          dq[NS - 1] = decode(seq_patch(it + NS));
+        }
+      }
+      if constexpr (MMA) {
+        __builtin_amdgcn_sched_group_barrier(H2_SG_DSREAD, 3 * KS, 0);
+#pragma unroll
+        for (int m = 0; m < 36; ++m) {
+          if (m < n_mfma) {
+            __builtin_amdgcn_sched_group_barrier(H2_SG_MFMA, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(H2_SG_VALU | H2_SG_SALU, 3, 0);
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    hs = hs + 1 == NS ? 0 : hs + 1;
+    ++it;
+  };
+  // patches p0 .. p_last (every workgroup has at least one), then one more pass that only stores p_last
+  for (;;) {
+    step(H2Int<0>(), H2Int<1>());
+    if (dq[0].y0 >= 0x4000) { step(H2Int<1>(), H2Int<0>()); break; }
+    step(H2Int<1>(), H2Int<1>());
+    if (dq[0].y0 >= 0x4000) { step(H2Int<0>(), H2Int<0>()); break; }
+  }
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // no LDS-DMA may outlive the workgroup
+  if constexpr (STATS) {
+    __syncthreads();
+    float* red = (float*)smem;                         // [WGM][2][BN]
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+          s1[j][r] += __shfl_xor(s1[j][r], o, 64);
+          s2[j][r] += __shfl_xor(s2[j][r], o, 64);
+        }
+      }
+    if (frow == 0) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int nl = wn * 32 + q * 8 + j * 4 + r;
+          red[(wm * 2 + 0) * BN + nl] = s1[j][r];
+          red[(wm * 2 + 1) * BN + nl] = s2[j][r];
+        }
+    }
+    __syncthreads();
+    if (tid < BN) {
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < WGM; ++w) { t1 += red[(w * 2 + 0) * BN + tid]; t2 += red[(w * 2 + 1) * BN + tid]; }
+      a.stats[((int64_t)blockIdx.x * 2 + 0) * a.co + tid] = t1;
+      a.stats[((int64_t)blockIdx.x * 2 + 1) * a.co + tid] = t2;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+// Halo ring depth (prefetch distance NS-1 patches): bytes in flight per CU, not arithmetic, set the speed of these
+// layers (one workgroup per CU at ci = 64).  ci = 64: 24 KB per stage, +16 KB for the mask stage.
+static int h2_ns(bool mask) {
+  static int v[2] = {0, 0};
+  if (v[mask] == 0) {
+    const char* e = getenv(mask ? "IMM_HALO2_NS_MASK" : "IMM_HALO2_NS");
+    int n = e ? atoi(e) : (mask ? 3 : 4);
+    if (n < 3) n = 3;
+    if (n > 4) n = 4;
+    v[mask] = n;
+  }
+  return v[mask];
+}
+
+static int h2_num_cu() {
+  static int cu = 0;
+  if (cu == 0) {
+    hipDeviceProp_t p; int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) cu = p.multiProcessorCount;
+    if (cu <= 0) cu = 256;
+  }
+  return cu;
+}
+
+bool imm_halo2_applicable(const imm_conv_desc* d) {
+  static const bool off = getenv("IMM_NO_HALO2") != nullptr || getenv("IMM_NO_HALO") != nullptr;
+  if (off) return false;
+  if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->updiv != 1 || d->pad_t != 1 || d->pad_l != 1) return false;
+  if (d->ci != 32 && d->ci != 64) return false;
+  if (d->co != 32 && d->co != 64) return false;
+  if (d->out_scale > 1 || (d->flags & (IMM_CONV_OUT_F32 | 0xf00))) return false;
+  if (d->hi != d->ho || d->wi != d->wo || d->ho % H2_PH || d->wo % H2_PW) return false;
+  if (d->ho * d->wo < 64 * 64) return false;
+  if (d->ldy % 8) return false;
+  if ((d->flags & IMM_CONV_MASK) && (d->ci != 64 || d->co != 64 || d->ldmask % 8 || (d->flags & IMM_CONV_STATS))) return false;
+  const int64_t px = (int64_t)d->batch * d->hi * d->wi;
+  return px * d->ldx * 2 < (1LL << 31) && px * d->ldy * 2 < (1LL << 31) && px * (int64_t)d->ldmask * 2 < (1LL << 31);
+}
+
+static size_t h2_lds(int ci, int bn, bool mask, int ns) {
+  return (size_t)ns * ((size_t)H2_HP * (ci / 8) + (mask ? (size_t)H2_PH * H2_PW * (bn / 8) : 0)) * 16;
+}
+
+template <typename ET, int CI, int BN, bool MASK, bool STATS, int NS>
+static int h2_occupancy() {
+  static int occ = 0;
+  if (occ == 0) {
+    const size_t lds = h2_lds(CI, BN, MASK, NS);
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute((const void*)conv_halo2_kernel<ET, CI, BN, MASK, STATS, NS>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_halo2_kernel<ET, CI, BN, MASK, STATS, NS>, 256, lds) != hipSuccess || n < 1) {
+      (void)hipGetLastError();
+      n = 1;
+    }
+    occ = n > 4 ? 4 : n;
+  }
+  return occ;
+}
+
+// dispatch over the instantiated (ci, co, mask, stats, ring depth) combinations
+template <typename F>
+static void h2_dispatch(int ci, int co, bool mask, bool stats, F&& f) {
+  const int ns = h2_ns(mask);
+  auto with_ns = [&](auto c, auto b, auto st) {
+    if (ns == 3) f(c, b, H2Int<0>(), st, H2Int<3>());
+    else f(c, b, H2Int<0>(), st, H2Int<4>());
+  };
+  auto with_stats = [&](auto c, auto b) {
+    if (stats) with_ns(c, b, H2Int<1>()); else with_ns(c, b, H2Int<0>());
+  };
+  if (mask) { if (ns == 3) f(H2Int<64>(), H2Int<64>(), H2Int<1>(), H2Int<0>(), H2Int<3>()); else f(H2Int<64>(), H2Int<64>(), H2Int<1>(), H2Int<0>(), H2Int<4>()); }
+  else if (ci == 64 && co == 64) with_stats(H2Int<64>(), H2Int<64>());
+  else if (ci == 64) with_stats(H2Int<64>(), H2Int<32>());
+  else if (co == 64) with_stats(H2Int<32>(), H2Int<64>());
+  else with_stats(H2Int<32>(), H2Int<32>());
+}
+
+// number of persistent workgroups (= rows of BN partial sums).  Queried on the bf16 instantiation: both element types
+// have the same register / LDS footprint, and the count must not depend on the dtype of a later launch.
+int imm_halo2_grid(const imm_conv_desc* d) {
+  const int n_patches = d->batch * (d->ho / H2_PH) * (d->wo / H2_PW);
+  int occ = 1;
+  h2_dispatch(d->ci, d->co, d->flags & IMM_CONV_MASK, d->flags & IMM_CONV_STATS, [&](auto ci, auto bn, auto mk, auto st, auto ns) {
+    occ = h2_occupancy<BF16, decltype(ci)::value, decltype(bn)::value, (bool)decltype(mk)::value, (bool)decltype(st)::value,
+                       decltype(ns)::value>();
+  });
+  const int grid = h2_num_cu() * occ;
+  return n_patches < grid ? n_patches : grid;
+}
+
+template <typename ET>
+static void h2_launch(const imm_conv_desc* d, const ConvArgs& a, hipStream_t s) {
+  Halo2Args ha;
+  ha.c = a;
+  ha.patches_x = d->wo / H2_PW; ha.patches_y = d->ho / H2_PH;
+  ha.n_patches = d->batch * ha.patches_x * ha.patches_y;
+  const int64_t px = (int64_t)d->batch * d->hi * d->wi;
+  ha.c.x_bytes = (uint32_t)(px * d->ldx * 2);
+  ha.c.wt_bytes = (uint32_t)((int64_t)d->co * d->kpad * 2);
+  ha.y_bytes = (uint32_t)(px * d->ldy * 2);
+  ha.mask_bytes = (uint32_t)(px * d->ldmask * 2);
+  const int per_img = ha.patches_x * ha.patches_y;
+  ha.lg_px = ha.lg_pi = -1;
+  if ((ha.patches_x & (ha.patches_x - 1)) == 0 && (per_img & (per_img - 1)) == 0) {
+    ha.lg_px = __builtin_ctz(ha.patches_x); ha.lg_pi = __builtin_ctz(per_img);
+  }
+  const int grid = imm_halo2_grid(d);
+  h2_dispatch(d->ci, d->co, d->flags & IMM_CONV_MASK, d->flags & IMM_CONV_STATS, [&](auto ci, auto bn, auto mk, auto st, auto ns) {
+    constexpr int CI = decltype(ci)::value, BN = decltype(bn)::value, NS = decltype(ns)::value;
+    constexpr bool MASK = decltype(mk)::value, STATS = decltype(st)::value;
+    (void)h2_occupancy<ET, CI, BN, MASK, STATS, NS>();          // sets the dynamic-LDS attribute on first use
+    hipLaunchKernelGGL((conv_halo2_kernel<ET, CI, BN, MASK, STATS, NS>), dim3(grid), dim3(256), h2_lds(CI, BN, MASK, NS), s, ha);
+  });
+}
+
+void imm_conv_halo2_launch(int dtype, const imm_conv_desc* d, const ConvArgs& a, hipStream_t s) {
+  if (dtype == IMM_BF16) h2_launch<BF16>(d, a, s);
+  else h2_launch<F16>(d, a, s);
+}

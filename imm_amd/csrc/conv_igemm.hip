@@ -18,6 +18,9 @@
 bool imm_halo_applicable(const imm_conv_desc* d);                                  // conv_halo.hip
 int imm_halo_grid(const imm_conv_desc* d);
 void imm_conv_halo_launch(int dtype, const imm_conv_desc* d, const ConvArgs& a, hipStream_t s);
+bool imm_halo2_applicable(const imm_conv_desc* d);                                 // conv_halo2.hip
+int imm_halo2_grid(const imm_conv_desc* d);
+void imm_conv_halo2_launch(int dtype, const imm_conv_desc* d, const ConvArgs& a, hipStream_t s);
 
 __device__ __forceinline__ int lds_chunk_idx(int row, int chunk) {
   // 64-byte rows; swizzle so the four 16-lane service groups of ds_read_b128 hit 16 distinct slots
@@ -253,6 +256,7 @@ static int validate_desc(const imm_conv_desc* d) {
 
 extern "C" int imm_conv_stats_blocks(const imm_conv_desc* d) {
   if (validate_desc(d)) return IMM_E_INVALID;
+  if (imm_halo2_applicable(d)) return imm_halo2_grid(d);
   if (imm_halo_applicable(d)) return imm_halo_grid(d);
   const int64_t M = (int64_t)d->batch * d->ho * d->wo;
   const TileCfg t = pick_tile(M, d->co);
@@ -282,6 +286,11 @@ static int conv_launch(const imm_conv_desc* d, const void* x, const void* wt, co
   a.kpad = d->kpad; a.KT = d->kpad / 32; a.ntaps = d->kh * d->kw;
   a.flags = d->flags; a.ldmask = d->ldmask;
   a.oscale = d->out_scale > 1 ? d->out_scale : 1; a.ooff_y = d->out_off_y; a.ooff_x = d->out_off_x;
+  if (imm_halo2_applicable(d)) {
+    imm_conv_halo2_launch(ET::kEnum, d, a, s);
+    IMM_CHECK_LAUNCH("imm_conv2d(halo2)");
+    return 0;
+  }
   if (imm_halo_applicable(d)) {
     imm_conv_halo_launch(ET::kEnum, d, a, s);
     IMM_CHECK_LAUNCH("imm_conv2d(halo)");

@@ -17,10 +17,11 @@
 template <typename ET>
 __global__ __launch_bounds__(256) void vgg_conv1_1_fwd_kernel(const float* __restrict__ gt, const float* __restrict__ pred,
                                                               int ldp, int batch, int s, const float* __restrict__ w,
-                                                              const float* __restrict__ bias, uint16_t* __restrict__ out) {
+                                                              const float* __restrict__ bias, uint16_t* __restrict__ out,
+                                                              int img0) {
   __shared__ float gray[(VF_TILE + 2) * (VF_TILE + 2)];
   const int tid = threadIdx.x;
-  const int img = blockIdx.z;
+  const int img = blockIdx.z + img0;
   const int ty0 = blockIdx.y * VF_TILE, tx0 = blockIdx.x * VF_TILE;
   const float* src = img < batch ? gt + (int64_t)img * s * s * 3 : pred + (int64_t)(img - batch) * s * s * ldp;
   const int ld = img < batch ? 3 : ldp;
@@ -124,12 +125,13 @@ __global__ __launch_bounds__(256) void vgg_conv1_1_bwd_kernel(const uint16_t* __
 }
 
 extern "C" int imm_vgg_conv1_1_fwd(const float* gt, const float* pred, int ldp, int batch, int s, const float* w9x64,
-                                   const float* b64, void* out, int dtype, void* stream) {
+                                   const float* b64, void* out, int dtype, int halves, void* stream) {
   IMM_REQUIRE(gt && pred && w9x64 && b64 && out, "vgg_conv1_1_fwd: null");
   IMM_REQUIRE(batch > 0 && s > 0 && ldp >= 3, "vgg_conv1_1_fwd: dims");
-  const dim3 grid((s + VF_TILE - 1) / VF_TILE, (s + VF_TILE - 1) / VF_TILE, 2 * batch);
+  IMM_REQUIRE(halves >= 1 && halves <= 3, "vgg_conv1_1_fwd: halves must be 1 (gt), 2 (pred) or 3 (both)");
+  const dim3 grid((s + VF_TILE - 1) / VF_TILE, (s + VF_TILE - 1) / VF_TILE, halves == 3 ? 2 * batch : batch);
   IMM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((vgg_conv1_1_fwd_kernel<ET>), grid, dim3(256), 0, (hipStream_t)stream, gt,
-                                               pred, ldp, batch, s, w9x64, b64, (uint16_t*)out));
+                                               pred, ldp, batch, s, w9x64, b64, (uint16_t*)out, halves == 2 ? batch : 0));
   IMM_CHECK_LAUNCH("imm_vgg_conv1_1_fwd");
   return 0;
 }

@@ -189,6 +189,10 @@ class IMMEngine:
 
         self.prog_pack, self.prog_fwd, self.prog_bwd, self.prog_opt = [], [], [], []
         self.two_streams = os.environ.get('IMM_TWO_STREAMS', '1') != '0'
+        # timing experiment only (results become wrong): drop every launch whose tag is listed, to measure how much of the
+        # step's critical path a kernel class occupies under graph replay / stream concurrency
+        self.vgg_split = int(os.environ.get('IMM_VGG_SPLIT', '0')) if self.two_streams else 0
+        self._skip_tags = set(t for t in os.environ.get('IMM_DEBUG_SKIP_TAGS', '').split(',') if t)
         self.wgrad_lane = int(os.environ.get('IMM_WGRAD_LANE', '0')) if self.two_streams else 0
         self._side = None
         self._pack_jobs, self._reduce_jobs = [], []
@@ -485,7 +489,13 @@ class IMMEngine:
         self._add(self.prog_fwd, lambda: ops.softargmax_gauss_fwd(self.heat, self.ldh, B, He, He, K, self.inv_std, 16,
                                                                   self.mu, self.py, self.px, gview, Cj, dt), 'bottleneck')
 
-        self._mark(self.prog_fwd, 'join')
+        if self.vgg_split == 2:
+            # the image-encoder stream carries on with the VGG gt half while the main stream renders
+            self._signal(self.prog_fwd, 'enc_im_done', lane=1)
+            self._wait(self.prog_fwd, 'enc_im_done', lane=0)
+            self._gt_splice = len(self.prog_fwd)
+        else:
+            self._mark(self.prog_fwd, 'join')
         # ---- renderer ---------------------------------------------------------------------------------
         self.ren, self.ren_up = [], []
         x, H, ci_real, ci_pad, ldx = self.joint, 16, 8 * nf + K, Cj, Cj
@@ -509,32 +519,71 @@ class IMMEngine:
         self.n_fwd_model = len(self.prog_fwd)   # launches up to here produce future_im_pred / gauss_yx
 
         # ---- frozen VGG16 on concat([gt, pred]) --------------------------------------------------------
+        # The activations keep the reference's concat layout [gt images; pred images] (imm_model.py:126).  With
+        # vgg_split the gt half -- which does not depend on the network -- is issued on a third stream at the very start
+        # of the step and fills the CUs the low-resolution encoder/renderer layers leave idle; the main stream then
+        # only runs the pred half before the loss.  Same kernels, same per-image arithmetic: results are bitwise equal.
         self.vgg_act, self.vgg_wt, self.vgg_wtd, self.vgg_desc, self.vgg_dd = OrderedDict(), {}, {}, {}, {}
         self.vgg_pool = {}
         self.w11 = self._zeros(9, 64); self.b11 = self._zeros(64)
         a = self._act(2 * B, S, S, 64)
         self.vgg_act['conv1_1'] = (a, S)
-        self._add(self.prog_fwd, lambda: ops.vgg_conv1_1_fwd(self.in_future, self.pred, self.ldp, B, S, self.w11, self.b11, a),
-                  'vgg_conv1_1', 2.0 * 2 * B * S * S * 9 * 64, 2 * B * S * S * 128.0)
+        split = self.vgg_split
+        nimg = B if split else 2 * B
+        gt_prog, pred_prog = [], self.prog_fwd
+
+        def vadd(fn_for, tag, flops, nbytes, name=''):
+            # fn_for(lo) -> launch closure over images [lo, lo + nimg)
+            if split:
+                self._cur_lane = 1 if split == 2 else 2
+                self._add(gt_prog, fn_for(0), tag, flops, nbytes, name + '[gt]')
+                self._cur_lane = 0
+                self._add(pred_prog, fn_for(B), tag, flops, nbytes, name + '[pred]')
+            else:
+                self._add(pred_prog, fn_for(0), tag, flops, nbytes, name)
+
+        if split:
+            vadd(lambda lo: (lambda: ops.vgg_conv1_1_fwd(self.in_future, self.pred, self.ldp, B, S, self.w11, self.b11, a,
+                                                         1 if lo == 0 else 2)),
+                 'vgg_conv1_1', 2.0 * B * S * S * 9 * 64, B * S * S * 128.0, 'vgg16/conv1_1')
+        else:
+            self._add(self.prog_fwd, lambda: ops.vgg_conv1_1_fwd(self.in_future, self.pred, self.ldp, B, S, self.w11, self.b11, a),
+                      'vgg_conv1_1', 2.0 * 2 * B * S * S * 9 * 64, 2 * B * S * S * 128.0)
         x, H = a, S
         for name, cin, cout in VGG_LAYERS[1:]:
-            fd = ops.fwd_desc(2 * B, H, H, cin, cin, cout, cout, 3, 1, L.CONV_BIAS | L.CONV_RELU)
+            fd = ops.fwd_desc(nimg, H, H, cin, cin, cout, cout, 3, 1, L.CONV_BIAS | L.CONV_RELU)
             wt = self._zeros(ops.round_up(cout, 128), fd.kpad, dtype=dt)
             wtd = self._zeros(ops.round_up(cin, 128), ops.round_up(9 * cout, 32), dtype=dt)
             y = self._act(2 * B, H, H, cout)
             self.vgg_wt[name], self.vgg_wtd[name], self.vgg_desc[name] = wt, wtd, fd
             bias = self.vgg_w['vgg16/%s/biases' % name]
-            self._add(self.prog_fwd, (lambda fd=fd, x=x, wt=wt, bias=bias, y=y: ops.conv2d(fd, x, wt, bias, y)), 'vgg_fwd',
-                      2.0 * 2 * B * H * H * 9 * cin * cout, 2.0 * (2 * B * H * H * (cin + cout) + 9 * cin * cout),
-                      name='vgg16/' + name)
+            vadd(lambda lo, fd=fd, x=x, wt=wt, bias=bias, y=y: (lambda: ops.conv2d(fd, x[lo:lo + nimg], wt, bias, y[lo:lo + nimg])),
+                 'vgg_fwd', 2.0 * nimg * H * H * 9 * cin * cout, 2.0 * (nimg * H * H * (cin + cout) + 9 * cin * cout),
+                 'vgg16/' + name)
             self.vgg_act[name] = (y, H)
             x = y
             if name in VGG_POOL_AFTER:
                 p = self._act(2 * B, H // 2, H // 2, cout)
-                self._add(self.prog_fwd, (lambda x=x, p=p, H=H, cout=cout: ops.maxpool2_fwd(x, p, 2 * B, H, H, cout)), 'maxpool',
-                          0.0, 2 * B * H * H * cout * 2.5)
+                vadd(lambda lo, x=x, p=p, H=H, cout=cout: (lambda: ops.maxpool2_fwd(x[lo:lo + nimg], p[lo:lo + nimg], nimg, H, H, cout)),
+                     'maxpool', 0.0, nimg * H * H * cout * 2.5)
                 self.vgg_pool[name] = p
                 x, H = p, H // 2
+        if split:
+            # splice: [start event, gt-half launches on lane 2, done event] at the head of the step; wait before the loss
+            head = []
+            if split == 2:
+                head.extend(gt_prog)
+                self._signal(head, 'vgg_gt', lane=1)
+                at = self._gt_splice
+            else:
+                self._signal(head, 'step_start', lane=0)
+                self._wait(head, 'step_start', lane=2)
+                head.extend(gt_prog)
+                self._signal(head, 'vgg_gt', lane=2)
+                at = 0
+            self.prog_fwd[at:at] = head
+            self.n_fwd_model += len(head)
+            self._wait(self.prog_fwd, 'vgg_gt', lane=0)
         self._pack_vgg()
 
         # ---- loss -------------------------------------------------------------------------------------------
@@ -745,6 +794,8 @@ class IMMEngine:
                 streams[i] = self._side_stream(i)
             return streams[i]
         for l in prog:
+            if l.fn is not None and l.tag in self._skip_tags:
+                continue
             if l.fn is not None:
                 if l.lane == 0:
                     l.fn()
@@ -797,7 +848,7 @@ class IMMEngine:
     def forward_model_only(self, training=False):
         """IMMModel.build(build_loss=False): encoders, bottleneck, renderer (no VGG, no loss)."""
         self._training = bool(training)
-        self.run(self.prog_fwd[:self.n_fwd_model])
+        self.run([l for l in self.prog_fwd[:self.n_fwd_model] if not l.name.endswith('[gt]')])   # VGG gt half: loss only
 
     def backward(self):
         self.run(self.prog_bwd)

@@ -250,8 +250,8 @@ def gauss_render_f32(mu, batch, k, inv_std, s, out):
 
 
 # ---- VGG head / loss --------------------------------------------------------------------------
-def vgg_conv1_1_fwd(gt, pred, ldp, batch, s, w, b, out):
-    call('imm_vgg_conv1_1_fwd', _p(gt), _p(pred), ldp, batch, s, _p(w), _p(b), _p(out), dtype_enum(out.dtype), _s())
+def vgg_conv1_1_fwd(gt, pred, ldp, batch, s, w, b, out, halves=3):
+    call('imm_vgg_conv1_1_fwd', _p(gt), _p(pred), ldp, batch, s, _p(w), _p(b), _p(out), dtype_enum(out.dtype), halves, _s())
 
 
 def vgg_conv1_1_bwd(dz, batch, s, w, gt, pred, ldp, mask, coef, dpred, lddp):

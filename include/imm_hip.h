@@ -175,9 +175,11 @@ int imm_softargmax_gauss_bwd(const void* dgauss, int ldg, int dtype, int batch, 
 int imm_gauss_render_f32(const float* mu, int batch, int k, float inv_std, int s, float* out, void* stream);
 
 /* ---- frozen VGG16 first layer (build_vgg16.py:22-26 grayscale+normalise, vgg16.py:345 conv1_1) -- */
-/* images: gt f32 [B,S,S,3] and pred f32 [B,S,S,ldp] (first 3 ch) -> out 16-bit [2B,S,S,64] */
+/* images: gt f32 [B,S,S,3] and pred f32 [B,S,S,ldp] (first 3 ch) -> out 16-bit [2B,S,S,64] = concat([gt, pred], 0)
+ * (imm_model.py:126).  halves: 1 = write only the gt images (out[0:B]), 2 = only the pred images (out[B:2B]), 3 = both;
+ * the gt half does not depend on the network, so a caller may run it ahead on another stream. */
 int imm_vgg_conv1_1_fwd(const float* gt, const float* pred, int ldp, int batch, int s, const float* w9x64,
-                        const float* b64, void* out, int dtype, void* stream);
+                        const float* b64, void* out, int dtype, int halves, void* stream);
 /* dz 16-bit [B,S,S,64] (pred half, already ReLU-masked) -> dpred 16-bit [B,S,S,lddp]:
  * ch<3 = dgray/(3*255) + coef[0]*mask[p]*(pred-gt), ch>=3 = 0.  coef is a device scalar table. */
 int imm_vgg_conv1_1_bwd(const void* dz, int dtype, int batch, int s, const float* w9x64, const float* gt,

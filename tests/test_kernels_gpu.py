@@ -117,22 +117,31 @@ def test_conv_forward(ops, case, dt):
         pass  # padding channels are not written by the kernel (caller owns them)
 
 
-@pytest.mark.parametrize('H,ci,co', [(32, 32, 64), (64, 64, 64), (64, 32, 32)], ids=['igemm', 'halo64', 'halo32'])
-def test_conv_relu_stats_mask(ops, H, ci, co):
+@pytest.mark.parametrize('B,H,ci,co,dt', [(2, 32, 32, 64, torch.bfloat16), (2, 64, 64, 64, torch.bfloat16),
+                                          (2, 64, 32, 32, torch.bfloat16), (3, 64, 64, 32, torch.bfloat16),
+                                          (3, 64, 32, 64, torch.bfloat16), (40, 64, 64, 64, torch.bfloat16),
+                                          (3, 128, 64, 64, torch.float16), (36, 64, 32, 32, torch.float16)],
+                         ids=['igemm', 'halo64', 'halo32', 'halo64_32', 'halo32_64', 'halo64_persistent', 'halo64_f16',
+                              'halo32_f16_persistent'])
+def test_conv_relu_stats_mask(ops, B, H, ci, co, dt):
+    """Epilogue variants (BN partial sums, ReLU, ReLU-backward mask).  The halo cases run conv_halo2.hip (filter in
+    registers, deferred epilogue); the *_persistent cases give every workgroup several patches, i.e. exercise the halo /
+    mask DMA rings and the counted waits in steady state."""
     from imm_amd import _lib as L
-    B = 2
-    x = rnd((B, H, H, ci), 4)
-    w = rnd((3, 3, ci, co), 5, 0.1)
+    x = rnd((B, H, H, ci), 4, 1.0, dt)
+    w = rnd((3, 3, ci, co), 5, 0.1, dt)
     b = rnd((co,), 6, 0.5, torch.float32)
     y, stats, desc = run_conv(ops, x, w, b, 3, 1, co, ci, False, extra_flags=L.CONV_STATS)
     ref = O.conv2d_same(x.float(), w.float(), b, 1)
     close(y, ref, 1e-2, 2e-3, 'conv+stats/y')
+    y1, _, _ = run_conv(ops, x, w, b, 3, 1, co, ci, False)
+    assert torch.equal(y1, y), 'the stats flag must not change the output'
     s = stats.sum(dim=0).cpu()
     close(s[0], ref.sum(dim=(0, 1, 2)), 1e-3, 1e-3, 'conv+stats/sum')      # f32 sums of f32 accumulators
     close(s[1], (ref ** 2).sum(dim=(0, 1, 2)), 1e-3, 1e-3, 'conv+stats/sumsq')
     y2, _, _ = run_conv(ops, x, w, b, 3, 1, co, ci, False, extra_flags=L.CONV_RELU)
     close(y2, torch.relu(ref), 1e-2, 2e-3, 'conv+relu')
-    mref = rnd((B, H, H, co), 7).to(DEV).contiguous()
+    mref = rnd((B, H, H, co), 7, 1.0, dt).to(DEV).contiguous()
     y3, _, _ = run_conv(ops, x, w, b, 3, 1, co, ci, False, extra_flags=L.CONV_MASK, mask=mref)
     close(y3, ref * (mref.float().cpu() > 0), 1e-2, 2e-3, 'conv+mask')
 
@@ -490,6 +499,14 @@ def test_vgg_conv1_1(ops):
     ops.vgg_conv1_1_fwd(gt.to(DEV), pred.to(DEV), ldp, B, S, w.reshape(9, 64).to(DEV).contiguous(), b.to(DEV), out)
     torch.cuda.synchronize()
     close(out, ref, 8e-3, 1e-3, 'vgg1_1_fwd')
+    # halves: 1 = gt images only, 2 = pred images only; together bitwise equal to the single launch
+    out2 = torch.zeros_like(out)
+    ops.vgg_conv1_1_fwd(gt.to(DEV), pred.to(DEV), ldp, B, S, w.reshape(9, 64).to(DEV).contiguous(), b.to(DEV), out2, 1)
+    torch.cuda.synchronize()
+    assert torch.equal(out2[:B], out[:B]) and float(out2[B:].float().abs().max()) == 0.0
+    ops.vgg_conv1_1_fwd(gt.to(DEV), pred.to(DEV), ldp, B, S, w.reshape(9, 64).to(DEV).contiguous(), b.to(DEV), out2, 2)
+    torch.cuda.synchronize()
+    assert torch.equal(out2, out)
     dz = rnd((B, S, S, 64), 73) * (ref[B:].detach() > 0)
     mask = torch.rand(B, S, S)
     coef = torch.tensor([0.37, 0, 0, 0, 0, 0])

@@ -15,6 +15,9 @@ LAYERS = [  # tag, images, H, ci, co, k, stride
     ('enc_conv2  128^2 32->32', 32, 128, 32, 32, 3, 1),
     ('enc_conv3  128^2 32->64 s2', 32, 128, 32, 64, 3, 2),
     ('vgg1_2     128^2 64->64', 64, 128, 64, 64, 3, 1),
+    ('vgg1_2 dgrad+mask 64->64', 32, 128, 64, 64, 3, 1),
+    ('enc_conv4   64^2 64->64', 32, 64, 64, 64, 3, 1),
+    ('ren_conv7d 128^2 32->64', 32, 128, 32, 64, 3, 1),
     ('vgg2_2      64^2 128->128', 64, 64, 128, 128, 3, 1),
     ('vgg3_2      32^2 256->256', 64, 32, 256, 256, 3, 1),
     ('vgg4_2      16^2 512->512', 64, 16, 512, 512, 3, 1),
@@ -53,14 +56,19 @@ def main():
         x = (torch.randn(n, H, H, ci, device=DEV) * 0.5).to(dt)
         w = torch.randn(k, k, ci, co, device=DEV) * 0.05
         b = torch.zeros(co, device=DEV)
+        use_mask = 'mask' in tag
+        mref = (torch.randn(n, H, H, co, device=DEV)).to(dt) if use_mask else None
         for vname, vflag in variants:
-            desc = ops.fwd_desc(n, H, H, ci, ci, co, co, k, stride, L.CONV_BIAS | L.CONV_RELU | vflag)
+            if use_mask:
+                desc = ops.fwd_desc(n, H, H, ci, ci, co, co, k, stride, L.CONV_MASK | vflag, ldmask=co)
+            else:
+                desc = ops.fwd_desc(n, H, H, ci, ci, co, co, k, stride, L.CONV_BIAS | L.CONV_RELU | vflag)
             wt = torch.zeros(ops.round_up(co, 128), desc.kpad, dtype=dt, device=DEV)
             ops.pack_weights(w, wt, 0, k, k, ci, co, ci, wt.shape[0], desc.kpad)
             y = torch.empty(n, desc.ho, desc.wo, co, dtype=dt, device=DEV)
-            us = time_launch(lambda: ops.conv2d(desc, x, wt, b, y))
+            us = time_launch(lambda: ops.conv2d(desc, x, wt, None if use_mask else b, y, None, mref))
             flops = 2.0 * n * desc.ho * desc.wo * k * k * ci * co
-            nbytes = x.numel() * 2 + y.numel() * 2 + wt.numel() * 2
+            nbytes = x.numel() * 2 + y.numel() * 2 + wt.numel() * 2 + (mref.numel() * 2 if use_mask else 0)
             print('%-30s %-13s %10.1f %9.1f %9.0f' % (tag, vname, us, flops / us / 1e6, nbytes / us / 1e3))
         if args.wgrad:
             desc = ops.fwd_desc(n, H, H, ci, ci, co, co, k, stride, 0)
