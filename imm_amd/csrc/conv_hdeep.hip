@@ -1,0 +1,343 @@
+// conv_hdeep.hip — 3x3 stride-1 convolution for the DEEP layers (ci % 64 == 0, co % 64 == 0, 16x16 .. 64x64 maps):
+// VGG conv2_1 .. conv4_3 and their data gradients (imm/models/selfsup/vgg16.py:349-362), encoder conv_6 / conv_8 and
+// renderer conv_2 .. conv_5 when the grid is large enough (imm/models/imm_model.py:213-241, :258-300).
+//
+// Why not the im2col kernel (conv_igemm64.hip) for these: rocprofv3 PMC on VGG conv4_2 shows its waves parked on
+// s_waitcnt/s_barrier for 30 % of their cycles with the matrix pipe 49 % busy — every 128x128x64 K-tile pulls 32 KB
+// through L2 for 2.1 MFLOP (65 FLOP/B; at the MFMA peak that would be 38 TB/s against 34 TB/s of L2), and the input
+// pixel tile is fetched nine times, once per filter tap.  Here a workgroup owns a 16x16-pixel output patch x BN
+// channels and walks K as (64-channel slice) x (9 taps): the 18x18-pixel input halo of a slice is DMA'd into LDS ONCE
+// and all nine taps read it at shifted addresses (immediate offsets), only the 64 x BN filter slice of each tap
+// streams through a 4-stage ring.  L2 -> LDS traffic per MFLOP drops 3x (204 FLOP/B at BN = 128).
+//
+// 512 threads = 8 waves (2 per SIMD): wave (wm, wn) owns patch rows 4wm..4wm+3 x BN/2 channels.  All loop DMA is
+// issued from inline asm with exactly (BN/64 + 1) instructions per wave and tap (halo pieces of the next slice ride on
+// taps 0-5, the rest are no-op pieces into a dump slot), so one counted s_waitcnt vmcnt per tap is exact.
+#include "conv_common.h"
+#include <stdlib.h>
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+
+#define HD_P 16                          // patch side
+#define HD_HW (HD_P + 2)                 // halo side 18
+#define HD_SLOTS (HD_HW * HD_HW)         // 324 halo pixels
+#define HD_HINSTR ((HD_SLOTS + 7) / 8)   // 41 DMA instructions (8 pixels x 128 B each)
+#define HD_HSTAGE (HD_HINSTR * 64)       // uint4 per halo stage (41984 B)
+#define HD_NSB 4                         // filter-slice ring depth
+#define HD_OOB 0x80000000u
+
+struct HdArgs {
+  ConvArgs c;
+  int n_patches, patches_x, patches_y;
+  int n_wg;                              // n_patches * n_nblk
+};
+
+__device__ __forceinline__ void hd_dma16(u32x4_t rsrc, uint32_t lds_addr, uint32_t voff, uint32_t soff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+               :: "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+// halo pixel -> chunk swizzle (same as conv_halo2.hip): a ds_read_b128 of 16 consecutive pixels is conflict-free
+__device__ __forceinline__ int hd_swz(int hx) { return ((hx >> 1) & 3) << 1; }
+// filter rows: conv_igemm64.hip's image
+__device__ __forceinline__ int hd_bidx(int row, int chunk) { return row * 8 + (chunk ^ ((row >> 1) & 7)); }
+
+template <int V> struct HdInt { static constexpr int value = V; };
+
+template <typename ET, int BN>
+__global__ __launch_bounds__(512) void conv_hdeep_kernel(const HdArgs ha) {
+  const ConvArgs& a = ha.c;
+  constexpr int TN = BN / 2, MT = 4, NT = TN / 16;
+  constexpr int B_I = BN / 64;                         // filter DMA instructions per wave and tap (BN rows / 8 / 8 waves)
+  constexpr int B_U4 = BN * 8;                         // uint4 per filter stage
+  constexpr int WN_STEADY = (HD_NSB - 2) * (B_I + 1);  // outstanding VMEM allowed at the top of a tap (see header)
+  constexpr int ROWB = HD_HW * 128;                    // bytes per halo row in LDS
+  extern __shared__ __attribute__((aligned(16))) uint4 smem[];   // [2][HD_HSTAGE] halo | [64] dump | [HD_NSB][B_U4] filter
+  constexpr int DUMP_U4 = 2 * HD_HSTAGE, BRING_U4 = DUMP_U4 + 64;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid >> 1, wn = wid & 1;
+  const int frow = lane & 15, q = lane >> 4;
+  int bid = blockIdx.x;
+  {   // XCD-contiguous order: the n-blocks of a patch and neighbouring patches share one L2
+    const int xq = ha.n_wg >> 3, xr = ha.n_wg & 7, xcd = bid & 7;
+    bid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
+  }
+  const int nblk = bid % a.n_nblk, patch = bid / a.n_nblk;
+  const int per_img = ha.patches_x * ha.patches_y;
+  const int img = patch / per_img, pr = patch - img * per_img;
+  const int y0 = (pr / ha.patches_x) * HD_P, x0 = (pr % ha.patches_x) * HD_P;
+  const int n0 = nblk * BN;
+
+  const uint64_t xa = (uint64_t)a.x, wa = (uint64_t)a.wt;
+  const u32x4_t xr = {(uint32_t)xa, (uint32_t)(xa >> 32) & 0xffffu, a.x_bytes, 0x00020000u};
+  const u32x4_t wr = {(uint32_t)wa, (uint32_t)(wa >> 32) & 0xffffu, a.wt_bytes, 0x00020000u};
+  const uint32_t lds_base = (uint32_t)(size_t)(lds_void_t*)smem;
+
+  // ---- loader state ------------------------------------------------------------------------------------------
+  // halo piece k of this wave = instruction wid + 8k (k < 6; instructions >= 41 do not exist -> dump slot)
+  uint32_t h_voff[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const int hp = (wid + 8 * k) * 8 + (lane >> 3);
+    const int hy = hp / HD_HW, hx = hp - hy * HD_HW;
+    const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+    const bool ok = hp < HD_SLOTS && (unsigned)iy < (unsigned)a.hi && (unsigned)ix < (unsigned)a.wi;
+    h_voff[k] = ok ? (uint32_t)((iy * a.wi + ix) * a.ldx * 2 + (((lane & 7) ^ hd_swz(hx)) * 16)) : HD_OOB;
+  }
+  const uint32_t img_soff = (uint32_t)(img * a.hi * a.wi) * (uint32_t)(a.ldx * 2);
+  uint32_t b_voff[B_I];
+#pragma unroll
+  for (int j = 0; j < B_I; ++j) {
+    const int r = (wid * B_I + j) * 8 + (lane >> 3);
+    b_voff[j] = (n0 + r < a.co) ? (uint32_t)((n0 + r) * a.kpad * 2 + (((lane & 7) ^ ((r >> 1) & 7)) * 16)) : HD_OOB;
+  }
+  const int ncc = a.ci8 >> 3;                          // 64-channel slices
+  const int T = ncc * 9;                               // taps in total
+  auto issue_b = [&](int t, int stage) {
+    // tap t = slice cc, tap index tp: filter columns [tp*ci + cc*64, +64) of Wt[n][kpad]
+    const int cc = t / 9, tp = t - cc * 9;
+    const uint32_t soff = (uint32_t)((tp * (a.ci8 << 3) + cc * 64) * 2);
+    const bool real = t < T;
+#pragma unroll
+    for (int j = 0; j < B_I; ++j)
+      hd_dma16(wr, lds_base + (uint32_t)((BRING_U4 + stage * B_U4 + (wid * B_I + j) * 64) * 16), real ? b_voff[j] : HD_OOB, soff);
+  };
+  auto issue_halo_piece = [&](int cc, int k, bool real) {
+    const int i = wid + 8 * k;
+    const bool exists = real && i < HD_HINSTR;
+    const uint32_t dst = exists ? (uint32_t)(((cc & 1) * HD_HSTAGE + i * 64) * 16) : (uint32_t)(DUMP_U4 * 16);
+    hd_dma16(xr, lds_base + dst, exists ? h_voff[k < 6 ? k : 0] : HD_OOB, img_soff + (uint32_t)(cc * 128));
+  };
+
+  // ---- prologue: halo of slice 0, filter taps 0 .. NSB-1 (every ring stage) ---------------------------------------
+#pragma unroll
+  for (int k = 0; k < 6; ++k) issue_halo_piece(0, k, true);
+#pragma unroll
+  for (int t = 0; t < HD_NSB; ++t) issue_b(t, t);
+
+  f32x4_t acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  // per-lane fragment offsets (uint4 units): A = halo pixel (row wm*4 + i + ky, col frow + kx), B = filter row
+  int aoff[3];
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx) aoff[kx] = (wm * 4 * HD_HW + frow + kx) * 8 + (q ^ hd_swz(frow + kx));
+  int boff[NT][2];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) boff[j][ks] = hd_bidx(wn * TN + j * 16 + frow, ks * 4 + q);
+
+  // Software pipeline at k-step granularity (a tap = two k-steps of 32 channels): the fragments of the next k-step are
+  // read from LDS while the 16 MFMAs of the current one run, and a k-step's MFMAs are already queued when the wave
+  // reaches the barrier — the matrix pipe keeps working through the barrier / DMA-issue / ds_read window that the two
+  // waves of a SIMD (same workgroup, same barrier) would otherwise both sit in.  Per tap t:
+  //     lgkmcnt(0)            fragments (t, k-step 0) are in registers
+  //     ds_read (t, 1)        same ring stage / halo
+  //     MFMA (t, 0)
+  //     lgkmcnt(0)            => this wave no longer reads ring stage t % NSB
+  //     vmcnt(N); s_barrier   filter tap t+1 (and the next slice's halo, when due) landed everywhere
+  //     DMA filter tap t+NSB -> stage t % NSB, one halo piece of the next slice
+  //     ds_read (t+1, 0)
+  //     MFMA (t, 1)
+  uint4 af[2][MT], bf[2][NT];                          // [k-step][tile]
+  auto read_frags = [&](const int ks, const uint4* Hs, const uint4* Bs, const int ky, const int kx) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) af[ks][i] = Hs[(aoff[kx] ^ (ks * 4)) + (i + ky) * (ROWB / 16)];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) bf[ks][j] = Bs[boff[j][ks]];
+  };
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"((HD_NSB - 1) * B_I) : "memory");   // halo(0) and filter tap 0
+  __builtin_amdgcn_s_barrier();
+  read_frags(0, smem, smem + BRING_U4, 0, 0);
+
+  int t = 0, bs = 0;
+  for (int cc = 0; cc < ncc; ++cc) {
+    const bool next_slice = cc + 1 < ncc;
+    const uint4* Hc = smem + (cc & 1) * HD_HSTAGE;
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp) {
+      const int ky = tp / 3, kx = tp % 3;
+      // next tap: (tp+1) of this slice, or tap 0 of the next slice (other halo stage)
+      const int ntp = tp == 8 ? 0 : tp + 1;
+      const uint4* Hn = smem + ((tp == 8 ? cc + 1 : cc) & 1) * HD_HSTAGE;
+      const uint4* Bc = smem + BRING_U4 + bs * B_U4;
+      int nbs = bs + 1; if (nbs == HD_NSB) nbs = 0;
+      const uint4* Bn = smem + BRING_U4 + nbs * B_U4;
+
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      read_frags(1, Hc, Bc, ky, kx);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = ET::mfma(bf[0][j], af[0][i], acc[i][j]);   // D[n][pixel]
+      // issue order inside the region: 1 MFMA, 1 ds_read, <= 2 address ops, ... (non-MFMA issues ride in the pipe's shadow)
+#pragma unroll
+      for (int m = 0; m < MT * NT; ++m) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x006, 2, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (t == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * B_I) : "memory");
+      else if (t == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * B_I + 1) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WN_STEADY) : "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      issue_b(t + HD_NSB, bs);
+      issue_halo_piece(cc + 1, tp, next_slice && tp < 6);
+      read_frags(0, Hn, Bn, ntp / 3, ntp % 3);         // past the last tap: reads of landed no-op data, never used
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = ET::mfma(bf[1][j], af[1][i], acc[i][j]);
+#pragma unroll
+      for (int m = 0; m < MT * NT; ++m) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x006, 2, 0);
+      }
+      bs = nbs;
+      ++t;
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // trailing no-op pieces: no LDS-DMA may outlive the workgroup
+  __syncthreads();
+
+  // ---- epilogue: lane = pixel (row wm*4 + i, col frow), 4 consecutive channels per tile ---------------------------
+  const bool f_bias = a.flags & IMM_CONV_BIAS, f_relu = a.flags & IMM_CONV_RELU;
+  const bool f_stats = a.flags & IMM_CONV_STATS, f_mask = a.flags & IMM_CONV_MASK;
+  float s1[NT][4], s2[NT][4];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int n = n0 + wn * TN + j * 16 + 4 * q;
+    float bv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { bv[r] = f_bias ? a.bias[n + r] : 0.f; s1[j][r] = 0.f; s2[j][r] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int64_t m = ((int64_t)img * a.ho + y0 + wm * 4 + i) * a.wo + x0 + frow;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[r] = acc[i][j][r] + bv[r];
+        if (f_relu) v[r] = fmaxf(v[r], 0.f);
+      }
+      if (f_mask) {
+        const uint2 mw = *(const uint2*)(a.mask + m * a.ldmask + n);
+        const uint16_t mh[4] = {(uint16_t)(mw.x & 0xffffu), (uint16_t)(mw.x >> 16), (uint16_t)(mw.y & 0xffffu), (uint16_t)(mw.y >> 16)};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (!(ET::to_f32(mh[r]) > 0.f)) v[r] = 0.f;
+      }
+      if (f_stats) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s1[j][r] += v[r]; s2[j][r] += v[r] * v[r]; }
+      }
+      *(uint2*)((uint16_t*)a.y + m * a.ldy + n) = make_uint2(ET::pack2(v[0], v[1]), ET::pack2(v[2], v[3]));
+    }
+  }
+  if (f_stats) {
+    float* red = (float*)smem;                         // [4 wm][2][BN]
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+          s1[j][r] += __shfl_xor(s1[j][r], o, 64);
+          s2[j][r] += __shfl_xor(s2[j][r], o, 64);
+        }
+      }
+    if (frow == 0) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int nl = wn * TN + j * 16 + 4 * q + r;
+          red[(wm * 2 + 0) * BN + nl] = s1[j][r];
+          red[(wm * 2 + 1) * BN + nl] = s2[j][r];
+        }
+    }
+    __syncthreads();
+    if (tid < BN) {
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) { t1 += red[(w * 2 + 0) * BN + tid]; t2 += red[(w * 2 + 1) * BN + tid]; }
+      a.stats[((int64_t)patch * 2 + 0) * a.co + n0 + tid] = t1;
+      a.stats[((int64_t)patch * 2 + 1) * a.co + n0 + tid] = t2;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+static int hd_num_cu() {
+  static int cu = 0;
+  if (cu == 0) {
+    hipDeviceProp_t p; int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) cu = p.multiProcessorCount;
+    else (void)hipGetLastError();
+    if (cu <= 0) cu = 256;
+  }
+  return cu;
+}
+
+// channel-block width: 128 when that still fills the chip, else 64
+static int hd_bn(const imm_conv_desc* d) {
+  const int n_patches = d->batch * (d->ho / HD_P) * (d->wo / HD_P);
+  if (d->co % 128 == 0 && n_patches * (d->co / 128) >= hd_num_cu()) return 128;
+  return 64;
+}
+
+bool imm_hdeep_applicable(const imm_conv_desc* d) {
+  static const bool off = getenv("IMM_NO_HDEEP") != nullptr;
+  if (off) return false;
+  if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->updiv != 1 || d->pad_t != 1 || d->pad_l != 1) return false;
+  if (d->ci % 64 || d->co % 64 || d->ci < 64) return false;
+  if (d->out_scale > 1 || (d->flags & (IMM_CONV_OUT_F32 | 0xf00))) return false;
+  if (d->hi != d->ho || d->wi != d->wo || d->ho % HD_P || d->wo % HD_P) return false;
+  if (d->ldy % 4 || ((d->flags & IMM_CONV_MASK) && d->ldmask % 4)) return false;
+  const int64_t px = (int64_t)d->batch * d->hi * d->wi;
+  if (px * d->ldx * 2 >= (1LL << 31) || (int64_t)d->co * d->kpad * 2 >= (1LL << 31)) return false;
+  // small grids keep the im2col kernel (64x64 tiles give it 4x the workgroups)
+  const int n_patches = d->batch * (d->ho / HD_P) * (d->wo / HD_P);
+  static const int min_wg = getenv("IMM_HDEEP_MIN_WG") ? atoi(getenv("IMM_HDEEP_MIN_WG")) : 192;
+  return n_patches * (d->co / hd_bn(d)) >= min_wg;
+}
+
+int imm_hdeep_stats_blocks(const imm_conv_desc* d) { return d->batch * (d->ho / HD_P) * (d->wo / HD_P); }
+
+template <typename ET, int BN>
+static void hd_launch_cfg(const HdArgs& ha, hipStream_t s) {
+  constexpr int lds = (2 * HD_HSTAGE + 64 + HD_NSB * BN * 8) * 16;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)conv_hdeep_kernel<ET, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_hdeep_kernel<ET, BN>), dim3(ha.n_wg), dim3(512), lds, s, ha);
+}
+
+void imm_conv_hdeep_launch(int dtype, const imm_conv_desc* d, const ConvArgs& a, hipStream_t s) {
+  HdArgs ha;
+  ha.c = a;
+  const int bn = hd_bn(d);
+  ha.patches_x = d->wo / HD_P; ha.patches_y = d->ho / HD_P;
+  ha.n_patches = d->batch * ha.patches_x * ha.patches_y;
+  ha.c.n_nblk = d->co / bn;
+  ha.n_wg = ha.n_patches * ha.c.n_nblk;
+  ha.c.x_bytes = (uint32_t)((int64_t)d->batch * d->hi * d->wi * d->ldx * 2);
+  ha.c.wt_bytes = (uint32_t)((int64_t)d->co * d->kpad * 2);
+  if (dtype == IMM_BF16) { if (bn == 128) hd_launch_cfg<BF16, 128>(ha, s); else hd_launch_cfg<BF16, 64>(ha, s); }
+  else { if (bn == 128) hd_launch_cfg<F16, 128>(ha, s); else hd_launch_cfg<F16, 64>(ha, s); }
+}

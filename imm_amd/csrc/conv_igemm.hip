@@ -18,6 +18,9 @@
 bool imm_halo_applicable(const imm_conv_desc* d);                                  // conv_halo.hip
 int imm_halo_grid(const imm_conv_desc* d);
 void imm_conv_halo_launch(int dtype, const imm_conv_desc* d, const ConvArgs& a, hipStream_t s);
+bool imm_hdeep_applicable(const imm_conv_desc* d);                                 // conv_hdeep.hip
+int imm_hdeep_stats_blocks(const imm_conv_desc* d);
+void imm_conv_hdeep_launch(int dtype, const imm_conv_desc* d, const ConvArgs& a, hipStream_t s);
 bool imm_halo2_applicable(const imm_conv_desc* d);                                 // conv_halo2.hip
 int imm_halo2_grid(const imm_conv_desc* d);
 void imm_conv_halo2_launch(int dtype, const imm_conv_desc* d, const ConvArgs& a, hipStream_t s);
@@ -258,6 +261,7 @@ extern "C" int imm_conv_stats_blocks(const imm_conv_desc* d) {
   if (validate_desc(d)) return IMM_E_INVALID;
   if (imm_halo2_applicable(d)) return imm_halo2_grid(d);
   if (imm_halo_applicable(d)) return imm_halo_grid(d);
+  if (imm_hdeep_applicable(d)) return imm_hdeep_stats_blocks(d);
   const int64_t M = (int64_t)d->batch * d->ho * d->wo;
   const TileCfg t = pick_tile(M, d->co);
   return (int)((M + t.bm - 1) / t.bm);
@@ -294,6 +298,11 @@ static int conv_launch(const imm_conv_desc* d, const void* x, const void* wt, co
   if (imm_halo_applicable(d)) {
     imm_conv_halo_launch(ET::kEnum, d, a, s);
     IMM_CHECK_LAUNCH("imm_conv2d(halo)");
+    return 0;
+  }
+  if (imm_hdeep_applicable(d)) {
+    imm_conv_hdeep_launch(ET::kEnum, d, a, s);
+    IMM_CHECK_LAUNCH("imm_conv2d(hdeep)");
     return 0;
   }
   const TileCfg t = pick_tile(a.M, a.co);

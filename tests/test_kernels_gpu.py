@@ -73,6 +73,11 @@ CONV_CASES = [
     (3, 64, 32, 32, 9, 3, 1, True, 'halo_32_9_f32'),
     (2, 64, 64, 64, 32, 3, 1, False, 'halo_64_32'),
     (70, 64, 32, 32, 64, 3, 1, False, 'halo_32_64_many_patches'),
+    # 3x3 s1, ci % 64 == 0, co % 64 == 0, maps % 16 == 0, >= 192 workgroups: LDS-halo deep-K kernel (conv_hdeep.hip)
+    (16, 64, 64, 64, 128, 3, 1, False, 'hdeep_bn128_one_slice'),
+    (13, 32, 128, 128, 256, 3, 1, False, 'hdeep_bn64_two_slices'),
+    (64, 16, 128, 128, 512, 3, 1, False, 'hdeep_bn128_whole_image_patches'),
+    (7, 64, 192, 192, 128, 3, 1, False, 'hdeep_three_slices'),
 ]
 
 
@@ -120,9 +125,10 @@ def test_conv_forward(ops, case, dt):
 @pytest.mark.parametrize('B,H,ci,co,dt', [(2, 32, 32, 64, torch.bfloat16), (2, 64, 64, 64, torch.bfloat16),
                                           (2, 64, 32, 32, torch.bfloat16), (3, 64, 64, 32, torch.bfloat16),
                                           (3, 64, 32, 64, torch.bfloat16), (40, 64, 64, 64, torch.bfloat16),
-                                          (3, 128, 64, 64, torch.float16), (36, 64, 32, 32, torch.float16)],
+                                          (3, 128, 64, 64, torch.float16), (36, 64, 32, 32, torch.float16),
+                                          (14, 32, 128, 256, torch.bfloat16), (64, 16, 256, 256, torch.float16)],
                          ids=['igemm', 'halo64', 'halo32', 'halo64_32', 'halo32_64', 'halo64_persistent', 'halo64_f16',
-                              'halo32_f16_persistent'])
+                              'halo32_f16_persistent', 'hdeep', 'hdeep_f16'])
 def test_conv_relu_stats_mask(ops, B, H, ci, co, dt):
     """Epilogue variants (BN partial sums, ReLU, ReLU-backward mask).  The halo cases run conv_halo2.hip (filter in
     registers, deferred epilogue); the *_persistent cases give every workgroup several patches, i.e. exercise the halo /
@@ -151,7 +157,8 @@ def test_conv_relu_stats_mask(ops, B, H, ci, co, dt):
 # ----------------------------------------------------------------------------------------------
 DGRAD_CASES = [(2, 16, 32, 32, 32, 32, 3, 1, 'k3s1'), (2, 16, 32, 32, 64, 64, 3, 2, 'k3s2'),
                (2, 16, 256, 256, 10, 16, 1, 1, 'k1_co10'), (1, 32, 32, 32, 9, 16, 3, 1, 'k3_co9'),
-               (2, 16, 266, 288, 256, 256, 3, 1, 'ci266'), (2, 32, 64, 64, 128, 128, 3, 2, 'k3s2_b')]
+               (2, 16, 266, 288, 256, 256, 3, 1, 'ci266'), (2, 32, 64, 64, 128, 128, 3, 2, 'k3s2_b'),
+               (16, 32, 128, 128, 256, 256, 3, 1, 'hdeep_256to128'), (32, 16, 256, 256, 512, 512, 3, 1, 'hdeep_512to256')]
 
 
 @pytest.mark.parametrize('case', DGRAD_CASES, ids=[c[-1] for c in DGRAD_CASES])
