@@ -311,7 +311,7 @@ bool imm_hdeep_applicable(const imm_conv_desc* d) {
   if (px * d->ldx * 2 >= (1LL << 31) || (int64_t)d->co * d->kpad * 2 >= (1LL << 31)) return false;
   // small grids keep the im2col kernel (64x64 tiles give it 4x the workgroups)
   const int n_patches = d->batch * (d->ho / HD_P) * (d->wo / HD_P);
-  static const int min_wg = getenv("IMM_HDEEP_MIN_WG") ? atoi(getenv("IMM_HDEEP_MIN_WG")) : 192;
+  static const int min_wg = getenv("IMM_HDEEP_MIN_WG") ? atoi(getenv("IMM_HDEEP_MIN_WG")) : 100;
   return n_patches * (d->co / hd_bn(d)) >= min_wg;
 }
 

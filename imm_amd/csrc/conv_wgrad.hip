@@ -298,13 +298,13 @@ bool imm_wgrad_tr_applicable(const imm_conv_desc* d, int lddy);            // co
 void imm_wgrad_tr_launch(int dtype, const imm_conv_desc* d, const void* x, const void* dy, int lddy, float* slab, int nsplit,
                          hipStream_t s);
 bool imm_wgrad_halo_applicable(const imm_conv_desc* d, int lddy);          // conv_wgrad_halo.hip
-int imm_wgrad_halo_splits(const imm_conv_desc* d);
+int imm_wgrad_halo_splits(const imm_conv_desc* d, int lddy);
 void imm_wgrad_halo_launch(int dtype, const imm_conv_desc* d, const void* x, const void* dy, int lddy, float* slab,
                            int nsplit, hipStream_t s);
 
 extern "C" int imm_conv2d_wgrad_splits(const imm_conv_desc* d, int lddy) {
   if (!d) return IMM_E_INVALID;
-  return imm_wgrad_halo_applicable(d, lddy) ? imm_wgrad_halo_splits(d) : 0;
+  return imm_wgrad_halo_applicable(d, lddy) ? imm_wgrad_halo_splits(d, lddy) : 0;
 }
 
 extern "C" int imm_conv2d_wgrad(const imm_conv_desc* d, int dtype, const void* x, const void* dy, int lddy,
@@ -317,7 +317,7 @@ extern "C" int imm_conv2d_wgrad(const imm_conv_desc* d, int dtype, const void* x
   IMM_REQUIRE(nsplit >= 1, "wgrad: nsplit");
   IMM_REQUIRE(d->wo % 2 == 0, "wgrad: output width must be even (pixel pairs)");
   IMM_REQUIRE(((uintptr_t)x % 16 == 0) && ((uintptr_t)dy % 16 == 0) && ((uintptr_t)slab % 16 == 0), "wgrad: alignment");
-  if (imm_wgrad_halo_applicable(d, lddy) && nsplit == imm_wgrad_halo_splits(d) && (dtype == IMM_BF16 || dtype == IMM_F16)) {
+  if (imm_wgrad_halo_applicable(d, lddy) && nsplit == imm_wgrad_halo_splits(d, lddy) && (dtype == IMM_BF16 || dtype == IMM_F16)) {
     imm_wgrad_halo_launch(dtype, d, x, dy, lddy, slab, nsplit, (hipStream_t)stream);
     IMM_CHECK_LAUNCH("imm_conv2d_wgrad(halo)");
     return 0;

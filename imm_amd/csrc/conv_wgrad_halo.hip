@@ -1,5 +1,10 @@
-// conv_wgrad_halo.hip — filter gradient of 3x3 stride-1 convolutions on high-resolution, low-channel layers
-// (ci in {32,64}, co <= 64, >= 64x64): encoder conv_2/conv_4, renderer conv_6..8.
+// conv_wgrad_halo.hip — filter gradient of 3x3 stride-1 convolutions (maps with H % 8 == 0, W % 16 == 0):
+// encoder conv_2/4/6/8, renderer conv_1..8 (reference: tf.gradients of imm/models/imm_model.py:213-300 convolutions).
+// A workgroup owns a (CI x CO)-channel slice of the filter (blockIdx.y / blockIdx.z; 32- or 64-channel slices) and one
+// of `nsplit` pixel ranges (blockIdx.x).  Slab traffic is nsplit x |dW| x 4 B, operand traffic per FLOP falls with the
+// slice size: shallow high-resolution layers take 64-channel slices (few, large workgroup tiles, many patches each),
+// deep low-resolution layers 32-channel slices (4x the channel blocks => 4x fewer pixel splits for the same number
+// of workgroups).
 //
 //     dW[tap][c][n] = sum_p X[p + off(tap)][c] * dY[p][n]
 //
@@ -43,7 +48,7 @@ __device__ __forceinline__ uint32_t wh_piece(int row, int ch) {
 
 struct WgradHaloArgs {
   const uint16_t* x; const uint16_t* dy; float* slab;
-  int batch, h, w, ldx, lddy, co, kpad;
+  int batch, h, w, ldx, lddy, co, kpad, ci_total;
   int n_patches, patches_x, patches_y;
   uint32_t x_bytes, dy_bytes;
 };
@@ -63,6 +68,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_halo_kernel(const WgradHaloArg
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wc = wid % WC, wn = wid / WC;
+  const int ci0 = blockIdx.y * CI, co0 = blockIdx.z * CO;     // channel slice of this workgroup
   constexpr uint32_t OOB = 0x80000000u;
   const uint64_t xa = (uint64_t)a.x, ya = (uint64_t)a.dy;
   const u32x4_t xr = {(uint32_t)xa, (uint32_t)(xa >> 32) & 0xffffu, a.x_bytes, 0x00020000u};
@@ -81,14 +87,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_halo_kernel(const WgradHaloArg
       const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
       const bool ok = (hp < (WH_PH + 2) * WH_HW) && ((unsigned)iy < (unsigned)a.h) && ((unsigned)ix < (unsigned)a.w);
       const int sc = (lane % XC8) ^ wh_swz<XC8>(hp);
-      const uint32_t vo = ok ? (uint32_t)((iy * a.w + ix) * a.ldx * 2 + sc * 16) : OOB;
+      const uint32_t vo = ok ? (uint32_t)(((iy * a.w + ix) * a.ldx + ci0) * 2 + sc * 16) : OOB;
       wh_dma16(xr, __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)(stage * STAGE + i * 1024)), vo, xs);
     }
     for (int i = wid; i < Y_DMA; i += 4) {
       const int p = i * Y_PIX_PER_DMA + lane / YC8;       // patch pixel 0..127
       const int ty = p >> 4, tx = p & 15;
       const int sc = (lane % YC8) ^ wh_swz<YC8>(p);
-      const uint32_t vo = (uint32_t)(((y0 + ty) * a.w + x0 + tx) * a.lddy * 2 + sc * 16);
+      const uint32_t vo = (uint32_t)((((y0 + ty) * a.w + x0 + tx) * a.lddy + co0) * 2 + sc * 16);
       wh_dma16(yr, __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)(stage * STAGE + X_BYTES + i * 1024)), vo, ys);
     }
   };
@@ -144,14 +150,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_halo_kernel(const WgradHaloArg
     stage ^= 1;
   }
 
-  // lane holds D[n = 4*(lane>>4)+r][c = lane&15] -> slab[block][kk = tap*CI + wc*16 + c][n..n+3]
+  // lane holds D[n = 4*(lane>>4)+r][c = lane&15] -> slab[split][kk = tap*ci + ci0 + wc*16 + c][co0 + n .. +3]
   float* out = a.slab + (int64_t)blockIdx.x * a.kpad * a.co;
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap) {
-    const int kk = tap * CI + wc * 16 + (lane & 15);
+    const int kk = tap * a.ci_total + ci0 + wc * 16 + (lane & 15);
 #pragma unroll
     for (int j = 0; j < TNT; ++j) {
-      const int n = (wn * TNT + j) * 16 + 4 * (lane >> 4);
+      const int n = co0 + (wn * TNT + j) * 16 + 4 * (lane >> 4);
       float* op = out + (int64_t)kk * a.co + n;
       if (n + 3 < a.co && (a.co & 3) == 0) {
         *(float4*)op = make_float4(acc[tap][j][0], acc[tap][j][1], acc[tap][j][2], acc[tap][j][3]);
@@ -176,54 +182,86 @@ static int wh_num_cu() {
   return n;
 }
 
+// Slice plan of a layer: channel slice widths, number of slices and pixel splits.
+struct WhPlan { int cs, ns, nci, nco, nsplit; };
+
+static bool wh_plan(const imm_conv_desc* d, int lddy, WhPlan* pl) {
+  if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->updiv != 1 || d->pad_t != 1 || d->pad_l != 1) return false;
+  if (d->hi != d->ho || d->wi != d->wo || d->ho % WH_PH || d->wo % WH_PW) return false;
+  if (d->kpad != 9 * d->ci || d->ci % 32) return false;
+  const int64_t xb = (int64_t)d->batch * d->hi * d->wi * d->ldx * 2, yb = (int64_t)d->batch * d->ho * d->wo * lddy * 2;
+  if (xb >= (1LL << 31) || yb >= (1LL << 31)) return false;
+  const int n_patches = d->batch * (d->ho / WH_PH) * (d->wo / WH_PW);
+  int cs, ns;
+  if (d->ci <= 64 && lddy <= 64 && (lddy == 32 || lddy == 64) && d->co <= lddy) {
+    // the whole filter is one slice (dY rows staged at their padded width): encoder conv_2/4, renderer conv_6..8
+    if (d->ho * d->wo < 64 * 64) return false;
+    cs = d->ci; ns = lddy;
+    pl->nci = 1; pl->nco = 1;
+  } else {
+    // 32-channel slices of deeper filters.  Measured (tools/bench_conv.py --wgrad): a win at 64x64 (renderer conv_5,
+    // 65 -> 45 us: 32 patches per workgroup), a loss at 32x32 / 16x16 where a workgroup sees only 2-16 patches and the
+    // transpose-read kernel with its larger tiles is faster => the default only takes maps >= 64x64.
+    if (d->co % 32 || lddy < d->co) return false;
+    static const int min_side = getenv("IMM_WGRAD_HALO_SLICE_MIN") ? atoi(getenv("IMM_WGRAD_HALO_SLICE_MIN")) : 64;
+    if (d->ho * d->wo < min_side * min_side) return false;
+    cs = 32; ns = 32;
+    pl->nci = d->ci / 32; pl->nco = d->co / 32;
+  }
+  pl->cs = cs; pl->ns = ns;
+  const int blocks = pl->nci * pl->nco;
+  int grid = 2 * wh_num_cu();
+  if (blocks > 1) grid = wh_num_cu();                  // sliced layers: slab bytes = nsplit x |dW|, keep nsplit small
+  int nsplit = (grid + blocks - 1) / blocks;
+  const int min_patches = blocks > 1 ? 2 : 4;          // patches per workgroup that amortise its slab write
+  if (nsplit > n_patches / min_patches) nsplit = n_patches / min_patches;
+  if (nsplit < 1) nsplit = 1;
+  pl->nsplit = nsplit;
+  return true;
+}
+
 bool imm_wgrad_halo_applicable(const imm_conv_desc* d, int lddy) {
   static const bool off = getenv("IMM_NO_WGRAD_HALO") != nullptr;
   if (off) return false;
-  if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->updiv != 1 || d->pad_t != 1 || d->pad_l != 1) return false;
-  if (d->ci != 32 && d->ci != 64) return false;
-  if (d->co > 64 || (lddy != 32 && lddy != 64) || d->co > lddy) return false;
-  if (d->hi != d->ho || d->wi != d->wo || d->ho % WH_PH || d->wo % WH_PW) return false;
-  if (d->ho * d->wo < 64 * 64) return false;
-  if (d->kpad != 9 * d->ci) return false;
-  const int64_t xb = (int64_t)d->batch * d->hi * d->wi * d->ldx * 2, yb = (int64_t)d->batch * d->ho * d->wo * lddy * 2;
-  return xb < (1LL << 31) && yb < (1LL << 31);
+  WhPlan pl;
+  return wh_plan(d, lddy, &pl);
 }
 
-// number of workgroups == number of slab splits the caller must allocate / reduce
-int imm_wgrad_halo_splits(const imm_conv_desc* d) {
-  const int n_patches = d->batch * (d->ho / WH_PH) * (d->wo / WH_PW);
-  int grid = 2 * wh_num_cu();
-  if (grid > n_patches / 4) grid = n_patches / 4;     // >= 4 patches per workgroup: the slab write is amortised
-  if (grid < 1) grid = 1;
-  return grid;
+// number of pixel splits == slab copies the caller must allocate / reduce
+int imm_wgrad_halo_splits(const imm_conv_desc* d, int lddy) {
+  WhPlan pl;
+  return wh_plan(d, lddy, &pl) ? pl.nsplit : 0;
 }
 
 template <typename ET, int CI, int CO>
-static void wh_launch_cfg(const WgradHaloArgs& a, int grid, hipStream_t s) {
+static void wh_launch_cfg(const WgradHaloArgs& a, dim3 grid, hipStream_t s) {
   constexpr int lds = 2 * (WH_HP * CI * 2 + 128 * CO * 2);
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {
     (void)hipFuncSetAttribute((const void*)conv_wgrad_halo_kernel<ET, CI, CO>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_wgrad_halo_kernel<ET, CI, CO>), dim3(grid), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((conv_wgrad_halo_kernel<ET, CI, CO>), grid, dim3(256), lds, s, a);
 }
 
 void imm_wgrad_halo_launch(int dtype, const imm_conv_desc* d, const void* x, const void* dy, int lddy, float* slab,
                            int nsplit, hipStream_t s) {
+  WhPlan pl;
+  (void)wh_plan(d, lddy, &pl);
   WgradHaloArgs a;
   a.x = (const uint16_t*)x; a.dy = (const uint16_t*)dy; a.slab = slab;
   a.batch = d->batch; a.h = d->ho; a.w = d->wo; a.ldx = d->ldx; a.lddy = lddy; a.co = d->co; a.kpad = d->kpad;
+  a.ci_total = d->ci;
   a.patches_x = d->wo / WH_PW; a.patches_y = d->ho / WH_PH;
   a.n_patches = d->batch * a.patches_x * a.patches_y;
   a.x_bytes = (uint32_t)((int64_t)d->batch * d->hi * d->wi * d->ldx * 2);
   a.dy_bytes = (uint32_t)((int64_t)d->batch * d->ho * d->wo * lddy * 2);
-  const int grid = nsplit;
+  const dim3 grid(nsplit, pl.nci, pl.nco);
 #define WH_GO(ET_) \
   do { \
-    if (d->ci == 64 && lddy == 64) wh_launch_cfg<ET_, 64, 64>(a, grid, s); \
-    else if (d->ci == 64) wh_launch_cfg<ET_, 64, 32>(a, grid, s); \
-    else if (lddy == 64) wh_launch_cfg<ET_, 32, 64>(a, grid, s); \
+    if (pl.cs == 64 && pl.ns == 64) wh_launch_cfg<ET_, 64, 64>(a, grid, s); \
+    else if (pl.cs == 64) wh_launch_cfg<ET_, 64, 32>(a, grid, s); \
+    else if (pl.ns == 64) wh_launch_cfg<ET_, 32, 64>(a, grid, s); \
     else wh_launch_cfg<ET_, 32, 32>(a, grid, s); \
   } while (0)
   if (dtype == IMM_BF16) WH_GO(BF16); else WH_GO(F16);

@@ -439,7 +439,7 @@ class IMMEngine:
         if s16 != 16:
             raise NotImplementedError('renderer starts at 16x16 (min_res 16, renderer_stride 2): got %d' % s16)
         He = S // 8                        # encoder output side
-        Cj = ops.round_up(8 * nf + K, 32)  # joint embedding channels (zero padded)
+        Cj = ops.round_up(8 * nf + K, 64)  # joint embedding channels, zero padded to whole 64-channel K slices (deep-K kernels)
         self.Cj, self.He = Cj, He
         self.joint = self._act(B, 16, 16, Cj)
         self.d_joint = self._act(B, 16, 16, Cj)

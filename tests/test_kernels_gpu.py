@@ -230,7 +230,9 @@ def test_conv_wgrad(ops, case):
 
 
 WGRAD_HALO_CASES = [(1, 128, 32, 32, 32, 'h32_32'), (2, 64, 64, 64, 64, 'h64_64'), (2, 64, 64, 32, 32, 'h64_32'),
-                    (3, 64, 32, 9, 32, 'h32_9'), (40, 64, 32, 64, 64, 'h32_64_many')]
+                    (3, 64, 32, 9, 32, 'h32_9'), (40, 64, 32, 64, 64, 'h32_64_many'),
+                    # deeper filters at >= 64x64: 32-channel slices (blockIdx.y / .z)
+                    (5, 64, 128, 64, 64, 'sliced_128_64'), (2, 64, 160, 96, 96, 'sliced_160_96')]
 
 
 @pytest.mark.parametrize('case', WGRAD_HALO_CASES, ids=[c[-1] for c in WGRAD_HALO_CASES])

@@ -24,6 +24,10 @@ LAYERS = [  # tag, images, H, ci, co, k, stride
     ('vgg5_1       8^2 512->512', 64, 8, 512, 512, 3, 1),
     ('ren_conv1   16^2 288->256', 32, 16, 288, 256, 3, 1),
     ('ren_conv7  128^2 64->32', 32, 128, 64, 32, 3, 1),
+    ('ren_conv5   64^2 128->64', 32, 64, 128, 64, 3, 1),
+    ('ren_conv3   32^2 256->128', 32, 32, 256, 128, 3, 1),
+    ('ren_conv2   16^2 256->256', 32, 16, 256, 256, 3, 1),
+    ('enc_conv6   32^2 128->128', 32, 32, 128, 128, 3, 1),
 ]
 
 
@@ -77,6 +81,9 @@ def main():
             bn_w = 128 if co > 64 else 64 if co > 32 else 32 if co > 16 else 16
             tiles = -(-desc.kpad // 128) * -(-co // bn_w)
             nsplit = max(1, min(-(-512 // tiles), max(1, npix // 512)))
+            forced = ops.conv2d_wgrad_splits(desc, co)
+            if forced > 0:
+                nsplit = forced
             slab = torch.empty(nsplit, desc.kpad, co, device=DEV)
             us = time_launch(lambda: ops.conv2d_wgrad(desc, x, dy, co, slab, nsplit))
             flops = 2.0 * npix * k * k * ci * co
