@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, 'libimm_hip.so')
 IMM_BF16, IMM_F16 = 0, 1
 CONV_BIAS, CONV_RELU, CONV_STATS, CONV_MASK, CONV_OUT_F32 = 1, 2, 4, 8, 16
 SSE_BLOCKS = 512
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class ImmHipError(RuntimeError):

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define IMM_ABI_VERSION 1
+#define IMM_ABI_VERSION 2   /* 2: imm_vgg_conv1_1_fwd gained `halves` */
 
 enum imm_dtype { IMM_BF16 = 0, IMM_F16 = 1 };
 
