@@ -79,57 +79,90 @@ extern "C" int imm_pack_image_taps(const float* src, void* dst, int dtype, int b
 // ---------------------------------------------------------------------------------------------
 // batch norm forward
 // ---------------------------------------------------------------------------------------------
-// Sums the per-M-block partials of one 32-channel group with a 32x32 thread block (32 row lanes, f64
-// accumulation, fixed order => deterministic), then lane row 0 finalises its channel.
-template <int NS>
+// Sums the per-block partials of one 32-channel group with a 1024-thread block (f64 accumulation, fixed order =>
+// deterministic); threads (x, y = 0) receive the totals of channel ch = 32*blockIdx.x + x.  The pass is latency-bound
+// (up to 4096 partial rows, one block per 32 channels): 16-byte loads, 4 independent row chains per thread, then a
+// fixed-order LDS reduction over the row lanes.  c % 4 == 0 takes the vector path.
+template <int NS, int CPB = 32>
 __device__ __forceinline__ void reduce_partials_32x32(const float* __restrict__ partial, int nblk, int c, int ch,
                                                       double (&out)[NS]) {
-  __shared__ double red[NS][32][33];
-  double acc[NS];
+  constexpr int QPB = CPB / 4;                 // float4 columns per sum
+  constexpr int COLS = QPB * NS;               // float4 columns of this block's CPB channels x NS sums
+  constexpr int RL = 1024 / COLS;              // row lanes
+  __shared__ double red[RL][NS * CPB + 1];
+  const int tid = threadIdx.y * 32 + threadIdx.x;
+  const int ch0 = blockIdx.x * CPB;
+  if ((c & 3) == 0) {
+    const int col = tid % COLS, rl = tid / COLS;
+    const int sidx = col / QPB, q4 = (col % QPB) * 4;
+    const bool live = ch0 + q4 < c;            // c % 4 == 0: a float4 is entirely inside or outside
+    double acc[4][4];
 #pragma unroll
-  for (int s = 0; s < NS; ++s) acc[s] = 0.0;
-  if (ch < c) {
-    // 4 independent row chains per lane keep 4*NS loads in flight (the loop is latency-, not bandwidth-bound)
-    double a1[NS], a2[NS], a3[NS];
+    for (int u = 0; u < 4; ++u)
 #pragma unroll
-    for (int s = 0; s < NS; ++s) { a1[s] = 0.0; a2[s] = 0.0; a3[s] = 0.0; }
-    int b = threadIdx.y;
-    for (; b + 96 < nblk; b += 128) {
+      for (int e = 0; e < 4; ++e) acc[u][e] = 0.0;
+    if (live) {
+      const float* base = partial + (int64_t)sidx * c + ch0 + q4;
+      int b = rl;
+      for (; b + 3 * RL < nblk; b += 4 * RL) {
+        float4 v[4];
 #pragma unroll
-      for (int s = 0; s < NS; ++s) {
-        const float v0 = partial[((int64_t)b * NS + s) * c + ch], v1 = partial[((int64_t)(b + 32) * NS + s) * c + ch];
-        const float v2 = partial[((int64_t)(b + 64) * NS + s) * c + ch], v3 = partial[((int64_t)(b + 96) * NS + s) * c + ch];
-        acc[s] += (double)v0; a1[s] += (double)v1; a2[s] += (double)v2; a3[s] += (double)v3;
+        for (int u = 0; u < 4; ++u) v[u] = *(const float4*)(base + (int64_t)(b + u * RL) * NS * c);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          acc[u][0] += (double)v[u].x; acc[u][1] += (double)v[u].y; acc[u][2] += (double)v[u].z; acc[u][3] += (double)v[u].w;
+        }
+      }
+      for (; b < nblk; b += RL) {
+        const float4 v = *(const float4*)(base + (int64_t)b * NS * c);
+        acc[0][0] += (double)v.x; acc[0][1] += (double)v.y; acc[0][2] += (double)v.z; acc[0][3] += (double)v.w;
       }
     }
-    for (; b < nblk; b += 32) {
 #pragma unroll
-      for (int s = 0; s < NS; ++s) acc[s] += (double)partial[((int64_t)b * NS + s) * c + ch];
+    for (int e = 0; e < 4; ++e) red[rl][sidx * CPB + q4 + e] = (acc[0][e] + acc[1][e]) + (acc[2][e] + acc[3][e]);
+  } else {
+    // scalar fallback (CPB = 32 only): thread (x, y) walks rows y, y+32, ... of channel ch; row lanes >= 32 hold zeros
+    double acc[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) acc[s] = 0.0;
+    if (ch < c && threadIdx.x < CPB) {
+      for (int b = threadIdx.y; b < nblk; b += 32) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) acc[s] += (double)partial[((int64_t)b * NS + s) * c + ch];
+      }
     }
+    if (threadIdx.x < CPB) {
 #pragma unroll
-    for (int s = 0; s < NS; ++s) acc[s] = (acc[s] + a1[s]) + (a2[s] + a3[s]);
+      for (int s = 0; s < NS; ++s) {
+        red[threadIdx.y][s * CPB + threadIdx.x] = acc[s];
+        for (int r = threadIdx.y + 32; r < RL; r += 32) red[r][s * CPB + threadIdx.x] = 0.0;
+      }
+    }
   }
-#pragma unroll
-  for (int s = 0; s < NS; ++s) red[s][threadIdx.y][threadIdx.x] = acc[s];
   __syncthreads();
-  if (threadIdx.y == 0) {
+  if (threadIdx.y == 0 && threadIdx.x < CPB) {
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-      double t = 0.0;
-      for (int r = 0; r < 32; ++r) t += red[s][r][threadIdx.x];
-      out[s] = t;
+      double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+      for (int r = 0; r < RL; r += 4) {
+        t0 += red[r][s * CPB + threadIdx.x]; t1 += red[r + 1][s * CPB + threadIdx.x];
+        t2 += red[r + 2][s * CPB + threadIdx.x]; t3 += red[r + 3][s * CPB + threadIdx.x];
+      }
+      out[s] = (t0 + t1) + (t2 + t3);
     }
   }
 }
 
+// CPB channels per block: 32, or 8 when there are many partial rows (4x the blocks pulling them in)
+template <int CPB>
 __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ partial, int nblk, int c, double count,
                                    const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                    float momentum, int training, float* moving_mean, float* moving_var,
                                    float* scale, float* shift, float* mean_out, float* rstd_out) {
-  const int ch = blockIdx.x * 32 + threadIdx.x;
+  const int ch = blockIdx.x * CPB + threadIdx.x;
   double s[2] = {0.0, 0.0};
-  if (training) reduce_partials_32x32<2>(partial, nblk, c, ch, s);
-  if (threadIdx.y != 0 || ch >= c) return;
+  if (training) reduce_partials_32x32<2, CPB>(partial, nblk, c, ch, s);
+  if (threadIdx.y != 0 || threadIdx.x >= CPB || ch >= c) return;
   float mean, var;
   if (training) {
     const double m = s[0] / count;
@@ -156,8 +189,12 @@ extern "C" int imm_bn_finalize(const float* partial, int nblk, int c, int64_t co
   IMM_REQUIRE(gamma && beta && moving_mean && moving_var && scale && shift && mean && rstd, "bn_finalize: null");
   IMM_REQUIRE(!training || (partial && nblk > 0), "bn_finalize: training needs partial sums");
   IMM_REQUIRE(c > 0 && count > 0, "bn_finalize: dims");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + 31) / 32), dim3(32, 32), 0, (hipStream_t)stream, partial, nblk, c,
-                     (double)count, gamma, beta, eps, momentum, training, moving_mean, moving_var, scale, shift, mean, rstd);
+  if (training && nblk >= 1024 && c % 8 == 0)
+    hipLaunchKernelGGL(bn_finalize_kernel<8>, dim3(c / 8), dim3(32, 32), 0, (hipStream_t)stream, partial, nblk, c,
+                       (double)count, gamma, beta, eps, momentum, training, moving_mean, moving_var, scale, shift, mean, rstd);
+  else
+    hipLaunchKernelGGL(bn_finalize_kernel<32>, dim3((c + 31) / 32), dim3(32, 32), 0, (hipStream_t)stream, partial, nblk, c,
+                       (double)count, gamma, beta, eps, momentum, training, moving_mean, moving_var, scale, shift, mean, rstd);
   IMM_CHECK_LAUNCH("imm_bn_finalize");
   return 0;
 }
@@ -287,13 +324,14 @@ extern "C" int imm_bn_bwd_reduce(const void* dout, int lddo, const void* y, int 
   return 0;
 }
 
+template <int CPB>
 __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int c, double count,
                                        const float* __restrict__ gamma, const float* __restrict__ rstd,
                                        float* dgamma, float* dbeta, float* coef) {
-  const int ch = blockIdx.x * 32 + threadIdx.x;
+  const int ch = blockIdx.x * CPB + threadIdx.x;
   double s[2] = {0.0, 0.0};
-  reduce_partials_32x32<2>(partial, nblk, c, ch, s);
-  if (threadIdx.y != 0 || ch >= c) return;
+  reduce_partials_32x32<2, CPB>(partial, nblk, c, ch, s);
+  if (threadIdx.y != 0 || threadIdx.x >= CPB || ch >= c) return;
   dbeta[ch] = (float)s[0];
   dgamma[ch] = (float)s[1];
   coef[ch] = gamma[ch] * rstd[ch];
@@ -304,8 +342,12 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
 extern "C" int imm_bn_bwd_finalize(const float* partial, int nblk, int c, int64_t count, const float* gamma,
                                    const float* rstd, float* dgamma, float* dbeta, float* coef, void* stream) {
   IMM_REQUIRE(partial && gamma && rstd && dgamma && dbeta && coef && nblk > 0 && c > 0 && count > 0, "bn_bwd_finalize: args");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 31) / 32), dim3(32, 32), 0, (hipStream_t)stream, partial, nblk, c,
-                     (double)count, gamma, rstd, dgamma, dbeta, coef);
+  if (nblk >= 1024 && c % 8 == 0)
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel<8>, dim3(c / 8), dim3(32, 32), 0, (hipStream_t)stream, partial, nblk, c,
+                       (double)count, gamma, rstd, dgamma, dbeta, coef);
+  else
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel<32>, dim3((c + 31) / 32), dim3(32, 32), 0, (hipStream_t)stream, partial, nblk, c,
+                       (double)count, gamma, rstd, dgamma, dbeta, coef);
   IMM_CHECK_LAUNCH("imm_bn_bwd_finalize");
   return 0;
 }
