@@ -53,24 +53,33 @@ __device__ __forceinline__ int h2_swz(int row) { return C8 == 8 ? (((row >> 1) &
 
 template <int V> struct H2Int { static constexpr int value = V; };
 
+// halo pixel slots of one LDS stage: (8 + kh - 1) x (16 + kw - 1) pixels, rounded up so that the tile is a whole number
+// of 1-KB DMA instructions per wave (4 waves)
+__host__ __device__ constexpr int h2_halo_slots(int ci, int kh, int kw) {
+  const int per_round = 4 * (64 / (ci / 8));
+  return ((H2_PH + kh - 1) * (H2_PW + kw - 1) + per_round - 1) / per_round * per_round;
+}
+
 // sched_group_barrier masks (LLVM AMDGPU): the MFMA loop of a halo row is laid out as "1 MFMA + up to 3 other issues"
 #define H2_SG_VALU 0x002
 #define H2_SG_SALU 0x004
 #define H2_SG_MFMA 0x008
 #define H2_SG_DSREAD 0x100
 
-template <typename ET, int CI, int BN, bool MASK, bool STATS, int NS>
+template <typename ET, int CI, int BN, bool MASK, bool STATS, int NS, int KH = 3, int KW = 3>
 __global__ __launch_bounds__(256) void conv_halo2_kernel(const Halo2Args ha) {
   const ConvArgs& a = ha.c;
   constexpr int C8 = CI / 8;                       // 16-byte chunks per input pixel
   constexpr int KS = CI / 32;                      // MFMA k-steps per tap
   constexpr int WGN = BN / 32, WGM = 4 / WGN;      // a wave owns 32 channels x MT patch rows
-  constexpr int MT = H2_PH / WGM, NT = 2, NR = MT + 2;   // NR halo rows per wave
-  constexpr int PIXB = CI * 2, ROWB = H2_HW * PIXB;      // bytes per halo pixel / halo row in LDS
+  constexpr int MT = H2_PH / WGM, NT = 2, NR = MT + KH - 1;   // NR halo rows per wave
+  constexpr int HW = H2_PW + KW - 1, HROWS = H2_PH + KH - 1;   // halo tile (KH x KW filter; 3x3 or the 7x1 first layer)
+  constexpr int PIXB = CI * 2, ROWB = HW * PIXB;         // bytes per halo pixel / halo row in LDS
   constexpr int PIX_PER_DMA = 64 / C8;             // halo pixels per 1-KB DMA instruction
-  constexpr int HALO_DMA = H2_HP / PIX_PER_DMA;    // 24 / 12
+  constexpr int HP = h2_halo_slots(CI, KH, KW);    // halo pixel slots, padded to 4 whole DMA instructions per wave step
+  constexpr int HALO_DMA = HP / PIX_PER_DMA;       // 24 / 12 (3x3)
   constexpr int DH = HALO_DMA / 4;                 // per wave
-  constexpr int H_U4 = H2_HP * C8;                 // uint4 per halo stage
+  constexpr int H_U4 = HP * C8;                    // uint4 per halo stage
   constexpr int O8 = BN / 8;                       // 16-byte chunks per output (= mask) pixel
   constexpr int M_U4 = MASK ? H2_PH * H2_PW * O8 : 0;
   constexpr int MASK_DMA = M_U4 / 64, DM = MASK_DMA / 4;
@@ -120,13 +129,13 @@ __global__ __launch_bounds__(256) void conv_halo2_kernel(const Halo2Args ha) {
   };
 
   // ---- filter -> registers (MFMA B operand layout; channel permutation described in the header) ---------------
-  u32x4_t bw[9][KS][NT];
+  u32x4_t bw[KH * KW][KS][NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int n = wn * 32 + (frow >> 2) * 8 + j * 4 + (frow & 3);
     const uint16_t* wrow = a.wt + (size_t)n * a.kpad + q * 8;
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap)
+    for (int tap = 0; tap < KH * KW; ++tap)
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) bw[tap][ks][j] = *(const u32x4_t*)(wrow + tap * CI + ks * 32);
   }
@@ -143,7 +152,7 @@ __global__ __launch_bounds__(256) void conv_halo2_kernel(const Halo2Args ha) {
   // Every compiler-visible global load ends here: pass the values through empty asm statements so the compiler's
   // own s_waitcnt for them is placed before the loop, not (conservatively, as vmcnt(0)) inside it.
 #pragma unroll
-  for (int tap = 0; tap < 9; ++tap)
+  for (int tap = 0; tap < KH * KW; ++tap)
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
@@ -161,13 +170,13 @@ __global__ __launch_bounds__(256) void conv_halo2_kernel(const Halo2Args ha) {
 #pragma unroll
   for (int k = 0; k < DH; ++k) {
     const int hp = (wid + 4 * k) * PIX_PER_DMA + lane / C8;        // halo slot 0..191
-    const int hy = hp / H2_HW, hx = hp - hy * H2_HW;
+    const int hy = hp / HW, hx = hp - hy * HW;
     const int sc = (lane % C8) ^ h2_swz<C8>(hx);
-    hyx[k] = ((hp < (H2_PH + 2) * H2_HW ? hy : 0x4000) << 16) | hx;
+    hyx[k] = ((hp < HROWS * HW ? hy : 0x4000) << 16) | hx;
     hrel[k] = (uint32_t)((hy * a.wi + hx) * a.ldx * 2 + sc * 16);
   }
   auto halo_piece = [&](const Pd& d, int stage, int k) {
-    const int y0 = d.y0 - 1, x0 = d.x0 - 1;
+    const int y0 = d.y0 - KH / 2, x0 = d.x0 - KW / 2;
     const uint32_t soff = (uint32_t)(d.img * a.hi * a.wi) * (uint32_t)(a.ldx * 2);
     const uint32_t base = (uint32_t)((y0 * a.wi + x0) * a.ldx * 2);     // may be "negative": only used when in range
     const int iy = y0 + (hyx[k] >> 16), ix = x0 + (hyx[k] & 0xffff);
@@ -197,9 +206,9 @@ __global__ __launch_bounds__(256) void conv_halo2_kernel(const Halo2Args ha) {
 
   // per-lane byte offset of the A fragments inside a halo stage, for the three horizontal taps (k-step 1 = XOR 64;
   // halo row rr = + rr * ROWB, an immediate of the ds_read)
-  int lrel[3];
+  int lrel[KW];
 #pragma unroll
-  for (int kx = 0; kx < 3; ++kx) lrel[kx] = wm * MT * ROWB + (frow + kx) * PIXB + (q ^ h2_swz<C8>(frow + kx)) * 16;
+  for (int kx = 0; kx < KW; ++kx) lrel[kx] = wm * MT * ROWB + (frow + kx) * PIXB + (q ^ h2_swz<C8>(frow + kx)) * 16;
   const int moff = frow * O8 + ((wn * 4 + q) ^ (frow & (O8 - 1)));   // + patch row * 16 * O8
   const uint32_t ovoff = (uint32_t)((frow * a.ldy + wn * 32 + q * 8) * 2);   // lane part of the output address
 
@@ -240,16 +249,16 @@ __global__ __launch_bounds__(256) void conv_halo2_kernel(const Halo2Args ha) {
     const int hprev = hs == 0 ? NS - 1 : hs - 1;                   // (it-1) % NS
     const int hprev2 = hprev == 0 ? NS - 1 : hprev - 1;            // (it-2) % NS
     const uint4* Ml = smem + NS * H_U4 + hprev * M_U4 + moff;
-    const uint4* rowp[3][KS];                                      // lane's fragment address in halo row 0 of this stage
+    const uint4* rowp[KW][KS];                                     // lane's fragment address in halo row 0 of this stage
 #pragma unroll
-    for (int kx = 0; kx < 3; ++kx)
+    for (int kx = 0; kx < KW; ++kx)
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks)
         rowp[kx][ks] = (const uint4*)((const char*)smem + hs * (H_U4 * 16) + (lrel[kx] ^ (ks * 64)));
-    uint4 fa[2][3][KS];
+    uint4 fa[2][KW][KS];
     if constexpr (MMA) {
 #pragma unroll
-      for (int kx = 0; kx < 3; ++kx)
+      for (int kx = 0; kx < KW; ++kx)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) fa[0][kx][ks] = rowp[kx][ks][0];
     }
@@ -270,7 +279,7 @@ __global__ __launch_bounds__(256) void conv_halo2_kernel(const Halo2Args ha) {
       if constexpr (MMA) {
         if (rr + 1 < NR) {
 #pragma unroll
-          for (int kx = 0; kx < 3; ++kx)
+          for (int kx = 0; kx < KW; ++kx)
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) fa[(rr + 1) & 1][kx][ks] = rowp[kx][ks][(rr + 1) * (ROWB / 16)];
         }
@@ -279,16 +288,16 @@ __global__ __launch_bounds__(256) void conv_halo2_kernel(const Halo2Args ha) {
 #pragma unroll
         for (int k = rr; k < DM; k += NR) mask_piece(dq[NS - 2], hprev2, k);
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx)
+        for (int kx = 0; kx < KW; ++kx)
 #pragma unroll
           for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
+            for (int ky = 0; ky < KH; ++ky) {
               const int i = rr - ky;
               if (i >= 0 && i < MT) {
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
-                  acc[PH][i][j] = ET::mfma(__builtin_bit_cast(uint4, bw[ky * 3 + kx][ks][j]), fa[rr & 1][kx][ks], acc[PH][i][j]);   // D[n][pixel]
+                  acc[PH][i][j] = ET::mfma(__builtin_bit_cast(uint4, bw[ky * KW + kx][ks][j]), fa[rr & 1][kx][ks], acc[PH][i][j]);   // D[n][pixel]
                 n_mfma += NT;
               }
             }
@@ -333,7 +342,7 @@ __global__ __launch_bounds__(256) void conv_halo2_kernel(const Halo2Args ha) {
         }
       }
       if constexpr (MMA) {
-        __builtin_amdgcn_sched_group_barrier(H2_SG_DSREAD, 3 * KS, 0);
+        __builtin_amdgcn_sched_group_barrier(H2_SG_DSREAD, KW * KS, 0);
 #pragma unroll
         for (int m = 0; m < 36; ++m) {
           if (m < n_mfma) {
@@ -420,9 +429,14 @@ static int h2_num_cu() {
 bool imm_halo2_applicable(const imm_conv_desc* d) {
   static const bool off = getenv("IMM_NO_HALO2") != nullptr || getenv("IMM_NO_HALO") != nullptr;
   if (off) return false;
-  if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->updiv != 1 || d->pad_t != 1 || d->pad_l != 1) return false;
+  const bool k33 = d->kh == 3 && d->kw == 3 && d->pad_t == 1 && d->pad_l == 1;
+  // the tap-unrolled first layer (imm_model.py:215 7x7 conv over the 7x3 horizontally unrolled image): 7x1 over 32 channels
+  const bool k71 = d->kh == 7 && d->kw == 1 && d->pad_t == 3 && d->pad_l == 0 && d->ci == 32 && d->co == 32 &&
+                   !(d->flags & IMM_CONV_MASK);
+  if ((!k33 && !k71) || d->stride != 1 || d->updiv != 1) return false;
   if (d->ci != 32 && d->ci != 64) return false;
   if (d->co != 32 && d->co != 64) return false;
+  if (d->kpad != d->kh * d->kw * d->ci) return false;
   if (d->out_scale > 1 || (d->flags & (IMM_CONV_OUT_F32 | 0xf00))) return false;
   if (d->hi != d->ho || d->wi != d->wo || d->ho % H2_PH || d->wo % H2_PW) return false;
   if (d->ho * d->wo < 64 * 64) return false;
@@ -432,20 +446,20 @@ bool imm_halo2_applicable(const imm_conv_desc* d) {
   return px * d->ldx * 2 < (1LL << 31) && px * d->ldy * 2 < (1LL << 31) && px * (int64_t)d->ldmask * 2 < (1LL << 31);
 }
 
-static size_t h2_lds(int ci, int bn, bool mask, int ns) {
-  return (size_t)ns * ((size_t)H2_HP * (ci / 8) + (mask ? (size_t)H2_PH * H2_PW * (bn / 8) : 0)) * 16;
+static size_t h2_lds(int ci, int bn, bool mask, int ns, int kh = 3, int kw = 3) {
+  return (size_t)ns * ((size_t)h2_halo_slots(ci, kh, kw) * (ci / 8) + (mask ? (size_t)H2_PH * H2_PW * (bn / 8) : 0)) * 16;
 }
 
-template <typename ET, int CI, int BN, bool MASK, bool STATS, int NS>
+template <typename ET, int CI, int BN, bool MASK, bool STATS, int NS, int KH = 3, int KW = 3>
 static int h2_occupancy() {
   static int occ = 0;
   if (occ == 0) {
-    const size_t lds = h2_lds(CI, BN, MASK, NS);
+    const size_t lds = h2_lds(CI, BN, MASK, NS, KH, KW);
     if (lds > 64 * 1024)
-      (void)hipFuncSetAttribute((const void*)conv_halo2_kernel<ET, CI, BN, MASK, STATS, NS>,
+      (void)hipFuncSetAttribute((const void*)conv_halo2_kernel<ET, CI, BN, MASK, STATS, NS, KH, KW>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_halo2_kernel<ET, CI, BN, MASK, STATS, NS>, 256, lds) != hipSuccess || n < 1) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_halo2_kernel<ET, CI, BN, MASK, STATS, NS, KH, KW>, 256, lds) != hipSuccess || n < 1) {
       (void)hipGetLastError();
       n = 1;
     }
@@ -454,18 +468,28 @@ static int h2_occupancy() {
   return occ;
 }
 
-// dispatch over the instantiated (ci, co, mask, stats, ring depth) combinations
+// dispatch over the instantiated (ci, co, mask, stats, ring depth, filter shape) combinations
 template <typename F>
-static void h2_dispatch(int ci, int co, bool mask, bool stats, F&& f) {
+static void h2_dispatch(const imm_conv_desc* d, F&& f) {
+  const int ci = d->ci, co = d->co;
+  const bool mask = d->flags & IMM_CONV_MASK, stats = d->flags & IMM_CONV_STATS;
   const int ns = h2_ns(mask);
+  if (d->kh == 7) {   // 7x1 first layer: 32 -> 32 channels
+    if (stats) f(H2Int<32>(), H2Int<32>(), H2Int<0>(), H2Int<1>(), H2Int<4>(), H2Int<7>(), H2Int<1>());
+    else f(H2Int<32>(), H2Int<32>(), H2Int<0>(), H2Int<0>(), H2Int<4>(), H2Int<7>(), H2Int<1>());
+    return;
+  }
   auto with_ns = [&](auto c, auto b, auto st) {
-    if (ns == 3) f(c, b, H2Int<0>(), st, H2Int<3>());
-    else f(c, b, H2Int<0>(), st, H2Int<4>());
+    if (ns == 3) f(c, b, H2Int<0>(), st, H2Int<3>(), H2Int<3>(), H2Int<3>());
+    else f(c, b, H2Int<0>(), st, H2Int<4>(), H2Int<3>(), H2Int<3>());
   };
   auto with_stats = [&](auto c, auto b) {
     if (stats) with_ns(c, b, H2Int<1>()); else with_ns(c, b, H2Int<0>());
   };
-  if (mask) { if (ns == 3) f(H2Int<64>(), H2Int<64>(), H2Int<1>(), H2Int<0>(), H2Int<3>()); else f(H2Int<64>(), H2Int<64>(), H2Int<1>(), H2Int<0>(), H2Int<4>()); }
+  if (mask) {
+    if (ns == 3) f(H2Int<64>(), H2Int<64>(), H2Int<1>(), H2Int<0>(), H2Int<3>(), H2Int<3>(), H2Int<3>());
+    else f(H2Int<64>(), H2Int<64>(), H2Int<1>(), H2Int<0>(), H2Int<4>(), H2Int<3>(), H2Int<3>());
+  }
   else if (ci == 64 && co == 64) with_stats(H2Int<64>(), H2Int<64>());
   else if (ci == 64) with_stats(H2Int<64>(), H2Int<32>());
   else if (co == 64) with_stats(H2Int<32>(), H2Int<64>());
@@ -477,9 +501,9 @@ static void h2_dispatch(int ci, int co, bool mask, bool stats, F&& f) {
 int imm_halo2_grid(const imm_conv_desc* d) {
   const int n_patches = d->batch * (d->ho / H2_PH) * (d->wo / H2_PW);
   int occ = 1;
-  h2_dispatch(d->ci, d->co, d->flags & IMM_CONV_MASK, d->flags & IMM_CONV_STATS, [&](auto ci, auto bn, auto mk, auto st, auto ns) {
+  h2_dispatch(d, [&](auto ci, auto bn, auto mk, auto st, auto ns, auto kh, auto kw) {
     occ = h2_occupancy<BF16, decltype(ci)::value, decltype(bn)::value, (bool)decltype(mk)::value, (bool)decltype(st)::value,
-                       decltype(ns)::value>();
+                       decltype(ns)::value, decltype(kh)::value, decltype(kw)::value>();
   });
   const int grid = h2_num_cu() * occ;
   return n_patches < grid ? n_patches : grid;
@@ -502,11 +526,13 @@ static void h2_launch(const imm_conv_desc* d, const ConvArgs& a, hipStream_t s) 
     ha.lg_px = __builtin_ctz(ha.patches_x); ha.lg_pi = __builtin_ctz(per_img);
   }
   const int grid = imm_halo2_grid(d);
-  h2_dispatch(d->ci, d->co, d->flags & IMM_CONV_MASK, d->flags & IMM_CONV_STATS, [&](auto ci, auto bn, auto mk, auto st, auto ns) {
+  h2_dispatch(d, [&](auto ci, auto bn, auto mk, auto st, auto ns, auto kh, auto kw) {
     constexpr int CI = decltype(ci)::value, BN = decltype(bn)::value, NS = decltype(ns)::value;
+    constexpr int KH = decltype(kh)::value, KW = decltype(kw)::value;
     constexpr bool MASK = decltype(mk)::value, STATS = decltype(st)::value;
-    (void)h2_occupancy<ET, CI, BN, MASK, STATS, NS>();          // sets the dynamic-LDS attribute on first use
-    hipLaunchKernelGGL((conv_halo2_kernel<ET, CI, BN, MASK, STATS, NS>), dim3(grid), dim3(256), h2_lds(CI, BN, MASK, NS), s, ha);
+    (void)h2_occupancy<ET, CI, BN, MASK, STATS, NS, KH, KW>();  // sets the dynamic-LDS attribute on first use
+    hipLaunchKernelGGL((conv_halo2_kernel<ET, CI, BN, MASK, STATS, NS, KH, KW>), dim3(grid), dim3(256),
+                       h2_lds(CI, BN, MASK, NS, KH, KW), s, ha);
   });
 }
 

@@ -418,10 +418,12 @@ def test_maxpool(ops):
             np.testing.assert_allclose(float(dx.float().sum()), float(dy.float().sum()), rtol=1e-3)
 
 
-def test_first_conv_as_tap_unrolled_7x1(ops):
-    """conv 7x7x3 == pack_image_taps (7 horizontal taps -> 21 channels) + 7x1 conv over 32 channels."""
+@pytest.mark.parametrize('B,S', [(2, 32), (5, 128)], ids=['igemm_32px', 'halo2_7x1_128px'])
+def test_first_conv_as_tap_unrolled_7x1(ops, B, S):
+    """conv 7x7x3 == pack_image_taps (7 horizontal taps -> 21 channels) + 7x1 conv over 32 channels.  At >= 64x64 the
+    7x1 instantiation of conv_halo2.hip serves it (filter in registers, 14-row halo tiles)."""
     from imm_amd import _lib as L
-    B, S, co, dt = 2, 32, 32, torch.bfloat16
+    co, dt = 32, torch.bfloat16
     src = torch.rand(B, S, S, 3) * 255
     w = rnd((7, 7, 3, co), 57, 0.01, torch.float32)
     xin = torch.full((B, S, S, 32), float('nan'), dtype=dt, device=DEV)
@@ -445,6 +447,17 @@ def test_first_conv_as_tap_unrolled_7x1(ops):
     ops.conv2d_wgrad_reduce(slab, 3, 7, 1, 32, 21, co, desc.kpad, dw)
     torch.cuda.synchronize()
     close(y, ref, 1e-2, 2e-3, 'conv7x1')
+    # epilogue variant used by the encoders: bias + BN partial sums
+    bias = rnd((co,), 59, 0.5, torch.float32)
+    d2 = ops.fwd_desc(B, S, S, 32, 32, co, co, 7, 1, L.CONV_BIAS | L.CONV_STATS, kw=1)
+    stats = torch.full((ops.conv_stats_blocks(d2), 2, co), float('nan'), dtype=torch.float32, device=DEV)
+    y2 = torch.empty(B, S, S, co, dtype=dt, device=DEV)
+    ops.conv2d(d2, xin, wt, bias.to(DEV), y2, stats)
+    torch.cuda.synchronize()
+    close(y2, ref + bias, 1e-2, 2e-3, 'conv7x1+bias')
+    st = stats.sum(dim=0).cpu()
+    close(st[0], (ref + bias).sum(dim=(0, 1, 2)), 1e-3, 1e-3, 'conv7x1/sum')
+    close(st[1], ((ref + bias) ** 2).sum(dim=(0, 1, 2)), 1e-3, 1e-3, 'conv7x1/sumsq')
     wr = torch.zeros(7, 7, 3, co, requires_grad=True)
     (gw,) = torch.autograd.grad(O.conv2d_same(src.to(dt).float(), wr, None, 1), wr, dy.float())
     close(dw, gw, 2e-3, 5e-4, 'wgrad7x1')
