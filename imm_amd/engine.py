@@ -412,7 +412,12 @@ class IMMEngine:
         lane_save = getattr(self, '_cur_lane', 0)
         if self.wgrad_lane:
             self._cur_lane = self.wgrad_lane
-        self._add(self.prog_bwd, lambda: ops.conv2d_wgrad(fd, lay.x, dy, lddy, lay.slab, lay.nsplit), 'conv_wgrad', flops)
+        if getattr(self, '_defer_wgrad', None) is not None:
+            # renderer: collected and issued as ONE side-stream branch next to the encoders' backward (one fork/join;
+            # per-layer cross-stream edges were measured slower, see above)
+            self._add(self._defer_wgrad, lambda: ops.conv2d_wgrad(fd, lay.x, dy, lddy, lay.slab, lay.nsplit), 'conv_wgrad', flops)
+        else:
+            self._add(self.prog_bwd, lambda: ops.conv2d_wgrad(fd, lay.x, dy, lddy, lay.slab, lay.nsplit), 'conv_wgrad', flops)
         self._cur_lane = lane_save
         self._reduce_jobs.append(((lay.slab.data_ptr(), gw.data_ptr(), lay.nsplit, k * lay.kw, lay.ci_pad, lay.ci_real, co, fd.kpad),
                                   k * lay.kw * lay.ci_real * co))
@@ -557,9 +562,19 @@ class IMMEngine:
             y = self._act(2 * B, H, H, cout)
             self.vgg_wt[name], self.vgg_wtd[name], self.vgg_desc[name] = wt, wtd, fd
             bias = self.vgg_w['vgg16/%s/biases' % name]
-            vadd(lambda lo, fd=fd, x=x, wt=wt, bias=bias, y=y: (lambda: ops.conv2d(fd, x[lo:lo + nimg], wt, bias, y[lo:lo + nimg])),
-                 'vgg_fwd', 2.0 * nimg * H * H * 9 * cin * cout, 2.0 * (nimg * H * H * (cin + cout) + 9 * cin * cout),
-                 'vgg16/' + name)
+            if cin == 64 and cout == 128 and H >= 64 and H % 16 == 0 and os.environ.get('IMM_VGG_NSPLIT', '0') != '0':
+                # conv2_1: K = 576 is too short for the deep-K kernel (9 taps, prologue + epilogue dominate: 59 us);
+                # two 64 -> 64 launches of the register-filter kernel over the two halves of the output channels
+                fh = ops.fwd_desc(nimg, H, H, cin, cin, 64, cout, 3, 1, L.CONV_BIAS | L.CONV_RELU)
+                for h in range(2):
+                    vadd(lambda lo, fh=fh, x=x, wt=wt, bias=bias, y=y, h=h: (
+                        lambda: ops.conv2d(fh, x[lo:lo + nimg], wt[64 * h:], bias[64 * h:], y[lo:lo + nimg, :, :, 64 * h:])),
+                         'vgg_fwd', 1.0 * nimg * H * H * 9 * cin * cout, 1.0 * (nimg * H * H * (cin + cout) + 9 * cin * cout),
+                         'vgg16/%s[%d]' % (name, h))
+            else:
+                vadd(lambda lo, fd=fd, x=x, wt=wt, bias=bias, y=y: (lambda: ops.conv2d(fd, x[lo:lo + nimg], wt, bias, y[lo:lo + nimg])),
+                     'vgg_fwd', 2.0 * nimg * H * H * 9 * cin * cout, 2.0 * (nimg * H * H * (cin + cout) + 9 * cin * cout),
+                     'vgg16/' + name)
             self.vgg_act[name] = (y, H)
             x = y
             if name in VGG_POOL_AFTER:
@@ -698,6 +713,8 @@ class IMMEngine:
         # ---- renderer backward -----------------------------------------------------------------------------
         ups = {idx: (ub, H, co) for idx, ub, H, co in self.ren_up}
         d_out, ldd = self.d_pred, last.lddy
+        defer = self.two_streams and not self.wgrad_lane and os.environ.get('IMM_WGRAD_DEFER_REN', '0') != '0'
+        self._defer_wgrad = [] if defer else None
         for i in range(len(self.ren) - 1, -1, -1):
             lay = self.ren[i]
             if i == 0:
@@ -722,15 +739,25 @@ class IMMEngine:
                 else:
                     d_out, ldd = dx, lddx
 
-        # renderer gradients are complete: reduce their slabs now so that a data-parallel run can all-reduce this
-        # bucket (the tail of the flat gradient buffer) while the encoders' backward is still running
-        self.reduce_tab_ren = ops.JobTable([j for j, _n in self._reduce_jobs], [n for _j, n in self._reduce_jobs], 64, self.dev)
-        self._add(self.prog_bwd, lambda: ops.wgrad_reduce_multi(self.reduce_tab_ren), 'wgrad_reduce', name='renderer')
-        self._reduce_jobs = []
-        self.n_bwd_bucket0 = len(self.prog_bwd)
+        deferred, self._defer_wgrad = self._defer_wgrad, None
+        if deferred is None:
+            # renderer gradients are complete: reduce their slabs now so that a data-parallel run can all-reduce this
+            # bucket (the tail of the flat gradient buffer) while the encoders' backward is still running
+            self.reduce_tab_ren = ops.JobTable([j for j, _n in self._reduce_jobs], [n for _j, n in self._reduce_jobs], 64, self.dev)
+            self._add(self.prog_bwd, lambda: ops.wgrad_reduce_multi(self.reduce_tab_ren), 'wgrad_reduce', name='renderer')
+            self._reduce_jobs = []
+        self.n_bwd_bucket0 = len(self.prog_bwd) if deferred is None else None
         self.bucket0_offset = self.tab.offsets[[n for n, _s, _w in self.spec].index('model/renderer/conv_1/w')]
         # ---- bottleneck + pose encoder backward (main stream) || image encoder backward (side stream) --------------
         self._mark(self.prog_bwd, 'fork')       # d_joint is complete here
+        if deferred:
+            # third branch: the renderer's filter gradients (their dY buffers are all live), beside the two encoder branches
+            self._signal(self.prog_bwd, 'ren_bwd_done', lane=0)
+            self._wait(self.prog_bwd, 'ren_bwd_done', lane=2)
+            for l in deferred:
+                l.lane = 2
+                self.prog_bwd.append(l)
+            self._signal(self.prog_bwd, 'ren_wgrad_done', lane=2)
         nf8 = 8 * self.cfg.n_filters
         He = self.He
         ph = self.pose_head
@@ -753,6 +780,8 @@ class IMMEngine:
             self._encoder_backward(self.enc_im, d_e, nf8)
         self._cur_lane = 0
         self._mark(self.prog_bwd, 'join')
+        if deferred:
+            self._wait(self.prog_bwd, 'ren_wgrad_done', lane=0)
         if self.wgrad_lane:
             self._signal(self.prog_bwd, 'wgrad_done', lane=self.wgrad_lane)
             self._wait(self.prog_bwd, 'wgrad_done', lane=0)

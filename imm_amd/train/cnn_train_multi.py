@@ -54,6 +54,8 @@ class TrainStep:
         # 1 GPU (RCCL single rank) the extra graph + collective launch costs 0.25 ms/step and cannot be validated on
         # 8 GPUs from the build box, so the default is ONE all-reduce of the whole 16.6 MB buffer per step.
         self.buckets = int(os.environ.get('IMM_DP_BUCKETS', '1'))
+        if self.buckets >= 2 and self.engine.n_bwd_bucket0 is None:
+            raise ValueError('IMM_DP_BUCKETS=2 needs the renderer gradients reduced early: set IMM_WGRAD_DEFER_REN=0')
         self.group = group
         self.engine = model._get_engine(batch_per_rank, image_size)
         if abs(self.engine.hp.grad_scale - 1.0 / world_size) > 1e-9:
