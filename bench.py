@@ -67,7 +67,7 @@ def pmc_traffic_per_launch():
     n = mb = 0.0
     with open(files[-1]) as f:
         for row in csv.reader(f):
-            if len(row) == 7 and ('conv_igemm' in row[0] or 'conv_halo' in row[0]):
+            if len(row) == 7 and ('conv_igemm' in row[0] or 'conv_halo' in row[0] or 'conv_hdeep' in row[0]):
                 n += float(row[1]); mb += float(row[1]) * (float(row[4]) + float(row[5]))
     return round(mb / n, 2) if n else None
 
@@ -170,7 +170,7 @@ def main():
         ig = [by_tag[t] for t in IGEMM_TAGS if t in by_tag]
         n_l, ms_l, fl_l, nb_l = sum(d[0] for d in ig), sum(d[1] for d in ig), sum(d[2] for d in ig), sum(d[3] for d in ig)
         achieved = fl_l / (ms_l * 1e-3) / 1e12
-        roof = {'bound': 'mfma', 'kernel': 'conv_igemm64 / conv_igemm / conv_halo kernels (convolution fwd + data-gradient, %d launches/step)' % n_l,
+        roof = {'bound': 'mfma', 'kernel': 'conv_hdeep / conv_halo2 / conv_igemm64 / conv_igemm kernels (convolution fwd + data-gradient, %d launches/step)' % n_l,
                 'achieved': round(achieved, 2), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': round(achieved / PEAK_BF16_TFLOPS, 4), 'traffic': pmc_traffic_per_launch(),
                 'traffic_unit': 'MB HBM per launch (rocprofv3 PMC FETCH_SIZE x2 [gfx950 correction] + WRITE_SIZE, profiles/)',
