@@ -360,8 +360,8 @@ class IMMEngine:
         tiles = -(-fd.kpad // 128) * -(-co // bn_w)
         # 2 workgroups per CU for small filters; 1 per CU once a slab copy exceeds 512 KB (slab traffic = nsplit x filter)
         big = fd.kpad * co * 4 > (1 << 19)
-        target = int(os.environ.get('IMM_WGRAD_TARGET_BIG', '1' if big else '2')) if big else 2
-        nsplit = max(1, min(-(-target * self.n_cu // tiles), max(1, npix // 512)))
+        target = float(os.environ.get('IMM_WGRAD_TARGET_BIG', '1')) if big else 2
+        nsplit = max(1, min(int(-(-target * self.n_cu // tiles)), max(1, npix // 512)))
         forced = ops.conv2d_wgrad_splits(fd, lay.lddy)     # LDS-resident-tile wgrad kernel: one slab per workgroup
         if forced > 0:
             nsplit = forced

@@ -312,3 +312,10 @@ class SegmentTable:
         self.blk_end = torch.tensor(blk_end, **i32)
         self.seg_first_blk = torch.tensor(first, **i32)
         self.seg_wd = torch.tensor([float(w) for w in wds], dtype=torch.float32, device=device)
+
+
+def tps_warp(src, basis_t, w_tps, dst=None, dst_c0=None, dst_rest=None):
+    """src [B,H,W,C] f32 NHWC; basis_t [M+3, H*W]; w_tps [B, M+3, 2]; outputs as in include/imm_hip.h (imm_tps_warp)."""
+    b, h, w, c = src.shape
+    call('imm_tps_warp', _p(src), src.stride(2), b, h, w, c, _p(basis_t), basis_t.shape[0], _p(w_tps), _p(dst),
+         dst.stride(2) if dst is not None else 0, _p(dst_c0), _p(dst_rest), dst_rest.stride(2) if dst_rest is not None else 0, _s())

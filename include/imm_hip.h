@@ -225,6 +225,15 @@ int imm_clip_adam_step(float* params, float* grads, float* m, float* v, const in
                        const int32_t* seg_first_blk, const float* seg_wd, float* blk_partial, float* seg_norm2,
                        int32_t* step_count, float* lr_state, const imm_opt_hparams* hp_host, void* stream);
 
+/* ---- thin-plate-spline augmentation (imm/utils/tps_sampler.py:76-99,142-157; imm/datasets/tps_dataset.py:70-96) ---- */
+/* dst[b][p] = bilinear(src[b], sum_j basis_t[j][p] * w_tps[b][j][0..1]) with F.grid_sample's align_corners=True mapping and
+ * zero padding.  src f32 NHWC [B,h,w,ld_src] (first c <= 8 channels), basis_t f32 [m3][h*w] (TPSGridGen's L matrix
+ * transposed, m3 = control points + 3), w_tps f32 [B][m3][2] ((x, y) columns).  Outputs (each may be NULL): dst = all c
+ * channels [B,h,w,ld_dst]; dst_c0 = channel 0 only [B,h,w] (the mask plane); dst_rest = channels 1..c-1 [B,h,w,ld_rest]
+ * (the image, e.g. straight into the training step's input buffer). */
+int imm_tps_warp(const float* src, int ld_src, int batch, int h, int w, int c, const float* basis_t, int m3,
+                 const float* w_tps, float* dst, int ld_dst, float* dst_c0, float* dst_rest, int ld_rest, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

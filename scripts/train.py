@@ -64,6 +64,22 @@ def npz_iter(path, batch, device, rank, world):
         i += batch * world
 
 
+def tps_pair_iter(source, size, device, cfg_dataset):
+    """imm/datasets/tps_dataset.py: every batch of single images becomes (image, future_image, mask) by two random
+    thin-plate-spline warps of mask||image — on the GPU (imm_amd/data/tps.py) instead of a CPU py_func.  The warp
+    parameters of the `dataset` config block are honoured when present (rotsd, scalesd, transsd, warpsd, *_points)."""
+    from imm_amd.data.tps import TPSPairAugmenter
+    kw = {}
+    for k in ('vertical_points', 'horizontal_points', 'rotsd', 'scalesd', 'transsd', 'warpsd'):
+        if cfg_dataset is not None and k in cfg_dataset:
+            kw[k] = cfg_dataset[k]
+    aug = TPSPairAugmenter((size, size), device=device, **kw)
+    base_mask = smooth_mask(size, size).reshape(1, size, size, 1).to(device)
+    for batch in source:
+        img = batch['image']
+        yield aug(img, base_mask.expand(img.shape[0], -1, -1, -1))
+
+
 def main(args):
     config = load_configs(args.configs)
     train_config = config.training
@@ -103,6 +119,9 @@ def main(args):
         eng.step_count.fill_(args.reset_global_step)
     per_rank = batch_size // world
     data = npz_iter(args.data_npz, per_rank, dev, rank, world) if args.data_npz else synthetic_iter(per_rank, size, dev, rank)
+    if args.tps:
+        ds = getattr(train_config, 'dataset', None)
+        data = tps_pair_iter(data, size, dev, ds if ds is not None and hasattr(ds, '__contains__') else None)
 
     def save(n):
         os.makedirs(train_config.logdir, exist_ok=True)
@@ -127,4 +146,6 @@ if __name__ == '__main__':
     parser.add_argument('--num-steps', type=int, default=30000000)
     parser.add_argument('--image-size', type=int, default=128)
     parser.add_argument('--data-npz', type=str, default=None, help='optional .npz with image/future_image/mask float32 NHWC arrays')
+    parser.add_argument('--tps', action='store_true', help='build (image, future_image, mask) from each batch\'s `image` by two '
+                        'random TPS warps on the GPU (imm/datasets/tps_dataset.py)')
     main(parser.parse_args())
