@@ -34,6 +34,7 @@ def colorize_landmark_maps(maps):
 
 
 class IMMModel(BaseModel):
+    _warned_vgg = False
 
     def __init__(self, config, global_step=None, dtype=torch.bfloat16, name='IMMModel', device=None, seed=1,
                  vgg_weights=None, hparams=None, world_size=1):
@@ -42,6 +43,20 @@ class IMMModel(BaseModel):
         self._global_step = global_step
         self._device = device
         self._seed = seed
+        if vgg_weights is None:
+            # imm_model.py:124: perceptual.net_file names the pretrained colourisation VGG16.  When the file exists it is
+            # loaded (BN folded as in selfsup/vgg16.py:17-92); otherwise the seeded synthetic network of the benchmarks is
+            # used and the model says so once.
+            import os
+            perc = getattr(config, 'perceptual', None)
+            net_file = getattr(perc, 'net_file', None) if perc is not None else None
+            if isinstance(net_file, str) and os.path.exists(net_file):
+                from ..utils.vgg_weights import load_vgg16
+                vgg_weights = load_vgg16(net_file)
+            elif isinstance(net_file, str) and not IMMModel._warned_vgg:
+                IMMModel._warned_vgg = True
+                import sys
+                sys.stderr.write('IMMModel: perceptual.net_file %r not found - using seeded synthetic VGG16 weights\n' % net_file)
         self._vgg_weights = vgg_weights
         self._hparams = hparams
         self._world_size = world_size
