@@ -53,7 +53,7 @@ class IMMModel(BaseModel):
             if isinstance(net_file, str) and os.path.exists(net_file):
                 from ..utils.vgg_weights import load_vgg16
                 vgg_weights = load_vgg16(net_file)
-            elif isinstance(net_file, str) and not IMMModel._warned_vgg:
+            elif isinstance(net_file, str) and net_file != 'synthetic' and not IMMModel._warned_vgg:
                 IMMModel._warned_vgg = True
                 import sys
                 sys.stderr.write('IMMModel: perceptual.net_file %r not found - using seeded synthetic VGG16 weights\n' % net_file)
