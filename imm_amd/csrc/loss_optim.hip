@@ -46,6 +46,55 @@ __global__ __launch_bounds__(LO_THREADS) void masked_sse_kernel(const uint16_t* 
   if (threadIdx.x == 0) partial[blockIdx.x] = acc;
 }
 
+// The same sum fused with the 2x2 max-pool that follows the tapped layer (conv1_2, conv2_2: imm/models/selfsup/vgg16.py
+// pool1 / pool2 right after the feature the loss reads): one pass over the two feature halves instead of two.
+// a = ground-truth half, b = prediction half [batch,s,s,c]; pool_a / pool_b [batch,s/2,s/2,c].
+template <typename ET>
+__global__ __launch_bounds__(LO_THREADS) void masked_sse_pool_kernel(const uint16_t* __restrict__ a, const uint16_t* __restrict__ b,
+                                                                     int batch, int s, int c8n, const float* __restrict__ mask,
+                                                                     int S, float* __restrict__ partial,
+                                                                     uint16_t* __restrict__ pool_a, uint16_t* __restrict__ pool_b) {
+  __shared__ float red[4];
+  const int r = S / s, so = s / 2, c = c8n * 8;
+  const int64_t total = (int64_t)batch * so * so * c8n;
+  float acc = 0.f;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int cg = (int)(idx % c8n);
+    int64_t t = idx / c8n;
+    const int X = (int)(t % so); t /= so;
+    const int Y = (int)(t % so);
+    const int64_t bi = t / so;
+    float ma[8], mb[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { ma[i] = -__builtin_huge_valf(); mb[i] = -__builtin_huge_valf(); }
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        const int yy = 2 * Y + dy, xx = 2 * X + dx;
+        const int64_t off = ((bi * s + yy) * s + xx) * c + cg * 8;
+        float fa[8], fb[8];
+        unpack8<ET>(*(const uint4*)(a + off), fa);
+        unpack8<ET>(*(const uint4*)(b + off), fb);
+        float sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float d = fa[i] - fb[i];
+          sq += d * d;
+          ma[i] = fmaxf(ma[i], fa[i]); mb[i] = fmaxf(mb[i], fb[i]);
+        }
+        const float mk = mask ? mask[(bi * S + (int64_t)yy * r) * S + (int64_t)xx * r] : 1.f;
+        acc += mk * sq;
+      }
+    const int64_t po = ((bi * so + Y) * so + X) * c + cg * 8;
+    *(uint4*)(pool_a + po) = pack8<ET>(ma);
+    *(uint4*)(pool_b + po) = pack8<ET>(mb);
+  }
+  acc = block_sum_256(acc, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = acc;
+}
+
 __global__ __launch_bounds__(LO_THREADS) void masked_sse_f32_kernel(const float* __restrict__ a, int lda,
                                                                     const float* __restrict__ b, int ldb, int64_t npix,
                                                                     int c, const float* __restrict__ mask,
@@ -69,6 +118,17 @@ extern "C" int imm_masked_sse(const void* a, const void* b, int dtype, int batch
                                                (hipStream_t)stream, (const uint16_t*)a, (const uint16_t*)b, batch, s, c / 8,
                                                mask, S, partial));
   IMM_CHECK_LAUNCH("imm_masked_sse");
+  return 0;
+}
+
+extern "C" int imm_masked_sse_pool(const void* a, const void* b, int dtype, int batch, int s, int c, const float* mask, int S,
+                                   float* partial, void* pool_a, void* pool_b, void* stream) {
+  IMM_REQUIRE(a && b && partial && pool_a && pool_b && batch > 0 && s > 0 && s % 2 == 0 && c > 0 && c % 8 == 0, "masked_sse_pool: args");
+  IMM_REQUIRE(mask == nullptr || (S >= s && S % s == 0), "masked_sse_pool: mask side %d not a multiple of feature side %d", S, s);
+  IMM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((masked_sse_pool_kernel<ET>), dim3(IMM_SSE_BLOCKS), dim3(LO_THREADS), 0,
+                                               (hipStream_t)stream, (const uint16_t*)a, (const uint16_t*)b, batch, s, c / 8,
+                                               mask, S, partial, (uint16_t*)pool_a, (uint16_t*)pool_b));
+  IMM_CHECK_LAUNCH("imm_masked_sse_pool");
   return 0;
 }
 

@@ -579,8 +579,17 @@ class IMMEngine:
             x = y
             if name in VGG_POOL_AFTER:
                 p = self._act(2 * B, H // 2, H // 2, cout)
-                vadd(lambda lo, x=x, p=p, H=H, cout=cout: (lambda: ops.maxpool2_fwd(x[lo:lo + nimg], p[lo:lo + nimg], nimg, H, H, cout)),
-                     'maxpool', 0.0, nimg * H * H * cout * 2.5)
+                if name in VGG_TAPS and not split and os.environ.get('IMM_SSE_POOL_FUSE', '1') != '0':
+                    # the loss taps this layer AND it is pooled next: one pass computes the masked SSE of the two halves
+                    # and both pooled halves (the feature map is read once instead of twice)
+                    idx = VGG_TAPS[name]
+                    self._fused_sse = getattr(self, '_fused_sse', set()) | {name}
+                    self._add(self.prog_fwd, (lambda x=x, p=p, H=H, cout=cout, idx=idx: ops.masked_sse_pool(
+                        x[:B], x[B:], B, H, cout, self.in_mask, S, self.sse_partial[idx], p[:B], p[B:])), 'sse',
+                              0.0, 2 * B * H * H * cout * 2.5, name='vgg16/%s+pool' % name)
+                else:
+                    vadd(lambda lo, x=x, p=p, H=H, cout=cout: (lambda: ops.maxpool2_fwd(x[lo:lo + nimg], p[lo:lo + nimg], nimg, H, H, cout)),
+                         'maxpool', 0.0, nimg * H * H * cout * 2.5)
                 self.vgg_pool[name] = p
                 x, H = p, H // 2
         if split:
@@ -614,6 +623,8 @@ class IMMEngine:
         self._add(self.prog_fwd, lambda: ops.masked_sse_f32(self.in_future, 3, self.pred, self.ldp, B, S, 3, mask,
                                                             self.sse_partial[0]), 'sse')
         for name, idx in VGG_TAPS.items():
+            if name in getattr(self, '_fused_sse', ()):
+                continue
             y, H = self.vgg_act[name]
             c = y.shape[-1]
             self._add(self.prog_fwd, (lambda y=y, H=H, c=c, idx=idx: ops.masked_sse(y[:B], y[B:], B, H, c, mask, S,

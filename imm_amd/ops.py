@@ -319,3 +319,7 @@ def tps_warp(src, basis_t, w_tps, dst=None, dst_c0=None, dst_rest=None):
     b, h, w, c = src.shape
     call('imm_tps_warp', _p(src), src.stride(2), b, h, w, c, _p(basis_t), basis_t.shape[0], _p(w_tps), _p(dst),
          dst.stride(2) if dst is not None else 0, _p(dst_c0), _p(dst_rest), dst_rest.stride(2) if dst_rest is not None else 0, _s())
+
+
+def masked_sse_pool(a, b, batch, s, c, mask, S, partial, pool_a, pool_b):
+    call('imm_masked_sse_pool', _p(a), _p(b), dtype_enum(a.dtype), batch, s, c, _p(mask), S, _p(partial), _p(pool_a), _p(pool_b), _s())

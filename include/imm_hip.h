@@ -192,6 +192,10 @@ int imm_vgg_conv1_1_bwd(const void* dz, int dtype, int batch, int s, const float
  * sampled with stride S/s (legacy resize == strided pick, imm_model.py:408-410). a/b 16-bit [B,s,s,c]. */
 int imm_masked_sse(const void* a, const void* b, int dtype, int batch, int s, int c, const float* mask, int S,
                    float* partial, void* stream);
+/* imm_masked_sse fused with the 2x2/2 max-pool that follows the tapped VGG layer (conv1_2, conv2_2): reads the two feature
+ * halves once, writes the SSE partials and both pooled halves [batch, s/2, s/2, c]. */
+int imm_masked_sse_pool(const void* a, const void* b, int dtype, int batch, int s, int c, const float* mask, int S,
+                        float* partial, void* pool_a, void* pool_b, void* stream);
 int imm_masked_sse_f32(const float* a, int lda, const float* b, int ldb, int batch, int s, int c, const float* mask,
                        float* partial, void* stream);
 /* nfeat features: partial [nfeat][IMM_SSE_BLOCKS], nel[nfeat] element counts, agg[nfeat] running

@@ -642,3 +642,26 @@ def test_graph_capture_replay(ops):
         g.launch()
         s.synchronize()
         assert torch.equal(dst[..., :3], x.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16], ids=['bf16', 'f16'])
+def test_masked_sse_fused_with_maxpool(ops, dt):
+    """imm_masked_sse_pool == imm_masked_sse + imm_maxpool2_fwd on both feature halves (pool bit for bit)."""
+    from imm_amd import _lib as L
+    B, s, c, S = 3, 16, 64, 64
+    a = rnd((B, s, s, c), 301, 1.0, dt).to(DEV).contiguous()
+    b = rnd((B, s, s, c), 302, 1.0, dt).to(DEV).contiguous()
+    mask = torch.rand(B, S, S, device=DEV)
+    for mk in (mask, None):
+        p1 = torch.zeros(L.SSE_BLOCKS, device=DEV); p2 = torch.zeros(L.SSE_BLOCKS, device=DEV)
+        pa = torch.empty(B, s // 2, s // 2, c, dtype=dt, device=DEV); pb = torch.empty_like(pa)
+        ops.masked_sse_pool(a, b, B, s, c, mk, S, p1, pa, pb)
+        ops.masked_sse(a, b, B, s, c, mk, S, p2)
+        ra = torch.empty_like(pa); rb = torch.empty_like(pb)
+        ops.maxpool2_fwd(a, ra, B, s, s, c); ops.maxpool2_fwd(b, rb, B, s, s, c)
+        torch.cuda.synchronize()
+        assert torch.equal(pa, ra) and torch.equal(pb, rb)
+        m4 = mk[:, ::S // s, ::S // s].unsqueeze(-1) if mk is not None else 1.0
+        ref = float((m4 * (a.float() - b.float()) ** 2).sum())
+        assert abs(float(p1.double().sum()) - ref) <= 1e-5 * abs(ref) + 1e-6
+        assert abs(float(p1.double().sum()) - float(p2.double().sum())) <= 1e-5 * abs(ref) + 1e-6
