@@ -228,6 +228,67 @@ __global__ void tap_grad_kernel(uint16_t* __restrict__ da, int has_in, const uin
   }
 }
 
+// tap_grad fused with the max-pool backward in front of it (conv1_2, conv2_2: the tapped layer is also the pooled one):
+// da[p] = relu'(ap[p]) * ( [p is the argmax of its 2x2 window] * dpool[window] + c_k * mask[p] * (ap[p] - ag[p]) ).
+// One pass instead of maxpool2_bwd (write da) + tap_grad (read da, ap again); bitwise equal to that sequence.
+template <typename ET>
+__global__ void unpool_tap_grad_kernel(uint16_t* __restrict__ da, const uint16_t* __restrict__ dpool,
+                                       const uint16_t* __restrict__ ap, const uint16_t* __restrict__ ag, int batch, int s,
+                                       int c8n, const float* __restrict__ mask, int S, const float* __restrict__ coef,
+                                       int idx_coef) {
+  const int r = S / s, so = s / 2, c = c8n * 8;
+  const float ck = coef[idx_coef];
+  const int64_t total = (int64_t)batch * so * so * c8n;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int cg = (int)(idx % c8n);
+    int64_t t = idx / c8n;
+    const int X = (int)(t % so); t /= so;
+    const int Y = (int)(t % so);
+    const int64_t bi = t / so;
+    const int64_t off = ((bi * s + 2 * Y) * s + 2 * X) * c + cg * 8;
+    const int64_t qoff[4] = {off, off + c, off + (int64_t)s * c, off + (int64_t)s * c + c};
+    float fp[4][8], fg[4][8], g[8], o[4][8], cm[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      unpack8<ET>(*(const uint4*)(ap + qoff[q]), fp[q]);
+      unpack8<ET>(*(const uint4*)(ag + qoff[q]), fg[q]);
+      const int yy = 2 * Y + (q >> 1), xx = 2 * X + (q & 1);
+      cm[q] = ck * (mask ? mask[(bi * S + (int64_t)yy * r) * S + (int64_t)xx * r] : 1.f);
+    }
+    unpack8<ET>(*(const uint4*)(dpool + ((bi * so + Y) * so + X) * c + cg * 8), g);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      int am = 0; float mv = fp[0][i];
+#pragma unroll
+      for (int q = 1; q < 4; ++q) if (fp[q][i] > mv) { mv = fp[q][i]; am = q; }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float v = ((q == am) ? g[i] : 0.f) + cm[q] * (fp[q][i] - fg[q][i]);
+        if (!(fp[q][i] > 0.f)) v = 0.f;
+        o[q][i] = v;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *(uint4*)(da + qoff[q]) = pack8<ET>(o[q]);
+  }
+}
+
+extern "C" int imm_unpool_tap_grad(void* da, const void* dpool, const void* a_pred, const void* a_gt, int dtype, int batch, int s,
+                                   int c, const float* mask, int S, const float* coef, int idx, void* stream) {
+  IMM_REQUIRE(da && dpool && a_pred && a_gt && coef && batch > 0 && s > 0 && s % 2 == 0 && c > 0 && c % 8 == 0 && idx >= 0,
+              "unpool_tap_grad: args");
+  IMM_REQUIRE(mask == nullptr || (S >= s && S % s == 0), "unpool_tap_grad: mask side");
+  const int64_t total = (int64_t)batch * (s / 2) * (s / 2) * (c / 8);
+  int64_t blocks = (total + LO_THREADS - 1) / LO_THREADS;
+  if (blocks > 16384) blocks = 16384;
+  IMM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((unpool_tap_grad_kernel<ET>), dim3((int)blocks), dim3(LO_THREADS), 0,
+                                               (hipStream_t)stream, (uint16_t*)da, (const uint16_t*)dpool,
+                                               (const uint16_t*)a_pred, (const uint16_t*)a_gt, batch, s, c / 8, mask, S, coef, idx));
+  IMM_CHECK_LAUNCH("imm_unpool_tap_grad");
+  return 0;
+}
+
 extern "C" int imm_tap_grad(void* da, int has_in, const void* a_pred, const void* a_gt, int dtype, int batch, int s, int c,
                             const float* mask, int S, const float* coef, int idx, int relu, void* stream) {
   IMM_REQUIRE(da && a_pred && a_gt && coef && batch > 0 && s > 0 && c > 0 && c % 8 == 0 && idx >= 0, "tap_grad: args");

@@ -694,6 +694,16 @@ class IMMEngine:
             self._add(self.prog_bwd, lambda: ops.maxpool2_bwd(y[B:], dy, dbuf[src_name], B, H, H, c, relu_mask), 'maxpool_bwd',
                       0.0, B * H * H * c * 5.0)
 
+        def unpool_tap(name, dy):
+            """unpool(name, dy, 0) + tap(name, True) in one pass (the tapped layer is the pooled one)."""
+            if os.environ.get('IMM_UNPOOL_TAP_FUSE', '1') == '0':
+                unpool(name, dy, 0); tap(name, True)
+                return
+            y, H = acts[name]
+            c = y.shape[-1]
+            self._add(self.prog_bwd, lambda: ops.unpool_tap_grad(dbuf[name], dy, y[B:], y[:B], B, H, c, mask, S, self.coef,
+                                                                 VGG_TAPS[name]), 'tap_grad', 0.0, B * H * H * c * 8.5)
+
         tap('conv5_2', False)
         dgrad('conv5_2', dbuf['conv5_1'], pred_half(acts['conv5_1'][0]))
         dgrad('conv5_1', dpool['conv4_3'], None)
@@ -707,12 +717,10 @@ class IMMEngine:
         tap('conv3_2', True)
         dgrad('conv3_2', dbuf['conv3_1'], pred_half(acts['conv3_1'][0]))
         dgrad('conv3_1', dpool['conv2_2'], None)
-        unpool('conv2_2', dpool['conv2_2'], 0)
-        tap('conv2_2', True)
+        unpool_tap('conv2_2', dpool['conv2_2'])
         dgrad('conv2_2', dbuf['conv2_1'], pred_half(acts['conv2_1'][0]))
         dgrad('conv2_1', dpool['conv1_2'], None)
-        unpool('conv1_2', dpool['conv1_2'], 0)
-        tap('conv1_2', True)
+        unpool_tap('conv1_2', dpool['conv1_2'])
         dgrad('conv1_2', dbuf['conv1_1'], pred_half(acts['conv1_1'][0]))
         # first layer + 'input' feature -> gradient of the renderer's last convolution
         last = self.ren[-1]

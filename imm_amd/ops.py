@@ -323,3 +323,8 @@ def tps_warp(src, basis_t, w_tps, dst=None, dst_c0=None, dst_rest=None):
 
 def masked_sse_pool(a, b, batch, s, c, mask, S, partial, pool_a, pool_b):
     call('imm_masked_sse_pool', _p(a), _p(b), dtype_enum(a.dtype), batch, s, c, _p(mask), S, _p(partial), _p(pool_a), _p(pool_b), _s())
+
+
+def unpool_tap_grad(da, dpool, a_pred, a_gt, batch, s, c, mask, S, coef, idx):
+    call('imm_unpool_tap_grad', _p(da), _p(dpool), _p(a_pred), _p(a_gt), dtype_enum(da.dtype), batch, s, c, _p(mask), S,
+         _p(coef), idx, _s())

@@ -204,6 +204,10 @@ int imm_masked_sse_f32(const float* a, int lda, const float* b, int ldb, int bat
  * out[3nfeat] = 1000*sum terms, out[3nfeat+1] = wd_loss, out[3nfeat+2] = total. */
 int imm_perceptual_finalize(const float* partial, int nfeat, const float* nel, float* agg, int training,
                             const float* wd_loss, float* out, void* stream);
+/* imm_maxpool2_bwd (no ReLU mask) followed by imm_tap_grad (has_in, relu) in one pass, for tapped layers that are pooled
+ * next (conv1_2, conv2_2); dpool [batch, s/2, s/2, c] is the gradient of the pooled tensor.  Bitwise equal to the sequence. */
+int imm_unpool_tap_grad(void* da, const void* dpool, const void* a_pred, const void* a_gt, int dtype, int batch, int s, int c,
+                        const float* mask, int S, const float* coef, int idx, void* stream);
 /* da = (has_in ? da : 0) + coef[idx]*mask*(a_pred-a_gt), then *= (a_pred>0) if relu. 16-bit [B,s,s,c] */
 int imm_tap_grad(void* da, int has_in, const void* a_pred, const void* a_gt, int dtype, int batch, int s, int c,
                  const float* mask, int S, const float* coef, int idx, int relu, void* stream);

@@ -665,3 +665,23 @@ def test_masked_sse_fused_with_maxpool(ops, dt):
         ref = float((m4 * (a.float() - b.float()) ** 2).sum())
         assert abs(float(p1.double().sum()) - ref) <= 1e-5 * abs(ref) + 1e-6
         assert abs(float(p1.double().sum()) - float(p2.double().sum())) <= 1e-5 * abs(ref) + 1e-6
+
+
+def test_unpool_fused_with_tap_grad(ops):
+    """imm_unpool_tap_grad == imm_maxpool2_bwd(relu_mask=0) then imm_tap_grad(has_in, relu), bit for bit."""
+    dt = torch.bfloat16
+    B, s, c, S = 2, 16, 64, 64
+    ap = rnd((B, s, s, c), 311, 1.0, dt).to(DEV).contiguous()
+    ap[0, :2, :2, :8] = 0.5          # ties inside a window: the first maximum takes the gradient
+    ag = rnd((B, s, s, c), 312, 1.0, dt).to(DEV).contiguous()
+    dpool = rnd((B, s // 2, s // 2, c), 313, 1.0, dt).to(DEV).contiguous()
+    mask = torch.rand(B, S, S, device=DEV)
+    coef = torch.tensor([0.0, 0.37, 0.0, 0.0, 0.0, 0.0], device=DEV)
+    for mk in (mask, None):
+        ref = torch.full((B, s, s, c), float('nan'), dtype=dt, device=DEV)
+        ops.maxpool2_bwd(ap, dpool, ref, B, s, s, c, 0)
+        ops.tap_grad(ref, True, ap, ag, B, s, c, mk, S, coef, 1, True)
+        got = torch.full((B, s, s, c), float('nan'), dtype=dt, device=DEV)
+        ops.unpool_tap_grad(got, dpool, ap, ag, B, s, c, mk, S, coef, 1)
+        torch.cuda.synchronize()
+        assert torch.equal(got, ref)
