@@ -51,6 +51,10 @@ struct BF16 {
     const f32x2_t v = {lo, hi};
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
   }
+  // c + a.lo*b.lo + a.hi*b.hi on packed pairs (v_dot2c_f32_bf16)
+  __device__ static __forceinline__ float dot2(uint32_t a, uint32_t b, float c) {
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a), __builtin_bit_cast(bf16x2_t, b), c, false);
+  }
   __device__ static __forceinline__ f32x4_t mfma(uint4 a, uint4 b, f32x4_t c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b),
                                                    c, 0, 0, 0);
@@ -64,6 +68,9 @@ struct F16 {
   __device__ static __forceinline__ uint32_t pack2(float lo, float hi) {
     const f32x2_t v = {lo, hi};
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_t));
+  }
+  __device__ static __forceinline__ float dot2(uint32_t a, uint32_t b, float c) {
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2_t, a), __builtin_bit_cast(f16x2_t, b), c, false);
   }
   __device__ static __forceinline__ f32x4_t mfma(uint4 a, uint4 b, f32x4_t c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b),

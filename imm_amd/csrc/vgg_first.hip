@@ -75,19 +75,33 @@ __global__ __launch_bounds__(256) void vgg_conv1_1_bwd_kernel(const uint16_t* __
   const int tid = threadIdx.x;
   const int img = blockIdx.z;
   const int ty0 = blockIdx.y * VF_TILE, tx0 = blockIdx.x * VF_TILE;
-  for (int i = tid; i < HT * HT * 8; i += 256) {
-    const int hp = i >> 3, c = i & 7;
-    const int yy = ty0 + hp / HT - 1, xx = tx0 + hp % HT - 1;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (yy >= 0 && yy < s && xx >= 0 && xx < s) v = *(const uint4*)(dz + (((int64_t)img * s + yy) * s + xx) * 64 + c * 8);
-    sdz[i] = v;
+  {
+    // all 11 loads of a thread in flight before the first LDS store (the tile load is a chain of HBM latencies otherwise)
+    constexpr int NL = (HT * HT * 8 + 255) / 256;
+    uint4 v[NL];
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      const int i = tid + k * 256;
+      const int hp = i >> 3, c = i & 7;
+      const int yy = ty0 + hp / HT - 1, xx = tx0 + hp % HT - 1;
+      v[k] = make_uint4(0, 0, 0, 0);
+      if (i < HT * HT * 8 && yy >= 0 && yy < s && xx >= 0 && xx < s)
+        v[k] = *(const uint4*)(dz + (((int64_t)img * s + yy) * s + xx) * 64 + c * 8);
+    }
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      const int i = tid + k * 256;
+      if (i < HT * HT * 8) sdz[i] = v[k];
+    }
   }
   const int cg = tid & 7, pl = tid >> 3;
-  float wr[9][8];
+  // filter taps of this lane's 8 channels as packed 16-bit pairs: the contraction runs on v_dot2c (2 MACs per issue;
+  // weights at the activation precision, like every other VGG data gradient)
+  uint32_t wr[9][4];
 #pragma unroll
-  for (int e = 0; e < 8; ++e)
+  for (int t = 0; t < 9; ++t)
 #pragma unroll
-    for (int t = 0; t < 9; ++t) wr[t][e] = w[t * 64 + cg * 8 + e];
+    for (int e = 0; e < 4; ++e) wr[t][e] = ET::pack2(w[t * 64 + cg * 8 + 2 * e], w[t * 64 + cg * 8 + 2 * e + 1]);
   const float c0 = coef[0];
   __syncthreads();
 #pragma unroll 2
@@ -100,10 +114,11 @@ __global__ __launch_bounds__(256) void vgg_conv1_1_bwd_kernel(const uint16_t* __
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
       const int hy = ly + 1 - (t / 3 - 1), hx = lx + 1 - (t % 3 - 1);     // halo coordinates of q
-      float d[8];
-      unpack8<ET>(sdz[(hy * HT + hx) * 8 + cg], d);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) part += d[e] * wr[t][e];
+      const uint4 d = sdz[(hy * HT + hx) * 8 + cg];
+      part = ET::dot2(d.x, wr[t][0], part);
+      part = ET::dot2(d.y, wr[t][1], part);
+      part = ET::dot2(d.z, wr[t][2], part);
+      part = ET::dot2(d.w, wr[t][3], part);
     }
     part += __shfl_xor(part, 1, 64);
     part += __shfl_xor(part, 2, 64);
