@@ -74,6 +74,7 @@ _SIGS = {
     'imm_vgg_conv1_1_fwd': [_P, _P, _I, _I, _I, _P, _P, _P, _I, _I, _P],
     'imm_vgg_conv1_1_bwd': [_P, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P, _I, _P],
     'imm_tps_warp': [_P, _I, _I, _I, _I, _I, _P, _I, _P, _P, _I, _P, _P, _I, _P],
+    'imm_conv2d_group': [_P, _I, _I, _P, _P, _P, _P],
     'imm_unpool_tap_grad': [_P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _P, _I, _P],
     'imm_masked_sse_pool': [_P, _P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P],
     'imm_masked_sse': [_P, _P, _I, _I, _I, _I, _P, _I, _P, _P],

@@ -276,11 +276,10 @@ static void launch_cfg(ConvArgs& a, bool fast, hipStream_t s) {
 }
 
 void imm_conv64_launch(int dtype, ConvArgs& a, int bm, int bn, hipStream_t s);   // conv_igemm64.hip
+bool imm_conv64_group_launch(int dtype, ConvArgs* args, int n, int bm, int bn, hipStream_t s);
 
-template <typename ET>
-static int conv_launch(const imm_conv_desc* d, const void* x, const void* wt, const float* bias, void* y,
-                       float* stats, const void* mask, hipStream_t s) {
-  ConvArgs a;
+static void fill_args(ConvArgs& a, const imm_conv_desc* d, const void* x, const void* wt, const float* bias, void* y,
+                      float* stats, const void* mask) {
   a.x = (const uint16_t*)x; a.wt = (const uint16_t*)wt; a.bias = bias; a.y = y; a.stats = stats;
   a.mask = (const uint16_t*)mask;
   a.M = d->batch * d->ho * d->wo;
@@ -290,6 +289,13 @@ static int conv_launch(const imm_conv_desc* d, const void* x, const void* wt, co
   a.kpad = d->kpad; a.KT = d->kpad / 32; a.ntaps = d->kh * d->kw;
   a.flags = d->flags; a.ldmask = d->ldmask;
   a.oscale = d->out_scale > 1 ? d->out_scale : 1; a.ooff_y = d->out_off_y; a.ooff_x = d->out_off_x;
+}
+
+template <typename ET>
+static int conv_launch(const imm_conv_desc* d, const void* x, const void* wt, const float* bias, void* y,
+                       float* stats, const void* mask, hipStream_t s) {
+  ConvArgs a;
+  fill_args(a, d, x, wt, bias, y, stats, mask);
   if (imm_halo2_applicable(d)) {
     imm_conv_halo2_launch(ET::kEnum, d, a, s);
     IMM_CHECK_LAUNCH("imm_conv2d(halo2)");
@@ -331,6 +337,45 @@ extern "C" int imm_conv2d(const imm_conv_desc* d, int dtype, const void* x, cons
   IMM_REQUIRE(!(d->flags & IMM_CONV_MASK) || (mask_ref && d->ldmask >= d->co), "conv: mask flag without mask/ldmask");
   IMM_REQUIRE(((uintptr_t)x % 16 == 0) && ((uintptr_t)wt % 16 == 0) && ((uintptr_t)y % 16 == 0), "conv: 16-byte alignment");
   IMM_DISPATCH_DTYPE(dtype, return conv_launch<ET>(d, x, wt, bias, y, stats_partial, mask_ref, (hipStream_t)stream));
+  return 0;
+}
+
+// Up to 4 convolutions reading the same x and writing (disjoint parts of) the same y in ONE launch — the four parity
+// classes of a stride-2 data gradient (ops.dgrad_s2_class_descs).  Members must be plain (no bias / stats / mask) and all
+// take the deep-K 64x64-tile kernel; otherwise the members are launched one after the other (same results either way).
+extern "C" int imm_conv2d_group(const imm_conv_desc* descs, int n, int dtype, const void* x, const void* const* wts, void* y,
+                                void* stream) {
+  IMM_REQUIRE(descs && wts && x && y && n >= 1 && n <= 4, "conv_group: 1..4 members");
+  IMM_REQUIRE(dtype == IMM_BF16 || dtype == IMM_F16, "unknown dtype %d", dtype);
+  static const bool off = getenv("IMM_NO_CONV_GROUP") != nullptr;
+  bool groupable = !off;
+  ConvArgs args[4];
+  int bm = 0, bn = 0;
+  for (int i = 0; i < n; ++i) {
+    const imm_conv_desc* d = descs + i;
+    if (validate_desc(d)) return IMM_E_INVALID;
+    IMM_REQUIRE(wts[i] && ((uintptr_t)wts[i] % 16 == 0), "conv_group: filter pointer %d", i);
+    IMM_REQUIRE(!(d->flags & (IMM_CONV_BIAS | IMM_CONV_STATS | IMM_CONV_MASK)), "conv_group: members carry no bias/stats/mask");
+    if (imm_halo2_applicable(d) || imm_halo_applicable(d) || imm_hdeep_applicable(d)) groupable = false;
+    const int64_t M = (int64_t)d->batch * d->ho * d->wo;
+    const TileCfg t = pick_tile(M, d->co);
+    const int64_t xb = (int64_t)d->batch * d->hi * d->wi * d->ldx * 2, wb = (int64_t)d->co * d->kpad * 2;
+    const bool deep = (d->ci % 64 == 0) && xb < (1LL << 31) && wb < (1LL << 31) && t.bn >= 64 && !(d->flags & 0xf00) &&
+                      !getenv("IMM_NO_DEEPK");
+    if (!deep || (i > 0 && (t.bm != bm || t.bn != bn))) groupable = false;
+    bm = t.bm; bn = t.bn;
+    fill_args(args[i], d, x, wts[i], nullptr, y, nullptr, nullptr);
+    args[i].n_nblk = (d->co + t.bn - 1) / t.bn;
+    args[i].x_bytes = (uint32_t)xb; args[i].wt_bytes = (uint32_t)wb;
+  }
+  if (groupable && imm_conv64_group_launch(dtype, args, n, bm, bn, (hipStream_t)stream)) {
+    IMM_CHECK_LAUNCH("imm_conv2d_group");
+    return 0;
+  }
+  for (int i = 0; i < n; ++i) {
+    const int rc = imm_conv2d(descs + i, dtype, x, wts[i], nullptr, y, nullptr, nullptr, stream);
+    if (rc) return rc;
+  }
   return 0;
 }
 

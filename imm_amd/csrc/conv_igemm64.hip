@@ -36,7 +36,7 @@ __device__ __forceinline__ void lds_dma16(u32x4_t rsrc, uint32_t lds_addr, uint3
 // NW waves per workgroup (4 or 8): 8 waves halve each wave's tile (more waves per SIMD to hide DMA / LDS latency, at
 // 1.5x the LDS bytes per MFMA).
 template <typename ET, int BM, int BN, int NS, int NW>
-__global__ __launch_bounds__(NW * 64) void conv_igemm64_kernel(const ConvArgs a) {
+__device__ __forceinline__ void conv_igemm64_body(const ConvArgs& a, int bid_in) {
   constexpr int WGM = NW / 2, WGN = 2;
   constexpr int TM = BM / WGM, TN = BN / WGN, MT = TM / 16, NT = TN / 16;
   constexpr int A_INSTR = BM / (8 * NW), B_INSTR = BN / (8 * NW);   // 8-row wave instructions per wave per tile
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm64_kernel(const ConvArgs a)
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WGN, wn = wid % WGN;
-  int bid = blockIdx.x;
+  int bid = bid_in;
   {
     const int q = a.n_blocks >> 3, r = a.n_blocks & 7, xcd = bid & 7;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
@@ -158,6 +158,30 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm64_kernel(const ConvArgs a)
   conv_epilogue<ET, BM, BN, WGM, WGN, MT, NT>(a, acc, tid, wm, wn, m0, n0, mblk, (float*)smem);
 }
 
+template <typename ET, int BM, int BN, int NS, int NW>
+__global__ __launch_bounds__(NW * 64) void conv_igemm64_kernel(const ConvArgs a) {
+  conv_igemm64_body<ET, BM, BN, NS, NW>(a, blockIdx.x);
+}
+
+// Several convolutions of the same tile shape in ONE launch (the four parity classes of a stride-2 data gradient: each
+// alone is a grid of 64-512 workgroups a few microseconds long).  Workgroup b belongs to member g with
+// first[g] <= b < first[g+1] and runs that member's argument block unchanged.
+#define IMM_CONV_GROUP_MAX 4
+struct ConvArgsGroup {
+  ConvArgs a[IMM_CONV_GROUP_MAX];
+  int first[IMM_CONV_GROUP_MAX + 1];
+  int n;
+};
+
+template <typename ET, int BM, int BN, int NS, int NW>
+__global__ __launch_bounds__(NW * 64) void conv_igemm64_group_kernel(const ConvArgsGroup g) {
+  int m = 0;
+#pragma unroll
+  for (int i = 1; i < IMM_CONV_GROUP_MAX; ++i)
+    if (i < g.n && (int)blockIdx.x >= g.first[i]) m = i;
+  conv_igemm64_body<ET, BM, BN, NS, NW>(g.a[m], (int)blockIdx.x - g.first[m]);
+}
+
 template <typename ET, int BM, int BN, int NS, int NW = 4>
 static void launch64_cfg(const ConvArgs& a, hipStream_t s) {
   constexpr int lds = NS * (BM + BN) * 128;
@@ -186,6 +210,35 @@ static void launch64(ConvArgs& a, int bm, int bn, hipStream_t s) {
   else if (ns64 == 3) launch64_cfg<ET, 64, 64, 3>(a, s);
   else if (ns64 == 6) launch64_cfg<ET, 64, 64, 6>(a, s);
   else launch64_cfg<ET, 64, 64, 4>(a, s);
+}
+
+template <typename ET>
+static bool launch64_group(ConvArgs* args, int n, int bm, int bn, hipStream_t s) {
+  if (!(bm == 64 && bn == 64) || n < 1 || n > IMM_CONV_GROUP_MAX) return false;
+  constexpr int NS = 4, lds = NS * (64 + 64) * 128;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)conv_igemm64_group_kernel<ET, 64, 64, NS, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  ConvArgsGroup g;
+  g.n = n;
+  int total = 0;
+  for (int i = 0; i < n; ++i) {
+    args[i].n_blocks = ((args[i].M + 63) / 64) * args[i].n_nblk;
+    args[i].KT = args[i].kpad / 64;
+    g.a[i] = args[i];
+    g.first[i] = total;
+    total += args[i].n_blocks;
+  }
+  for (int i = n; i <= IMM_CONV_GROUP_MAX; ++i) g.first[i] = total;
+  hipLaunchKernelGGL((conv_igemm64_group_kernel<ET, 64, 64, NS, 4>), dim3(total), dim3(256), lds, s, g);
+  return true;
+}
+
+// grouped launch of up to 4 deep-K convolutions that all take the 64x64 tile; false = not applicable (caller falls back)
+bool imm_conv64_group_launch(int dtype, ConvArgs* args, int n, int bm, int bn, hipStream_t s) {
+  return dtype == IMM_BF16 ? launch64_group<BF16>(args, n, bm, bn, s) : launch64_group<F16>(args, n, bm, bn, s);
 }
 
 // called from conv_igemm.hip's dispatcher

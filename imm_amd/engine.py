@@ -422,11 +422,21 @@ class IMMEngine:
         self._reduce_jobs.append(((lay.slab.data_ptr(), gw.data_ptr(), lay.nsplit, k * lay.kw, lay.ci_pad, lay.ci_real, co, fd.kpad),
                                   k * lay.kw * lay.ci_real * co))
         if lay.needs_dgrad and dx is not None and getattr(lay, 's2', None) is not None:
-            for (dd0, _mode), wt_c in zip(ops.dgrad_s2_class_descs(B, lay.H, lay.W, lay.ci_real, lddx, lddy, lddy, k), lay.wt_s2):
-                ntap = dd0.kh * dd0.kw
-                self._add(self.prog_bwd, (lambda dd0=dd0, wt_c=wt_c: ops.conv2d(dd0, dy, wt_c, None, dx)), 'conv_dgrad',
-                          2.0 * npix * ntap * lay.ci_real * co,
-                          2.0 * (npix * lddy + npix * lay.ci_real + dd0.kpad * lay.ci_real))
+            classes = ops.dgrad_s2_class_descs(B, lay.H, lay.W, lay.ci_real, lddx, lddy, lddy, k)
+            if os.environ.get('IMM_S2_GROUP', '1') != '0':
+                # the four parity classes as one grouped launch (falls back to four launches inside the library when the
+                # members do not take the deep-K 64x64 tile)
+                grp = ops.ConvGroup([dd0 for dd0, _m in classes], list(lay.wt_s2))
+                ntaps = sum(dd0.kh * dd0.kw for dd0, _m in classes)
+                self._add(self.prog_bwd, (lambda grp=grp: ops.conv2d_group(grp, dy, dx)), 'conv_dgrad',
+                          2.0 * npix * ntaps * lay.ci_real * co,
+                          2.0 * (4 * npix * lddy + 4 * npix * lay.ci_real + sum(dd0.kpad for dd0, _m in classes) * lay.ci_real))
+            else:
+                for (dd0, _mode), wt_c in zip(classes, lay.wt_s2):
+                    ntap = dd0.kh * dd0.kw
+                    self._add(self.prog_bwd, (lambda dd0=dd0, wt_c=wt_c: ops.conv2d(dd0, dy, wt_c, None, dx)), 'conv_dgrad',
+                              2.0 * npix * ntap * lay.ci_real * co,
+                              2.0 * (npix * lddy + npix * lay.ci_real + dd0.kpad * lay.ci_real))
         elif lay.needs_dgrad and dx is not None:
             dd = ops.dgrad_desc(B, lay.H, lay.W, lay.ci_real, lddx, lddy, lddy, k, lay.stride, 0)
             assert dd.kpad == lay.wt_d.shape[1], (dd.kpad, lay.wt_d.shape)

@@ -328,3 +328,19 @@ def masked_sse_pool(a, b, batch, s, c, mask, S, partial, pool_a, pool_b):
 def unpool_tap_grad(da, dpool, a_pred, a_gt, batch, s, c, mask, S, coef, idx):
     call('imm_unpool_tap_grad', _p(da), _p(dpool), _p(a_pred), _p(a_gt), dtype_enum(da.dtype), batch, s, c, _p(mask), S,
          _p(coef), idx, _s())
+
+
+class ConvGroup(object):
+    """Descriptor array + filter pointer array for imm_conv2d_group (kept alive by this object)."""
+
+    def __init__(self, descs, wts):
+        assert 1 <= len(descs) <= 4 and len(descs) == len(wts)
+        self.n = len(descs)
+        self.descs = (ConvDesc * self.n)(*descs)
+        self.wts = wts
+        self.ptrs = (C.c_void_p * self.n)(*[w.data_ptr() for w in wts])
+
+
+def conv2d_group(group, x, y):
+    call('imm_conv2d_group', C.cast(group.descs, C.c_void_p), group.n, dtype_enum(x.dtype), _p(x), C.cast(group.ptrs, C.c_void_p),
+         _p(y), _s())

@@ -93,6 +93,11 @@ int imm_pack_weights_multi(const int64_t* jobs, const int32_t* blk_first, int n_
 int imm_wgrad_reduce_multi(const int64_t* jobs, const int32_t* blk_first, int n_jobs, int n_blocks, void* stream);
 
 /* ---- convolution (implicit GEMM on MFMA) ----------------------------------------------------- */
+/* n <= 4 convolutions that read the same x and write (disjoint pixels of) the same y, issued as ONE launch when every member
+ * takes the deep-K 64x64-tile kernel, else one after the other (identical results): the four parity classes of a stride-2
+ * data gradient (tf.nn.conv2d_backprop_input at nn_utils.py:100 call sites with stride 2).  Members carry no bias / stats /
+ * mask; descs is an array of n descriptors, wts an array of n packed filter images. */
+int imm_conv2d_group(const imm_conv_desc* descs, int n, int dtype, const void* x, const void* const* wts, void* y, void* stream);
 /* y[m][n] = epilogue( sum_k gather(x)[m][k] * wt[n][k] ).  stats_partial: [n_mblocks][2][co] f32
  * with n_mblocks = imm_conv_stats_blocks(desc).  Replaces tf.nn.conv2d+bias_add (nn_utils.py:100,108),
  * vgg conv+bias+relu (vgg16.py:182-189,230) and their data gradients. */

@@ -685,3 +685,27 @@ def test_unpool_fused_with_tap_grad(ops):
         ops.unpool_tap_grad(got, dpool, ap, ag, B, s, c, mk, S, coef, 1)
         torch.cuda.synchronize()
         assert torch.equal(got, ref)
+
+
+@pytest.mark.parametrize('H,ci,co', [(32, 64, 128), (64, 128, 256), (16, 32, 64)], ids=['grouped_64x64', 'grouped_deep', 'fallback_bk32'])
+def test_conv_group_equals_sequential(ops, H, ci, co):
+    """imm_conv2d_group (stride-2 dgrad parity classes in one launch) == the four launches, bit for bit."""
+    B, k, dt = 8, 3, torch.bfloat16
+    w = rnd((k, k, ci, co), 401, 0.05)
+    dy = rnd((B, H // 2, H // 2, co), 402).to(DEV).contiguous()
+    classes = ops.dgrad_s2_class_descs(B, H, H, ci, ci, co, co, k)
+    rows = ops.round_up(ci, 128)
+    wts = []
+    for d, mode in classes:
+        wt = torch.zeros(rows, d.kpad, dtype=dt, device=DEV)
+        ops.pack_weights(w.float().to(DEV).contiguous(), wt, mode, k, k, ci, co, co, rows, d.kpad)
+        wts.append(wt)
+    ref = torch.full((B, H, H, ci), float('nan'), dtype=dt, device=DEV)
+    for (d, _m), wt in zip(classes, wts):
+        ops.conv2d(d, dy, wt, None, ref)
+    got = torch.full((B, H, H, ci), float('nan'), dtype=dt, device=DEV)
+    grp = ops.ConvGroup([d for d, _m in classes], wts)
+    ops.conv2d_group(grp, dy, got)
+    torch.cuda.synchronize()
+    assert not bool(torch.isnan(got.float()).any())
+    assert torch.equal(got, ref)
