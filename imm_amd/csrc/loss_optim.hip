@@ -356,10 +356,24 @@ __global__ __launch_bounds__(LO_THREADS) void grad_prepare_kernel(const float* _
   const int blk = blockIdx.x;
   const float wd = seg_wd[blk_seg[blk]];
   float acc = 0.f;
-  for (int i = blk_begin[blk] + threadIdx.x; i < blk_end[blk]; i += LO_THREADS) {
+  // 16-byte accesses over the aligned body of the chunk, scalars on the (<= 3 element) head and tail
+  const int b0 = blk_begin[blk], b1 = blk_end[blk];
+  const int a0 = min((b0 + 3) & ~3, b1), a1 = max(a0, b1 & ~3);
+  for (int i = b0 + threadIdx.x; i < a0; i += LO_THREADS) {
     const float g = grads[i] * grad_scale + wd * params[i];
-    grads[i] = g;
-    acc += g * g;
+    grads[i] = g; acc += g * g;
+  }
+  for (int i = a0 + 4 * threadIdx.x; i < a1; i += 4 * LO_THREADS) {
+    float4 g = *(const float4*)(grads + i);
+    const float4 w = *(const float4*)(params + i);
+    g.x = g.x * grad_scale + wd * w.x; g.y = g.y * grad_scale + wd * w.y;
+    g.z = g.z * grad_scale + wd * w.z; g.w = g.w * grad_scale + wd * w.w;
+    *(float4*)(grads + i) = g;
+    acc += (g.x * g.x + g.y * g.y) + (g.z * g.z + g.w * g.w);
+  }
+  for (int i = a1 + threadIdx.x; i < b1; i += LO_THREADS) {
+    const float g = grads[i] * grad_scale + wd * params[i];
+    grads[i] = g; acc += g * g;
   }
   acc = block_sum_256(acc, red);
   if (threadIdx.x == 0) blk_partial[blk] = acc;
@@ -395,14 +409,22 @@ __global__ __launch_bounds__(LO_THREADS) void clip_adam_kernel(float* __restrict
   float factor = 1.f;
   if (hp.clip > 0.f) factor = hp.clip / fmaxf(sqrtf(seg_norm2[blk_seg[blk]]), hp.clip);
   const float lr_t = lr_state[0];
-  for (int i = blk_begin[blk] + threadIdx.x; i < blk_end[blk]; i += LO_THREADS) {
-    const float g = grads[i] * factor;
-    const float mi = hp.beta1 * m[i] + (1.f - hp.beta1) * g;
-    const float vi = hp.beta2 * v[i] + (1.f - hp.beta2) * g * g;
-    m[i] = mi;
-    v[i] = vi;
-    params[i] -= lr_t * mi / (sqrtf(vi) + hp.eps);
+  auto one = [&](float g, float& mi, float& vi, float& w) {
+    g *= factor;
+    mi = hp.beta1 * mi + (1.f - hp.beta1) * g;
+    vi = hp.beta2 * vi + (1.f - hp.beta2) * g * g;
+    w -= lr_t * mi / (sqrtf(vi) + hp.eps);
+  };
+  const int b0 = blk_begin[blk], b1 = blk_end[blk];
+  const int a0 = min((b0 + 3) & ~3, b1), a1 = max(a0, b1 & ~3);
+  for (int i = b0 + threadIdx.x; i < a0; i += LO_THREADS) one(grads[i], m[i], v[i], params[i]);
+  for (int i = a0 + 4 * threadIdx.x; i < a1; i += 4 * LO_THREADS) {
+    const float4 g = *(const float4*)(grads + i);
+    float4 mi = *(const float4*)(m + i), vi = *(const float4*)(v + i), w = *(const float4*)(params + i);
+    one(g.x, mi.x, vi.x, w.x); one(g.y, mi.y, vi.y, w.y); one(g.z, mi.z, vi.z, w.z); one(g.w, mi.w, vi.w, w.w);
+    *(float4*)(m + i) = mi; *(float4*)(v + i) = vi; *(float4*)(params + i) = w;
   }
+  for (int i = a1 + threadIdx.x; i < b1; i += LO_THREADS) one(grads[i], m[i], v[i], params[i]);
 }
 
 extern "C" int imm_clip_adam_step(float* params, float* grads, float* m, float* v, const int32_t* blk_seg,
