@@ -104,6 +104,15 @@ __device__ __forceinline__ void reduce_partials_32x32(const float* __restrict__ 
     if (live) {
       const float* base = partial + (int64_t)sidx * c + ch0 + q4;
       int b = rl;
+      for (; b + 7 * RL < nblk; b += 8 * RL) {        // 8 loads in flight: the pass is a chain of L2 round trips
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = *(const float4*)(base + (int64_t)(b + u * RL) * NS * c);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          acc[u & 3][0] += (double)v[u].x; acc[u & 3][1] += (double)v[u].y; acc[u & 3][2] += (double)v[u].z; acc[u & 3][3] += (double)v[u].w;
+        }
+      }
       for (; b + 3 * RL < nblk; b += 4 * RL) {
         float4 v[4];
 #pragma unroll

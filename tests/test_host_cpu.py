@@ -48,6 +48,12 @@ def test_product_package_never_imports_the_oracle():
                 assert 'imm_oracle' not in src and 'np_ref' not in src, os.path.join(dirpath, f)
     src = open(os.path.join(ROOT, 'scripts', 'train.py')).read() if os.path.exists(os.path.join(ROOT, 'scripts', 'train.py')) else ''
     assert 'import oracle' not in src and 'from oracle' not in src
+    # tools/ and scripts/ are product-side utilities: they may not pull the checker in either
+    for sub in ('tools', 'scripts'):
+        for f in os.listdir(os.path.join(ROOT, sub)):
+            if f.endswith('.py'):
+                src = open(os.path.join(ROOT, sub, f)).read()
+                assert not re.search(r'^\s*(import|from)\s+oracle', src, flags=re.M), os.path.join(sub, f)
 
 
 def test_box_and_config_loader(tmp_path):

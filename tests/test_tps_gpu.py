@@ -100,3 +100,19 @@ def test_sampler_errors_and_cache(tps):
     s = tps.TPSRandomSampler(16, 16, pad=False, device=DEV, cache_size=2, cache_evict_prob=0.0, rng=np.random.RandomState(0))
     a = s.sample_params(64)
     assert len({a[i].cpu().numpy().tobytes() for i in range(64)}) <= 2       # only two cached parameter sets are reused
+
+
+def test_cpu_restatement_rate(tps, capsys):
+    """Reported, not asserted: the numpy restatement's rate beside the kernel's (tools/bench_tps.py times the kernel)."""
+    import time
+    S = 128
+    rng = np.random.RandomState(0)
+    img = (rng.rand(4, S, S, 3) * 255).astype(np.float32)
+    msk = rng.rand(4, S, S, 1).astype(np.float32)
+    w1 = np.stack([T.sample_tps_w(10, 10, (0.001, 0.005), 0.0, 0.0, 0.1, rng) for _ in range(4)]).astype(np.float32)
+    w2 = np.stack([T.sample_tps_w(10, 10, (0.001, 0.01), 5.0, 0.1, 0.1, rng) for _ in range(4)]).astype(np.float32)
+    t0 = time.time()
+    T.apply_pair(img, msk, w1, w2)
+    dt = time.time() - t0
+    with capsys.disabled():
+        print('\n[tps] numpy restatement: %.1f ms per 4 pairs = %.0f pairs/s' % (dt * 1e3, 4 / dt))

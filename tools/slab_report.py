@@ -1,9 +1,9 @@
+"""Split-K slab sizes per trainable convolution (MI355X; needs a GPU for the engine build).  Usage: python tools/slab_report.py"""
 import torch, sys
 sys.path.insert(0, '/root/repo')
 from imm_amd.engine import IMMEngine
-from imm_amd.models.imm_model import IMMModel
-from oracle import imm_oracle as O
-cfg = O.default_model_config(10)
+import bench
+cfg = bench.model_config(10)
 e = IMMEngine(cfg, 32, 128)
 tot = 0
 for lay in e.enc_im + e.enc_pose + [e.pose_head] + e.ren:
