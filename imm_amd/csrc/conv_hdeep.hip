@@ -19,11 +19,14 @@
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 
-#define HD_P 16                          // patch side
-#define HD_HW (HD_P + 2)                 // halo side 18
-#define HD_SLOTS (HD_HW * HD_HW)         // 324 halo pixels
-#define HD_HINSTR ((HD_SLOTS + 7) / 8)   // 41 DMA instructions (8 pixels x 128 B each)
-#define HD_HSTAGE (HD_HINSTR * 64)       // uint4 per halo stage (41984 B)
+#define HD_PW 16                         // patch width (= MFMA operand rows)
+#define HD_HW (HD_PW + 2)                // halo width 18
+// patch height PH = 16 (8 waves, 512 threads) or 8 (4 waves, 256 threads: half the tile, for grids that would
+// otherwise leave CUs idle; 78 KB of LDS at BN = 64, so two workgroups share a CU and cover each other's prologue,
+// epilogue and barriers)
+#define HD_SLOTS(PH) (((PH) + 2) * HD_HW)            // halo pixels: 324 / 180
+#define HD_HINSTR(PH) ((HD_SLOTS(PH) + 7) / 8)       // DMA instructions (8 pixels x 128 B each): 41 / 23
+#define HD_HSTAGE(PH) (HD_HINSTR(PH) * 64)           // uint4 per halo stage
 #define HD_NSB 4                         // filter-slice ring depth
 #define HD_OOB 0x80000000u
 
@@ -44,16 +47,19 @@ __device__ __forceinline__ int hd_bidx(int row, int chunk) { return row * 8 + (c
 
 template <int V> struct HdInt { static constexpr int value = V; };
 
-template <typename ET, int BN>
-__global__ __launch_bounds__(512) void conv_hdeep_kernel(const HdArgs ha) {
+template <typename ET, int BN, int NW, int PH>
+__global__ __launch_bounds__(NW * 64) void conv_hdeep_kernel(const HdArgs ha) {
   const ConvArgs& a = ha.c;
+  static_assert((NW == 8 && PH == 16) || (NW == 4 && PH == 8), "wave (wm, wn) owns patch rows 4wm..4wm+3 x BN/2 channels");
   constexpr int TN = BN / 2, MT = 4, NT = TN / 16;
-  constexpr int B_I = BN / 64;                         // filter DMA instructions per wave and tap (BN rows / 8 / 8 waves)
+  constexpr int B_I = BN / (8 * NW);                   // filter DMA instructions per wave and tap (BN rows / 8 / NW waves)
+  constexpr int HSTAGE = HD_HSTAGE(PH), HINSTR = HD_HINSTR(PH), SLOTS = HD_SLOTS(PH);
+  static_assert(B_I >= 1 && 6 * NW >= HINSTR, "6 halo pieces per wave cover the halo");
   constexpr int B_U4 = BN * 8;                         // uint4 per filter stage
   constexpr int WN_STEADY = (HD_NSB - 2) * (B_I + 1);  // outstanding VMEM allowed at the top of a tap (see header)
   constexpr int ROWB = HD_HW * 128;                    // bytes per halo row in LDS
-  extern __shared__ __attribute__((aligned(16))) uint4 smem[];   // [2][HD_HSTAGE] halo | [64] dump | [HD_NSB][B_U4] filter
-  constexpr int DUMP_U4 = 2 * HD_HSTAGE, BRING_U4 = DUMP_U4 + 64;
+  extern __shared__ __attribute__((aligned(16))) uint4 smem[];   // [2][HSTAGE] halo | [64] dump | [HD_NSB][B_U4] filter
+  constexpr int DUMP_U4 = 2 * HSTAGE, BRING_U4 = DUMP_U4 + 64;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -67,7 +73,7 @@ __global__ __launch_bounds__(512) void conv_hdeep_kernel(const HdArgs ha) {
   const int nblk = bid % a.n_nblk, patch = bid / a.n_nblk;
   const int per_img = ha.patches_x * ha.patches_y;
   const int img = patch / per_img, pr = patch - img * per_img;
-  const int y0 = (pr / ha.patches_x) * HD_P, x0 = (pr % ha.patches_x) * HD_P;
+  const int y0 = (pr / ha.patches_x) * PH, x0 = (pr % ha.patches_x) * HD_PW;
   const int n0 = nblk * BN;
 
   const uint64_t xa = (uint64_t)a.x, wa = (uint64_t)a.wt;
@@ -76,14 +82,14 @@ __global__ __launch_bounds__(512) void conv_hdeep_kernel(const HdArgs ha) {
   const uint32_t lds_base = (uint32_t)(size_t)(lds_void_t*)smem;
 
   // ---- loader state ------------------------------------------------------------------------------------------
-  // halo piece k of this wave = instruction wid + 8k (k < 6; instructions >= 41 do not exist -> dump slot)
+  // halo piece k of this wave = instruction wid + NW*k (k < 6; instructions >= HINSTR do not exist -> dump slot)
   uint32_t h_voff[6];
 #pragma unroll
   for (int k = 0; k < 6; ++k) {
-    const int hp = (wid + 8 * k) * 8 + (lane >> 3);
+    const int hp = (wid + NW * k) * 8 + (lane >> 3);
     const int hy = hp / HD_HW, hx = hp - hy * HD_HW;
     const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
-    const bool ok = hp < HD_SLOTS && (unsigned)iy < (unsigned)a.hi && (unsigned)ix < (unsigned)a.wi;
+    const bool ok = hp < SLOTS && (unsigned)iy < (unsigned)a.hi && (unsigned)ix < (unsigned)a.wi;
     h_voff[k] = ok ? (uint32_t)((iy * a.wi + ix) * a.ldx * 2 + (((lane & 7) ^ hd_swz(hx)) * 16)) : HD_OOB;
   }
   const uint32_t img_soff = (uint32_t)(img * a.hi * a.wi) * (uint32_t)(a.ldx * 2);
@@ -105,9 +111,9 @@ __global__ __launch_bounds__(512) void conv_hdeep_kernel(const HdArgs ha) {
       hd_dma16(wr, lds_base + (uint32_t)((BRING_U4 + stage * B_U4 + (wid * B_I + j) * 64) * 16), real ? b_voff[j] : HD_OOB, soff);
   };
   auto issue_halo_piece = [&](int cc, int k, bool real) {
-    const int i = wid + 8 * k;
-    const bool exists = real && i < HD_HINSTR;
-    const uint32_t dst = exists ? (uint32_t)(((cc & 1) * HD_HSTAGE + i * 64) * 16) : (uint32_t)(DUMP_U4 * 16);
+    const int i = wid + NW * k;
+    const bool exists = real && i < HINSTR;
+    const uint32_t dst = exists ? (uint32_t)(((cc & 1) * HSTAGE + i * 64) * 16) : (uint32_t)(DUMP_U4 * 16);
     hd_dma16(xr, lds_base + dst, exists ? h_voff[k < 6 ? k : 0] : HD_OOB, img_soff + (uint32_t)(cc * 128));
   };
 
@@ -159,13 +165,13 @@ __global__ __launch_bounds__(512) void conv_hdeep_kernel(const HdArgs ha) {
   int t = 0, bs = 0;
   for (int cc = 0; cc < ncc; ++cc) {
     const bool next_slice = cc + 1 < ncc;
-    const uint4* Hc = smem + (cc & 1) * HD_HSTAGE;
+    const uint4* Hc = smem + (cc & 1) * HSTAGE;
 #pragma unroll
     for (int tp = 0; tp < 9; ++tp) {
       const int ky = tp / 3, kx = tp % 3;
       // next tap: (tp+1) of this slice, or tap 0 of the next slice (other halo stage)
       const int ntp = tp == 8 ? 0 : tp + 1;
-      const uint4* Hn = smem + ((tp == 8 ? cc + 1 : cc) & 1) * HD_HSTAGE;
+      const uint4* Hn = smem + ((tp == 8 ? cc + 1 : cc) & 1) * HSTAGE;
       const uint4* Bc = smem + BRING_U4 + bs * B_U4;
       int nbs = bs + 1; if (nbs == HD_NSB) nbs = 0;
       const uint4* Bn = smem + BRING_U4 + nbs * B_U4;
@@ -271,7 +277,7 @@ __global__ __launch_bounds__(512) void conv_hdeep_kernel(const HdArgs ha) {
     if (tid < BN) {
       float t1 = 0.f, t2 = 0.f;
 #pragma unroll
-      for (int w = 0; w < 4; ++w) { t1 += red[(w * 2 + 0) * BN + tid]; t2 += red[(w * 2 + 1) * BN + tid]; }
+      for (int w = 0; w < NW / 2; ++w) { t1 += red[(w * 2 + 0) * BN + tid]; t2 += red[(w * 2 + 1) * BN + tid]; }
       a.stats[((int64_t)patch * 2 + 0) * a.co + n0 + tid] = t1;
       a.stats[((int64_t)patch * 2 + 1) * a.co + n0 + tid] = t2;
     }
@@ -292,11 +298,26 @@ static int hd_num_cu() {
   return cu;
 }
 
-// channel-block width: 128 when that still fills the chip, else 64
-static int hd_bn(const imm_conv_desc* d) {
-  const int n_patches = d->batch * (d->ho / HD_P) * (d->wo / HD_P);
-  if (d->co % 128 == 0 && n_patches * (d->co / 128) >= hd_num_cu()) return 128;
-  return 64;
+// Tile plan of a layer: patch height (16 = 8-wave kernel, 8 = 4-wave kernel) and channel-block width.
+//   16 x 16 patch x 128 channels when that still gives every CU a workgroup;
+//   16 x 16 x 64 when THAT does;
+//   else 8 x 16 x 64 (4 waves, two workgroups per CU) when the map height allows — the small-grid layers (16x16 maps of
+//   a 32-image batch: 32 patches) otherwise leave half the chip idle.
+struct HdPlan { int ph, bn, n_patches, n_wg; };
+
+static HdPlan hd_plan(const imm_conv_desc* d) {
+  static const bool no_small = getenv("IMM_HDEEP_NO_SMALL") != nullptr;
+  const int cus = hd_num_cu();
+  static const int small_below = getenv("IMM_HDEEP_SMALL_BELOW") ? atoi(getenv("IMM_HDEEP_SMALL_BELOW")) : 4;   // x CUs
+  static const bool no_big = getenv("IMM_HDEEP_NO_BIG") != nullptr;
+  HdPlan p;
+  const int np16 = (d->ho % 16 == 0) ? d->batch * (d->ho / 16) * (d->wo / HD_PW) : 0;
+  if (!no_big && np16 > 0 && d->co % 128 == 0 && np16 * (d->co / 128) >= cus) { p.ph = 16; p.bn = 128; p.n_patches = np16; }
+  else if (np16 > 0 && (np16 * (d->co / 64) >= small_below * cus || no_small)) { p.ph = 16; p.bn = 64; p.n_patches = np16; }
+  else if (!no_small) { p.ph = 8; p.bn = 64; p.n_patches = d->batch * (d->ho / 8) * (d->wo / HD_PW); }
+  else { p.ph = 16; p.bn = 64; p.n_patches = np16; }
+  p.n_wg = p.n_patches * (d->co / p.bn);
+  return p;
 }
 
 bool imm_hdeep_applicable(const imm_conv_desc* d) {
@@ -305,39 +326,45 @@ bool imm_hdeep_applicable(const imm_conv_desc* d) {
   if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->updiv != 1 || d->pad_t != 1 || d->pad_l != 1) return false;
   if (d->ci % 64 || d->co % 64 || d->ci < 64) return false;
   if (d->out_scale > 1 || (d->flags & (IMM_CONV_OUT_F32 | 0xf00))) return false;
-  if (d->hi != d->ho || d->wi != d->wo || d->ho % HD_P || d->wo % HD_P) return false;
+  if (d->hi != d->ho || d->wi != d->wo || d->ho % 8 || d->wo % HD_PW) return false;
   if (d->ldy % 4 || ((d->flags & IMM_CONV_MASK) && d->ldmask % 4)) return false;
   const int64_t px = (int64_t)d->batch * d->hi * d->wi;
   if (px * d->ldx * 2 >= (1LL << 31) || (int64_t)d->co * d->kpad * 2 >= (1LL << 31)) return false;
   // small grids keep the im2col kernel (64x64 tiles give it 4x the workgroups)
-  const int n_patches = d->batch * (d->ho / HD_P) * (d->wo / HD_P);
   static const int min_wg = getenv("IMM_HDEEP_MIN_WG") ? atoi(getenv("IMM_HDEEP_MIN_WG")) : 100;
-  return n_patches * (d->co / hd_bn(d)) >= min_wg;
+  const HdPlan p = hd_plan(d);
+  return p.n_patches > 0 && p.n_wg >= min_wg;
 }
 
-int imm_hdeep_stats_blocks(const imm_conv_desc* d) { return d->batch * (d->ho / HD_P) * (d->wo / HD_P); }
+int imm_hdeep_stats_blocks(const imm_conv_desc* d) { return hd_plan(d).n_patches; }
 
-template <typename ET, int BN>
+template <typename ET, int BN, int NW, int PH>
 static void hd_launch_cfg(const HdArgs& ha, hipStream_t s) {
-  constexpr int lds = (2 * HD_HSTAGE + 64 + HD_NSB * BN * 8) * 16;
+  constexpr int lds = (2 * HD_HSTAGE(PH) + 64 + HD_NSB * BN * 8) * 16;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)conv_hdeep_kernel<ET, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)conv_hdeep_kernel<ET, BN, NW, PH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_hdeep_kernel<ET, BN>), dim3(ha.n_wg), dim3(512), lds, s, ha);
+  hipLaunchKernelGGL((conv_hdeep_kernel<ET, BN, NW, PH>), dim3(ha.n_wg), dim3(NW * 64), lds, s, ha);
+}
+
+template <typename ET>
+static void hd_launch(const HdPlan& p, const HdArgs& ha, hipStream_t s) {
+  if (p.ph == 16 && p.bn == 128) hd_launch_cfg<ET, 128, 8, 16>(ha, s);
+  else if (p.ph == 16) hd_launch_cfg<ET, 64, 8, 16>(ha, s);
+  else hd_launch_cfg<ET, 64, 4, 8>(ha, s);
 }
 
 void imm_conv_hdeep_launch(int dtype, const imm_conv_desc* d, const ConvArgs& a, hipStream_t s) {
   HdArgs ha;
   ha.c = a;
-  const int bn = hd_bn(d);
-  ha.patches_x = d->wo / HD_P; ha.patches_y = d->ho / HD_P;
-  ha.n_patches = d->batch * ha.patches_x * ha.patches_y;
-  ha.c.n_nblk = d->co / bn;
-  ha.n_wg = ha.n_patches * ha.c.n_nblk;
+  const HdPlan p = hd_plan(d);
+  ha.patches_x = d->wo / HD_PW; ha.patches_y = d->ho / p.ph;
+  ha.n_patches = p.n_patches;
+  ha.c.n_nblk = d->co / p.bn;
+  ha.n_wg = p.n_wg;
   ha.c.x_bytes = (uint32_t)((int64_t)d->batch * d->hi * d->wi * d->ldx * 2);
   ha.c.wt_bytes = (uint32_t)((int64_t)d->co * d->kpad * 2);
-  if (dtype == IMM_BF16) { if (bn == 128) hd_launch_cfg<BF16, 128>(ha, s); else hd_launch_cfg<BF16, 64>(ha, s); }
-  else { if (bn == 128) hd_launch_cfg<F16, 128>(ha, s); else hd_launch_cfg<F16, 64>(ha, s); }
+  if (dtype == IMM_BF16) hd_launch<BF16>(p, ha, s); else hd_launch<F16>(p, ha, s);
 }
