@@ -210,7 +210,8 @@ static bool wh_plan(const imm_conv_desc* d, int lddy, WhPlan* pl) {
   }
   pl->cs = cs; pl->ns = ns;
   const int blocks = pl->nci * pl->nco;
-  int grid = 2 * wh_num_cu();
+  static const int per_cu = getenv("IMM_WGRAD_HALO_PER_CU") ? atoi(getenv("IMM_WGRAD_HALO_PER_CU")) : 2;
+  int grid = per_cu * wh_num_cu();
   if (blocks > 1) grid = wh_num_cu();                  // sliced layers: slab bytes = nsplit x |dW|, keep nsplit small
   int nsplit = (grid + blocks - 1) / blocks;
   const int min_patches = blocks > 1 ? 2 : 4;          // patches per workgroup that amortise its slab write
