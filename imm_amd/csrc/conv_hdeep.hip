@@ -42,8 +42,15 @@ __device__ __forceinline__ void hd_dma16(u32x4_t rsrc, uint32_t lds_addr, uint32
 }
 // halo pixel -> chunk swizzle (same as conv_halo2.hip): a ds_read_b128 of 16 consecutive pixels is conflict-free
 __device__ __forceinline__ int hd_swz(int hx) { return ((hx >> 1) & 3) << 1; }
-// filter rows: conv_igemm64.hip's image
-__device__ __forceinline__ int hd_bidx(int row, int chunk) { return row * 8 + (chunk ^ ((row >> 1) & 7)); }
+// Filter stage in LDS: row = output channel of the BN block (128 B = 8 chunks), chunk XOR-swizzled by hd_bswz.  The MFMA
+// B-operand row rho of tile j is NOT channel 16j + rho but channel (rho>>2)*4NT + 4j + (rho&3) of the wave's TN = 16 NT
+// channels: then a lane (which holds D rows 4q..4q+3 of every tile) owns 4NT CONSECUTIVE channels of its pixel — 16-byte
+// stores / mask loads in the epilogue instead of 8-byte ones.  A ds_read_b128 lane group therefore touches rows
+// {0-3, 12NT..12NT+3} at chunk c and {4NT..4NT+3, 8NT..8NT+3} at chunk c^1 (plus 4j): the swizzle spreads exactly those.
+template <int NT>
+__device__ __forceinline__ int hd_bswz(int row) { return ((row >> 1) & 1) | (((row >> (NT == 4 ? 4 : 3)) & 3) << 1); }
+template <int NT>
+__device__ __forceinline__ int hd_bidx(int row, int chunk) { return row * 8 + (chunk ^ hd_bswz<NT>(row)); }
 
 template <int V> struct HdInt { static constexpr int value = V; };
 
@@ -97,7 +104,7 @@ __global__ __launch_bounds__(NW * 64) void conv_hdeep_kernel(const HdArgs ha) {
 #pragma unroll
   for (int j = 0; j < B_I; ++j) {
     const int r = (wid * B_I + j) * 8 + (lane >> 3);
-    b_voff[j] = (n0 + r < a.co) ? (uint32_t)((n0 + r) * a.kpad * 2 + (((lane & 7) ^ ((r >> 1) & 7)) * 16)) : HD_OOB;
+    b_voff[j] = (n0 + r < a.co) ? (uint32_t)((n0 + r) * a.kpad * 2 + (((lane & 7) ^ hd_bswz<NT>(r)) * 16)) : HD_OOB;
   }
   const int ncc = a.ci8 >> 3;                          // 64-channel slices
   const int T = ncc * 9;                               // taps in total
@@ -137,7 +144,8 @@ __global__ __launch_bounds__(NW * 64) void conv_hdeep_kernel(const HdArgs ha) {
 #pragma unroll
   for (int j = 0; j < NT; ++j)
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) boff[j][ks] = hd_bidx(wn * TN + j * 16 + frow, ks * 4 + q);
+    for (int ks = 0; ks < 2; ++ks)
+      boff[j][ks] = hd_bidx<NT>(wn * TN + (frow >> 2) * (4 * NT) + j * 4 + (frow & 3), ks * 4 + q);
 
   // Software pipeline at k-step granularity (a tap = two k-steps of 32 channels): the fragments of the next k-step are
   // read from LDS while the 16 MFMAs of the current one run, and a k-step's MFMAs are already queued when the wave
@@ -219,36 +227,37 @@ __global__ __launch_bounds__(NW * 64) void conv_hdeep_kernel(const HdArgs ha) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // trailing no-op pieces: no LDS-DMA may outlive the workgroup
   __syncthreads();
 
-  // ---- epilogue: lane = pixel (row wm*4 + i, col frow), 4 consecutive channels per tile ---------------------------
+  // ---- epilogue: lane = pixel (row wm*4 + i, col frow), 4*NT consecutive channels (see hd_bswz) ----------------------
   const bool f_bias = a.flags & IMM_CONV_BIAS, f_relu = a.flags & IMM_CONV_RELU;
   const bool f_stats = a.flags & IMM_CONV_STATS, f_mask = a.flags & IMM_CONV_MASK;
-  float s1[NT][4], s2[NT][4];
+  const int nb = n0 + wn * TN + q * (4 * NT);          // first channel of this lane
+  float s1[NT][4], s2[NT][4], bv[NT][4];
 #pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int n = n0 + wn * TN + j * 16 + 4 * q;
-    float bv[4];
+  for (int j = 0; j < NT; ++j)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { bv[r] = f_bias ? a.bias[n + r] : 0.f; s1[j][r] = 0.f; s2[j][r] = 0.f; }
+    for (int r = 0; r < 4; ++r) { bv[j][r] = f_bias ? a.bias[nb + j * 4 + r] : 0.f; s1[j][r] = 0.f; s2[j][r] = 0.f; }
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      const int64_t m = ((int64_t)img * a.ho + y0 + wm * 4 + i) * a.wo + x0 + frow;
-      float v[4];
+  for (int i = 0; i < MT; ++i) {
+    const int64_t m = ((int64_t)img * a.ho + y0 + wm * 4 + i) * a.wo + x0 + frow;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        v[r] = acc[i][j][r] + bv[r];
-        if (f_relu) v[r] = fmaxf(v[r], 0.f);
+    for (int h = 0; h < NT / 2; ++h) {                 // 8 channels = one 16-byte store
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        v[e] = acc[i][2 * h + (e >> 2)][e & 3] + bv[2 * h + (e >> 2)][e & 3];
+        if (f_relu) v[e] = fmaxf(v[e], 0.f);
       }
       if (f_mask) {
-        const uint2 mw = *(const uint2*)(a.mask + m * a.ldmask + n);
-        const uint16_t mh[4] = {(uint16_t)(mw.x & 0xffffu), (uint16_t)(mw.x >> 16), (uint16_t)(mw.y & 0xffffu), (uint16_t)(mw.y >> 16)};
+        float mf[8];
+        unpack8<ET>(*(const uint4*)(a.mask + m * a.ldmask + nb + 8 * h), mf);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) if (!(ET::to_f32(mh[r]) > 0.f)) v[r] = 0.f;
+        for (int e = 0; e < 8; ++e) if (!(mf[e] > 0.f)) v[e] = 0.f;
       }
       if (f_stats) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { s1[j][r] += v[r]; s2[j][r] += v[r] * v[r]; }
+        for (int e = 0; e < 8; ++e) { s1[2 * h + (e >> 2)][e & 3] += v[e]; s2[2 * h + (e >> 2)][e & 3] += v[e] * v[e]; }
       }
-      *(uint2*)((uint16_t*)a.y + m * a.ldy + n) = make_uint2(ET::pack2(v[0], v[1]), ET::pack2(v[2], v[3]));
+      *(uint4*)((uint16_t*)a.y + m * a.ldy + nb + 8 * h) = pack8<ET>(v);
     }
   }
   if (f_stats) {
@@ -268,7 +277,7 @@ __global__ __launch_bounds__(NW * 64) void conv_hdeep_kernel(const HdArgs ha) {
       for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int nl = wn * TN + j * 16 + 4 * q + r;
+          const int nl = wn * TN + q * (4 * NT) + j * 4 + r;
           red[(wm * 2 + 0) * BN + nl] = s1[j][r];
           red[(wm * 2 + 1) * BN + nl] = s2[j][r];
         }
@@ -327,7 +336,7 @@ bool imm_hdeep_applicable(const imm_conv_desc* d) {
   if (d->ci % 64 || d->co % 64 || d->ci < 64) return false;
   if (d->out_scale > 1 || (d->flags & (IMM_CONV_OUT_F32 | 0xf00))) return false;
   if (d->hi != d->ho || d->wi != d->wo || d->ho % 8 || d->wo % HD_PW) return false;
-  if (d->ldy % 4 || ((d->flags & IMM_CONV_MASK) && d->ldmask % 4)) return false;
+  if (d->ldy % 8 || ((d->flags & IMM_CONV_MASK) && d->ldmask % 8)) return false;
   const int64_t px = (int64_t)d->batch * d->hi * d->wi;
   if (px * d->ldx * 2 >= (1LL << 31) || (int64_t)d->co * d->kpad * 2 >= (1LL << 31)) return false;
   // small grids keep the im2col kernel (64x64 tiles give it 4x the workgroups)
