@@ -27,13 +27,13 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 #define HD_SLOTS(PH) (((PH) + 2) * HD_HW)            // halo pixels: 324 / 180
 #define HD_HINSTR(PH) ((HD_SLOTS(PH) + 7) / 8)       // DMA instructions (8 pixels x 128 B each): 41 / 23
 #define HD_HSTAGE(PH) (HD_HINSTR(PH) * 64)           // uint4 per halo stage
-#define HD_NSB 4                         // filter-slice ring depth
 #define HD_OOB 0x80000000u
 
 struct HdArgs {
   ConvArgs c;
   int n_patches, patches_x, patches_y;
   int n_wg;                              // n_patches * n_nblk
+  int n_img;                             // batch (MAP8 tiles hold two images)
 };
 
 __device__ __forceinline__ void hd_dma16(u32x4_t rsrc, uint32_t lds_addr, uint32_t voff, uint32_t soff) {
@@ -54,17 +54,24 @@ __device__ __forceinline__ int hd_bidx(int row, int chunk) { return row * 8 + (c
 
 template <int V> struct HdInt { static constexpr int value = V; };
 
-template <typename ET, int BN, int NW, int PH>
+// MAP8: the maps are 8x8 (VGG conv5 at 128x128 inputs): a workgroup tile is TWO whole images (each with its own 10x10
+// zero-padded halo), wave wm owns image wm, and an MFMA operand row of 16 pixels is two image rows of 8.
+template <typename ET, int BN, int NW, int PH, bool MAP8 = false>
 __global__ __launch_bounds__(NW * 64) void conv_hdeep_kernel(const HdArgs ha) {
   const ConvArgs& a = ha.c;
   static_assert((NW == 8 && PH == 16) || (NW == 4 && PH == 8), "wave (wm, wn) owns patch rows 4wm..4wm+3 x BN/2 channels");
+  static_assert(!MAP8 || NW == 4, "two 8x8 images per 4-wave workgroup");
+  constexpr int HD_NSB = MAP8 ? 3 : 4;                 // filter-slice ring depth (MAP8: 3 keeps two workgroups per CU)
+  constexpr int NPIECE = MAP8 ? 7 : 6;                 // halo DMA pieces per wave and slice
   constexpr int TN = BN / 2, MT = 4, NT = TN / 16;
   constexpr int B_I = BN / (8 * NW);                   // filter DMA instructions per wave and tap (BN rows / 8 / NW waves)
-  constexpr int HSTAGE = HD_HSTAGE(PH), HINSTR = HD_HINSTR(PH), SLOTS = HD_SLOTS(PH);
-  static_assert(B_I >= 1 && 6 * NW >= HINSTR, "6 halo pieces per wave cover the halo");
+  constexpr int SLOTS = MAP8 ? 200 : HD_SLOTS(PH);     // halo pixels
+  constexpr int HINSTR = (SLOTS + 7) / 8, HSTAGE = HINSTR * 64;
+  static_assert(B_I >= 1 && NPIECE * NW >= HINSTR && NPIECE <= 11 - HD_NSB, "halo pieces per wave cover the halo and land in time");
+  // fragment row strides (uint4 units): output tile row i, vertical tap ky
+  constexpr int STEP_I = MAP8 ? 160 : (HD_HW * 128) / 16, STEP_KY = MAP8 ? 80 : (HD_HW * 128) / 16;
   constexpr int B_U4 = BN * 8;                         // uint4 per filter stage
   constexpr int WN_STEADY = (HD_NSB - 2) * (B_I + 1);  // outstanding VMEM allowed at the top of a tap (see header)
-  constexpr int ROWB = HD_HW * 128;                    // bytes per halo row in LDS
   extern __shared__ __attribute__((aligned(16))) uint4 smem[];   // [2][HSTAGE] halo | [64] dump | [HD_NSB][B_U4] filter
   constexpr int DUMP_U4 = 2 * HSTAGE, BRING_U4 = DUMP_U4 + 64;
 
@@ -79,8 +86,9 @@ __global__ __launch_bounds__(NW * 64) void conv_hdeep_kernel(const HdArgs ha) {
   }
   const int nblk = bid % a.n_nblk, patch = bid / a.n_nblk;
   const int per_img = ha.patches_x * ha.patches_y;
-  const int img = patch / per_img, pr = patch - img * per_img;
-  const int y0 = (pr / ha.patches_x) * PH, x0 = (pr % ha.patches_x) * HD_PW;
+  // MAP8: `patch` is a pair of images (2*patch, 2*patch + 1), origin (0, 0)
+  const int img = MAP8 ? 2 * patch : patch / per_img, pr = MAP8 ? 0 : patch - img * per_img;
+  const int y0 = MAP8 ? 0 : (pr / ha.patches_x) * PH, x0 = MAP8 ? 0 : (pr % ha.patches_x) * HD_PW;
   const int n0 = nblk * BN;
 
   const uint64_t xa = (uint64_t)a.x, wa = (uint64_t)a.wt;
@@ -90,14 +98,16 @@ __global__ __launch_bounds__(NW * 64) void conv_hdeep_kernel(const HdArgs ha) {
 
   // ---- loader state ------------------------------------------------------------------------------------------
   // halo piece k of this wave = instruction wid + NW*k (k < 6; instructions >= HINSTR do not exist -> dump slot)
-  uint32_t h_voff[6];
+  uint32_t h_voff[NPIECE];
 #pragma unroll
-  for (int k = 0; k < 6; ++k) {
+  for (int k = 0; k < NPIECE; ++k) {
     const int hp = (wid + NW * k) * 8 + (lane >> 3);
-    const int hy = hp / HD_HW, hx = hp - hy * HD_HW;
+    int hy, hx, il = 0;                                // halo row / column (, image of the pair)
+    if (MAP8) { il = hp / 100; const int rr = hp - il * 100; hy = rr / 10; hx = rr - hy * 10; }
+    else { hy = hp / HD_HW; hx = hp - hy * HD_HW; }
     const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
-    const bool ok = hp < SLOTS && (unsigned)iy < (unsigned)a.hi && (unsigned)ix < (unsigned)a.wi;
-    h_voff[k] = ok ? (uint32_t)((iy * a.wi + ix) * a.ldx * 2 + (((lane & 7) ^ hd_swz(hx)) * 16)) : HD_OOB;
+    const bool ok = hp < SLOTS && (unsigned)iy < (unsigned)a.hi && (unsigned)ix < (unsigned)a.wi && (!MAP8 || img + il < ha.n_img);
+    h_voff[k] = ok ? (uint32_t)(((il * a.hi + iy) * a.wi + ix) * a.ldx * 2 + (((lane & 7) ^ hd_swz(hx)) * 16)) : HD_OOB;
   }
   const uint32_t img_soff = (uint32_t)(img * a.hi * a.wi) * (uint32_t)(a.ldx * 2);
   uint32_t b_voff[B_I];
@@ -121,12 +131,12 @@ __global__ __launch_bounds__(NW * 64) void conv_hdeep_kernel(const HdArgs ha) {
     const int i = wid + NW * k;
     const bool exists = real && i < HINSTR;
     const uint32_t dst = exists ? (uint32_t)(((cc & 1) * HSTAGE + i * 64) * 16) : (uint32_t)(DUMP_U4 * 16);
-    hd_dma16(xr, lds_base + dst, exists ? h_voff[k < 6 ? k : 0] : HD_OOB, img_soff + (uint32_t)(cc * 128));
+    hd_dma16(xr, lds_base + dst, exists ? h_voff[k < NPIECE ? k : 0] : HD_OOB, img_soff + (uint32_t)(cc * 128));
   };
 
   // ---- prologue: halo of slice 0, filter taps 0 .. NSB-1 (every ring stage) ---------------------------------------
 #pragma unroll
-  for (int k = 0; k < 6; ++k) issue_halo_piece(0, k, true);
+  for (int k = 0; k < NPIECE; ++k) issue_halo_piece(0, k, true);
 #pragma unroll
   for (int t = 0; t < HD_NSB; ++t) issue_b(t, t);
 
@@ -139,7 +149,10 @@ __global__ __launch_bounds__(NW * 64) void conv_hdeep_kernel(const HdArgs ha) {
   // per-lane fragment offsets (uint4 units): A = halo pixel (row wm*4 + i + ky, col frow + kx), B = filter row
   int aoff[3];
 #pragma unroll
-  for (int kx = 0; kx < 3; ++kx) aoff[kx] = (wm * 4 * HD_HW + frow + kx) * 8 + (q ^ hd_swz(frow + kx));
+  for (int kx = 0; kx < 3; ++kx) {
+    if (MAP8) aoff[kx] = (wm * 100 + (frow >> 3) * 10 + (frow & 7) + kx) * 8 + (q ^ hd_swz((frow & 7) + kx));
+    else aoff[kx] = (wm * 4 * HD_HW + frow + kx) * 8 + (q ^ hd_swz(frow + kx));
+  }
   int boff[NT][2];
 #pragma unroll
   for (int j = 0; j < NT; ++j)
@@ -162,7 +175,7 @@ __global__ __launch_bounds__(NW * 64) void conv_hdeep_kernel(const HdArgs ha) {
   uint4 af[2][MT], bf[2][NT];                          // [k-step][tile]
   auto read_frags = [&](const int ks, const uint4* Hs, const uint4* Bs, const int ky, const int kx) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < MT; ++i) af[ks][i] = Hs[(aoff[kx] ^ (ks * 4)) + (i + ky) * (ROWB / 16)];
+    for (int i = 0; i < MT; ++i) af[ks][i] = Hs[(aoff[kx] ^ (ks * 4)) + i * STEP_I + ky * STEP_KY];
 #pragma unroll
     for (int j = 0; j < NT; ++j) bf[ks][j] = Bs[boff[j][ks]];
   };
@@ -201,13 +214,13 @@ __global__ __launch_bounds__(NW * 64) void conv_hdeep_kernel(const HdArgs ha) {
       }
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (t == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * B_I) : "memory");
-      else if (t == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * B_I + 1) : "memory");
+      if (t == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((HD_NSB - 2) * B_I) : "memory");          // prologue: taps 2.. in flight
+      else if (t == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((HD_NSB - 2) * B_I + 1) : "memory");
       else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WN_STEADY) : "memory");
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
       issue_b(t + HD_NSB, bs);
-      issue_halo_piece(cc + 1, tp, next_slice && tp < 6);
+      issue_halo_piece(cc + 1, tp, next_slice && tp < NPIECE);
       read_frags(0, Hn, Bn, ntp / 3, ntp % 3);         // past the last tap: reads of landed no-op data, never used
 #pragma unroll
       for (int i = 0; i < MT; ++i)
@@ -238,7 +251,9 @@ __global__ __launch_bounds__(NW * 64) void conv_hdeep_kernel(const HdArgs ha) {
     for (int r = 0; r < 4; ++r) { bv[j][r] = f_bias ? a.bias[nb + j * 4 + r] : 0.f; s1[j][r] = 0.f; s2[j][r] = 0.f; }
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
-    const int64_t m = ((int64_t)img * a.ho + y0 + wm * 4 + i) * a.wo + x0 + frow;
+    const int64_t m = MAP8 ? ((int64_t)(img + wm) * 8 + 2 * i + (frow >> 3)) * 8 + (frow & 7)
+                           : ((int64_t)img * a.ho + y0 + wm * 4 + i) * a.wo + x0 + frow;
+    if (MAP8 && img + wm >= ha.n_img) continue;        // odd batch: the second image of the last pair does not exist
 #pragma unroll
     for (int h = 0; h < NT / 2; ++h) {                 // 8 channels = one 16-byte store
       float v[8];
@@ -312,7 +327,7 @@ static int hd_num_cu() {
 //   16 x 16 x 64 when THAT does;
 //   else 8 x 16 x 64 (4 waves, two workgroups per CU) when the map height allows — the small-grid layers (16x16 maps of
 //   a 32-image batch: 32 patches) otherwise leave half the chip idle.
-struct HdPlan { int ph, bn, n_patches, n_wg; };
+struct HdPlan { int ph, bn, n_patches, n_wg; bool map8; };
 
 static HdPlan hd_plan(const imm_conv_desc* d) {
   static const bool no_small = getenv("IMM_HDEEP_NO_SMALL") != nullptr;
@@ -320,6 +335,14 @@ static HdPlan hd_plan(const imm_conv_desc* d) {
   static const int small_below = getenv("IMM_HDEEP_SMALL_BELOW") ? atoi(getenv("IMM_HDEEP_SMALL_BELOW")) : 4;   // x CUs
   static const bool no_big = getenv("IMM_HDEEP_NO_BIG") != nullptr;
   HdPlan p;
+  p.map8 = false;
+  if (d->ho == 8 && d->wo == 8) {                      // two whole 8x8 images per (4-wave) workgroup
+    static const bool no_map8 = getenv("IMM_HDEEP_NO_MAP8") != nullptr;
+    p.ph = 8; p.bn = 64; p.map8 = true;
+    p.n_patches = no_map8 ? 0 : (d->batch + 1) / 2;
+    p.n_wg = p.n_patches * (d->co / 64);
+    return p;
+  }
   const int np16 = (d->ho % 16 == 0) ? d->batch * (d->ho / 16) * (d->wo / HD_PW) : 0;
   if (!no_big && np16 > 0 && d->co % 128 == 0 && np16 * (d->co / 128) >= cus) { p.ph = 16; p.bn = 128; p.n_patches = np16; }
   else if (np16 > 0 && (np16 * (d->co / 64) >= small_below * cus || no_small)) { p.ph = 16; p.bn = 64; p.n_patches = np16; }
@@ -335,7 +358,7 @@ bool imm_hdeep_applicable(const imm_conv_desc* d) {
   if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->updiv != 1 || d->pad_t != 1 || d->pad_l != 1) return false;
   if (d->ci % 64 || d->co % 64 || d->ci < 64) return false;
   if (d->out_scale > 1 || (d->flags & (IMM_CONV_OUT_F32 | 0xf00))) return false;
-  if (d->hi != d->ho || d->wi != d->wo || d->ho % 8 || d->wo % HD_PW) return false;
+  if (d->hi != d->ho || d->wi != d->wo || d->ho % 8 || (d->wo % HD_PW && !(d->ho == 8 && d->wo == 8))) return false;
   if (d->ldy % 8 || ((d->flags & IMM_CONV_MASK) && d->ldmask % 8)) return false;
   const int64_t px = (int64_t)d->batch * d->hi * d->wi;
   if (px * d->ldx * 2 >= (1LL << 31) || (int64_t)d->co * d->kpad * 2 >= (1LL << 31)) return false;
@@ -347,20 +370,22 @@ bool imm_hdeep_applicable(const imm_conv_desc* d) {
 
 int imm_hdeep_stats_blocks(const imm_conv_desc* d) { return hd_plan(d).n_patches; }
 
-template <typename ET, int BN, int NW, int PH>
+template <typename ET, int BN, int NW, int PH, bool MAP8 = false>
 static void hd_launch_cfg(const HdArgs& ha, hipStream_t s) {
-  constexpr int lds = (2 * HD_HSTAGE(PH) + 64 + HD_NSB * BN * 8) * 16;
+  constexpr int hstage = MAP8 ? 25 * 64 : HD_HSTAGE(PH), nsb = MAP8 ? 3 : 4;
+  constexpr int lds = (2 * hstage + 64 + nsb * BN * 8) * 16;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)conv_hdeep_kernel<ET, BN, NW, PH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)conv_hdeep_kernel<ET, BN, NW, PH, MAP8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_hdeep_kernel<ET, BN, NW, PH>), dim3(ha.n_wg), dim3(NW * 64), lds, s, ha);
+  hipLaunchKernelGGL((conv_hdeep_kernel<ET, BN, NW, PH, MAP8>), dim3(ha.n_wg), dim3(NW * 64), lds, s, ha);
 }
 
 template <typename ET>
 static void hd_launch(const HdPlan& p, const HdArgs& ha, hipStream_t s) {
-  if (p.ph == 16 && p.bn == 128) hd_launch_cfg<ET, 128, 8, 16>(ha, s);
+  if (p.map8) hd_launch_cfg<ET, 64, 4, 8, true>(ha, s);
+  else if (p.ph == 16 && p.bn == 128) hd_launch_cfg<ET, 128, 8, 16>(ha, s);
   else if (p.ph == 16) hd_launch_cfg<ET, 64, 8, 16>(ha, s);
   else hd_launch_cfg<ET, 64, 4, 8>(ha, s);
 }
@@ -369,7 +394,8 @@ void imm_conv_hdeep_launch(int dtype, const imm_conv_desc* d, const ConvArgs& a,
   HdArgs ha;
   ha.c = a;
   const HdPlan p = hd_plan(d);
-  ha.patches_x = d->wo / HD_PW; ha.patches_y = d->ho / p.ph;
+  ha.patches_x = p.map8 ? 1 : d->wo / HD_PW; ha.patches_y = p.map8 ? 1 : d->ho / p.ph;
+  ha.n_img = d->batch;
   ha.n_patches = p.n_patches;
   ha.c.n_nblk = d->co / p.bn;
   ha.n_wg = p.n_wg;

@@ -81,6 +81,9 @@ CONV_CASES = [
     # small grids: 8x16 patches, 4 waves, two workgroups per CU
     (32, 16, 128, 128, 256, 3, 1, False, 'hdeep_small_patch'),
     (5, 40, 64, 64, 64, 3, 1, False, 'hdeep_small_patch_h40'),
+    # 8x8 maps (VGG conv5): two whole images per workgroup; odd batch = a half-empty last pair
+    (64, 8, 512, 512, 512, 3, 1, False, 'hdeep_map8'),
+    (33, 8, 128, 128, 256, 3, 1, False, 'hdeep_map8_odd_batch'),
 ]
 
 
@@ -130,9 +133,9 @@ def test_conv_forward(ops, case, dt):
                                           (3, 64, 32, 64, torch.bfloat16), (40, 64, 64, 64, torch.bfloat16),
                                           (3, 128, 64, 64, torch.float16), (36, 64, 32, 32, torch.float16),
                                           (14, 32, 128, 256, torch.bfloat16), (64, 16, 256, 256, torch.float16),
-                                          (24, 16, 128, 256, torch.bfloat16)],
+                                          (24, 16, 128, 256, torch.bfloat16), (51, 8, 128, 256, torch.bfloat16)],
                          ids=['igemm', 'halo64', 'halo32', 'halo64_32', 'halo32_64', 'halo64_persistent', 'halo64_f16',
-                              'halo32_f16_persistent', 'hdeep', 'hdeep_f16', 'hdeep_small_patch'])
+                              'halo32_f16_persistent', 'hdeep', 'hdeep_f16', 'hdeep_small_patch', 'hdeep_map8_odd'])
 def test_conv_relu_stats_mask(ops, B, H, ci, co, dt):
     """Epilogue variants (BN partial sums, ReLU, ReLU-backward mask).  The halo cases run conv_halo2.hip (filter in
     registers, deferred epilogue); the *_persistent cases give every workgroup several patches, i.e. exercise the halo /
