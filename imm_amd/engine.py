@@ -192,6 +192,7 @@ class IMMEngine:
         # timing experiment only (results become wrong): drop every launch whose tag is listed, to measure how much of the
         # step's critical path a kernel class occupies under graph replay / stream concurrency
         self.vgg_split = int(os.environ.get('IMM_VGG_SPLIT', '0')) if self.two_streams else 0
+        self.reduce_per_layer = os.environ.get('IMM_REDUCE_PER_LAYER', '0') != '0'
         self._skip_tags = set(t for t in os.environ.get('IMM_DEBUG_SKIP_TAGS', '').split(',') if t)
         self.wgrad_lane = int(os.environ.get('IMM_WGRAD_LANE', '0')) if self.two_streams else 0
         self._side = None
@@ -419,8 +420,14 @@ class IMMEngine:
         else:
             self._add(self.prog_bwd, lambda: ops.conv2d_wgrad(fd, lay.x, dy, lddy, lay.slab, lay.nsplit), 'conv_wgrad', flops)
         self._cur_lane = lane_save
-        self._reduce_jobs.append(((lay.slab.data_ptr(), gw.data_ptr(), lay.nsplit, k * lay.kw, lay.ci_pad, lay.ci_real, co, fd.kpad),
-                                  k * lay.kw * lay.ci_real * co))
+        job = (lay.slab.data_ptr(), gw.data_ptr(), lay.nsplit, k * lay.kw, lay.ci_pad, lay.ci_real, co, fd.kpad)
+        if self.reduce_per_layer and getattr(self, '_defer_wgrad', None) is None and not self.wgrad_lane:
+            # sum this layer's slabs right away, while they still sit in the 256 MB memory-side cache (one table-driven
+            # launch for all layers at the end reads 467 MB back from HBM)
+            tab1 = ops.JobTable([job], [k * lay.kw * lay.ci_real * co], 64, self.dev)
+            self._add(self.prog_bwd, (lambda tab1=tab1: ops.wgrad_reduce_multi(tab1)), 'wgrad_reduce')
+        else:
+            self._reduce_jobs.append((job, k * lay.kw * lay.ci_real * co))
         if lay.needs_dgrad and dx is not None and getattr(lay, 's2', None) is not None:
             classes = ops.dgrad_s2_class_descs(B, lay.H, lay.W, lay.ci_real, lddx, lddy, lddy, k)
             if os.environ.get('IMM_S2_GROUP', '1') != '0':
@@ -772,8 +779,9 @@ class IMMEngine:
         if deferred is None:
             # renderer gradients are complete: reduce their slabs now so that a data-parallel run can all-reduce this
             # bucket (the tail of the flat gradient buffer) while the encoders' backward is still running
-            self.reduce_tab_ren = ops.JobTable([j for j, _n in self._reduce_jobs], [n for _j, n in self._reduce_jobs], 64, self.dev)
-            self._add(self.prog_bwd, lambda: ops.wgrad_reduce_multi(self.reduce_tab_ren), 'wgrad_reduce', name='renderer')
+            if self._reduce_jobs:
+                self.reduce_tab_ren = ops.JobTable([j for j, _n in self._reduce_jobs], [n for _j, n in self._reduce_jobs], 64, self.dev)
+                self._add(self.prog_bwd, lambda: ops.wgrad_reduce_multi(self.reduce_tab_ren), 'wgrad_reduce', name='renderer')
             self._reduce_jobs = []
         self.n_bwd_bucket0 = len(self.prog_bwd) if deferred is None else None
         self.bucket0_offset = self.tab.offsets[[n for n, _s, _w in self.spec].index('model/renderer/conv_1/w')]
@@ -815,8 +823,9 @@ class IMMEngine:
             self._signal(self.prog_bwd, 'wgrad_done', lane=self.wgrad_lane)
             self._wait(self.prog_bwd, 'wgrad_done', lane=0)
         # one table-driven launch sums every layer's split-K slabs into the flat gradient buffer
-        self.reduce_tab = ops.JobTable([j for j, _n in self._reduce_jobs], [n for _j, n in self._reduce_jobs], 64, self.dev)
-        self._add(self.prog_bwd, lambda: ops.wgrad_reduce_multi(self.reduce_tab), 'wgrad_reduce', name='encoders')
+        if self._reduce_jobs:
+            self.reduce_tab = ops.JobTable([j for j, _n in self._reduce_jobs], [n for _j, n in self._reduce_jobs], 64, self.dev)
+            self._add(self.prog_bwd, lambda: ops.wgrad_reduce_multi(self.reduce_tab), 'wgrad_reduce', name='encoders')
 
     def _encoder_backward(self, layers, d_out, ldd):
         B = self.B
