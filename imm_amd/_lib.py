@@ -12,7 +12,8 @@ import os
 import torch  # noqa: F401  (side effect: loads the ROCm runtime libraries bundled with PyTorch)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libimm_hip.so')
+# IMM_HIP_LIB: another build of the same ABI (A/B timing of kernel changes on one box); default = the in-tree library
+LIB_PATH = os.environ.get('IMM_HIP_LIB') or os.path.join(_HERE, 'libimm_hip.so')
 
 IMM_BF16, IMM_F16 = 0, 1
 CONV_BIAS, CONV_RELU, CONV_STATS, CONV_MASK, CONV_OUT_F32 = 1, 2, 4, 8, 16
