@@ -107,20 +107,32 @@ class TPSPairAugmenter(object):
         self.source = TPSRandomSampler(h, w, rotsd=rotsd[1], scalesd=scalesd[1], transsd=transsd[1], warpsd=warpsd[2:], **kw)
         self._stack = None
 
+    def stack(self, b):
+        """The [B,H,W,4] float32 mask||image staging tensor of this augmenter (channel 0 = mask, 1..3 = image): producers
+        (e.g. imm_resize_crop_u8 in imm_amd/datasets) may fill it directly and call warp_stack()."""
+        h, w = self.target.height, self.target.width
+        if self._stack is None or self._stack.shape[0] != b:
+            self._stack = torch.empty(b, h, w, 4, dtype=torch.float32, device=self.target.device)
+            self._future = torch.empty_like(self._stack)
+        return self._stack
+
+    def warp_stack(self, stack, out_image=None, out_future=None, out_mask=None, w_target=None, w_source=None):
+        b, h, w, _ = stack.shape
+        assert stack is self._stack, 'warp_stack() takes the tensor returned by stack()'
+        wt = self.target.sample_params(b) if w_target is None else w_target
+        ws = self.source.sample_params(b) if w_source is None else w_source
+        out_image = torch.empty(b, h, w, 3, dtype=torch.float32, device=stack.device) if out_image is None else out_image
+        out_future = torch.empty_like(out_image) if out_future is None else out_future
+        out_mask = torch.empty(b, h, w, dtype=torch.float32, device=stack.device) if out_mask is None else out_mask
+        self.target.warp(stack, wt, dst=self._future, dst_c0=out_mask, dst_rest=out_future)
+        self.source.warp(self._future, ws, dst_rest=out_image)
+        return {'image': out_image, 'future_image': out_future, 'mask': out_mask}
+
     def __call__(self, image, mask, out_image=None, out_future=None, out_mask=None, w_target=None, w_source=None):
         """image [B,H,W,3] float32 in [0,255], mask [B,H,W,1] or [B,H,W].  The optional out_* tensors (e.g. the engine's
         in_image / in_future / in_mask) are filled in place."""
         b, h, w, _ = image.shape
-        if self._stack is None or self._stack.shape[0] != b:
-            self._stack = torch.empty(b, h, w, 4, dtype=torch.float32, device=image.device)
-            self._future = torch.empty_like(self._stack)
-        self._stack[..., 0] = mask.reshape(b, h, w)
-        self._stack[..., 1:] = image
-        wt = self.target.sample_params(b) if w_target is None else w_target
-        ws = self.source.sample_params(b) if w_source is None else w_source
-        out_image = torch.empty(b, h, w, 3, dtype=torch.float32, device=image.device) if out_image is None else out_image
-        out_future = torch.empty_like(out_image) if out_future is None else out_future
-        out_mask = torch.empty(b, h, w, dtype=torch.float32, device=image.device) if out_mask is None else out_mask
-        self.target.warp(self._stack, wt, dst=self._future, dst_c0=out_mask, dst_rest=out_future)
-        self.source.warp(self._future, ws, dst_rest=out_image)
-        return {'image': out_image, 'future_image': out_future, 'mask': out_mask}
+        stack = self.stack(b)
+        stack[..., 0] = mask.reshape(b, h, w)
+        stack[..., 1:] = image
+        return self.warp_stack(stack, out_image, out_future, out_mask, w_target, w_source)

@@ -1,0 +1,185 @@
+"""Single-image datasets turned into (image, future_image, mask) pairs by two random thin-plate-spline warps
+(imm/datasets/tps_dataset.py) — host index/sampling logic with the reference's method names, pixel work on the GPU.
+
+Per batch (tps_dataset.py:134-158 + the dataset's `_proc_im_pair`):
+  host   sample_image_pair -> [shuffle] -> batch -> JPEG decode (thread pool)         (PairBatchLoader)
+  GPU    imm_resize_crop_u8: u8 -> float, bilinear align_corners resize, central crop, written as channels 1..3 of the
+         mask||image stack; channel 0 = the smooth border mask (tps_dataset.py:47-67)
+  GPU    imm_tps_warp x2: future = target_warp(stack), image = source_warp(future)     (tps_dataset.py:70-96)
+Landmarks are rescaled on the host exactly as the reference does (they are not warped: `landmarks and tps` is refused,
+tps_dataset.py:28-29)."""
+import os.path as osp
+
+import numpy as np
+import torch
+
+from .. import ops
+from ..data.tps import TPSPairAugmenter
+from .impair_dataset import ImagePairDataset, PairBatchLoader
+
+
+def smooth_step(n, b):
+    """tps_dataset.py:47-50: 0.5 + 0.5 * tanh(linspace(-1, 1, n) / b), float32."""
+    x = np.linspace(-1.0, 1.0, n).astype(np.float32)
+    return (np.float32(0.5) + np.float32(0.5) * np.tanh(x / np.float32(b))).astype(np.float32)
+
+
+def smooth_mask(h, w, margin, step):
+    """tps_dataset.py:53-67: separable mask, 0 on a `margin`-wide border, tanh ramps of `step` pixels, 1 inside."""
+    b = 0.4
+
+    def strip(size):
+        return np.concatenate([np.zeros(margin, np.float32), smooth_step(step, b),
+                               np.ones(size - 2 * margin - 2 * step, np.float32), smooth_step(step, -b),
+                               np.zeros(margin, np.float32)])
+    return strip(h)[:, None] * strip(w)[None]
+
+
+class TPSDataset(ImagePairDataset):
+    LANDMARK_LABELS = {}
+    N_LANDMARKS = 0
+
+    def __init__(self, data_dir, subset, max_samples=None, image_size=[128, 128], order_stream=False, landmarks=False,
+                 tps=True, vertical_points=10, horizontal_points=10, rotsd=[0.0, 5.0], scalesd=[0.0, 0.1],
+                 transsd=[0.1, 0.1], warpsd=[0.001, 0.005, 0.001, 0.01], name='TPSDataset'):
+        super(TPSDataset, self).__init__(data_dir, subset, image_size=image_size, jittering=False, name=name)
+        if landmarks and tps:
+            raise ValueError('Outputing landmarks is not supported with TPS transform.')
+        self._max_samples = max_samples
+        self._order_stream = order_stream
+        self._tps = tps
+        self._tps_args = dict(vertical_points=vertical_points, horizontal_points=horizontal_points, rotsd=tuple(rotsd),
+                              scalesd=tuple(scalesd), transsd=tuple(transsd), warpsd=tuple(warpsd))
+        self._aug = {}           # device -> TPSPairAugmenter (target + source samplers, tps_dataset.py:34-41)
+        self._mask_dev = {}
+        self._staging = None
+        self._images, self._keypoints, self._image_dir = [], None, ''
+
+    def num_samples(self):
+        raise NotImplementedError()
+
+    # -- sample stream (host) -------------------------------------------------------------------------------
+    def _get_smooth_step(self, n, b):
+        return smooth_step(n, b)
+
+    def _get_smooth_mask(self, h, w, margin, step):
+        return smooth_mask(h, w, margin, step)
+
+    def _get_image(self, idx):
+        """tps_dataset.py:99-105: file name, landmarks as (y, x), the dataset's landmark labels."""
+        inputs = {'image': osp.join(self._image_dir, self._images[idx]), 'landmarks': self._keypoints[idx][:, [1, 0]]}
+        inputs.update({k: v for k, v in self.LANDMARK_LABELS.items()})
+        return inputs
+
+    def _get_random_image(self):
+        return self._get_image(np.random.randint(len(self._images)))
+
+    def _get_ordered_stream(self):
+        for i in range(len(self._images)):
+            yield self._get_image(i)
+
+    def sample_image_pair(self):
+        """tps_dataset.py:118-131: random draws forever (or `max_samples` of them); `order_stream` walks the index once
+        (the generator ends when the index or max_samples is exhausted)."""
+        g = self._get_ordered_stream() if self._order_stream else None
+        i_samp = 0
+        while self._max_samples is None or i_samp < self._max_samples:
+            if g is not None:
+                try:
+                    yield next(g)
+                except StopIteration:
+                    return
+            else:
+                yield self._get_random_image()
+            if self._max_samples is not None:
+                i_samp += 1
+
+    # -- dataset-specific geometry ----------------------------------------------------------------------------
+    def _geometry(self):
+        """(resize_size, margin): images are resized to resize_size^2 and the central image_size^2 window starting at
+        `margin` is kept."""
+        return int(self._image_size[0]), 0
+
+    def _proc_landmarks(self, sample, original_hw):
+        return sample.get('landmarks')
+
+    # -- device stage -----------------------------------------------------------------------------------------
+    def _apply_tps(self, stack, device):
+        """tps_dataset.py:70-96 on the filled mask||image stack [B,H,W,4]."""
+        aug = self._aug[str(device)]
+        return aug.warp_stack(stack)
+
+    def _device_batch(self, samples, decoded, device):
+        dev = torch.device(device)
+        if dev.type != 'cuda':
+            from .._lib import ImmHipError
+            raise ImmHipError('the input pipeline\'s pixel stages (resize/crop/TPS) run on the GPU only; device=%s' % device)
+        key = str(dev)
+        b = len(samples)
+        height, width = self._image_size[:2]
+        assert height == width
+        final = int(height)
+        resize_sz, margin = self._geometry()
+        # pack the decoded images back to back (16-byte aligned starts) in pinned memory: one H2D copy per batch
+        sizes = np.array([d.shape[:2] for d in decoded], dtype=np.int32)
+        nbytes = [int(d.size) for d in decoded]
+        offs = np.zeros(b, dtype=np.int64)
+        total = 0
+        for i, n in enumerate(nbytes):
+            offs[i] = total
+            total += (n + 15) & ~15
+        # two pinned staging buffers, alternated: the async H2D copy of batch i may still be reading its buffer while the
+        # host packs batch i+1; a buffer is rewritten only after the event recorded behind its copy has completed
+        if self._staging is None:
+            self._staging, self._staging_ev, self._staging_i = [None, None], [None, None], 0
+        i = self._staging_i = self._staging_i ^ 1
+        if self._staging_ev[i] is not None:
+            self._staging_ev[i].synchronize()
+        if self._staging[i] is None or self._staging[i].numel() < total:
+            self._staging[i] = torch.empty(max(total, 1 << 20), dtype=torch.uint8).pin_memory()
+        stage = self._staging[i].numpy()
+        for d, o, n in zip(decoded, offs, nbytes):
+            assert d.shape[2] == 3 and d.dtype == np.uint8
+            stage[o:o + n] = np.ascontiguousarray(d).reshape(-1)
+        src = self._staging[i][:total].to(dev, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        self._staging_ev[i] = ev
+        offs_d = torch.from_numpy(offs).to(dev, non_blocking=True)
+        hw_d = torch.from_numpy(sizes).to(dev, non_blocking=True)
+        if key not in self._mask_dev:
+            self._mask_dev[key] = torch.from_numpy(self._get_smooth_mask(height, width, 10, 20)).to(dev)
+            if self._tps:
+                self._aug[key] = TPSPairAugmenter((width, height), device=dev, **self._tps_args)
+        mask = self._mask_dev[key]
+        if self._tps:
+            stack = self._aug[key].stack(b)
+            stack[..., 0] = mask
+            ops.resize_crop_u8(src, offs_d, hw_d, 3, (resize_sz, resize_sz), (margin, margin), (final, final), stack[..., 1:])
+            out = self._apply_tps(stack, dev)
+            out['mask'] = out['mask'].unsqueeze(-1)
+        else:
+            image = torch.empty(b, final, final, 3, dtype=torch.float32, device=dev)
+            ops.resize_crop_u8(src, offs_d, hw_d, 3, (resize_sz, resize_sz), (margin, margin), (final, final), image)
+            out = {'image': image, 'future_image': image, 'mask': mask.reshape(1, final, final, 1).expand(b, -1, -1, -1)}
+        # per-sample annotations (host arithmetic, then one small copy)
+        lms = [self._proc_landmarks(s, hw) for s, hw in zip(samples, sizes)]
+        if lms and lms[0] is not None:
+            lm = torch.from_numpy(np.stack(lms).astype(np.float32)).to(dev, non_blocking=True)
+            out['landmarks'] = lm
+            out['future_landmarks'] = lm
+        for k in self._get_sample_dtype().keys():
+            if k in ('image', 'landmarks'):
+                continue
+            out[k] = torch.from_numpy(np.stack([np.asarray(s[k]) for s in samples])).to(dev, non_blocking=True)
+        return out
+
+    def get_dataset(self, batch_size, repeat=False, shuffle=False, num_preprocess_threads=12, keep_aspect=True,
+                    prefetch=True, device=None, rank=0, world=1):
+        """tps_dataset.py:134-158.  Returns an iterable of device batches (dicts of tensors): 'image', 'future_image'
+        [B,S,S,3] float32 in [0,255], 'mask' [B,S,S,1], 'landmarks'/'future_landmarks' [B,N,2] (y, x) pixels, and the
+        dataset's label keys."""
+        if device is None:
+            device = 'cuda:%d' % torch.cuda.current_device()
+        return PairBatchLoader(self, batch_size, repeat=repeat, shuffle=shuffle, num_preprocess_threads=num_preprocess_threads,
+                               prefetch=prefetch, device=device, rank=rank, world=world)

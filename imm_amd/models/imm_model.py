@@ -64,17 +64,29 @@ class IMMModel(BaseModel):
         self.engine = None
 
     # -- engine management ---------------------------------------------------------------------------
+    @staticmethod
+    def _mirror(dst, src):
+        dst.load_parameters(src.named_parameters(), src.named_state())
+        dst.adam_m.copy_(src.adam_m); dst.adam_v.copy_(src.adam_v)
+        dst.step_count.copy_(src.step_count)
+
     def _get_engine(self, batch, size):
+        """One engine (buffers + launch programs) per (batch, size); the variables are shared between instantiations
+        like the reference's reuse_variables: a new engine starts from the current one, and while a TrainStep trains
+        `self._master`, every other engine is refreshed from it when selected (periodic test passes with other batch
+        sizes, cnn_train_multi.py:471-508)."""
         key = (int(batch), int(size))
+        master = getattr(self, '_master', None)
         if key not in self._engines:
             dev = self._device or ('cuda:%d' % torch.cuda.current_device())
             eng = IMMEngine(self._config, batch, size, device=dev, act_dtype=self.dtype, seed=self._seed,
                             vgg_weights=self._vgg_weights, hparams=self._hparams, world_size=self._world_size)
-            if self.engine is not None:      # variables are shared between instantiations (reuse_variables)
-                eng.load_parameters(self.engine.named_parameters(), self.engine.named_state())
-                eng.adam_m.copy_(self.engine.adam_m); eng.adam_v.copy_(self.engine.adam_v)
-                eng.step_count.copy_(self.engine.step_count)
+            src = master if master is not None else self.engine
+            if src is not None:
+                self._mirror(eng, src)
             self._engines[key] = eng
+        elif master is not None and self._engines[key] is not master:
+            self._mirror(self._engines[key], master)
         self.engine = self._engines[key]
         return self.engine
 

@@ -321,6 +321,13 @@ def tps_warp(src, basis_t, w_tps, dst=None, dst_c0=None, dst_rest=None):
          dst.stride(2) if dst is not None else 0, _p(dst_c0), _p(dst_rest), dst_rest.stride(2) if dst_rest is not None else 0, _s())
 
 
+def resize_crop_u8(src_u8, offsets, hw, c, resize_hw, crop_yx, out_hw, dst, ld_dst=None):
+    """src_u8: flat u8 device buffer of packed HWC images; offsets i64 [B]; hw i32 [B,2]; dst f32 view whose element
+    (b,y,x,0) is dst.data_ptr() + ((b*oh+y)*ow+x)*ld_dst floats (include/imm_hip.h: imm_resize_crop_u8)."""
+    call('imm_resize_crop_u8', _p(src_u8), _p(offsets), _p(hw), hw.shape[0], c, resize_hw[0], resize_hw[1], crop_yx[0], crop_yx[1],
+         out_hw[0], out_hw[1], _p(dst), dst.stride(2) if ld_dst is None else ld_dst, _s())
+
+
 def masked_sse_pool(a, b, batch, s, c, mask, S, partial, pool_a, pool_b):
     call('imm_masked_sse_pool', _p(a), _p(b), dtype_enum(a.dtype), batch, s, c, _p(mask), S, _p(partial), _p(pool_a), _p(pool_b), _s())
 

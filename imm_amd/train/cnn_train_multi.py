@@ -12,6 +12,7 @@ optimizer are HIP graphs replayed each step; nothing synchronises with the host 
 BN statistics and the loss normalisers stay rank-local exactly like the reference's per-tower
 statistics (:155, S11).
 """
+import json
 import os
 import time
 
@@ -54,10 +55,11 @@ class TrainStep:
         # 1 GPU (RCCL single rank) the extra graph + collective launch costs 0.25 ms/step and cannot be validated on
         # 8 GPUs from the build box, so the default is ONE all-reduce of the whole 16.6 MB buffer per step.
         self.buckets = int(os.environ.get('IMM_DP_BUCKETS', '1'))
-        if self.buckets >= 2 and self.engine.n_bwd_bucket0 is None:
-            raise ValueError('IMM_DP_BUCKETS=2 needs the renderer gradients reduced early: set IMM_WGRAD_DEFER_REN=0')
         self.group = group
         self.engine = model._get_engine(batch_per_rank, image_size)
+        model._master = self.engine               # the engine whose variables are trained; others mirror it (eval batches)
+        if self.buckets >= 2 and self.engine.n_bwd_bucket0 is None:
+            raise ValueError('IMM_DP_BUCKETS=2 needs the renderer gradients reduced early: set IMM_WGRAD_DEFER_REN=0')
         if abs(self.engine.hp.grad_scale - 1.0 / world_size) > 1e-9:
             raise ValueError('engine was built for world_size %g' % (1.0 / self.engine.hp.grad_scale))
         self.use_graph = use_graph
@@ -118,6 +120,9 @@ class TrainStep:
         with torch.cuda.stream(self.stream):
             if inputs is not None:
                 eng.set_inputs(inputs['image'], inputs['future_image'], inputs.get('mask'))
+                for v in (inputs['image'], inputs['future_image'], inputs.get('mask')):
+                    if torch.is_tensor(v) and v.is_cuda:      # produced on another stream (the loader's): keep the
+                        v.record_stream(self.stream)          # allocator from recycling it before this copy ran
             if self.use_graph:
                 if self._graphs is None:
                     self._capture()
@@ -154,27 +159,93 @@ def setup_training(opts, model_factory, clip_value=None, use_graph=True):
     return TrainStep(model, opts['batch_size'] // world, opts['image_size'], world_size=world, use_graph=use_graph)
 
 
-def train_loop(opts, train_step, data_iter, num_steps, log_every=10, checkpoint_fn=None):
-    """cnn_train_multi.py:371-516 (session loop): step, NaN assert (:463), examples/sec (:466-469),
-    periodic checkpoint (:511-513).  The loss is read back only on logging steps."""
+class SummaryWriter(object):
+    """Scalar summaries as JSON lines in <log_dir>/summaries.jsonl — the counterpart of the tf.summary.FileWriter of
+    cnn_train_multi.py:436,447-452,489,504-508 (scalars only: loss, loss terms, lr, throughput; no image summaries)."""
+
+    def __init__(self, log_dir):
+        os.makedirs(log_dir, exist_ok=True)
+        self.path = os.path.join(log_dir, 'summaries.jsonl')
+        self._f = open(self.path, 'a')
+
+    def add_summary(self, record, step):
+        rec = {'step': int(step), 'time': time.time()}
+        rec.update(record)
+        self._f.write(json.dumps(rec) + '\n')
+
+    def flush(self):
+        self._f.flush()
+
+    def close(self):
+        self._f.close()
+
+
+def run_test_pass(model, test_dataset, step, writer=None, verbose=True):
+    """cnn_train_multi.py:471-508: one pass over the test split in inference mode (BN moving averages), loss per batch;
+    returns the sample-weighted mean loss.  `test_dataset` is re-iterated from its start each time (:478)."""
+    total, count, it_n = 0.0, 0, 0
+    for inputs in test_dataset:
+        t0 = time.time()
+        _, loss, _ = model.build(inputs, training_pl=False, build_loss=True)
+        value = float(loss)
+        n = int(inputs['image'].shape[0])
+        total, count = total + value * n, count + n
+        if verbose:
+            dt = time.time() - t0
+            print('test: step %d, loss = %.4f (%.1f examples/sec) %.3f sec/batch' % (step, value, n / dt, dt))
+        it_n += 1
+    if verbose:
+        print('iteration through test set finished')
+    mean = total / max(count, 1)
+    if writer is not None and count:
+        writer.add_summary({'tag': 'test', 'loss': mean, 'n_samples': count}, step)
+        writer.flush()
+    return mean
+
+
+def train_loop(opts, train_step, data_iter, num_steps, log_every=10, checkpoint_fn=None, test_dataset=None, model=None,
+               summary_writer=None):
+    """cnn_train_multi.py:371-516 (session loop).  Steps run from the restored global step to num_steps (:441-444);
+    NaN assert (:463); examples/sec (:466-469); every opts['n_summary'] steps a scalar summary (:447-452); every
+    opts['n_test'] steps a pass over `test_dataset` in inference mode (:471-508); every opts['n_checkpoint'] steps
+    `checkpoint_fn(step)` (:511-513, `step % n == 0` like the reference, so also at the first step).  Unlike the
+    reference the loss is read back (a device sync) only on logging/summary steps, not every step."""
     t_start, n_seen = time.time(), 0
     rank = int(os.environ.get('RANK', '0'))
-    for step in range(num_steps):
+    eng = train_step.engine
+    start_step = int(eng.step_count)
+    n_summary = int(opts.get('n_summary') or 0)
+    n_test = int(opts.get('n_test') or 0)
+    n_ckpt = int(opts.get('n_checkpoint') or 0)
+    for step in range(start_step, num_steps):
         t0 = time.time()
         loss = train_step.step(next(data_iter))
         n_seen += opts['batch_size']
-        if step % log_every == 0:
+        do_log = (step - start_step) % log_every == 0
+        do_sum = summary_writer is not None and n_summary and step % n_summary == 0
+        if do_log or do_sum:
             train_step.synchronize()
             loss_value = float(loss)
             assert loss_value == loss_value, 'Model diverged with loss = NaN'
-            if rank == 0:
-                dt = time.time() - t0
+            dt = time.time() - t0
+            if rank == 0 and do_log:
                 print('step %d, loss = %.4f (%.1f examples/sec; %.3f sec/batch)' % (step, loss_value,
                                                                                     opts['batch_size'] / dt, dt))
-        if checkpoint_fn is not None and opts.get('n_checkpoint') and (step + 1) % opts['n_checkpoint'] == 0:
+            if rank == 0 and do_sum:
+                summary_writer.add_summary({'tag': 'train', 'loss': loss_value, 'lr': float(eng.lr_state[1]),
+                                            'loss_terms': [float(v) for v in eng.loss_terms],
+                                            'examples_per_sec': opts['batch_size'] / dt}, step)
+                summary_writer.flush()
+        if test_dataset is not None and model is not None and n_test and step % n_test == 0:
             train_step.synchronize()
             if rank == 0:
-                checkpoint_fn(step + 1)
+                run_test_pass(model, test_dataset, step, summary_writer)
+            if train_step.world_size > 1:
+                torch.distributed.barrier(group=train_step.group)
+        if checkpoint_fn is not None and n_ckpt and step % n_ckpt == 0:
+            train_step.synchronize()
+            if rank == 0:
+                checkpoint_fn(step)
     train_step.synchronize()
     if rank == 0:
-        print('Avg. samples per second %.2f' % (n_seen / (time.time() - t_start)))
+        print('Avg. samples per second %.2f' % (n_seen / max(time.time() - t_start, 1e-9)))

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define IMM_ABI_VERSION 2   /* 2: imm_vgg_conv1_1_fwd gained `halves` */
+#define IMM_ABI_VERSION 3   /* 2: imm_vgg_conv1_1_fwd gained `halves` */
 
 enum imm_dtype { IMM_BF16 = 0, IMM_F16 = 1 };
 
@@ -246,6 +246,16 @@ int imm_clip_adam_step(float* params, float* grads, float* m, float* v, const in
  * (the image, e.g. straight into the training step's input buffer). */
 int imm_tps_warp(const float* src, int ld_src, int batch, int h, int w, int c, const float* basis_t, int m3,
                  const float* w_tps, float* dst, int ld_dst, float* dst_c0, float* dst_rest, int ld_rest, void* stream);
+
+/* ---- decoded-image ingest (imm/datasets/celeba_dataset.py:136-174, aflw_dataset.py:81-114: to_float -> bilinear
+ *      align_corners=True resize -> central crop) ---- */
+/* src: `batch` u8 HWC images of different sizes packed in one device buffer, image b at src + offsets[b] with
+ * hw[2b] rows x hw[2b+1] columns x c channels (1 <= c <= 4).  Each is resized (TF1 resize_bilinear, align_corners=True) to
+ * resize_h x resize_w and the window [crop_y0, crop_y0+out_h) x [crop_x0, crop_x0+out_w) of that is written as float32
+ * (values stay in [0, 255]) to dst[b][y][x][0..c-1], pixel stride ld_dst floats (>= c: dst may point at channel 1 of
+ * the mask||image stack imm_tps_warp reads).  Float32 arithmetic in TF's order, unfused: bit-exact vs the host oracle. */
+int imm_resize_crop_u8(const uint8_t* src, const int64_t* offsets, const int32_t* hw, int batch, int c, int resize_h,
+                       int resize_w, int crop_y0, int crop_x0, int out_h, int out_w, float* dst, int ld_dst, void* stream);
 
 #ifdef __cplusplus
 }

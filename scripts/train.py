@@ -3,10 +3,10 @@
     python scripts/train.py --configs configs/paths/default.yaml configs/experiments/celeba-10pts.yaml [--ngpus N]
     torchrun --nnodes=1 --nproc-per-node N scripts/train.py --configs ... --ngpus N      (one process per GPU)
 
-The accelerated part is the training step itself (imm_amd/engine.py -> libimm_hip.so).  The reference's
-tf.data input pipelines (CelebA / AFLW decode + thin-plate-spline warps, imm/datasets/*) are outside this
-build's scope: batches are synthetic unless --data-npz points at pre-rendered pairs
-{image, future_image, mask} stored as float32 NHWC arrays.
+The training step runs on the HIP engine (imm_amd/engine.py -> libimm_hip.so).  Data: by default the dataset the
+config names (`training.dset` + `train_dset_params` / `test_dset_params` under `training.datadir`, like the
+reference: imm_amd/datasets — JPEG decode on host threads, resize/crop/TPS pairs on the GPU); `--synthetic` uses random
+batches instead (no files needed), `--data-npz` pre-rendered pairs {image, future_image, mask} (float32 NHWC).
 """
 from __future__ import print_function
 
@@ -35,15 +35,34 @@ class model_factory():
         return self.network(**self.net_args)
 
 
-def smooth_mask(h, w, margin=10, step=20, b=0.4):
+def smooth_mask(h, w, margin=10, step=20):
     """imm/datasets/tps_dataset.py:47-67."""
-    def sstep(n, bb):
-        return 0.5 + 0.5 * torch.tanh(torch.linspace(-1.0, 1.0, n) / bb)
+    from imm_amd.datasets.tps_dataset import smooth_mask as _m
+    return torch.from_numpy(_m(h, w, margin, step))
 
-    def strip(size):
-        return torch.cat([torch.zeros(margin), sstep(step, b), torch.ones(size - 2 * margin - 2 * step), sstep(step, -b),
-                          torch.zeros(margin)])
-    return strip(h)[:, None] * strip(w)[None]
+
+def dataset_loaders(train_config, batch_per_rank, size, device, rank, world):
+    """scripts/train.py:115-148 of the reference: the training stream (repeat, no shuffle, 12 decode threads) and the
+    test stream (one pass) from the dataset class the config names."""
+    from imm_amd.utils.dataset_import import import_dataset
+    dset_class = import_dataset(train_config.dset)
+    train_params, test_params = {}, {}
+    train_subset, test_subset = 'train', 'test'
+    if hasattr(train_config, 'train_dset_params'):
+        train_params.update(train_config.train_dset_params)
+        train_subset = train_params.pop('subset', train_subset)
+    if hasattr(train_config, 'test_dset_params'):
+        test_params.update(train_config.test_dset_params)
+        test_subset = test_params.pop('subset', test_subset)
+    if hasattr(train_config, 'max_test_samples'):
+        raise ValueError('max_test_samples attribute deprecated')
+    for p in (train_params, test_params):
+        p.setdefault('image_size', [size, size])
+    train = dset_class(train_config.datadir, subset=train_subset, **train_params)
+    test = dset_class(train_config.datadir, subset=test_subset, **test_params)
+    return (train.get_dataset(batch_per_rank, repeat=True, shuffle=False, num_preprocess_threads=12, device=device,
+                              rank=rank, world=world),
+            test.get_dataset(batch_per_rank, repeat=False, shuffle=False, num_preprocess_threads=12, device=device))
 
 
 def synthetic_iter(batch, size, device, seed):
@@ -107,18 +126,28 @@ def main(args):
     size = int(args.image_size)
     factory = model_factory(IMMModel, config=config.model, global_step=None, device=dev, hparams=hparams, world_size=world)
     opts = {'gpu_ids': list(range(args.ngpus)), 'batch_size': batch_size, 'image_size': size,
-            'log_dir': train_config.logdir, 'n_checkpoint': int(train_config.ncheckpoint)}
+            'log_dir': train_config.logdir, 'n_checkpoint': int(train_config.ncheckpoint), 'n_summary': 10,
+            'n_test': int(train_config.n_test) if hasattr(train_config, 'n_test') else 500}
     step = tru.setup_training(opts, factory, clip_value=train_config.gradclip)
     eng = step.engine
     if args.checkpoint is not None and osp.exists(args.checkpoint):
         ck = torch.load(args.checkpoint, map_location='cpu')
         eng.load_parameters(ck['params'], ck.get('state'))
+        if 'step' in ck:                      # global_step is a model variable upstream: restored in both modes
+            eng.step_count.fill_(int(ck['step']))
         if args.restore_optim and 'adam_m' in ck:
-            eng.adam_m.copy_(ck['adam_m']); eng.adam_v.copy_(ck['adam_v']); eng.step_count.fill_(int(ck['step']))
+            eng.adam_m.copy_(ck['adam_m']); eng.adam_v.copy_(ck['adam_v'])
     if args.reset_global_step >= 0:
         eng.step_count.fill_(args.reset_global_step)
     per_rank = batch_size // world
-    data = npz_iter(args.data_npz, per_rank, dev, rank, world) if args.data_npz else synthetic_iter(per_rank, size, dev, rank)
+    test_data = None
+    if args.data_npz:
+        data = npz_iter(args.data_npz, per_rank, dev, rank, world)
+    elif args.synthetic:
+        data = synthetic_iter(per_rank, size, dev, rank)
+    else:
+        train_data, test_data = dataset_loaders(train_config, per_rank, size, dev, rank, world)
+        data = iter(train_data)
     if args.tps:
         ds = getattr(train_config, 'dataset', None)
         data = tps_pair_iter(data, size, dev, ds if ds is not None and hasattr(ds, '__contains__') else None)
@@ -130,7 +159,9 @@ def main(args):
                     'adam_v': eng.adam_v.cpu(), 'step': int(eng.step_count)}, path)
         print('saved', path)
 
-    tru.train_loop(opts, step, data, args.num_steps, log_every=10, checkpoint_fn=save)
+    writer = tru.SummaryWriter(train_config.logdir) if rank == 0 else None
+    tru.train_loop(opts, step, data, args.num_steps, log_every=10, checkpoint_fn=save, test_dataset=test_data,
+                   model=step.model, summary_writer=writer)
 
 
 if __name__ == '__main__':
@@ -145,6 +176,7 @@ if __name__ == '__main__':
     # additions of this build
     parser.add_argument('--num-steps', type=int, default=30000000)
     parser.add_argument('--image-size', type=int, default=128)
+    parser.add_argument('--synthetic', action='store_true', help='random batches instead of the configured dataset')
     parser.add_argument('--data-npz', type=str, default=None, help='optional .npz with image/future_image/mask float32 NHWC arrays')
     parser.add_argument('--tps', action='store_true', help='build (image, future_image, mask) from each batch\'s `image` by two '
                         'random TPS warps on the GPU (imm/datasets/tps_dataset.py)')
