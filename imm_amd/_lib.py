@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get('IMM_HIP_LIB') or os.path.join(_HERE, 'libimm_hip.so')
 IMM_BF16, IMM_F16 = 0, 1
 CONV_BIAS, CONV_RELU, CONV_STATS, CONV_MASK, CONV_OUT_F32 = 1, 2, 4, 8, 16
 SSE_BLOCKS = 512
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class ImmHipError(RuntimeError):
@@ -76,6 +76,7 @@ _SIGS = {
     'imm_vgg_conv1_1_bwd': [_P, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P, _I, _P],
     'imm_tps_warp': [_P, _I, _I, _I, _I, _I, _P, _I, _P, _P, _I, _P, _P, _I, _P],
     'imm_conv2d_group': [_P, _I, _I, _P, _P, _P, _P],
+    'imm_crc32c': [_P, C.c_uint64, C.POINTER(C.c_uint32)],
     'imm_resize_crop_u8': [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P],
     'imm_unpool_tap_grad': [_P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _P, _I, _P],
     'imm_masked_sse_pool': [_P, _P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P],

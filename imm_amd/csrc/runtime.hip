@@ -3,6 +3,7 @@
 // (/root/reference/imm/train/cnn_train_multi.py:459): a whole training-step launch sequence is
 // captured once on the caller's stream and replayed without host work.
 #include "common.h"
+#include <string.h>
 
 thread_local char imm_err_buf[512] = "";
 
@@ -65,5 +66,41 @@ extern "C" int imm_graph_launch(void* graph_exec, void* stream) {
 
 extern "C" int imm_graph_destroy(void* graph_exec) {
   if (graph_exec) (void)hipGraphExecDestroy((hipGraphExec_t)graph_exec);
+  return 0;
+}
+
+// ---- CRC-32C (Castagnoli), host-side: the checksum of TensorFlow's checkpoint bundles (tensor_bundle's per-tensor and
+// per-block crc32c; imm_amd/utils/tf_checkpoint.py reads/writes the authors' `model.ckpt-N.{index,data-*}` files,
+// reference: cnn_train_multi.py:404-439 tf.train.Saver).  Slicing-by-8 tables, reflected polynomial 0x82F63B78.
+namespace {
+struct Crc32cTables {
+  uint32_t t[8][256];
+  Crc32cTables() {
+    for (uint32_t i = 0; i < 256; ++i) {
+      uint32_t c = i;
+      for (int k = 0; k < 8; ++k) c = (c >> 1) ^ (0x82F63B78u & (0u - (c & 1u)));
+      t[0][i] = c;
+    }
+    for (uint32_t i = 0; i < 256; ++i)
+      for (int s = 1; s < 8; ++s) t[s][i] = (t[s - 1][i] >> 8) ^ t[0][t[s - 1][i] & 0xff];
+  }
+};
+}  // namespace
+
+extern "C" int imm_crc32c(const void* data, uint64_t n, uint32_t* crc_inout) {
+  IMM_REQUIRE(crc_inout && (data || n == 0), "crc32c: null pointer");
+  static const Crc32cTables tab;
+  const uint8_t* p = (const uint8_t*)data;
+  uint32_t c = ~*crc_inout;
+  while (n && ((uintptr_t)p & 7)) { c = (c >> 8) ^ tab.t[0][(c ^ *p++) & 0xff]; --n; }
+  while (n >= 8) {
+    uint64_t v = *(const uint64_t*)p;      // p is 8-byte aligned here
+    v ^= c;
+    c = tab.t[7][v & 0xff] ^ tab.t[6][(v >> 8) & 0xff] ^ tab.t[5][(v >> 16) & 0xff] ^ tab.t[4][(v >> 24) & 0xff] ^
+        tab.t[3][(v >> 32) & 0xff] ^ tab.t[2][(v >> 40) & 0xff] ^ tab.t[1][(v >> 48) & 0xff] ^ tab.t[0][(v >> 56) & 0xff];
+    p += 8; n -= 8;
+  }
+  while (n) { c = (c >> 8) ^ tab.t[0][(c ^ *p++) & 0xff]; --n; }
+  *crc_inout = ~c;
   return 0;
 }

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define IMM_ABI_VERSION 3   /* 2: imm_vgg_conv1_1_fwd gained `halves` */
+#define IMM_ABI_VERSION 4   /* 2: imm_vgg_conv1_1_fwd gained `halves` */
 
 enum imm_dtype { IMM_BF16 = 0, IMM_F16 = 1 };
 
@@ -256,6 +256,10 @@ int imm_tps_warp(const float* src, int ld_src, int batch, int h, int w, int c, c
  * the mask||image stack imm_tps_warp reads).  Float32 arithmetic in TF's order, unfused: bit-exact vs the host oracle. */
 int imm_resize_crop_u8(const uint8_t* src, const int64_t* offsets, const int32_t* hw, int batch, int c, int resize_h,
                        int resize_w, int crop_y0, int crop_x0, int out_h, int out_w, float* dst, int ld_dst, void* stream);
+
+/* ---- host utility: CRC-32C of TensorFlow checkpoint bundles (cnn_train_multi.py:404-439 tf.train.Saver files) ---- */
+/* *crc_inout = crc32c(*crc_inout continued over data[0..n)); start with 0.  Host memory, no GPU work. */
+int imm_crc32c(const void* data, uint64_t n, uint32_t* crc_inout);
 
 #ifdef __cplusplus
 }

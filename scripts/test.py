@@ -49,10 +49,12 @@ def main(args):
     net = IMMModel(config.model, device=dev)
     ckpt = args.checkpoint
     if ckpt is None:
-        ckpt = osp.join(config.training.logdir, 'model.ckpt' + ('-%d' % args.iteration if args.iteration is not None else '') + '.pt')
-    if not osp.isfile(ckpt):
+        ckpt = osp.join(config.training.logdir, 'model.ckpt' + ('-%d' % args.iteration if args.iteration is not None else ''))
+        if not osp.isfile(ckpt + '.index'):
+            ckpt += '.pt'
+    is_tf = osp.isfile(ckpt + '.index')       # a TensorFlow bundle prefix (the authors' released checkpoints)
+    if not is_tf and not osp.isfile(ckpt):
         raise ValueError('Checkpoint file %s not found.' % ckpt)
-    ck = torch.load(ckpt, map_location='cpu')
     if args.train_npz is not None:
         first = min(args.batch_size, np.load(args.train_npz)['image'].shape[0])
         train_it = npz_batches(args.train_npz, args.batch_size, dev)
@@ -63,7 +65,13 @@ def main(args):
         first = min(args.batch_size, train_dset.num_samples())
         train_it = train_dset.get_dataset(args.batch_size, repeat=False, shuffle=False, device=dev)
         test_it = test_dset.get_dataset(args.batch_size, repeat=False, shuffle=False, device=dev)
-    net._get_engine(first, args.im_size).load_parameters(ck['params'], ck.get('state'))
+    eng = net._get_engine(first, args.im_size)
+    if is_tf:
+        from imm_amd.utils.tf_checkpoint import load_tf_checkpoint
+        load_tf_checkpoint(eng, ckpt)
+    else:
+        ck = torch.load(ckpt, map_location='cpu')
+        eng.load_parameters(ck['params'], ck.get('state'))
     err = eval_imm.evaluate_regression(net, train_it, test_it, [args.im_size, args.im_size], batch_size=args.batch_size,
                                        bias=args.bias)
     model_dataset = config.training.train_dset_params.dataset if hasattr(config.training, 'train_dset_params') and \

@@ -130,13 +130,21 @@ def main(args):
             'n_test': int(train_config.n_test) if hasattr(train_config, 'n_test') else 500}
     step = tru.setup_training(opts, factory, clip_value=train_config.gradclip)
     eng = step.engine
-    if args.checkpoint is not None and osp.exists(args.checkpoint):
+    if args.checkpoint is not None and osp.exists(args.checkpoint + '.index'):
+        # a TensorFlow bundle (the authors' released checkpoints, or one written by --tf-checkpoints)
+        from imm_amd.utils.tf_checkpoint import load_tf_checkpoint
+        skipped = load_tf_checkpoint(eng, args.checkpoint, restore_optim=args.restore_optim,
+                                     ignore_missing_vars=args.ignore_missing_vars)
+        print('RESTORING MODEL from: %s (TensorFlow bundle%s)' % (args.checkpoint, '; %d variables not found' % len(skipped) if skipped else ''))
+    elif args.checkpoint is not None and osp.exists(args.checkpoint):
         ck = torch.load(args.checkpoint, map_location='cpu')
         eng.load_parameters(ck['params'], ck.get('state'))
         if 'step' in ck:                      # global_step is a model variable upstream: restored in both modes
             eng.step_count.fill_(int(ck['step']))
         if args.restore_optim and 'adam_m' in ck:
             eng.adam_m.copy_(ck['adam_m']); eng.adam_v.copy_(ck['adam_v'])
+    elif args.checkpoint is not None:
+        print('No checkpoint at %s. Initializing randomly.' % args.checkpoint)
     if args.reset_global_step >= 0:
         eng.step_count.fill_(args.reset_global_step)
     per_rank = batch_size // world
@@ -158,6 +166,9 @@ def main(args):
         torch.save({'params': eng.named_parameters(), 'state': eng.named_state(), 'adam_m': eng.adam_m.cpu(),
                     'adam_v': eng.adam_v.cpu(), 'step': int(eng.step_count)}, path)
         print('saved', path)
+        if args.tf_checkpoints:
+            from imm_amd.utils.tf_checkpoint import save_tf_checkpoint
+            save_tf_checkpoint(eng, osp.join(train_config.logdir, 'model.ckpt-%d' % n))
 
     writer = tru.SummaryWriter(train_config.logdir) if rank == 0 else None
     tru.train_loop(opts, step, data, args.num_steps, log_every=10, checkpoint_fn=save, test_dataset=test_data,
@@ -176,6 +187,8 @@ if __name__ == '__main__':
     # additions of this build
     parser.add_argument('--num-steps', type=int, default=30000000)
     parser.add_argument('--image-size', type=int, default=128)
+    parser.add_argument('--tf-checkpoints', action='store_true', help='also write TensorFlow bundles model.ckpt-N.{index,data-*} '
+                        '(variable names of the reference graph, readable by tf.train.Saver)')
     parser.add_argument('--synthetic', action='store_true', help='random batches instead of the configured dataset')
     parser.add_argument('--data-npz', type=str, default=None, help='optional .npz with image/future_image/mask float32 NHWC arrays')
     parser.add_argument('--tps', action='store_true', help='build (image, future_image, mask) from each batch\'s `image` by two '

@@ -210,10 +210,19 @@ def test_train_and_test_scripts_on_dataset_tree(celeba, tmp_path, capsys):
     ck = torch.load(logs / 'model.ckpt-2.pt', map_location='cpu')
     assert ck['step'] == 3
     # resume: the loop continues at the restored global step (3) and stops at num_steps (5)
-    _run_script(train_py, ['--configs', cfg, '--num-steps', '5', '--checkpoint', str(logs / 'model.ckpt-2.pt'), '--restore-optim'])
+    _run_script(train_py, ['--configs', cfg, '--num-steps', '5', '--checkpoint', str(logs / 'model.ckpt-2.pt'), '--restore-optim',
+                           '--tf-checkpoints'])
     out = capsys.readouterr().out
     assert 'step 3, loss' in out and 'step 0, loss' not in out and (logs / 'model.ckpt-4.pt').exists()
     assert torch.load(logs / 'model.ckpt-4.pt', map_location='cpu')['step'] == 5
+    # TensorFlow bundles next to the .pt files; resuming from the bundle prefix continues at its global step
+    assert (logs / 'model.ckpt-4.index').exists() and (logs / 'model.ckpt-4.data-00000-of-00001').exists()
+    _run_script(train_py, ['--configs', cfg, '--num-steps', '6', '--checkpoint', str(logs / 'model.ckpt-4'), '--restore-optim'])
+    out = capsys.readouterr().out
+    assert 'TensorFlow bundle' in out and 'step 5, loss' in out and 'step 4, loss' not in out
+    _run_script(os.path.join(repo, 'scripts', 'test.py'), ['--configs', cfg, '--train-dataset', 'mafl', '--test-dataset', 'mafl',
+                                                           '--iteration', '4', '--batch-size', '4'])
+    assert 'error on mafl datset test set:' in capsys.readouterr().out
     _run_script(os.path.join(repo, 'scripts', 'test.py'), ['--configs', cfg, '--train-dataset', 'mafl', '--test-dataset', 'mafl',
                                                            '--checkpoint', str(logs / 'model.ckpt-4.pt'), '--batch-size', '4'])
     out = capsys.readouterr().out
