@@ -9,8 +9,8 @@ folded into the convolution: sigma = sqrt(1e-5 + var/scale), mu = mean/scale, W 
 b = (b - mu) / sigma.
 
 File formats: `.npz` (either the final keys `vgg16/conv1_1/weights` ... or caffe-style `conv1_1/0`, `batch_conv1_1/2`
-...) and the original `.h5` (deepdish layout `/data/<layer>/<idx>`), which needs `h5py` — not installed in the build
-image, so that branch raises ImportError with the conversion hint instead of guessing."""
+...) and the original `.h5` (Caffe HDF5 snapshot, `/data/<layer>/<blob index>`) through the pure-Python reader
+imm_amd/utils/hdf5_lite.py (no h5py / libhdf5 needed)."""
 import numpy as np
 
 VGG_CONV_LAYERS = ('conv1_1', 'conv1_2', 'conv2_1', 'conv2_2', 'conv3_1', 'conv3_2', 'conv3_3',
@@ -70,15 +70,12 @@ def load_vgg16(path, fold_bn=True):
         else:
             arrs = from_caffe_blobs(_nest({k: flat[k] for k in flat.files}), fold_bn=fold_bn)
     elif path.endswith('.h5') or path.endswith('.hdf5'):
-        try:
-            import h5py
-        except ImportError:
-            raise ImportError('reading %s needs h5py, which is not installed here: convert the file once on a machine that '
-                              'has it (python -c "import h5py, numpy as np; f=h5py.File(p); np.savez(out, **{g+\'/\'+k: f[\'data\'][g][k][()] '
-                              'for g in f[\'data\'] for k in f[\'data\'][g]})") and pass the .npz' % path)
-        with h5py.File(path, 'r') as f:
-            root = f['data'] if 'data' in f else f
-            data = {g: {k: root[g][k][()] for k in root[g]} for g in root}
+        # pure-Python reader (imm_amd/utils/hdf5_lite.py): the Caffe snapshot layout /data/<layer>/<blob index>, what the
+        # reference gets from deepdish.io.load (vgg16.py:74-92)
+        from .hdf5_lite import H5File
+        tree = H5File(path).load('/')
+        root = tree['data'] if 'data' in tree else tree
+        data = {g: {k: np.asarray(v) for k, v in blobs.items()} for g, blobs in root.items() if isinstance(blobs, dict)}
         arrs = from_caffe_blobs(data, fold_bn=fold_bn)
     else:
         raise ValueError('unknown VGG16 weight file type: %s' % path)
