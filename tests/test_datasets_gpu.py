@@ -253,3 +253,36 @@ def test_periodic_test_pass_sees_trained_weights(celeba):
     assert other is not ts.engine and int(other.step_count) == 4
     assert torch.equal(other.params, ts.engine.params)
     assert l0 != l1
+
+
+def test_visualize_script(celeba, tmp_path, capsys):
+    """scripts/visualize.py (examples/visualize.ipynb upstream): images from a folder -> landmarks drawn on a sheet."""
+    from PIL import Image
+    from imm_amd.models.imm_model import IMMModel
+    from imm_amd.utils import tf_checkpoint as T
+    from imm_amd.utils.box import Box
+    from oracle import imm_oracle as O
+    root, names, pixels = celeba
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    imdir = tmp_path / 'faces'
+    imdir.mkdir()
+    for n in names[:5]:
+        Image.fromarray(pixels[n]).save(imdir / (n[:-4] + '.png'))
+    eng = IMMModel(Box(dict(O.default_model_config(10))), dtype=torch.bfloat16, device=DEV)._get_engine(5, 128)
+    ckpt = str(tmp_path / 'model.ckpt')
+    T.save_tf_checkpoint(eng, ckpt, with_optimizer=False)
+    out_png, out_npy = str(tmp_path / 'sheet.png'), str(tmp_path / 'lm.npy')
+    _run_script(os.path.join(repo, 'scripts', 'visualize.py'), [
+        '--configs', os.path.join(repo, 'tests', 'configs', 'paths.yaml'), os.path.join(repo, 'tests', 'configs', 'smoke-10pts.yaml'),
+        '--images-dir', str(imdir), '--checkpoint', ckpt, '--out', out_png, '--save-landmarks', out_npy])
+    assert 'wrote' in capsys.readouterr().out
+    sheet = Image.open(out_png)
+    assert sheet.size == (4 * 384, 2 * 384)                      # 5 images: 4 columns x 2 rows of 3x-enlarged tiles
+    lm = np.load(out_npy)
+    assert lm.shape == (5, 10, 2) and (lm >= 0).all() and (lm <= 128).all()
+    # same landmarks as the engine run directly on the PIL-resized images
+    imgs = np.stack([np.array(Image.fromarray(pixels[n]).resize((128, 128)), dtype=np.float32) for n in names[:5]])
+    x = torch.from_numpy(imgs).to(DEV)
+    eng.set_inputs(x, x, torch.ones(5, 128, 128, 1)); eng.forward_model_only(False)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(lm, ((eng.mu.float().cpu().numpy() + 1) / 2) * 128, atol=1e-3)
