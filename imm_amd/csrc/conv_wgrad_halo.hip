@@ -199,20 +199,33 @@ static bool wh_plan(const imm_conv_desc* d, int lddy, WhPlan* pl) {
     cs = d->ci; ns = lddy;
     pl->nci = 1; pl->nco = 1;
   } else {
-    // 32-channel slices of deeper filters.  Measured (tools/bench_conv.py --wgrad): a win at 64x64 (renderer conv_5,
-    // 65 -> 45 us: 32 patches per workgroup), a loss at 32x32 / 16x16 where a workgroup sees only 2-16 patches and the
-    // transpose-read kernel with its larger tiles is faster => the default only takes maps >= 64x64.
+    // Channel slices of deeper filters: X is fetched co/ns times and dY ci/cs times.  32-slices (default) pay off at
+    // >= 64x64 maps only (renderer conv_5: 65 -> 45 us; below, a workgroup sees too few patches and the transpose-read
+    // kernel with its larger tiles is faster).  64x64 slices (IMM_WGRAD_HALO_SLICE=64) are faster per launch wherever both
+    // channel counts allow (tools/wgrad_sweep.sh: conv_5 45 -> 31 us, 32^2 128->128 29.7 -> 20.3, 32^2 256->128 36.4 -> 30.6,
+    // 16^2 256->256 23.2 -> 20.4) but SLOWER per training step (3.747 -> 3.785 ms, same box, either split count): the filter
+    // gradients run on the second stream under the data-gradient chain, which is the critical path, and the 4x larger slab
+    // traffic of 2-block layers (nsplit 128 vs 32; wgrad_reduce 0.144 -> 0.180 ms) costs more there than the shorter
+    // launches give back => off by default.
     if (d->co % 32 || lddy < d->co) return false;
+    static const int slice = getenv("IMM_WGRAD_HALO_SLICE") ? atoi(getenv("IMM_WGRAD_HALO_SLICE")) : 32;
+    static const int min64 = getenv("IMM_WGRAD_HALO_SLICE64_MIN") ? atoi(getenv("IMM_WGRAD_HALO_SLICE64_MIN")) : 16;
     static const int min_side = getenv("IMM_WGRAD_HALO_SLICE_MIN") ? atoi(getenv("IMM_WGRAD_HALO_SLICE_MIN")) : 64;
-    if (d->ho * d->wo < min_side * min_side) return false;
-    cs = 32; ns = 32;
-    pl->nci = d->ci / 32; pl->nco = d->co / 32;
+    if (slice == 64 && d->ci % 64 == 0 && d->co % 64 == 0 && d->ho * d->wo >= min64 * min64) {
+      cs = 64; ns = 64;
+    } else {
+      if (d->ho * d->wo < min_side * min_side) return false;
+      cs = 32; ns = 32;
+    }
+    pl->nci = d->ci / cs; pl->nco = d->co / ns;
   }
   pl->cs = cs; pl->ns = ns;
   const int blocks = pl->nci * pl->nco;
   static const int per_cu = getenv("IMM_WGRAD_HALO_PER_CU") ? atoi(getenv("IMM_WGRAD_HALO_PER_CU")) : 2;
   int grid = per_cu * wh_num_cu();
   if (blocks > 1) grid = wh_num_cu();                  // sliced layers: slab bytes = nsplit x |dW|, keep nsplit small
+  static const int grid64 = getenv("IMM_WGRAD_HALO_GRID64") ? atoi(getenv("IMM_WGRAD_HALO_GRID64")) : 0;
+  if (blocks > 1 && cs == 64 && grid64 > 0) grid = grid64;
   int nsplit = (grid + blocks - 1) / blocks;
   const int min_patches = blocks > 1 ? 2 : 4;          // patches per workgroup that amortise its slab write
   if (nsplit > n_patches / min_patches) nsplit = n_patches / min_patches;
