@@ -206,12 +206,16 @@ static bool wh_plan(const imm_conv_desc* d, int lddy, WhPlan* pl) {
     // 16^2 256->256 23.2 -> 20.4) but SLOWER per training step (3.747 -> 3.785 ms, same box, either split count): the filter
     // gradients run on the second stream under the data-gradient chain, which is the critical path, and the 4x larger slab
     // traffic of 2-block layers (nsplit 128 vs 32; wgrad_reduce 0.144 -> 0.180 ms) costs more there than the shorter
-    // launches give back => off by default.
+    // launches give back => off by default.  Restricting 64-slices to the small maps (=6400) is neutral (3.734 vs 3.731 ms):
+    // their split counts grow too (16^2: 15 -> 64), the reduction eats the gain.
     if (d->co % 32 || lddy < d->co) return false;
     static const int slice = getenv("IMM_WGRAD_HALO_SLICE") ? atoi(getenv("IMM_WGRAD_HALO_SLICE")) : 32;
     static const int min64 = getenv("IMM_WGRAD_HALO_SLICE64_MIN") ? atoi(getenv("IMM_WGRAD_HALO_SLICE64_MIN")) : 16;
     static const int min_side = getenv("IMM_WGRAD_HALO_SLICE_MIN") ? atoi(getenv("IMM_WGRAD_HALO_SLICE_MIN")) : 64;
-    if (slice == 64 && d->ci % 64 == 0 && d->co % 64 == 0 && d->ho * d->wo >= min64 * min64) {
+    // IMM_WGRAD_HALO_SLICE=6400: 64-slices only BELOW the 32-slice threshold (the layers the transpose-read kernel
+    // takes otherwise; their split count, hence slab traffic, stays about the same)
+    const bool small_map = d->ho * d->wo < min_side * min_side;
+    if ((slice == 64 || (slice == 6400 && small_map)) && d->ci % 64 == 0 && d->co % 64 == 0 && d->ho * d->wo >= min64 * min64) {
       cs = 64; ns = 64;
     } else {
       if (d->ho * d->wo < min_side * min_side) return false;
