@@ -43,6 +43,32 @@ def sample_tps_w(hc, wc, warpsd, rotsd, scalesd, transsd, rng=np.random):
     return np.concatenate([w, aff], 0)
 
 
+class TPSParamCache(object):
+    """Host side of the reference's sampler (tps_sampler.py:12-74): random TPS parameters with its cache policy; no
+    device state, so it can live in a loader process."""
+
+    def __init__(self, vertical_points=10, horizontal_points=10, rotsd=0.0, scalesd=0.0, transsd=0.1,
+                 warpsd=(0.001, 0.005), cache_size=1000, cache_evict_prob=0.01, rng=None):
+        self.vertical_points, self.horizontal_points = int(vertical_points), int(horizontal_points)
+        self.rotsd, self.scalesd, self.transsd, self.warpsd = rotsd, scalesd, transsd, tuple(warpsd)
+        self.cache_size, self.cache_evict_prob = int(cache_size), float(cache_evict_prob)
+        self.rng = rng
+        self.cache = [None] * self.cache_size
+
+    def _sample_w(self):
+        return sample_tps_w(self.vertical_points, self.horizontal_points, self.warpsd, self.rotsd, self.scalesd,
+                            self.transsd, self.rng if self.rng is not None else np.random).astype(np.float32)
+
+    def sample(self, batch_size):
+        ws = []
+        for _ in range(batch_size):
+            slot = random.randint(0, self.cache_size - 1)
+            if self.cache[slot] is None or random.random() < self.cache_evict_prob:
+                self.cache[slot] = self._sample_w()
+            ws.append(self.cache[slot])
+        return np.stack(ws)
+
+
 class TPSRandomSampler(object):
     """Random TPS warps of NHWC float32 device batches.  `pad=True` (replicate-pad by half the size, warp, crop) is not
     used by the reference's datasets and is not implemented."""
@@ -57,26 +83,20 @@ class TPSRandomSampler(object):
         self.rotsd, self.scalesd, self.transsd, self.warpsd = rotsd, scalesd, transsd, tuple(warpsd)
         self.cache_size, self.cache_evict_prob = int(cache_size), float(cache_evict_prob)
         self.device = torch.device(device)
-        self.rng = rng if rng is not None else np.random
-        self.cache = [None] * self.cache_size
+        self.params = TPSParamCache(self.vertical_points, self.horizontal_points, rotsd, scalesd, transsd, self.warpsd,
+                                    self.cache_size, self.cache_evict_prob, rng)
         self.m3 = self.vertical_points * self.horizontal_points + 3
         self.basis_t = torch.from_numpy(tps_basis_t(self.height, self.width, self.vertical_points,
                                                     self.horizontal_points)).to(self.device)
 
-    def _sample_w(self):
-        return sample_tps_w(self.vertical_points, self.horizontal_points, self.warpsd, self.rotsd, self.scalesd,
-                            self.transsd, self.rng).astype(np.float32)
+    def sample_params_host(self, batch_size):
+        """[B, M+3, 2] float32 numpy.  Cache policy of the reference (tps_sampler.py:60-74): a random slot per sample,
+        refilled when empty or with probability cache_evict_prob."""
+        return self.params.sample(batch_size)
 
     def sample_params(self, batch_size):
-        """[B, M+3, 2] float32 on the device.  Cache policy of the reference (tps_sampler.py:60-74): a random slot per
-        sample, refilled when empty or with probability cache_evict_prob."""
-        ws = []
-        for _ in range(batch_size):
-            slot = random.randint(0, self.cache_size - 1)
-            if self.cache[slot] is None or random.random() < self.cache_evict_prob:
-                self.cache[slot] = self._sample_w()
-            ws.append(self.cache[slot])
-        return torch.from_numpy(np.stack(ws)).to(self.device)
+        """The same on the device."""
+        return torch.from_numpy(self.sample_params_host(batch_size)).to(self.device)
 
     def warp(self, x, w_tps, dst=None, dst_c0=None, dst_rest=None):
         """x [B,H,W,C] float32 NHWC on the device, w_tps [B, M+3, 2].  Writes any of: dst (all channels), dst_c0

@@ -50,7 +50,8 @@ class TPSDataset(ImagePairDataset):
         self._tps = tps
         self._tps_args = dict(vertical_points=vertical_points, horizontal_points=horizontal_points, rotsd=tuple(rotsd),
                               scalesd=tuple(scalesd), transsd=tuple(transsd), warpsd=tuple(warpsd))
-        self._aug = {}           # device -> TPSPairAugmenter (target + source samplers, tps_dataset.py:34-41)
+        self._aug = {}           # device -> TPSPairAugmenter (the two device-side warps, tps_dataset.py:34-41)
+        self._tps_host = None    # host-side parameter caches of the two samplers
         self._mask_dev = {}
         self._staging = None
         self._images, self._keypoints, self._image_dir = [], None, ''
@@ -109,18 +110,27 @@ class TPSDataset(ImagePairDataset):
         aug = self._aug[str(device)]
         return aug.warp_stack(stack)
 
-    def _device_batch(self, samples, decoded, device):
-        dev = torch.device(device)
-        if dev.type != 'cuda':
-            from .._lib import ImmHipError
-            raise ImmHipError('the input pipeline\'s pixel stages (resize/crop/TPS) run on the GPU only; device=%s' % device)
-        key = str(dev)
+    def __getstate__(self):
+        """Picklable for the loader process: device-side members are rebuilt lazily where they are needed."""
+        st = dict(self.__dict__)
+        st['_aug'], st['_mask_dev'], st['_staging'] = {}, {}, None
+        return st
+
+    def _host_samplers(self):
+        """(target, source) host-side TPS parameter caches (tps_dataset.py:34-41)."""
+        if getattr(self, '_tps_host', None) is None:
+            from ..data.tps import TPSParamCache
+            a = self._tps_args
+            kw = dict(vertical_points=a['vertical_points'], horizontal_points=a['horizontal_points'])
+            self._tps_host = (TPSParamCache(rotsd=a['rotsd'][0], scalesd=a['scalesd'][0], transsd=a['transsd'][0], warpsd=a['warpsd'][:2], **kw),
+                              TPSParamCache(rotsd=a['rotsd'][1], scalesd=a['scalesd'][1], transsd=a['transsd'][1], warpsd=a['warpsd'][2:], **kw))
+        return self._tps_host
+
+    def _host_pack(self, samples, decoded, out=None):
+        """Everything of a batch that is host arithmetic, as plain numpy: the decoded images packed back to back
+        (16-byte aligned starts) into `out` (a u8 buffer; allocated when None), their offsets and sizes, the TPS parameters
+        of both warps (target first, like the reference draws them), rescaled landmarks and the label columns."""
         b = len(samples)
-        height, width = self._image_size[:2]
-        assert height == width
-        final = int(height)
-        resize_sz, margin = self._geometry()
-        # pack the decoded images back to back (16-byte aligned starts) in pinned memory: one H2D copy per batch
         sizes = np.array([d.shape[:2] for d in decoded], dtype=np.int32)
         nbytes = [int(d.size) for d in decoded]
         offs = np.zeros(b, dtype=np.int64)
@@ -128,58 +138,125 @@ class TPSDataset(ImagePairDataset):
         for i, n in enumerate(nbytes):
             offs[i] = total
             total += (n + 15) & ~15
-        # two pinned staging buffers, alternated: the async H2D copy of batch i may still be reading its buffer while the
-        # host packs batch i+1; a buffer is rewritten only after the event recorded behind its copy has completed
+        if out is None:
+            out = np.empty(total, np.uint8)
+        if out.size < total:
+            raise ValueError('batch of %d bytes does not fit the %d-byte staging slot' % (total, out.size))
+        for d, o, n in zip(decoded, offs, nbytes):
+            assert d.shape[2] == 3 and d.dtype == np.uint8
+            out[o:o + n] = d.reshape(-1)
+        meta = {'n': b, 'total': total, 'offsets': offs, 'sizes': sizes}
+        if self._tps:
+            tgt, src = self._host_samplers()
+            meta['w_target'] = tgt.sample(b)
+            meta['w_source'] = src.sample(b)
+        lms = [self._proc_landmarks(s, hw) for s, hw in zip(samples, sizes)]
+        if lms and lms[0] is not None:
+            meta['landmarks'] = np.stack(lms).astype(np.float32)
+        for k in self._get_sample_dtype().keys():
+            if k not in ('image', 'landmarks'):
+                meta[k] = np.stack([np.asarray(s[k]) for s in samples])
+        return out, meta
+
+    def _device_stage(self, packed, meta, device):
+        """packed: u8 numpy view holding meta['total'] bytes (pageable: copied into pinned staging here; the pinned
+        buffers are alternated and guarded by events)."""
+        dev = torch.device(device)
+        if dev.type != 'cuda':
+            from .._lib import ImmHipError
+            raise ImmHipError('the input pipeline\'s pixel stages (resize/crop/TPS) run on the GPU only; device=%s' % device)
+        key = str(dev)
+        b, total = int(meta['n']), int(meta['total'])
+        height, width = self._image_size[:2]
+        assert height == width
+        final = int(height)
+        resize_sz, margin = self._geometry()
+        # The loader has its own (non-blocking) stream: issued on the legacy default stream its copies and kernels would wait
+        # for the blocking streams a replayed training graph runs on — the H2D of batch i+1 could not start before step i
+        # had finished, and any pageable copy would stall the host for that long (measured: 6.6 k images/s from files vs
+        # 8.6 k resident).  Everything the batch needs on the device travels in ONE pinned buffer (pixels, offsets, sizes,
+        # TPS parameters, landmarks, labels): one async H2D per batch, nothing pageable.  Two such buffers are alternated; a
+        # buffer is rewritten only after the event recorded behind its copy has completed.
         if self._staging is None:
-            self._staging, self._staging_ev, self._staging_i = [None, None], [None, None], 0
+            self._staging, self._staging_ev, self._staging_i, self._streams = [None, None], [None, None], 0, {}
+        if key not in self._streams:
+            self._streams[key] = torch.cuda.Stream(device=dev)
+        st = self._streams[key]
         i = self._staging_i = self._staging_i ^ 1
         if self._staging_ev[i] is not None:
             self._staging_ev[i].synchronize()
-        if self._staging[i] is None or self._staging[i].numel() < total:
-            self._staging[i] = torch.empty(max(total, 1 << 20), dtype=torch.uint8).pin_memory()
-        stage = self._staging[i].numpy()
-        for d, o, n in zip(decoded, offs, nbytes):
-            assert d.shape[2] == 3 and d.dtype == np.uint8
-            stage[o:o + n] = np.ascontiguousarray(d).reshape(-1)
-        src = self._staging[i][:total].to(dev, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(dev))
-        self._staging_ev[i] = ev
-        offs_d = torch.from_numpy(offs).to(dev, non_blocking=True)
-        hw_d = torch.from_numpy(sizes).to(dev, non_blocking=True)
-        if key not in self._mask_dev:
-            self._mask_dev[key] = torch.from_numpy(self._get_smooth_mask(height, width, 10, 20)).to(dev)
-            if self._tps:
-                self._aug[key] = TPSPairAugmenter((width, height), device=dev, **self._tps_args)
-        mask = self._mask_dev[key]
+        small = [('offsets', np.ascontiguousarray(meta['offsets'], dtype=np.int64)), ('sizes', np.ascontiguousarray(meta['sizes'], dtype=np.int32))]
         if self._tps:
-            stack = self._aug[key].stack(b)
-            stack[..., 0] = mask
-            ops.resize_crop_u8(src, offs_d, hw_d, 3, (resize_sz, resize_sz), (margin, margin), (final, final), stack[..., 1:])
-            out = self._apply_tps(stack, dev)
-            out['mask'] = out['mask'].unsqueeze(-1)
-        else:
-            image = torch.empty(b, final, final, 3, dtype=torch.float32, device=dev)
-            ops.resize_crop_u8(src, offs_d, hw_d, 3, (resize_sz, resize_sz), (margin, margin), (final, final), image)
-            out = {'image': image, 'future_image': image, 'mask': mask.reshape(1, final, final, 1).expand(b, -1, -1, -1)}
-        # per-sample annotations (host arithmetic, then one small copy)
-        lms = [self._proc_landmarks(s, hw) for s, hw in zip(samples, sizes)]
-        if lms and lms[0] is not None:
-            lm = torch.from_numpy(np.stack(lms).astype(np.float32)).to(dev, non_blocking=True)
-            out['landmarks'] = lm
-            out['future_landmarks'] = lm
+            small += [('w_target', np.ascontiguousarray(meta['w_target'], dtype=np.float32)),
+                      ('w_source', np.ascontiguousarray(meta['w_source'], dtype=np.float32))]
+        if 'landmarks' in meta:
+            small.append(('landmarks', np.ascontiguousarray(meta['landmarks'], dtype=np.float32)))
         for k in self._get_sample_dtype().keys():
-            if k in ('image', 'landmarks'):
-                continue
-            out[k] = torch.from_numpy(np.stack([np.asarray(s[k]) for s in samples])).to(dev, non_blocking=True)
+            if k in meta and k not in ('image', 'landmarks'):
+                a = np.ascontiguousarray(meta[k])
+                small.append((k, a.astype(np.int32) if a.dtype.kind in 'iu' and a.dtype.itemsize != 8 else a))
+        pix = (total + 15) & ~15
+        need = pix + sum((a.nbytes + 15) & ~15 for _k, a in small)
+        if self._staging[i] is None or self._staging[i].numel() < need:
+            self._staging[i] = torch.empty(max(need, 1 << 20), dtype=torch.uint8).pin_memory()
+        stage = self._staging[i].numpy()
+        stage[:total] = packed[:total]
+        pos, where = pix, {}
+        for k, a in small:
+            stage[pos:pos + a.nbytes] = a.view(np.uint8).reshape(-1)
+            where[k] = (pos, a)
+            pos += (a.nbytes + 15) & ~15
+        cur = torch.cuda.current_stream(dev)
+        with torch.cuda.stream(st):
+            blob = self._staging[i][:need].to(dev, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(st)
+            self._staging_ev[i] = ev
+
+            def view(k):
+                p0, a = where[k]
+                return blob[p0:p0 + a.nbytes].view(getattr(torch, str(a.dtype))).reshape(a.shape)
+
+            src, offs_d, hw_d = blob[:total], view('offsets'), view('sizes')
+            if key not in self._mask_dev:
+                self._mask_dev[key] = torch.from_numpy(self._get_smooth_mask(height, width, 10, 20)).to(dev)
+                if self._tps:
+                    self._aug[key] = TPSPairAugmenter((width, height), device=dev, **self._tps_args)
+            mask = self._mask_dev[key]
+            if self._tps:
+                aug = self._aug[key]
+                stack = aug.stack(b)
+                stack[..., 0] = mask
+                ops.resize_crop_u8(src, offs_d, hw_d, 3, (resize_sz, resize_sz), (margin, margin), (final, final), stack[..., 1:])
+                out = aug.warp_stack(stack, w_target=view('w_target'), w_source=view('w_source'))
+                out['mask'] = out['mask'].unsqueeze(-1)
+            else:
+                image = torch.empty(b, final, final, 3, dtype=torch.float32, device=dev)
+                ops.resize_crop_u8(src, offs_d, hw_d, 3, (resize_sz, resize_sz), (margin, margin), (final, final), image)
+                out = {'image': image, 'future_image': image, 'mask': mask.reshape(1, final, final, 1).expand(b, -1, -1, -1)}
+            if 'landmarks' in where:
+                out['landmarks'] = view('landmarks')
+                out['future_landmarks'] = out['landmarks']
+            for k, _a in small[2:]:
+                if k not in ('w_target', 'w_source', 'landmarks'):
+                    out[k] = view(k)
+        # hand-over: the caller's stream is ordered behind the loader's (a GPU-side dependency, the host does not wait)
+        cur.wait_stream(st)
+        for v in out.values():
+            if torch.is_tensor(v) and v.is_cuda:
+                v.record_stream(cur)
         return out
 
+    def _device_batch(self, samples, decoded, device):
+        packed, meta = self._host_pack(samples, decoded)
+        return self._device_stage(packed, meta, device)
+
     def get_dataset(self, batch_size, repeat=False, shuffle=False, num_preprocess_threads=12, keep_aspect=True,
-                    prefetch=True, device=None, rank=0, world=1):
+                    prefetch=True, device=None, rank=0, world=1, loader_process=None):
         """tps_dataset.py:134-158.  Returns an iterable of device batches (dicts of tensors): 'image', 'future_image'
         [B,S,S,3] float32 in [0,255], 'mask' [B,S,S,1], 'landmarks'/'future_landmarks' [B,N,2] (y, x) pixels, and the
         dataset's label keys."""
         if device is None:
             device = 'cuda:%d' % torch.cuda.current_device()
         return PairBatchLoader(self, batch_size, repeat=repeat, shuffle=shuffle, num_preprocess_threads=num_preprocess_threads,
-                               prefetch=prefetch, device=device, rank=rank, world=world)
+                               prefetch=prefetch, device=device, rank=rank, world=world, loader_process=loader_process)
