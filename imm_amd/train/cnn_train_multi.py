@@ -160,24 +160,59 @@ def setup_training(opts, model_factory, clip_value=None, use_graph=True):
 
 
 class SummaryWriter(object):
-    """Scalar summaries as JSON lines in <log_dir>/summaries.jsonl — the counterpart of the tf.summary.FileWriter of
-    cnn_train_multi.py:436,447-452,489,504-508 (scalars only: loss, loss terms, lr, throughput; no image summaries)."""
+    """Summaries of the train loop — the counterpart of the tf.summary.FileWriter of cnn_train_multi.py:436,447-452,489,
+    504-508: every record goes to <log_dir>/summaries.jsonl (one JSON object per line) AND to a TensorBoard event file
+    (imm_amd/utils/tf_events.py) as scalars `<tag>/<key>`; `images` ({name: HxWxC uint8}) become image summaries."""
 
     def __init__(self, log_dir):
+        from ..utils.tf_events import EventFileWriter
         os.makedirs(log_dir, exist_ok=True)
         self.path = os.path.join(log_dir, 'summaries.jsonl')
         self._f = open(self.path, 'a')
+        self.events = EventFileWriter(log_dir)
 
-    def add_summary(self, record, step):
+    def add_summary(self, record, step, images=None):
         rec = {'step': int(step), 'time': time.time()}
         rec.update(record)
         self._f.write(json.dumps(rec) + '\n')
+        family = str(record.get('tag', 'train'))
+        scalars = {}
+        for k, v in record.items():
+            if k == 'tag':
+                continue
+            if isinstance(v, (list, tuple)):
+                for i, x in enumerate(v):
+                    scalars['%s/%s/%d' % (family, k, i)] = float(x)
+            else:
+                scalars['%s/%s' % (family, k)] = float(v)
+        self.events.add_scalars(scalars, step, images={'%s/%s' % (family, k): v for k, v in (images or {}).items()})
 
     def flush(self):
         self._f.flush()
+        self.events.flush()
 
     def close(self):
         self._f.close()
+        self.events.close()
+
+
+def image_summaries(eng, max_outputs=3):
+    """The reference's image summaries (imm_model.py:456-468): inputs `im`, `future_im`, the clipped prediction
+    `future_im_pred` and the colourised landmark maps `pose_embedding`; the first `max_outputs` samples side by side."""
+    from ..models.imm_model import colorize_landmark_maps
+    n = min(int(max_outputs), eng.B)
+    S = eng.S
+
+    def tile(x):           # [n,S,S,3] in 0..255 -> one S x n*S uint8 image
+        x = x[:n].float().clamp(0, 255).to(torch.uint8).cpu().numpy()
+        return x.transpose(1, 0, 2, 3).reshape(S, n * S, 3)
+
+    full = torch.empty(eng.B, S, S, eng.K, device=eng.dev)
+    ops.gauss_render_f32(eng.mu, eng.B, eng.K, eng.inv_std, S, full)
+    maps = colorize_landmark_maps(full[:n])
+    maps = maps / maps.amax().clamp_min(1e-12) * 255.0
+    return {'im': tile(eng.in_image), 'future_im': tile(eng.in_future), 'future_im_pred': tile(eng.future_im_pred),
+            'pose_embedding': tile(maps)}
 
 
 def run_test_pass(model, test_dataset, step, writer=None, verbose=True):
@@ -215,6 +250,7 @@ def train_loop(opts, train_step, data_iter, num_steps, log_every=10, checkpoint_
     eng = train_step.engine
     start_step = int(eng.step_count)
     n_summary = int(opts.get('n_summary') or 0)
+    n_image = int(opts.get('n_image_summary', 100) or 0)      # image summaries: every n_image steps (upstream: every summary)
     n_test = int(opts.get('n_test') or 0)
     n_ckpt = int(opts.get('n_checkpoint') or 0)
     for step in range(start_step, num_steps):
@@ -232,9 +268,10 @@ def train_loop(opts, train_step, data_iter, num_steps, log_every=10, checkpoint_
                 print('step %d, loss = %.4f (%.1f examples/sec; %.3f sec/batch)' % (step, loss_value,
                                                                                     opts['batch_size'] / dt, dt))
             if rank == 0 and do_sum:
+                images = image_summaries(eng) if n_image and step % n_image == 0 else None
                 summary_writer.add_summary({'tag': 'train', 'loss': loss_value, 'lr': float(eng.lr_state[1]),
                                             'loss_terms': [float(v) for v in eng.loss_terms],
-                                            'examples_per_sec': opts['batch_size'] / dt}, step)
+                                            'examples_per_sec': opts['batch_size'] / dt}, step, images=images)
                 summary_writer.flush()
         if test_dataset is not None and model is not None and n_test and step % n_test == 0:
             train_step.synchronize()

@@ -207,6 +207,16 @@ def test_train_and_test_scripts_on_dataset_tree(celeba, tmp_path, capsys):
     assert [r['step'] for r in recs if r['tag'] == 'train'] == [0]
     assert [r['step'] for r in recs if r['tag'] == 'test'] == [0, 2] and all(r['n_samples'] == 6 for r in recs if r['tag'] == 'test')
     assert abs(recs[0]['lr'] - 1e-3) < 1e-9 and len(recs[0]['loss_terms']) == 6
+    # the same summaries as a TensorBoard event file, with the image summaries of step 0
+    import glob
+    from imm_amd.utils import tf_events as E
+    (evpath,) = glob.glob(str(logs / 'events.out.tfevents.*'))
+    evs = E.read_events(evpath)
+    first = [e for e in evs if 'train/loss' in e['scalars']][0]
+    assert first['step'] == 0 and abs(first['scalars']['train/lr'] - 1e-3) < 1e-9
+    assert sorted(first['images']) == ['train/future_im', 'train/future_im_pred', 'train/im', 'train/pose_embedding']
+    assert first['images']['train/im'][:3] == (128, 3 * 128, 3)
+    assert [e['step'] for e in evs if 'test/loss' in e['scalars']] == [0, 2]
     ck = torch.load(logs / 'model.ckpt-2.pt', map_location='cpu')
     assert ck['step'] == 3
     # resume: the loop continues at the restored global step (3) and stops at num_steps (5)
