@@ -130,3 +130,28 @@ def test_variable_name_map():
     names = [f(k) for k in list(P) + list(S)]
     assert len(set(names)) == len(names)
     assert 'model/pose_encoder/encoder/conv_6/batch_normalization/beta' in names
+
+
+def test_snappy_against_vectors_of_the_real_library(tmp_path):
+    """tests/golden/snappy_golden.npz was produced by libsnappy 1.1.8 (tests/golden/make_snappy_golden.py)."""
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'snappy_golden.npz'))
+    for k in ('text', 'random', 'zeros', 'mixed', 'empty', 'short', 'block'):
+        assert T.snappy_decompress(g[k + '_snappy'].tobytes()) == g[k + '_raw'].tobytes(), k
+    # a table whose only data block is stored snappy-compressed (type byte 1), assembled by hand around the real bytes
+    comp, raw = g['block_snappy'].tobytes(), g['block_raw'].tobytes()
+    entries = list(T._block_entries(raw))
+    assert len(entries) == 40 and entries[7] == (b'model/renderer/conv_07/batch_normalization/gamma', bytes([7]) * 3)
+
+    def framed(block, ctype):
+        return block + bytes([ctype]) + struct.pack('<I', T.mask_crc(T.crc32c(block + bytes([ctype]))))
+    meta_block = struct.pack('<II', 0, 1)
+    ib = T._BlockBuilder(restart_interval=1)
+    ib.add(entries[-1][0], T._put_varint(0) + T._put_varint(len(comp)))
+    index_block = ib.finish()
+    off_meta = len(comp) + 5
+    off_index = off_meta + len(meta_block) + 5
+    footer = T._put_varint(off_meta) + T._put_varint(len(meta_block)) + T._put_varint(off_index) + T._put_varint(len(index_block))
+    p = tmp_path / 'snappy.index'
+    p.write_bytes(framed(comp, 1) + framed(meta_block, 0) + framed(index_block, 0) + footer + b'\x00' * (40 - len(footer))
+                  + struct.pack('<Q', T.TABLE_MAGIC))
+    assert list(T.read_table(str(p)).items()) == entries
