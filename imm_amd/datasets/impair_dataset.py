@@ -218,11 +218,28 @@ class ImagePairDataset(object):
 
 
 _END = object()
+_TEMP_FILES = set()     # shared-memory files of live loaders: removed at interpreter exit if an iterator was never closed
+
+
+def _cleanup_temp_files():
+    for path in list(_TEMP_FILES):
+        try:
+            os.unlink(path)
+        except OSError:
+            pass
+        _TEMP_FILES.discard(path)
+
+
+atexit.register(_cleanup_temp_files)
 
 
 def _loader_server_main(loader, ring_path, cap, n_slots, conn, sem, seed):
     """Body of the loader process: PairBatchLoader.host_batches() -> dataset._host_pack() into shared-memory slots."""
     import mmap
+    import signal
+    # the parent stops this process with SIGTERM: turn it into a normal exit so that `finally` below runs (it closes
+    # the decode workers and removes their shared-memory ring)
+    signal.signal(signal.SIGTERM, lambda *_a: sys.exit(0))
     random.seed(seed)
     np.random.seed(seed % (2 ** 32))
     fd = os.open(ring_path, os.O_RDWR)
@@ -238,6 +255,8 @@ def _loader_server_main(loader, ring_path, cap, n_slots, conn, sem, seed):
             conn.send((slot, meta))
             k += 1
         conn.send(None)
+    except SystemExit:
+        pass
     except BaseException as e:                  # surfaced in the consumer
         try:
             conn.send(RuntimeError('loader process: %s: %s' % (type(e).__name__, e)))
@@ -369,6 +388,7 @@ class PairBatchLoader(object):
         cap = self.batch_size * (4 << 20)
         shm_dir = '/dev/shm' if os.path.isdir('/dev/shm') and os.access('/dev/shm', os.W_OK) else None
         fd, ring_path = tempfile.mkstemp(prefix='imm_loader_ring_', dir=shm_dir)
+        _TEMP_FILES.add(ring_path)
         os.ftruncate(fd, cap * self.SERVER_SLOTS)            # sparse: only the bytes of real batches are ever backed
         mm = mmap.mmap(fd, cap * self.SERVER_SLOTS)
         os.close(fd)
@@ -404,6 +424,7 @@ class PairBatchLoader(object):
                 os.unlink(ring_path)
             except OSError:
                 pass
+            _TEMP_FILES.discard(ring_path)
 
     def __iter__(self):
         if self.loader_process:
