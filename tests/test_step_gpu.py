@@ -376,3 +376,22 @@ def test_training_reduces_the_loss_on_a_fixed_batch():
     assert not torch.equal(eng.loss_agg, agg0)
     mu = eng.mu.float().cpu().numpy()
     assert np.abs(mu).max() <= 1.0 + 1e-3                              # landmarks stay inside the image frame
+
+
+def test_bench_rccl_path_single_rank():
+    """bench.py with --force-dist: RCCL process group of one rank, the split-graph step with the gradient all-reduce between
+    the backward and the optimizer graphs — the code path every rank runs under `torch.distributed.run` at N > 1."""
+    import json
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29533', RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+    out = subprocess.run([sys.executable, os.path.join(repo, 'bench.py'), '--force-dist', '--steps', '3', '--warmup', '1',
+                          '--no-cpu-baseline'], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    lines = [l for l in out.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1, lines                                   # exactly one JSON line on stdout
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 1 and d['steps'] == 3 and d['value'] > 0 and d['scaling'] == 'weak'
+    assert d['roofline']['frac'] > 0
