@@ -3,7 +3,6 @@
 Layout under data_dir (aflw_dataset.py:15-37): aflw_{train,test}_images.txt, aflw_{train,test}_keypoints.mat with
 'gt' [N,5,2] and 'hw' [N,2], images under output/."""
 import os
-import os.path as osp
 
 import numpy as np
 
@@ -28,40 +27,29 @@ def load_dataset(data_dir, subset):
 
 
 class AFLWDataset(TPSDataset):
+    """Same constructor as the reference (aflw_dataset.py:47-62); every sample also carries the annotated image `size`."""
     LANDMARK_LABELS = {'left_eye': 0, 'right_eye': 1}
     N_LANDMARKS = 5
+    EXTRA_FIELDS = {'size': ('int32', 2)}
 
     def __init__(self, data_dir, subset, max_samples=None, image_size=[128, 128], order_stream=False, landmarks=False,
                  tps=True, vertical_points=10, horizontal_points=10, rotsd=[0.0, 5.0], scalesd=[0.0, 0.1],
                  transsd=[0.1, 0.1], warpsd=[0.001, 0.005, 0.001, 0.01], name='CelebADataset'):
-        super(AFLWDataset, self).__init__(
-            data_dir, subset, max_samples=max_samples, image_size=image_size, order_stream=order_stream,
-            landmarks=landmarks, tps=tps, vertical_points=vertical_points, horizontal_points=horizontal_points,
-            rotsd=rotsd, scalesd=scalesd, transsd=transsd, warpsd=warpsd, name=name)
-        self._image_dir, self._images, self._keypoints, self._sizes = load_dataset(self._data_dir, self._subset)
+        TPSDataset.__init__(self, data_dir, subset, max_samples, image_size, order_stream, landmarks, tps, vertical_points,
+                            horizontal_points, rotsd, scalesd, transsd, warpsd, name)
+        self._image_dir, self._images, self._keypoints, self._sizes = load_dataset(data_dir, subset)
 
     def num_samples(self):
         return len(self._images)
 
-    def _get_sample_dtype(self):
-        d = {'image': 'string', 'landmarks': 'float32', 'size': 'int32'}
-        d.update({k: 'int32' for k in self.LANDMARK_LABELS.keys()})
-        return d
-
-    def _get_sample_shape(self):
-        d = {'image': None, 'landmarks': [self.N_LANDMARKS, 2], 'size': 2}
-        d.update({k: [] for k in self.LANDMARK_LABELS.keys()})
-        return d
-
     def _get_image(self, idx):
-        """aflw_dataset.py:116-123."""
-        inputs = {'image': osp.join(self._image_dir, self._images[idx]),
-                  'landmarks': np.asarray(self._keypoints[idx][:, [1, 0]], dtype=np.float32),
-                  'size': np.asarray(self._sizes[idx], dtype=np.int32)}
-        inputs.update({k: v for k, v in self.LANDMARK_LABELS.items()})
-        return inputs
+        """aflw_dataset.py:116-123: like TPSDataset._get_image plus the 'hw' row of the annotation file."""
+        sample = TPSDataset._get_image(self, idx)
+        sample['landmarks'] = np.asarray(sample['landmarks'], dtype=np.float32)
+        sample['size'] = np.asarray(self._sizes[idx], dtype=np.int32)
+        return sample
 
     def _proc_landmarks(self, sample, original_hw):
         """aflw_dataset.py:95-98: rescaled by the ANNOTATED size ('hw' of the .mat), not the decoded one."""
-        final = self._image_size[0]
-        return self._resize_points(np.asarray(sample['landmarks'], np.float32), sample['size'], [final, final])
+        side = self._image_size[0]
+        return self._resize_points(np.asarray(sample['landmarks'], np.float32), sample['size'], [side, side])

@@ -48,43 +48,33 @@ def load_dataset(data_root, dataset, subset):
 
 
 class CelebADataset(TPSDataset):
+    """Same constructor as the reference (celeba_dataset.py:101-118): `dataset` is 'celeba' or 'mafl', the remaining
+    arguments are TPSDataset's."""
     LANDMARK_LABELS = {'left_eye': 0, 'right_eye': 1}
     N_LANDMARKS = 5
+    CROP_PERCENT = 0.8            # the central 80 % of the resized image is kept (celeba_dataset.py:148)
 
     def __init__(self, data_dir, subset, dataset=None, max_samples=None, image_size=[128, 128], order_stream=False,
                  landmarks=False, tps=True, vertical_points=10, horizontal_points=10, rotsd=[0.0, 5.0], scalesd=[0.0, 0.1],
                  transsd=[0.1, 0.1], warpsd=[0.001, 0.005, 0.001, 0.01], name='CelebADataset'):
-        super(CelebADataset, self).__init__(
-            data_dir, subset, max_samples=max_samples, image_size=image_size, order_stream=order_stream,
-            landmarks=landmarks, tps=tps, vertical_points=vertical_points, horizontal_points=horizontal_points,
-            rotsd=rotsd, scalesd=scalesd, transsd=transsd, warpsd=warpsd, name=name)
-        assert dataset is not None
+        if dataset is None:
+            raise AssertionError('CelebADataset needs dataset="celeba" or "mafl"')
+        TPSDataset.__init__(self, data_dir, subset, max_samples, image_size, order_stream, landmarks, tps, vertical_points,
+                            horizontal_points, rotsd, scalesd, transsd, warpsd, name)
         self._dataset = dataset
-        self._image_dir, self._images, self._keypoints = load_dataset(self._data_dir, self._dataset, self._subset)
+        self._image_dir, self._images, self._keypoints = load_dataset(data_dir, dataset, subset)
+        side = int(self._image_size[0])
+        resize = int(np.round(side / self.CROP_PERCENT))
+        self._resize_margin = (resize, int(np.round((resize - side) / 2.0)))
 
     def num_samples(self):
         return len(self._images)
 
-    def _get_sample_dtype(self):
-        d = {'image': 'string', 'landmarks': 'float32'}
-        d.update({k: 'int32' for k in self.LANDMARK_LABELS.keys()})
-        return d
-
-    def _get_sample_shape(self):
-        d = {'image': None, 'landmarks': [self.N_LANDMARKS, 2]}
-        d.update({k: [] for k in self.LANDMARK_LABELS.keys()})
-        return d
-
     def _geometry(self):
         """celeba_dataset.py:148-152: resize to round(size / 0.8), keep the central size^2 window."""
-        crop_percent = 0.8
-        final_sz = self._image_size[0]
-        resize_sz = np.round(final_sz / crop_percent).astype(np.int32)
-        margin = np.round((resize_sz - final_sz) / 2.0).astype(np.int32)
-        return int(resize_sz), int(margin)
+        return self._resize_margin
 
     def _proc_landmarks(self, sample, original_hw):
         """celeba_dataset.py:154-158: (y, x) landmarks follow the resize and the crop offset."""
-        resize_sz, margin = self._geometry()
-        lm = self._resize_points(np.asarray(sample['landmarks'], np.float32), original_hw, [resize_sz, resize_sz])
-        return lm - np.float32(margin)
+        resize, margin = self._resize_margin
+        return self._resize_points(np.asarray(sample['landmarks'], np.float32), original_hw, [resize, resize]) - np.float32(margin)

@@ -9,6 +9,7 @@ Per batch (tps_dataset.py:134-158 + the dataset's `_proc_im_pair`):
 Landmarks are rescaled on the host exactly as the reference does (they are not warped: `landmarks and tps` is refused,
 tps_dataset.py:28-29)."""
 import os.path as osp
+from collections import OrderedDict
 
 import numpy as np
 import torch
@@ -36,8 +37,9 @@ def smooth_mask(h, w, margin, step):
 
 
 class TPSDataset(ImagePairDataset):
-    LANDMARK_LABELS = {}
+    LANDMARK_LABELS = {}          # label name -> index into the landmarks (e.g. the two eyes, used by the evaluation)
     N_LANDMARKS = 0
+    EXTRA_FIELDS = {}             # further per-sample fields of a dataset: name -> (dtype, shape)
 
     def __init__(self, data_dir, subset, max_samples=None, image_size=[128, 128], order_stream=False, landmarks=False,
                  tps=True, vertical_points=10, horizontal_points=10, rotsd=[0.0, 5.0], scalesd=[0.0, 0.1],
@@ -58,6 +60,21 @@ class TPSDataset(ImagePairDataset):
 
     def num_samples(self):
         raise NotImplementedError()
+
+    def _fields(self):
+        """name -> (dtype, shape) of one sample, what the reference spells out per dataset in _get_sample_dtype /
+        _get_sample_shape (celeba_dataset.py:120-133, aflw_dataset.py:64-78)."""
+        f = OrderedDict([('image', ('string', None)), ('landmarks', ('float32', [self.N_LANDMARKS, 2]))])
+        f.update(self.EXTRA_FIELDS)
+        for k in self.LANDMARK_LABELS:
+            f[k] = ('int32', [])
+        return f
+
+    def _get_sample_dtype(self):
+        return OrderedDict((k, v[0]) for k, v in self._fields().items())
+
+    def _get_sample_shape(self):
+        return OrderedDict((k, v[1]) for k, v in self._fields().items())
 
     # -- sample stream (host) -------------------------------------------------------------------------------
     def _get_smooth_step(self, n, b):

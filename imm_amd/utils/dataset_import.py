@@ -1,13 +1,12 @@
-"""Dynamic import of a dataset class by its short name (imm/utils/dataset_import.py): 'celeba' ->
-imm_amd.datasets.celeba_dataset.CelebADataset, 'aflw' -> ...AFLWDataset (case-insensitive match on <name>dataset)."""
+"""Dataset classes by short name (the role of imm/utils/dataset_import.py): 'celeba' -> CelebADataset, 'aflw' ->
+AFLWDataset, ...  A module imm_amd/datasets/<name>_dataset.py is looked up and the class whose lower-cased name is
+"<name without underscores>dataset" is returned (None when the module has no such class, like the reference)."""
 import importlib
+import inspect
 
 
 def import_dataset(dataset_name):
-    lib = importlib.import_module('imm_amd.datasets.' + dataset_name + '_dataset')
-    target = dataset_name.replace('_', '') + 'dataset'
-    found = None
-    for name, cls in lib.__dict__.items():
-        if name.lower() == target.lower():
-            found = cls
-    return found
+    module = importlib.import_module('imm_amd.datasets.%s_dataset' % dataset_name)
+    wanted = (dataset_name.replace('_', '') + 'dataset').lower()
+    matches = [cls for name, cls in inspect.getmembers(module, inspect.isclass) if name.lower() == wanted]
+    return matches[-1] if matches else None
