@@ -1,16 +1,26 @@
 """bench.py — IMM conditional-generation training step on MI355X: training images/sec at 128x128, K=10.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: re-executes itself under
+                                                            torch.distributed.run, one rank per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 One process per GPU; batch 32 per GPU (BASELINE.json configs[1]; N>1 = configs[2] weak scaling); synthetic
 inputs resident in HBM; a step = forward (both encoders, landmark bottleneck, renderer, VGG16 perceptual
 loss) + backward + RCCL gradient all-reduce + per-tensor clip + Adam.  Rank 0 prints ONE JSON line.
+
+Timing protocol: the step is first spun for a fixed wall time (default 1 s, untimed) so that the clocks have
+settled, then W untimed warm-up steps, then `--windows` (default 3) windows of EXACTLY K steps, each bracketed by
+barrier + torch.cuda.synchronize() on both sides and reduced with MAX over ranks; `ms_per_step` / `value` are the
+MEDIAN window, all windows are listed under `step.windows_ms`.
 """
 import argparse
 import json
 import os
+import shutil
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 import torch
@@ -24,7 +34,8 @@ PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.m
 BATCH_PER_GPU = 32
 IMAGE_SIZE = 128
 N_MAPS = 10
-IGEMM_TAGS = ('conv_fwd', 'vgg_fwd', 'conv_dgrad', 'vgg_dgrad')    # all launches of conv_igemm_kernel
+IGEMM_TAGS = ('conv_fwd', 'vgg_fwd', 'conv_dgrad', 'vgg_dgrad')    # forward + data-gradient convolution launches
+CONV_FAMILY = ('conv_igemm', 'conv_halo', 'conv_hdeep')            # kernel-name prefixes of those launches (not wgrad)
 
 
 def model_config(n_maps):
@@ -56,38 +67,168 @@ def synthetic_batch(batch, size, seed, device):
     return {'image': im.to(device), 'future_image': fut.to(device), 'mask': mask.to(device).contiguous()}
 
 
-def pmc_traffic_per_launch():
-    """HBM MB per launch of the conv_igemm kernels from the committed PMC profile (separate rocprofv3 --pmc passes,
-    profiles/r*_pmc_hbm_bytes.csv: newest round wins); None when no profile is present."""
+# ---------------------------------------------------------------------------------------------------------
+# HBM traffic of the dominant kernel family (rocprofv3 PMC, separate passes for FETCH_SIZE and WRITE_SIZE)
+# ---------------------------------------------------------------------------------------------------------
+def _pmc_rows(root, counter):
+    import csv
+    import glob
+    for p in glob.glob(os.path.join(root, '**', '*counter_collection.csv'), recursive=True):
+        with open(p, newline='') as f:
+            for r in csv.DictReader(f):
+                if r.get('Counter_Name') == counter:
+                    yield r['Kernel_Name'], float(r['Counter_Value'])
+
+
+def pmc_traffic_live(timeout_s=240):
+    """Runs this file's --pmc-pass (3 eager training steps, same workload) under `rocprofv3 --kernel-trace --pmc X`, once
+    for FETCH_SIZE and once for WRITE_SIZE (the two do not fit one pass; no other tracing domain is enabled), and returns
+    (MB per launch of the conv forward / data-gradient family, total GB per step, dispatch count) with the gfx950
+    correction FETCH_SIZE x 2 (MI355X_MICROARCH.md, HBM section).  None when rocprofv3 is absent or a pass fails."""
+    exe = shutil.which('rocprofv3')
+    if exe is None:
+        return None
+    tmp = tempfile.mkdtemp(prefix='imm_pmc_', dir='/tmp')
+    env = dict(os.environ, TMPDIR='/tmp')
+    env.pop('WORLD_SIZE', None); env.pop('RANK', None); env.pop('LOCAL_RANK', None)
+    steps = 3
+    try:
+        sums = {}
+        for ctr in ('FETCH_SIZE', 'WRITE_SIZE'):
+            d = os.path.join(tmp, ctr)
+            cmd = [exe, '--kernel-trace', '--output-format', 'csv', '--pmc', ctr, '-d', d, '--', sys.executable,
+                   os.path.abspath(__file__), '--pmc-pass', '--steps', str(steps)]
+            r = subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s)
+            if r.returncode != 0:
+                sys.stderr.write('bench: rocprofv3 %s pass failed (rc %d): %s\n' % (ctr, r.returncode, r.stderr.decode()[-400:]))
+                return None
+            fam_kb = tot_kb = 0.0
+            fam_n = 0
+            for name, val in _pmc_rows(d, ctr):
+                tot_kb += val
+                if any(k in name for k in CONV_FAMILY) and 'wgrad' not in name:
+                    fam_kb += val; fam_n += 1
+            if fam_n == 0:
+                return None
+            sums[ctr] = (fam_kb, fam_n, tot_kb)
+        f, w = sums['FETCH_SIZE'], sums['WRITE_SIZE']
+        mb_per_launch = (2.0 * f[0] / f[1] + w[0] / w[1]) / 1024.0
+        gb_per_step = (2.0 * f[2] + w[2]) / 1024.0 / 1024.0 / steps
+        return round(mb_per_launch, 2), round(gb_per_step, 3), f[1] // steps
+    except Exception as e:      # a profiler hiccup must not lose the bench line
+        sys.stderr.write('bench: live PMC traffic unavailable (%s)\n' % (e,))
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def pmc_traffic_from_profiles():
+    """Fallback: the newest committed PMC summary (profiles/r*_pmc_hbm_bytes.csv)."""
     import csv
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_hbm_bytes.csv')))
     if not files:
-        return None
+        return None, None
     n = mb = 0.0
     with open(files[-1]) as f:
         for row in csv.reader(f):
-            if len(row) == 7 and ('conv_igemm' in row[0] or 'conv_halo' in row[0] or 'conv_hdeep' in row[0]):
+            if len(row) == 7 and any(k in row[0] for k in CONV_FAMILY) and 'wgrad' not in row[0]:
                 n += float(row[1]); mb += float(row[1]) * (float(row[4]) + float(row[5]))
-    return round(mb / n, 2) if n else None
+    return (round(mb / n, 2) if n else None), os.path.relpath(files[-1], ROOT)
 
 
-def cpu_baseline(sample_batch=8, steps=2):
-    """CPU restatement of the TF1 graph (oracle/imm_oracle.py) timed on this node's host cores: the same
-    algorithmic work per image as the GPU step (forward + backward + clip + Adam)."""
+def pmc_pass(steps):
+    """Child of pmc_traffic_live: the same training step, eager (one dispatch per launch), no timing."""
+    from imm_amd.models.imm_model import IMMModel
+    from imm_amd.train.cnn_train_multi import TrainStep
+    torch.cuda.set_device(0)
+    model = IMMModel(model_config(N_MAPS), dtype=torch.bfloat16, device='cuda:0')
+    ts = TrainStep(model, BATCH_PER_GPU, IMAGE_SIZE, world_size=1, use_graph=False)
+    inputs = synthetic_batch(BATCH_PER_GPU, IMAGE_SIZE, seed=0, device='cuda:0')
+    ts.engine.set_inputs(inputs['image'], inputs['future_image'], inputs['mask'])
+    torch.cuda.synchronize()
+    for _ in range(steps):
+        ts.step(None)
+    ts.synchronize()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# CPU baseline (oracle = "port"), bounded sample
+# ---------------------------------------------------------------------------------------------------------
+def cpu_baseline(budget_s=12.0):
+    """CPU restatement of the TF1 graph (oracle/imm_oracle.py) timed on this node's host cores, bounded so
+    that the default bench run stays within minutes:
+      A  configs[0]: forward + perceptual loss, batch 4, all cores        (1 warm + up to 10 timed within the budget, median)
+      B  configs[1]: training step (fwd + bwd + clip + Adam), batch 32, all cores   (1 timed after the warm legs)
+      C  leg A on ONE thread                                              (up to 3 timed within the budget, median)
+    `value` = leg B in the metric's unit (training images/s); the other legs are listed under `legs`.
+    `python bench.py --cpu-baseline-full` runs the unbounded protocol of BASELINE.md §3 (>= 3 warm + >= 10 timed)."""
     from oracle import imm_oracle as O
+    full = budget_s <= 0
     cfg = O.default_model_config(N_MAPS)
     P, S = O.init_params(cfg, IMAGE_SIZE)
+    n_all = torch.get_num_threads()
+
+    def median(v):
+        v = sorted(v)
+        return v[len(v) // 2] if len(v) % 2 else 0.5 * (v[len(v) // 2 - 1] + v[len(v) // 2])
+
+    def timed(fn, warm, n_max, budget):
+        for _ in range(warm):
+            fn()
+        ts, t_start = [], time.time()
+        while len(ts) < n_max and (not ts or full or time.time() - t_start < budget):
+            t0 = time.time(); fn(); ts.append(time.time() - t0)
+        return ts
+
+    legs = {}
+    inp4 = O.synthetic_inputs(4, IMAGE_SIZE)
+    with torch.no_grad():
+        tA = timed(lambda: O.forward(P, S, inp4, cfg, training=True), 3 if full else 1, 10, budget_s)
+    legs['fwd_loss_b4_all_cores'] = {'images_per_s': round(4 / median(tA), 3), 'timed': len(tA), 'threads': n_all}
+    inp32 = O.synthetic_inputs(BATCH_PER_GPU, IMAGE_SIZE)
     opt = O.new_adam_state(P)
-    inp = O.synthetic_inputs(sample_batch, IMAGE_SIZE)
-    P, S, _ = O.train_step(P, S, opt, [inp], cfg)          # warm-up (thread pools, allocator)
-    t0 = time.time()
-    for _ in range(steps):
-        P, S, _ = O.train_step(P, S, opt, [inp], cfg)
-    dt = (time.time() - t0) / steps
-    return {'value': round(sample_batch / dt, 3), 'unit': 'images/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': '%d fp32 training steps of batch %d at 128x128 K=10 (torch-CPU restatement of the TF1 graph; '
-                      'TF 1.10 itself is not installable here)' % (steps, sample_batch)}
+    tB = timed(lambda: O.train_step(P, S, opt, [inp32], cfg), 3 if full else 0, 10 if full else 1, budget_s)
+    legs['train_step_b32_all_cores'] = {'images_per_s': round(BATCH_PER_GPU / median(tB), 3), 'timed': len(tB), 'threads': n_all}
+    torch.set_num_threads(1)
+    try:
+        with torch.no_grad():
+            tC = timed(lambda: O.forward(P, S, inp4, cfg, training=True), 3 if full else 0, 10 if full else 3, budget_s)
+        legs['fwd_loss_b4_one_thread'] = {'images_per_s': round(4 / median(tC), 3), 'timed': len(tC), 'threads': 1}
+        if full:
+            tD = timed(lambda: O.train_step(P, S, opt, [inp32], cfg), 1, 3, 0)
+            legs['train_step_b32_one_thread'] = {'images_per_s': round(BATCH_PER_GPU / median(tD), 3), 'timed': len(tD), 'threads': 1}
+    finally:
+        torch.set_num_threads(n_all)
+    return {'value': legs['train_step_b32_all_cores']['images_per_s'], 'unit': 'images/s', 'cores': n_all, 'kind': 'port',
+            'sample': '%d fp32 training step(s) of batch 32 at 128x128 K=10 on %d threads (torch-CPU restatement of the TF1 graph, '
+                      'oracle/imm_oracle.py; TF 1.10 itself is not installable here); legs: batch-4 forward+loss on all cores and on '
+                      'one thread, median of the timed runs' % (len(tB), n_all),
+            'legs': legs}
+
+
+# ---------------------------------------------------------------------------------------------------------
+def free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_spawn(args, argv):
+    """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run, one rank per GPU; the
+    children's stdout is ours, so rank 0's JSON line is the only line printed."""
+    n_dev = torch.cuda.device_count()
+    if n_dev < args.gpus and not args.share_gpu:
+        sys.stderr.write('bench.py: --gpus %d but only %d device(s) visible\n' % (args.gpus, n_dev))
+        return 2
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(free_port()), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -95,10 +236,23 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--windows', type=int, default=3, help='timed windows of --steps steps each; the median is reported')
+    ap.add_argument('--spin-seconds', type=float, default=1.0, help='untimed wall time of steps before the counted warm-up (clock settling)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-baseline-full', action='store_true', help='BASELINE.md §3 protocol (>=3 warm, >=10 timed): minutes of CPU time')
     ap.add_argument('--no-graph', action='store_true')
-    ap.add_argument('--force-dist', action='store_true', help='initialise RCCL and run the split-graph + all-reduce path even at 1 GPU')
+    ap.add_argument('--no-pmc', action='store_true', help='do not collect live HBM traffic with rocprofv3 (falls back to profiles/)')
+    ap.add_argument('--force-dist', action='store_true', help='initialise the process group and run the split-graph + all-reduce path even at 1 GPU')
+    ap.add_argument('--backend', default='nccl', help="torch.distributed backend: 'nccl' (= RCCL on ROCm) or 'gloo' (tests)")
+    ap.add_argument('--share-gpu', action='store_true', help='tests: let several ranks share one device (needs --backend gloo)')
+    ap.add_argument('--pmc-pass', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    if args.pmc_pass:
+        pmc_pass(args.steps)
+        return 0
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        return self_spawn(args, sys.argv[1:])
 
     # stdout carries exactly ONE JSON line: route everything else written to fd 1 (RCCL's version banner, library
     # chatter from any rank) to stderr and keep a private handle on the real stdout for the result
@@ -110,15 +264,23 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch with torch.distributed.run --nproc-per-node %d' % args.gpus)
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+    n_dev = torch.cuda.device_count()
+    if args.share_gpu:
+        local_rank %= max(n_dev, 1)
+    elif local_rank >= n_dev:
+        raise SystemExit('rank %d: local rank %d but only %d device(s) visible' % (rank, local_rank, n_dev))
     torch.cuda.set_device(local_rank)
     dev = 'cuda:%d' % local_rank
-    if world > 1 or args.force_dist:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
         os.environ.setdefault('RANK', '0'); os.environ.setdefault('WORLD_SIZE', '1')
-        dist.init_process_group('nccl', device_id=torch.device(dev))
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device(dev))
+        else:
+            dist.init_process_group(args.backend)
 
     from imm_amd.models.imm_model import IMMModel
     from imm_amd.train.cnn_train_multi import TrainStep
@@ -135,26 +297,43 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(max(args.warmup, 1)):
-        ts.step(None)
-    ts.synchronize()
+    def run_steps(n):
+        for _ in range(n):
+            ts.step(None)
+        ts.synchronize()
+
+    # ---- clock settling: a fixed wall time of steps, the same count on every rank (the collectives must pair up) ----
+    run_steps(2)                                  # graph capture, code-object loading
     barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        ts.step(None)
-    ts.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    t0 = time.perf_counter(); run_steps(10); t10 = (time.perf_counter() - t0) / 10
+    n_spin = torch.tensor([max(0, int(args.spin_seconds / max(t10, 1e-5)))], dtype=torch.int64, device=dev)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t)
+        dist.broadcast(n_spin, 0)
+    run_steps(int(n_spin))
+    run_steps(max(args.warmup, 1))
+    windows = []
+    for _ in range(max(args.windows, 1)):
+        barrier()
+        t0 = time.perf_counter()
+        run_steps(args.steps)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t)
+        windows.append(elapsed)
+    elapsed = sorted(windows)[len(windows) // 2]
     loss = float(eng.loss)
     assert loss == loss, 'NaN loss'
+    if world > 1 or args.force_dist:
+        # the printed loss of the reference is the tower mean (cnn_train_multi.py:173)
+        lt = eng.loss.detach().clone().reshape(1)
+        dist.all_reduce(lt)
+        loss = float(lt) / world
 
     if rank == 0:
         # per-kernel timing with HIP events on the launch stream (eager pass; graph replay hides launches)
-        roof = None
         with torch.cuda.stream(ts.stream):
             eng._training = True
             rows = []
@@ -170,15 +349,26 @@ def main():
         ig = [by_tag[t] for t in IGEMM_TAGS if t in by_tag]
         n_l, ms_l, fl_l, nb_l = sum(d[0] for d in ig), sum(d[1] for d in ig), sum(d[2] for d in ig), sum(d[3] for d in ig)
         achieved = fl_l / (ms_l * 1e-3) / 1e12
+        traffic, traffic_src, hbm_gb_step = None, None, None
+        if world == 1 and not args.no_pmc:
+            live = pmc_traffic_live()
+            if live is not None:
+                traffic, hbm_gb_step, _n = live
+                traffic_src = 'live: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (two passes) on this run\'s workload, 3 eager steps'
+        if traffic is None:
+            traffic, f = pmc_traffic_from_profiles()
+            traffic_src = ('profiles: ' + f) if f else None
         roof = {'bound': 'mfma', 'kernel': 'conv_hdeep / conv_halo2 / conv_igemm64 / conv_igemm kernels (convolution fwd + data-gradient, %d launches/step)' % n_l,
                 'achieved': round(achieved, 2), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': round(achieved / PEAK_BF16_TFLOPS, 4), 'traffic': pmc_traffic_per_launch(),
-                'traffic_unit': 'MB HBM per launch (rocprofv3 PMC FETCH_SIZE x2 [gfx950 correction] + WRITE_SIZE, profiles/)',
+                'frac': round(achieved / PEAK_BF16_TFLOPS, 4), 'traffic': traffic,
+                'traffic_unit': 'MB HBM per launch (rocprofv3 PMC FETCH_SIZE x2 [gfx950 correction] + WRITE_SIZE)',
+                'traffic_source': traffic_src,
                 'algorithmic_mb_per_launch': round(nb_l / n_l / 1e6, 2),
                 'avg_launch_us': round(ms_l * 1e3 / n_l, 2), 'gflop_per_launch': round(fl_l / n_l / 1e9, 3)}
         breakdown = {t: {'launches': d[0], 'ms': round(d[1], 3), 'tflops': (round(d[2] / (d[1] * 1e-3) / 1e12, 1) if d[2] else None)}
                      for t, d in sorted(by_tag.items(), key=lambda kv: -kv[1][1])}
         total_ms = sum(d[1] for d in by_tag.values())
+        tr = [by_tag[t] for t in ('conv_fwd', 'conv_dgrad', 'conv_wgrad') if t in by_tag]
         step_flops = eng.step_flops()
         ms_per_step = elapsed / args.steps * 1e3
         out = {
@@ -190,23 +380,30 @@ def main():
                                    'clip + Adam), batch %d per GPU' % BATCH_PER_GPU,
                        'global_batch': world * BATCH_PER_GPU, 'image_size': IMAGE_SIZE, 'n_maps': N_MAPS,
                        'parallelism': 'dp%d' % world, 'hip_graph': not args.no_graph,
+                       'collective': ({'backend': dist.get_backend(), 'world_size': dist.get_world_size(),
+                                       'buckets': ts.buckets} if dist.is_initialized() else None),
                        'weights': 'seeded random init; synthetic VGG16 (vgg16.caffemodel.h5 unavailable offline)'},
             'roofline': roof,
-            'step': {'conv_gflop_per_image': round(step_flops / BATCH_PER_GPU / 1e9, 2),
+            'step': {'windows_ms': [round(w / args.steps * 1e3, 4) for w in windows],
+                     'min_ms': round(min(windows) / args.steps * 1e3, 4), 'max_ms': round(max(windows) / args.steps * 1e3, 4),
+                     'spin_steps': int(n_spin),
+                     'conv_gflop_per_image': round(step_flops / BATCH_PER_GPU / 1e9, 2),
                      'step_tflops': round(step_flops / (ms_per_step * 1e-3) / 1e12, 1),
                      'frac_of_peak': round(step_flops / (ms_per_step * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
-                     'sum_kernel_ms_eager': round(total_ms, 3), 'loss': round(loss, 3),
+                     'trainable_conv_tflops': round(sum(d[2] for d in tr) / (sum(d[1] for d in tr) * 1e-3) / 1e12, 1) if tr else None,
+                     'sum_kernel_ms_eager': round(total_ms, 3), 'hbm_gb_per_step': hbm_gb_step, 'loss': round(loss, 3),
                      'hbm_bytes_allocated': eng.memory_bytes()},
             'kernels': breakdown,
         }
-        if not args.no_cpu_baseline and world == 1:
-            out['cpu_baseline'] = cpu_baseline()
+        if (not args.no_cpu_baseline and world == 1) or args.cpu_baseline_full:
+            out['cpu_baseline'] = cpu_baseline(0.0 if args.cpu_baseline_full else 12.0)
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + '\n').encode())
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == '__main__':
-    main()
+    sys.exit(main())

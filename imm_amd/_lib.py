@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get('IMM_HIP_LIB') or os.path.join(_HERE, 'libimm_hip.so')
 IMM_BF16, IMM_F16 = 0, 1
 CONV_BIAS, CONV_RELU, CONV_STATS, CONV_MASK, CONV_OUT_F32 = 1, 2, 4, 8, 16
 SSE_BLOCKS = 512
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class ImmHipError(RuntimeError):
@@ -85,14 +85,14 @@ _SIGS = {
     'imm_perceptual_finalize': [_P, _I, _P, _P, _I, _P, _P, _P],
     'imm_tap_grad': [_P, _I, _P, _P, _I, _I, _I, _I, _P, _I, _P, _I, _I, _P],
     'imm_weight_decay_loss': [_P, _P, _P, _P, _I, _P, _P, _P, _P],
-    'imm_clip_adam_step': [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, C.POINTER(OptHParams), _P],
+    'imm_clip_adam_step': [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, C.POINTER(OptHParams), _P],
 }
 
 _lib = None
 
 
 def declared_symbols():
-    return sorted(list(_SIGS) + ['imm_last_error'])
+    return sorted(list(_SIGS) + ['imm_last_error', 'imm_source_digest'])
 
 
 def load():
@@ -103,9 +103,20 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise ImmHipError('libimm_hip.so not found at %s: build it with `python imm_amd/build.py` '
                           '(there is no CPU fallback for the product path)' % LIB_PATH)
+    if 'IMM_HIP_LIB' not in os.environ and os.path.isdir(os.path.join(_HERE, 'csrc')):
+        # source checkout: the binary must have been built from THESE sources (a stale .so next to edited kernels is the
+        # classic silent failure); rebuild when a compiler is at hand, otherwise refuse
+        from . import build as _b
+        want, have = _b.source_digest(), _b.library_digest(LIB_PATH)
+        if want != have:
+            if not _b.have_compiler():
+                raise ImmHipError('libimm_hip.so is stale (built from sources %s.., checkout is %s..) and hipcc is not '
+                                  'available to rebuild it' % (have[:12] or '?', want[:12]))
+            _b.build(verbose=False)
     lib = C.CDLL(LIB_PATH)
-    lib.imm_last_error.restype = C.c_char_p
-    lib.imm_last_error.argtypes = []
+    for name in ('imm_last_error', 'imm_source_digest'):
+        getattr(lib, name).restype = C.c_char_p
+        getattr(lib, name).argtypes = []
     for name, args in _SIGS.items():
         fn = getattr(lib, name)
         fn.argtypes = args

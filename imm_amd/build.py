@@ -2,6 +2,8 @@
 
 In-tree output: the .so is git-ignored but travels with the working tree to the GPU box.
 hipcc cross-compiles without a GPU, so this runs in the CPU-only build container too.
+The library carries the sha256 of its sources (imm_source_digest(), repo-relative paths + contents); a rebuild is
+skipped only when the existing binary carries the digest of the current checkout — there is no stamp file to go stale.
 """
 import glob
 import hashlib
@@ -10,9 +12,9 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libimm_hip.so')
-STAMP = os.path.join(HERE, '.libimm_hip.stamp')
 ARCH = 'gfx950'
 
 
@@ -20,17 +22,35 @@ def _sources():
     return sorted(glob.glob(os.path.join(CSRC, '*.hip')))
 
 
-def _digest():
+def source_digest():
     h = hashlib.sha256()
-    for p in _sources() + sorted(glob.glob(os.path.join(CSRC, '*.h'))) + [os.path.join(HERE, '..', 'include', 'imm_hip.h')]:
+    for p in _sources() + sorted(glob.glob(os.path.join(CSRC, '*.h'))) + [os.path.join(ROOT, 'include', 'imm_hip.h')]:
         with open(p, 'rb') as f:
-            h.update(p.encode() + b'\0' + f.read())
+            h.update(os.path.relpath(p, ROOT).replace(os.sep, '/').encode() + b'\0' + f.read() + b'\0')
     return h.hexdigest()
 
 
+def library_digest(path=LIB):
+    """Digest embedded in a built library, read from the file's bytes (no dlopen); '' when absent."""
+    try:
+        with open(path, 'rb') as f:
+            blob = f.read()
+    except OSError:
+        return ''
+    i = blob.find(b'IMM_SOURCE_DIGEST=')
+    if i < 0:
+        return ''
+    d = blob[i + 18:i + 18 + 64]
+    return d.decode('ascii', 'replace') if len(d) == 64 and all(c in b'0123456789abcdef' for c in d) else ''
+
+
+def have_compiler():
+    return os.path.exists(os.environ.get('HIPCC', '/opt/rocm/bin/hipcc'))
+
+
 def build(force=False, verbose=True):
-    dig = _digest()
-    if not force and os.path.exists(LIB) and os.path.exists(STAMP) and open(STAMP).read().strip() == dig:
+    dig = source_digest()
+    if not force and library_digest() == dig:
         return LIB
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     objs = []
@@ -41,7 +61,7 @@ def build(force=False, verbose=True):
         obj = os.path.join(objdir, os.path.basename(src) + '.o')
         objs.append(obj)
         cmd = [hipcc, '--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function',
-               '-c', src, '-o', obj]
+               '-DIMM_SOURCE_DIGEST="%s"' % dig, '-c', src, '-o', obj]
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     for cmd, p in procs:
         out, _ = p.communicate()
@@ -50,10 +70,9 @@ def build(force=False, verbose=True):
             raise RuntimeError('hipcc failed: ' + ' '.join(cmd))
         if verbose and out.strip():
             sys.stderr.write(out.decode())
-    cmd = [hipcc, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', LIB] + objs
-    subprocess.check_call(cmd)
-    with open(STAMP, 'w') as f:
-        f.write(dig)
+    tmp = LIB + '.tmp.%d' % os.getpid()
+    subprocess.check_call([hipcc, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', tmp] + objs)
+    os.replace(tmp, LIB)     # a process that has the old file mapped keeps its inode
     return LIB
 
 

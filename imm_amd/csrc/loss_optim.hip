@@ -380,7 +380,8 @@ __global__ __launch_bounds__(LO_THREADS) void grad_prepare_kernel(const float* _
 }
 
 __global__ void opt_tick_kernel(const float* __restrict__ blk_partial, const int32_t* __restrict__ seg_first_blk, int nseg,
-                                float* __restrict__ seg_norm2, int32_t* step_count, float* lr_state, imm_opt_hparams hp) {
+                                float* __restrict__ seg_norm2, int32_t* step_count, int32_t* adam_t, float* lr_state,
+                                imm_opt_hparams hp) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t < nseg) {
     double s = 0.0;
@@ -388,13 +389,14 @@ __global__ void opt_tick_kernel(const float* __restrict__ blk_partial, const int
     seg_norm2[t] = (float)s;
   }
   if (t == 0) {
-    const int gs = step_count[0];           // TF global_step before this apply
-    const int tt = gs + 1;                  // Adam's t
+    const int gs = step_count[0];           // TF global_step before this apply: learning-rate schedule only
+    const int tt = adam_t[0] + 1;           // Adam's t (TF: beta1_power / beta2_power, independent of global_step)
     const double lr = (double)hp.lr_multiple * (double)hp.lr_start * pow((double)hp.lr_decay, (double)(gs / hp.lr_step));
     const double lr_t = lr * sqrt(1.0 - pow((double)hp.beta2, (double)tt)) / (1.0 - pow((double)hp.beta1, (double)tt));
     lr_state[0] = (float)lr_t;
     lr_state[1] = (float)lr;
-    step_count[0] = tt;
+    step_count[0] = gs + 1;
+    adam_t[0] = tt;
   }
 }
 
@@ -430,15 +432,16 @@ __global__ __launch_bounds__(LO_THREADS) void clip_adam_kernel(float* __restrict
 extern "C" int imm_clip_adam_step(float* params, float* grads, float* m, float* v, const int32_t* blk_seg,
                                   const int32_t* blk_begin, const int32_t* blk_end, int nblk, int nseg,
                                   const int32_t* seg_first_blk, const float* seg_wd, float* blk_partial, float* seg_norm2,
-                                  int32_t* step_count, float* lr_state, const imm_opt_hparams* hp, void* stream) {
+                                  int32_t* step_count, int32_t* adam_t, float* lr_state, const imm_opt_hparams* hp,
+                                  void* stream) {
   IMM_REQUIRE(params && grads && m && v && blk_seg && blk_begin && blk_end && seg_first_blk && seg_wd && blk_partial &&
-                  seg_norm2 && step_count && lr_state && hp, "clip_adam_step: null");
+                  seg_norm2 && step_count && adam_t && lr_state && hp, "clip_adam_step: null");
   IMM_REQUIRE(nblk > 0 && nseg > 0 && hp->lr_step > 0, "clip_adam_step: dims");
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(grad_prepare_kernel, dim3(nblk), dim3(LO_THREADS), 0, s, params, grads, blk_seg, blk_begin, blk_end,
                      seg_wd, hp->grad_scale, blk_partial);
   hipLaunchKernelGGL(opt_tick_kernel, dim3((nseg + 63) / 64), dim3(64), 0, s, blk_partial, seg_first_blk, nseg, seg_norm2,
-                     step_count, lr_state, *hp);
+                     step_count, adam_t, lr_state, *hp);
   hipLaunchKernelGGL(clip_adam_kernel, dim3(nblk), dim3(LO_THREADS), 0, s, params, grads, m, v, blk_seg, blk_begin, blk_end,
                      seg_norm2, lr_state, *hp);
   IMM_CHECK_LAUNCH("imm_clip_adam_step");

@@ -17,6 +17,12 @@ int imm_fail(int code, const char* fmt, ...) {
 
 extern "C" int imm_abi_version(void) { return IMM_ABI_VERSION; }
 extern "C" const char* imm_last_error(void) { return imm_err_buf; }
+#ifndef IMM_SOURCE_DIGEST
+#define IMM_SOURCE_DIGEST "unknown"
+#endif
+// the marker makes the digest readable from the file without loading it (imm_amd/build.py)
+static const char imm_digest_marker[] = "IMM_SOURCE_DIGEST=" IMM_SOURCE_DIGEST;
+extern "C" const char* imm_source_digest(void) { return imm_digest_marker + 18; }
 
 extern "C" int imm_device_info(int32_t* out2) {
   IMM_REQUIRE(out2, "device_info: null");

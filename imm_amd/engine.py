@@ -174,7 +174,8 @@ class IMMEngine:
             self.gview[name] = self.grads[o0:o1].view(shape)
         self.opt_blk_partial = self._zeros(self.tab.nblk)
         self.seg_norm2 = self._zeros(self.tab.nseg)
-        self.step_count = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        self.step_count = torch.zeros(1, dtype=torch.int32, device=self.dev)    # TF global_step (lr schedule)
+        self.adam_t = torch.zeros(1, dtype=torch.int32, device=self.dev)        # Adam updates applied to m/v (beta powers)
         self.lr_state = self._zeros(2)
         self.wd_loss = self._zeros(1)
         hp = dict(lr_start=1e-3, lr_decay=0.95, lr_step=100000, lr_multiple=1.0, beta1=0.9, beta2=0.999, eps=1e-8,
@@ -228,7 +229,7 @@ class IMMEngine:
         for k, v in self.state.items():
             v.fill_(1.0 if k.endswith('moving_variance') else 0.0)
         self.loss_agg.copy_(torch.tensor(PERCEPTUAL_WS))
-        self.adam_m.zero_(); self.adam_v.zero_(); self.grads.zero_(); self.step_count.zero_()
+        self.adam_m.zero_(); self.adam_v.zero_(); self.grads.zero_(); self.step_count.zero_(); self.adam_t.zero_()
         self.run(self.prog_pack)
 
     def load_parameters(self, named, state=None):
@@ -661,7 +662,7 @@ class IMMEngine:
         # ---- optimizer --------------------------------------------------------------------------------------
         self._add(self.prog_opt, lambda: ops.clip_adam_step(self.params, self.grads, self.adam_m, self.adam_v, self.tab,
                                                             self.opt_blk_partial, self.seg_norm2, self.step_count,
-                                                            self.lr_state, self.hp), 'clip_adam', 0.0, self.tab.total * 36.0)
+                                                            self.adam_t, self.lr_state, self.hp), 'clip_adam', 0.0, self.tab.total * 36.0)
         self.prog_opt.extend(self.prog_pack)
 
     def _pack_vgg(self):
@@ -923,12 +924,12 @@ class IMMEngine:
     def snapshot(self):
         """Everything a step mutates (used to warm kernels up before graph capture without side effects)."""
         return {'params': self.params.clone(), 'm': self.adam_m.clone(), 'v': self.adam_v.clone(),
-                'step': self.step_count.clone(), 'agg': self.loss_agg.clone(), 'grads': self.grads.clone(),
+                'step': self.step_count.clone(), 'adam_t': self.adam_t.clone(), 'agg': self.loss_agg.clone(), 'grads': self.grads.clone(),
                 'state': {k: v.clone() for k, v in self.state.items()}}
 
     def restore(self, snap):
         self.params.copy_(snap['params']); self.adam_m.copy_(snap['m']); self.adam_v.copy_(snap['v'])
-        self.step_count.copy_(snap['step']); self.loss_agg.copy_(snap['agg']); self.grads.copy_(snap['grads'])
+        self.step_count.copy_(snap['step']); self.adam_t.copy_(snap['adam_t']); self.loss_agg.copy_(snap['agg']); self.grads.copy_(snap['grads'])
         for k, v in snap['state'].items():
             self.state[k].copy_(v)
         self.run(self.prog_pack)

@@ -34,8 +34,6 @@ def colorize_landmark_maps(maps):
 
 
 class IMMModel(BaseModel):
-    _warned_vgg = False
-
     def __init__(self, config, global_step=None, dtype=torch.bfloat16, name='IMMModel', device=None, seed=1,
                  vgg_weights=None, hparams=None, world_size=1):
         super(IMMModel, self).__init__(dtype, name)
@@ -43,32 +41,45 @@ class IMMModel(BaseModel):
         self._global_step = global_step
         self._device = device
         self._seed = seed
+        self.vgg_source = 'caller-supplied tensors'
         if vgg_weights is None:
-            # imm_model.py:124: perceptual.net_file names the pretrained colourisation VGG16.  When the file exists it is
-            # loaded (BN folded as in selfsup/vgg16.py:17-92); otherwise the seeded synthetic network of the benchmarks is
-            # used and the model says so once.
+            # imm_model.py:124: perceptual.net_file names the pretrained colourisation VGG16 (loaded with the caffe BN folded
+            # as in selfsup/vgg16.py:17-92).  Like the reference (dd.io.load raises) a missing file is an ERROR: training
+            # against a random perceptual network must be asked for explicitly with net_file: 'synthetic' (benchmarks, tests).
             import os
             perc = getattr(config, 'perceptual', None)
             net_file = getattr(perc, 'net_file', None) if perc is not None else None
-            if isinstance(net_file, str) and os.path.exists(net_file):
+            if net_file == 'synthetic':
+                self.vgg_source = 'synthetic (seeded He-normal stand-in)'
+            elif isinstance(net_file, str) and os.path.exists(net_file):
                 from ..utils.vgg_weights import load_vgg16
                 vgg_weights = load_vgg16(net_file)
-            elif isinstance(net_file, str) and net_file != 'synthetic' and not IMMModel._warned_vgg:
-                IMMModel._warned_vgg = True
-                import sys
-                sys.stderr.write('IMMModel: perceptual.net_file %r not found - using seeded synthetic VGG16 weights\n' % net_file)
+                self.vgg_source = os.path.abspath(net_file)
+            else:
+                # raised by require_vgg() as soon as a loss is built; landmark inference (build_loss=False, scripts/test.py)
+                # never touches the perceptual network, in the reference (imm_model.py:446-448) as here
+                self._vgg_missing = net_file
+                self.vgg_source = 'MISSING: %r' % (net_file,)
         self._vgg_weights = vgg_weights
         self._hparams = hparams
         self._world_size = world_size
         self._engines = {}
         self.engine = None
 
+    def require_vgg(self):
+        """The loss needs the perceptual network: a missing perceptual.net_file is an error (the reference's dd.io.load
+        raises), never a silent fall-back to random weights."""
+        if hasattr(self, '_vgg_missing'):
+            missing = self._vgg_missing
+            raise FileNotFoundError("perceptual.net_file %r does not exist (set it to the vgg16.caffemodel.h5 / .npz file, or to "
+                                    "'synthetic' to train against seeded random VGG16 weights)" % (missing,))
+
     # -- engine management ---------------------------------------------------------------------------
     @staticmethod
     def _mirror(dst, src):
         dst.load_parameters(src.named_parameters(), src.named_state())
         dst.adam_m.copy_(src.adam_m); dst.adam_v.copy_(src.adam_v)
-        dst.step_count.copy_(src.step_count)
+        dst.step_count.copy_(src.step_count); dst.adam_t.copy_(src.adam_t)
 
     def _get_engine(self, batch, size):
         """One engine (buffers + launch programs) per (batch, size); the variables are shared between instantiations
@@ -101,6 +112,8 @@ class IMMModel(BaseModel):
         cfg = self._config
         if build_loss and cfg.loss_mask and mask is None:
             raise RuntimeError('No loss mask recieved but is required.')
+        if build_loss:
+            self.require_vgg()
         eng = self._get_engine(im.shape[0], future_im_size[0])
         if mask is None and eng.use_mask:
             mask = torch.ones(im.shape[0], future_im_size[0], future_im_size[0], 1)

@@ -282,10 +282,10 @@ def weight_decay_loss(params, tab, blk_partial, out):
          _p(blk_partial), _p(out), _s())
 
 
-def clip_adam_step(params, grads, m, v, tab, blk_partial, seg_norm2, step_count, lr_state, hp):
+def clip_adam_step(params, grads, m, v, tab, blk_partial, seg_norm2, step_count, adam_t, lr_state, hp):
     call('imm_clip_adam_step', _p(params), _p(grads), _p(m), _p(v), _p(tab.blk_seg), _p(tab.blk_begin), _p(tab.blk_end),
          tab.nblk, tab.nseg, _p(tab.seg_first_blk), _p(tab.seg_wd), _p(blk_partial), _p(seg_norm2), _p(step_count),
-         _p(lr_state), C.byref(hp), _s())
+         _p(adam_t), _p(lr_state), C.byref(hp), _s())
 
 
 class SegmentTable:

@@ -56,6 +56,7 @@ class TrainStep:
         # 8 GPUs from the build box, so the default is ONE all-reduce of the whole 16.6 MB buffer per step.
         self.buckets = int(os.environ.get('IMM_DP_BUCKETS', '1'))
         self.group = group
+        model.require_vgg()                       # training against a missing perceptual network is an error, not a fallback
         self.engine = model._get_engine(batch_per_rank, image_size)
         model._master = self.engine               # the engine whose variables are trained; others mirror it (eval batches)
         if self.buckets >= 2 and self.engine.n_bwd_bucket0 is None:

@@ -382,8 +382,11 @@ def engine_to_tf(engine, with_optimizer=True):
             o0, o1 = engine.tab.offsets[i], engine.tab.offsets[i + 1]
             out[tf_variable_name(name) + '/Adam'] = m[o0:o1].reshape(shape)
             out[tf_variable_name(name) + '/Adam_1'] = v[o0:o1].reshape(shape)
-        out['beta1_power'] = np.asarray(float(engine.hp.beta1) ** (step + 1), dtype=np.float32)
-        out['beta2_power'] = np.asarray(float(engine.hp.beta2) ** (step + 1), dtype=np.float32)
+        # tf.train.AdamOptimizer: beta_power starts at beta and is multiplied by beta after every apply => beta^(t+1) after
+        # t updates of these slots (NOT global_step: the two differ after a restore without the optimizer)
+        t = int(engine.adam_t)
+        out['beta1_power'] = np.asarray(float(engine.hp.beta1) ** (t + 1), dtype=np.float32)
+        out['beta2_power'] = np.asarray(float(engine.hp.beta2) ** (t + 1), dtype=np.float32)
     return out
 
 
@@ -405,7 +408,7 @@ def load_tf_checkpoint(engine, prefix, restore_optim=False, ignore_missing_vars=
     missing = [n for n in needed if n not in have]
     if missing and not ignore_missing_vars:
         raise KeyError('%s lacks %d variables (e.g. %s); pass ignore_missing_vars to skip them' % (prefix, len(missing), missing[0]))
-    data = read_bundle(prefix, names=set(needed) | {'global_step'})
+    data = read_bundle(prefix, names=set(needed) | {'global_step', 'beta1_power', 'beta2_power'})
     params = engine.named_parameters()
     for k, n in want_params.items():
         if n in data:
@@ -423,6 +426,20 @@ def load_tf_checkpoint(engine, prefix, restore_optim=False, ignore_missing_vars=
                 m[o0:o1] = data[n + '/Adam'].reshape(-1)
                 v[o0:o1] = data[n + '/Adam_1'].reshape(-1)
         engine.adam_m.copy_(torch.from_numpy(m)); engine.adam_v.copy_(torch.from_numpy(v))
+        # Adam's t from the saved accumulators beta^(t+1) (beta2_power first: it resolves t up to ~1e5 before float32
+        # underflow, beta1_power only up to ~1e3); both underflown = the correction factors are 1 anyway: any large t
+        t = 0
+        for key, beta in (('beta2_power', engine.hp.beta2), ('beta1_power', engine.hp.beta1)):
+            if key in data:
+                bp = float(data[key])
+                if 0.0 < bp < 1.0:
+                    t = max(0, int(round(np.log(bp) / np.log(float(beta)))) - 1)
+                    break
+                if bp == 0.0:
+                    t = max(t, 1 << 20)
+        engine.adam_t.fill_(t)
+    else:
+        engine.adam_m.zero_(); engine.adam_v.zero_(); engine.adam_t.zero_()
     if reset_global_step >= 0:
         engine.step_count.fill_(int(reset_global_step))
     elif 'global_step' in data:

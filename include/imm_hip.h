@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define IMM_ABI_VERSION 4   /* 2: imm_vgg_conv1_1_fwd gained `halves` */
+#define IMM_ABI_VERSION 5   /* 2: imm_vgg_conv1_1_fwd gained `halves` */
 
 enum imm_dtype { IMM_BF16 = 0, IMM_F16 = 1 };
 
@@ -64,6 +64,9 @@ typedef struct imm_conv_desc {
 /* ---- runtime ------------------------------------------------------------------------------- */
 int imm_abi_version(void);
 const char* imm_last_error(void);
+/* sha256 (hex) of the sources this library was built from (every .hip and .h file under csrc/ plus this header, by repo-relative
+ * path + content): the host binding compares it with the checkout and refuses (or rebuilds) a stale binary */
+const char* imm_source_digest(void);
 /* device properties the host needs to size launches: [0]=CU count, [1]=gfx arch number (950) */
 int imm_device_info(int32_t* out2_host);
 /* HIP-graph capture of a launch sequence on `stream` (replaces TF's session.run of a static graph,
@@ -231,12 +234,15 @@ int imm_weight_decay_loss(const float* params, const int32_t* blk_seg, const int
                           const int32_t* blk_end, int nblk, const float* seg_wd, float* blk_partial, float* out,
                           void* stream);
 /* g <- g*grad_scale + wd*w (in place), norm2[seg] = sum g^2; then Adam with per-tensor clip.
- * step_count: device int32 (Adam's t; incremented by this call, lr uses global_step = t-1 before
- * the increment); lr_state: device f32[2] = {lr_t, lr} written for inspection. */
+ * step_count: device int32 = TF global_step (drives the staircase learning rate only; incremented by this call);
+ * adam_t: device int32 = number of Adam updates applied to these m/v slots, i.e. TF's beta{1,2}_power accumulators
+ * (tf.train.AdamOptimizer keeps them apart from global_step: a restore without the optimizer slots restarts the bias
+ * correction at t = 1 while global_step carries on; cnn_train_multi.py:404-433); incremented by this call;
+ * lr_state: device f32[2] = {lr_t, lr} written for inspection. */
 int imm_clip_adam_step(float* params, float* grads, float* m, float* v, const int32_t* blk_seg,
                        const int32_t* blk_begin, const int32_t* blk_end, int nblk, int nseg,
                        const int32_t* seg_first_blk, const float* seg_wd, float* blk_partial, float* seg_norm2,
-                       int32_t* step_count, float* lr_state, const imm_opt_hparams* hp_host, void* stream);
+                       int32_t* step_count, int32_t* adam_t, float* lr_state, const imm_opt_hparams* hp_host, void* stream);
 
 /* ---- thin-plate-spline augmentation (imm/utils/tps_sampler.py:76-99,142-157; imm/datasets/tps_dataset.py:70-96) ---- */
 /* dst[b][p] = bilinear(src[b], sum_j basis_t[j][p] * w_tps[b][j][0..1]) with F.grid_sample's align_corners=True mapping and

@@ -141,8 +141,13 @@ def main(args):
         eng.load_parameters(ck['params'], ck.get('state'))
         if 'step' in ck:                      # global_step is a model variable upstream: restored in both modes
             eng.step_count.fill_(int(ck['step']))
+        # Adam's slots AND its bias-correction counter (TF: beta1_power / beta2_power) travel together: without
+        # --restore-optim both start afresh (m = v = 0, t = 0) whatever the restored global_step is
         if args.restore_optim and 'adam_m' in ck:
             eng.adam_m.copy_(ck['adam_m']); eng.adam_v.copy_(ck['adam_v'])
+            eng.adam_t.fill_(int(ck.get('adam_t', ck.get('step', 0))))
+        else:
+            eng.adam_m.zero_(); eng.adam_v.zero_(); eng.adam_t.zero_()
     elif args.checkpoint is not None:
         print('No checkpoint at %s. Initializing randomly.' % args.checkpoint)
     if args.reset_global_step >= 0:
@@ -164,7 +169,8 @@ def main(args):
         os.makedirs(train_config.logdir, exist_ok=True)
         path = osp.join(train_config.logdir, 'model.ckpt-%d.pt' % n)
         torch.save({'params': eng.named_parameters(), 'state': eng.named_state(), 'adam_m': eng.adam_m.cpu(),
-                    'adam_v': eng.adam_v.cpu(), 'step': int(eng.step_count)}, path)
+                    'adam_v': eng.adam_v.cpu(), 'step': int(eng.step_count), 'adam_t': int(eng.adam_t),
+                    'vgg_weights': getattr(step.model, 'vgg_source', 'unknown')}, path)
         print('saved', path)
         if args.tf_checkpoints:
             from imm_amd.utils.tf_checkpoint import save_tf_checkpoint

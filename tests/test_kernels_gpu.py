@@ -612,6 +612,7 @@ def test_clip_adam_and_weight_decay(ops):
     m, v = torch.zeros_like(params), torch.zeros_like(params)
     part = torch.empty(tab.nblk, device=DEV); norm2 = torch.empty(tab.nseg, device=DEV)
     step = torch.zeros(1, dtype=torch.int32, device=DEV); lrs = torch.zeros(2, device=DEV)
+    adam_t = torch.zeros(1, dtype=torch.int32, device=DEV)
     wdl = torch.zeros(1, device=DEV)
     ops.weight_decay_loss(params, tab, part, wdl)
     torch.cuda.synchronize()
@@ -626,10 +627,23 @@ def test_clip_adam_and_weight_decay(ops):
         gref = {k: O.clip_by_norm(x, 1.0) for k, x in gref.items()}
         Pref = O.adam_apply(Pref, gref, opt, lr=O.learning_rate(it))
         grads = flat(G) * 2.0
-        ops.clip_adam_step(params, grads, m, v, tab, part, norm2, step, lrs, hp)
+        ops.clip_adam_step(params, grads, m, v, tab, part, norm2, step, adam_t, lrs, hp)
         torch.cuda.synchronize()
         close(params, flat(Pref), 1e-5, 1e-6, 'adam params step %d' % it)
-    assert int(step) == 3
+    assert int(step) == 3 and int(adam_t) == 3
+    # TF keeps Adam's bias correction in beta{1,2}_power, apart from global_step: a restored global_step (here 250000, i.e.
+    # two staircase decays of the learning rate) with fresh m = v = 0 slots must restart the correction at t = 1
+    step.fill_(250000); adam_t.zero_(); m.zero_(); v.zero_()
+    p0 = params.clone()
+    grads = flat(G) * 2.0
+    ops.clip_adam_step(params, grads, m, v, tab, part, norm2, step, adam_t, lrs, hp)
+    torch.cuda.synchronize()
+    lr = 1e-3 * 0.95 ** 2
+    np.testing.assert_allclose(float(lrs[1]), lr, rtol=1e-6)
+    np.testing.assert_allclose(float(lrs[0]), lr * (1 - 0.999) ** 0.5 / (1 - 0.9), rtol=1e-5)
+    assert int(step) == 250001 and int(adam_t) == 1
+    big = grads.abs() > 1e-4          # first bias-corrected step: |dw| = lr * |g| / (|g| + eps') ~ lr
+    np.testing.assert_allclose((params - p0).abs()[big].max().item(), lr, rtol=1e-3)
 
 
 def test_graph_capture_replay(ops):
