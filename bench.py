@@ -105,6 +105,8 @@ def pmc_traffic_live(timeout_s=240):
             fam_kb = tot_kb = 0.0
             fam_n = 0
             for name, val in _pmc_rows(d, ctr):
+                if 'at::native' in name or 'rocclr' in name:
+                    continue                         # torch's zero-fills / copies while the engine is being built: not the step
                 tot_kb += val
                 if any(k in name for k in CONV_FAMILY) and 'wgrad' not in name:
                     fam_kb += val; fam_n += 1
@@ -306,7 +308,8 @@ def main():
     run_steps(2)                                  # graph capture, code-object loading
     barrier()
     t0 = time.perf_counter(); run_steps(10); t10 = (time.perf_counter() - t0) / 10
-    n_spin = torch.tensor([max(0, int(args.spin_seconds / max(t10, 1e-5)))], dtype=torch.int64, device=dev)
+    ctrl = dev if args.backend == 'nccl' else 'cpu'      # small control collectives: device tensors for RCCL, host for gloo
+    n_spin = torch.tensor([max(0, int(args.spin_seconds / max(t10, 1e-5)))], dtype=torch.int64, device=ctrl)
     if world > 1:
         dist.broadcast(n_spin, 0)
     run_steps(int(n_spin))
@@ -319,7 +322,7 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            t = torch.tensor([elapsed], dtype=torch.float64, device=ctrl)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t)
         windows.append(elapsed)
@@ -328,7 +331,7 @@ def main():
     assert loss == loss, 'NaN loss'
     if world > 1 or args.force_dist:
         # the printed loss of the reference is the tower mean (cnn_train_multi.py:173)
-        lt = eng.loss.detach().clone().reshape(1)
+        lt = eng.loss.detach().clone().reshape(1).to(ctrl)
         dist.all_reduce(lt)
         loss = float(lt) / world
 

@@ -883,7 +883,10 @@ class IMMEngine:
         if self._side is None:
             self._side = {}
         if i not in self._side:
-            self._side[i] = torch.cuda.Stream(device=self.dev)
+            # IMM_LANE<i>_PRIO: stream priority of a side lane (-1 = high, 0 = normal); with the training stream raised to
+            # -1 (IMM_MAIN_PRIO) a lane left at 0 only gets the CUs the critical chain leaves idle
+            prio = int(os.environ.get('IMM_LANE%d_PRIO' % i, os.environ.get('IMM_MAIN_PRIO', '0')))
+            self._side[i] = torch.cuda.Stream(device=self.dev, priority=prio)
         return self._side[i]
 
     def run_timed(self, prog):

@@ -37,10 +37,29 @@ def average_gradients(flat_grads, world_size, group=None, force=False, async_op=
     """cnn_train_multi.py:66-106.  Sum-all-reduce of (a bucket of) the flat gradient buffer; the division by the
     number of towers happens inside imm_clip_adam_step (grad_scale = 1/world_size), before the
     per-tensor clip, as in the reference.  With async_op the RCCL work handle is returned (the collective runs
-    on RCCL's stream, ordered after everything already enqueued on the current stream)."""
+    on RCCL's stream, ordered after everything already enqueued on the current stream).
+    Backend "gloo" (CPU-side tests of the multi-rank path, several ranks sharing one GPU): device tensors are bounced
+    through the host — same sum, same flat layout, no claim about speed."""
     if world_size > 1 or (force and dist.is_initialized()):
+        if flat_grads.is_cuda and dist.get_backend(group) == 'gloo':
+            host = flat_grads.detach().cpu()          # synchronises with the producing stream
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            flat_grads.copy_(host)
+            return None
         return dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
     return None
+
+
+def mean_tower_loss(loss, world_size, group=None):
+    """The loss the reference prints and summarises is the mean over towers (cnn_train_multi.py:173 avg_tower_loss): a
+    scalar all-reduce, issued on logging steps only.  Returns a Python float."""
+    if world_size > 1 and dist.is_initialized():
+        t = loss.detach().reshape(1).to(torch.float32).clone()
+        if t.is_cuda and dist.get_backend(group) == 'gloo':
+            t = t.cpu()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        return float(t) / world_size
+    return float(loss)
 
 
 class TrainStep:
@@ -51,20 +70,22 @@ class TrainStep:
         self.world_size = world_size
         # two graphs with the all-reduce in between (always for world_size > 1; selectable at 1 to test that path)
         self.split = split_graphs or world_size > 1
-        # IMM_DP_BUCKETS=2: renderer gradients are all-reduced while the encoders' backward still runs.  Measured at
-        # 1 GPU (RCCL single rank) the extra graph + collective launch costs 0.25 ms/step and cannot be validated on
-        # 8 GPUs from the build box, so the default is ONE all-reduce of the whole 16.6 MB buffer per step.
-        self.buckets = int(os.environ.get('IMM_DP_BUCKETS', '1'))
+        # Two buckets at N > 1: the renderer's gradients (the tail of the flat buffer, 43 % of the 16.6 MB) are all-reduced on
+        # RCCL's stream while the encoders' backward graph still runs; the encoder bucket follows it.  One bucket when the
+        # split path is only being exercised on a single rank (the extra graph launch costs 0.25 ms there and overlaps
+        # nothing).  IMM_DP_BUCKETS overrides.
         self.group = group
         model.require_vgg()                       # training against a missing perceptual network is an error, not a fallback
         self.engine = model._get_engine(batch_per_rank, image_size)
         model._master = self.engine               # the engine whose variables are trained; others mirror it (eval batches)
+        default_buckets = 2 if (world_size > 1 and self.engine.n_bwd_bucket0 is not None) else 1
+        self.buckets = int(os.environ.get('IMM_DP_BUCKETS', str(default_buckets)))
         if self.buckets >= 2 and self.engine.n_bwd_bucket0 is None:
             raise ValueError('IMM_DP_BUCKETS=2 needs the renderer gradients reduced early: set IMM_WGRAD_DEFER_REN=0')
         if abs(self.engine.hp.grad_scale - 1.0 / world_size) > 1e-9:
             raise ValueError('engine was built for world_size %g' % (1.0 / self.engine.hp.grad_scale))
         self.use_graph = use_graph
-        self.stream = torch.cuda.Stream(device=self.engine.dev)
+        self.stream = torch.cuda.Stream(device=self.engine.dev, priority=int(os.environ.get('IMM_MAIN_PRIO', '0')))
         self._graphs = None
         torch.cuda.synchronize(self.engine.dev)   # engine construction ran on the default stream
 
@@ -259,16 +280,16 @@ def train_loop(opts, train_step, data_iter, num_steps, log_every=10, checkpoint_
         loss = train_step.step(next(data_iter))
         n_seen += opts['batch_size']
         do_log = (step - start_step) % log_every == 0
-        do_sum = summary_writer is not None and n_summary and step % n_summary == 0
+        do_sum = bool(n_summary) and step % n_summary == 0      # the same on every rank: the loss mean is a collective
         if do_log or do_sum:
             train_step.synchronize()
-            loss_value = float(loss)
+            loss_value = mean_tower_loss(loss, train_step.world_size, train_step.group)   # every rank takes part
             assert loss_value == loss_value, 'Model diverged with loss = NaN'
             dt = time.time() - t0
             if rank == 0 and do_log:
                 print('step %d, loss = %.4f (%.1f examples/sec; %.3f sec/batch)' % (step, loss_value,
                                                                                     opts['batch_size'] / dt, dt))
-            if rank == 0 and do_sum:
+            if rank == 0 and do_sum and summary_writer is not None:
                 images = image_summaries(eng) if n_image and step % n_image == 0 else None
                 summary_writer.add_summary({'tag': 'train', 'loss': loss_value, 'lr': float(eng.lr_state[1]),
                                             'loss_terms': [float(v) for v in eng.loss_terms],

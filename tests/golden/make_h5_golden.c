@@ -10,6 +10,12 @@
  *
  *   gcc tests/golden/make_h5_golden.c -I/opt/conda/include -L/opt/conda/lib -Wl,-rpath,/opt/conda/lib -lhdf5_hl -lhdf5 -lm \
  *       -o /tmp/make_h5_golden && /tmp/make_h5_golden tests/golden/caffe_vgg_tiny.h5
+ *
+ * `make_h5_golden <out.h5> full` writes the REAL shapes of the colourisation VGG16 instead (conv1_1 [64,1,3,3] ... conv5_3
+ * [512,512,3,3], 59 MB; every layer with its batch_<layer> group): blob values are a counter-based hash (hash_unit below,
+ * restated in numpy by tests/test_vgg_file_gpu.py) scaled He-style, so that a network built from the file has healthy
+ * activations.  That file is generated at test time (it is too large to commit) and feeds
+ * hdf5_lite -> load_vgg16 -> engine on the GPU against the oracle with the same folded weights.
  */
 #include <hdf5.h>
 #include <hdf5_hl.h>
@@ -18,6 +24,52 @@
 #include <stdlib.h>
 
 static float val(int l, int b, long e) { return (float)sin(0.37 * (double)e + 1.3 * b + 0.11 * l); }
+
+/* uniform in [0,1): 32-bit mix of (element, layer, blob) */
+static double hash_unit(int l, int b, long e) {
+  unsigned int h = (unsigned int)e * 2654435761u + (unsigned int)l * 97u + (unsigned int)b * 13u + 12345u;
+  h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
+  return (double)h / 4294967296.0;
+}
+
+static void hash_blob(hid_t g, const char* name, int rank, const hsize_t* dims, int l, int b, double lo, double hi) {
+  long n = 1;
+  for (int i = 0; i < rank; ++i) n *= (long)dims[i];
+  float* buf = (float*)malloc(sizeof(float) * n);
+  for (long e = 0; e < n; ++e) buf[e] = (float)(lo + (hi - lo) * hash_unit(l, b, e));
+  H5LTmake_dataset_float(g, name, rank, dims, buf);
+  free(buf);
+}
+
+static int write_full(const char* path) {
+  static const char* names[13] = {"conv1_1", "conv1_2", "conv2_1", "conv2_2", "conv3_1", "conv3_2", "conv3_3",
+                                  "conv4_1", "conv4_2", "conv4_3", "conv5_1", "conv5_2", "conv5_3"};
+  static const int couts[13] = {64, 64, 128, 128, 256, 256, 256, 512, 512, 512, 512, 512, 512};
+  hid_t f = H5Fcreate(path, H5F_ACC_TRUNC, H5P_DEFAULT, H5P_DEFAULT);
+  hid_t data = H5Gcreate2(f, "data", H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
+  int cin = 1;
+  for (int l = 0; l < 13; ++l) {
+    const int cout = couts[l];
+    hid_t g = H5Gcreate2(data, names[l], H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
+    hsize_t wd[4] = {(hsize_t)cout, (hsize_t)cin, 3, 3}, bd[1] = {(hsize_t)cout}, one[1] = {1};
+    const double a = sqrt(6.0 / (9.0 * cin));          /* uniform(-a, a): variance 2 / fan_in (He) */
+    hash_blob(g, "0", 4, wd, l, 0, -a, a);
+    hash_blob(g, "1", 1, bd, l, 1, -0.1, 0.1);
+    H5Gclose(g);
+    char bn[64];
+    snprintf(bn, sizeof bn, "batch_%s", names[l]);
+    g = H5Gcreate2(data, bn, H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
+    const float scale = 2.0f + 0.25f * (float)l;      /* caffe's accumulated scale factor: sums are scale x the statistic */
+    hash_blob(g, "0", 1, bd, l, 2, -0.05 * scale, 0.05 * scale);   /* mean sums */
+    hash_blob(g, "1", 1, bd, l, 3, 0.5 * scale, 1.5 * scale);      /* variance sums (positive) */
+    H5LTmake_dataset_float(g, "2", 1, one, &scale);
+    H5Gclose(g);
+    cin = cout;
+  }
+  H5Gclose(data);
+  H5Fclose(f);
+  return 0;
+}
 
 static void blob(hid_t g, const char* name, int rank, const hsize_t* dims, int l, int b) {
   long n = 1;
@@ -30,6 +82,7 @@ static void blob(hid_t g, const char* name, int rank, const hsize_t* dims, int l
 
 int main(int argc, char** argv) {
   if (argc < 2) return 2;
+  if (argc > 2 && argv[2][0] == 'f') return write_full(argv[1]);
   hid_t f = H5Fcreate(argv[1], H5F_ACC_TRUNC, H5P_DEFAULT, H5P_DEFAULT);
   hid_t data = H5Gcreate2(f, "data", H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
   /* 13 conv layers with toy channel counts (conv1_1 has ONE input channel: the colourisation VGG is grayscale) + their batch norms:
