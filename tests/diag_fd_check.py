@@ -78,11 +78,12 @@ def main():
                     wd += w * float((eng.params[sl].double() * d[sl].double()).sum())
             pnorm = float((eng.params * (d != 0)).norm())
             row = []
-            for rel in (3e-4, 1e-3, 3e-3, 1e-2, 3e-2):
+            pnorm = max(pnorm, 0.01 * float((d != 0).sum()) ** 0.5)      # beta = 0 at initialisation
+            for rel in (3e-5, 1e-4, 3e-4, 1e-3, 3e-3):
                 eps = rel * pnorm
                 fd = directional(eng, d, eps, agg0) - wd
                 row.append('%8.3g' % (fd / analytic))
-            print('FD %-8s %-24s <g,d> %10.4g  |theta_grp| %8.3g  FD/analytic at eps/|theta| 3e-4,1e-3,3e-3,1e-2,3e-2: %s'
+            print('FD %-8s %-24s <g,d> %10.4g  |theta_grp| %8.3g  FD/analytic at eps/|theta| 3e-5,1e-4,3e-4,1e-3,3e-3: %s'
                   % (str(dt).split('.')[-1], gname, analytic, pnorm, ' '.join(row)))
         del model, eng
 

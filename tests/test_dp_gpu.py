@@ -92,8 +92,7 @@ def test_two_engines_equal_the_two_tower_reference(emu):
         e = float((got - ref).norm() / ref.norm())
         print('DP_GRAD %-32s rel %.3g' % (k, e))
         assert e < lim, (k, e)
-    # (iii) after ONE update (A's parameters were cloned into `first` below? no: compare directions of the first step
-    #       through a fresh emulation of one step) — every tensor moves in the oracle's direction
+    # (iii) after ONE update (a fresh one-step emulation) every tensor moves in the oracle's direction
     A1, _B1, _l, _a, _b = emulate_two_towers(1)
     got = A1.named_parameters()
     worst = []
@@ -102,8 +101,8 @@ def test_two_engines_equal_the_two_tower_reference(emu):
             continue                     # bias in front of a BN: noise gradient in the oracle, exact zero here
         du_ref = (v - Pe[k]).flatten().double()
         du_got = (got[k].cpu() - P[k]).flatten().double()
-        if float(du_ref.norm()) == 0.0:
-            continue
+        if float(info['grads'][k].norm()) < 1e-6:
+            continue                     # pose 1x1 bias: |g| ~ 3e-8, cancellation noise in every implementation
         cos = float((du_ref * du_got).sum() / (du_ref.norm() * du_got.norm() + 1e-30))
         lim = 0.97 if k in ('model/renderer/conv_8/w', 'model/renderer/conv_7/gamma', 'model/renderer/conv_7/beta') else 0.5
         if cos < lim:
