@@ -73,22 +73,30 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4_t (&acc)[
         v[r] = acc[i][j][r] + bv[r];
         if (f_relu) v[r] = fmaxf(v[r], 0.f);
       }
+      // with IMM_CONV_STATS | IMM_CONV_MASK the second partial sum is sum(v * mask_ref) instead of sum(v^2): the
+      // batch-norm backward sums (sum dz, sum dz * out) of the layer whose output gradient this data gradient is
+      float mv[4] = {0.f, 0.f, 0.f, 0.f};
       if (f_mask && mok) {
         const uint16_t* mp = a.mask + (int64_t)m * a.ldmask + n;
         if (n + 3 < a.co && (a.ldmask & 3) == 0) {
           const uint2 mw = *(const uint2*)mp;
           const uint16_t mh[4] = {(uint16_t)(mw.x & 0xffffu), (uint16_t)(mw.x >> 16), (uint16_t)(mw.y & 0xffffu), (uint16_t)(mw.y >> 16)};
 #pragma unroll
-          for (int r = 0; r < 4; ++r) if (!(ET::to_f32(mh[r]) > 0.f)) v[r] = 0.f;
+          for (int r = 0; r < 4; ++r) { mv[r] = ET::to_f32(mh[r]); if (!(mv[r] > 0.f)) v[r] = 0.f; }
         } else {
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            if (n + r < a.co && !(ET::to_f32(mp[r]) > 0.f)) v[r] = 0.f;
+            if (n + r < a.co) { mv[r] = ET::to_f32(mp[r]); if (!(mv[r] > 0.f)) v[r] = 0.f; }
         }
       }
       if (f_stats && mok) {
+        if (f_mask) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { s1[j][r] += v[r]; s2[j][r] += v[r] * v[r]; }
+          for (int r = 0; r < 4; ++r) { s1[j][r] += v[r]; s2[j][r] += v[r] * mv[r]; }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { s1[j][r] += v[r]; s2[j][r] += v[r] * v[r]; }
+        }
       }
       if (mok) {
         if (f_f32) {

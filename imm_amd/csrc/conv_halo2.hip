@@ -310,20 +310,21 @@ __global__ __launch_bounds__(256) void conv_halo2_kernel(const Halo2Args ha) {
         for (int j = 0; j < NT; ++j)
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[j * 4 + r] = fmaxf(acc[PH ^ 1][i][j][r] + bv[j][r], relu_floor);
+        float mf[8];
         if constexpr (MASK) {
           const uint4 mk = Ml[(wm * MT + i) * 16 * O8];
-          float mf[8];
           unpack8<ET>(mk, mf);
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = (mf[e] > 0.f) ? v[e] : 0.f;
         }
         if constexpr (STATS) {
+          // MASK && STATS: second sum = sum(v * mask_ref), the batch-norm backward sums of the layer this gradient enters
 #pragma unroll
           for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const float t = v[j * 4 + r] * prev_w;
-              s1[j][r] += t; s2[j][r] += t * t;
+              s1[j][r] += t; s2[j][r] += t * (MASK ? mf[j * 4 + r] : t);
             }
         }
         const uint4 o = pack8<ET>(v);
@@ -441,7 +442,7 @@ bool imm_halo2_applicable(const imm_conv_desc* d) {
   if (d->hi != d->ho || d->wi != d->wo || d->ho % H2_PH || d->wo % H2_PW) return false;
   if (d->ho * d->wo < 64 * 64) return false;
   if (d->ldy % 8) return false;
-  if ((d->flags & IMM_CONV_MASK) && (d->ci != 64 || d->co != 64 || d->ldmask % 8 || (d->flags & IMM_CONV_STATS))) return false;
+  if ((d->flags & IMM_CONV_MASK) && (d->ci != d->co || d->ldmask % 8)) return false;
   const int64_t px = (int64_t)d->batch * d->hi * d->wi;
   return px * d->ldx * 2 < (1LL << 31) && px * d->ldy * 2 < (1LL << 31) && px * (int64_t)d->ldmask * 2 < (1LL << 31);
 }
@@ -486,9 +487,13 @@ static void h2_dispatch(const imm_conv_desc* d, F&& f) {
   auto with_stats = [&](auto c, auto b) {
     if (stats) with_ns(c, b, H2Int<1>()); else with_ns(c, b, H2Int<0>());
   };
-  if (mask) {
-    if (ns == 3) f(H2Int<64>(), H2Int<64>(), H2Int<1>(), H2Int<0>(), H2Int<3>(), H2Int<3>(), H2Int<3>());
-    else f(H2Int<64>(), H2Int<64>(), H2Int<1>(), H2Int<0>(), H2Int<4>(), H2Int<3>(), H2Int<3>());
+  if (mask) {      // ci == co in {32, 64}: ReLU-backward mask (VGG conv1_2) and, with stats, the batch-norm backward sums
+    auto with_mask = [&](auto c, auto st) {
+      if (ns == 3) f(c, c, H2Int<1>(), st, H2Int<3>(), H2Int<3>(), H2Int<3>());
+      else f(c, c, H2Int<1>(), st, H2Int<4>(), H2Int<3>(), H2Int<3>());
+    };
+    if (ci == 64) { if (stats) with_mask(H2Int<64>(), H2Int<1>()); else with_mask(H2Int<64>(), H2Int<0>()); }
+    else { if (stats) with_mask(H2Int<32>(), H2Int<1>()); else with_mask(H2Int<32>(), H2Int<0>()); }
   }
   else if (ci == 64 && co == 64) with_stats(H2Int<64>(), H2Int<64>());
   else if (ci == 64) with_stats(H2Int<64>(), H2Int<32>());

@@ -262,15 +262,19 @@ __global__ __launch_bounds__(NW * 64) void conv_hdeep_kernel(const HdArgs ha) {
         v[e] = acc[i][2 * h + (e >> 2)][e & 3] + bv[2 * h + (e >> 2)][e & 3];
         if (f_relu) v[e] = fmaxf(v[e], 0.f);
       }
+      float mf[8];
       if (f_mask) {
-        float mf[8];
         unpack8<ET>(*(const uint4*)(a.mask + m * a.ldmask + nb + 8 * h), mf);
 #pragma unroll
         for (int e = 0; e < 8; ++e) if (!(mf[e] > 0.f)) v[e] = 0.f;
       }
       if (f_stats) {
+        // STATS | MASK: second sum = sum(v * mask_ref) — the batch-norm backward sums of the layer this gradient enters
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { s1[2 * h + (e >> 2)][e & 3] += v[e]; s2[2 * h + (e >> 2)][e & 3] += v[e] * v[e]; }
+        for (int e = 0; e < 8; ++e) {
+          s1[2 * h + (e >> 2)][e & 3] += v[e];
+          s2[2 * h + (e >> 2)][e & 3] += v[e] * (f_mask ? mf[e] : v[e]);
+        }
       }
       *(uint4*)((uint16_t*)a.y + m * a.ldy + nb + 8 * h) = pack8<ET>(v);
     }

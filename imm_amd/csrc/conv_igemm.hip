@@ -253,7 +253,7 @@ static int validate_desc(const imm_conv_desc* d) {
   IMM_REQUIRE(d->out_scale >= 0 && d->out_scale <= 2 && d->out_off_y >= 0 && d->out_off_x >= 0 &&
                   d->out_off_y < (d->out_scale > 1 ? d->out_scale : 1) && d->out_off_x < (d->out_scale > 1 ? d->out_scale : 1),
               "conv: output scatter");
-  IMM_REQUIRE(d->out_scale <= 1 || !(d->flags & (IMM_CONV_STATS | IMM_CONV_MASK)), "conv: scatter excludes stats/mask");
+  IMM_REQUIRE(!(d->flags & IMM_CONV_OUT_F32) || !(d->flags & IMM_CONV_MASK), "conv: f32 output excludes the mask");
   return 0;
 }
 
@@ -341,40 +341,74 @@ extern "C" int imm_conv2d(const imm_conv_desc* d, int dtype, const void* x, cons
 }
 
 // Up to 4 convolutions reading the same x and writing (disjoint parts of) the same y in ONE launch — the four parity
-// classes of a stride-2 data gradient (ops.dgrad_s2_class_descs).  Members must be plain (no bias / stats / mask) and all
-// take the deep-K 64x64-tile kernel; otherwise the members are launched one after the other (same results either way).
-extern "C" int imm_conv2d_group(const imm_conv_desc* descs, int n, int dtype, const void* x, const void* const* wts, void* y,
-                                void* stream) {
-  IMM_REQUIRE(descs && wts && x && y && n >= 1 && n <= 4, "conv_group: 1..4 members");
-  IMM_REQUIRE(dtype == IMM_BF16 || dtype == IMM_F16, "unknown dtype %d", dtype);
+// classes of a stride-2 data gradient (ops.dgrad_s2_class_descs).  Members carry no bias; all must take the deep-K
+// 64x64-tile kernel to share a launch, otherwise they are launched one after the other (same results either way).
+// With IMM_CONV_STATS | IMM_CONV_MASK on the members (batch-norm backward sums of the layer the gradient enters) the
+// partial-sum rows of member i follow those of members 0..i-1; imm_conv2d_group_stats_blocks = total row count.
+struct GroupPlan { bool grouped; int bm, bn; int rows[4]; int total_rows; };
+
+static int group_plan(const imm_conv_desc* descs, int n, GroupPlan* gp) {
   static const bool off = getenv("IMM_NO_CONV_GROUP") != nullptr;
-  bool groupable = !off;
-  ConvArgs args[4];
-  int bm = 0, bn = 0;
+  gp->grouped = !off; gp->bm = gp->bn = 0; gp->total_rows = 0;
   for (int i = 0; i < n; ++i) {
     const imm_conv_desc* d = descs + i;
     if (validate_desc(d)) return IMM_E_INVALID;
-    IMM_REQUIRE(wts[i] && ((uintptr_t)wts[i] % 16 == 0), "conv_group: filter pointer %d", i);
-    IMM_REQUIRE(!(d->flags & (IMM_CONV_BIAS | IMM_CONV_STATS | IMM_CONV_MASK)), "conv_group: members carry no bias/stats/mask");
-    if (imm_halo2_applicable(d) || imm_halo_applicable(d) || imm_hdeep_applicable(d)) groupable = false;
+    IMM_REQUIRE(!(d->flags & IMM_CONV_BIAS), "conv_group: members carry no bias");
+    if (imm_halo2_applicable(d) || imm_halo_applicable(d) || imm_hdeep_applicable(d)) gp->grouped = false;
     const int64_t M = (int64_t)d->batch * d->ho * d->wo;
     const TileCfg t = pick_tile(M, d->co);
     const int64_t xb = (int64_t)d->batch * d->hi * d->wi * d->ldx * 2, wb = (int64_t)d->co * d->kpad * 2;
     const bool deep = (d->ci % 64 == 0) && xb < (1LL << 31) && wb < (1LL << 31) && t.bn >= 64 && !(d->flags & 0xf00) &&
                       !getenv("IMM_NO_DEEPK");
-    if (!deep || (i > 0 && (t.bm != bm || t.bn != bn))) groupable = false;
-    bm = t.bm; bn = t.bn;
-    fill_args(args[i], d, x, wts[i], nullptr, y, nullptr, nullptr);
-    args[i].n_nblk = (d->co + t.bn - 1) / t.bn;
-    args[i].x_bytes = (uint32_t)xb; args[i].wt_bytes = (uint32_t)wb;
+    if (!deep || (i > 0 && (t.bm != gp->bm || t.bn != gp->bn))) gp->grouped = false;
+    gp->bm = t.bm; gp->bn = t.bn;
   }
-  if (groupable && imm_conv64_group_launch(dtype, args, n, bm, bn, (hipStream_t)stream)) {
+  if (gp->grouped && !(gp->bm == 64 && gp->bn == 64)) gp->grouped = false;   // the grouped kernel exists for the 64x64 tile only
+  for (int i = 0; i < n; ++i) {
+    const int64_t M = (int64_t)descs[i].batch * descs[i].ho * descs[i].wo;
+    gp->rows[i] = gp->grouped ? (int)((M + 63) / 64) : imm_conv_stats_blocks(descs + i);
+    gp->total_rows += gp->rows[i];
+  }
+  return 0;
+}
+
+extern "C" int imm_conv2d_group_stats_blocks(const imm_conv_desc* descs, int n) {
+  if (!descs || n < 1 || n > 4) return IMM_E_INVALID;
+  GroupPlan gp;
+  if (group_plan(descs, n, &gp)) return IMM_E_INVALID;
+  return gp.total_rows;
+}
+
+extern "C" int imm_conv2d_group(const imm_conv_desc* descs, int n, int dtype, const void* x, const void* const* wts, void* y,
+                                float* stats_partial, const void* mask_ref, void* stream) {
+  IMM_REQUIRE(descs && wts && x && y && n >= 1 && n <= 4, "conv_group: 1..4 members");
+  IMM_REQUIRE(dtype == IMM_BF16 || dtype == IMM_F16, "unknown dtype %d", dtype);
+  GroupPlan gp;
+  if (group_plan(descs, n, &gp)) return IMM_E_INVALID;
+  ConvArgs args[4];
+  int row0 = 0;
+  for (int i = 0; i < n; ++i) {
+    const imm_conv_desc* d = descs + i;
+    IMM_REQUIRE(wts[i] && ((uintptr_t)wts[i] % 16 == 0), "conv_group: filter pointer %d", i);
+    IMM_REQUIRE(!(d->flags & IMM_CONV_STATS) || stats_partial, "conv_group: stats flag without buffer");
+    IMM_REQUIRE(!(d->flags & IMM_CONV_MASK) || (mask_ref && d->ldmask >= d->co), "conv_group: mask flag without mask/ldmask");
+    float* st = (d->flags & IMM_CONV_STATS) ? stats_partial + (int64_t)row0 * 2 * d->co : nullptr;
+    fill_args(args[i], d, x, wts[i], nullptr, y, st, mask_ref);
+    args[i].n_nblk = (d->co + gp.bn - 1) / gp.bn;
+    args[i].x_bytes = (uint32_t)((int64_t)d->batch * d->hi * d->wi * d->ldx * 2);
+    args[i].wt_bytes = (uint32_t)((int64_t)d->co * d->kpad * 2);
+    row0 += gp.rows[i];
+  }
+  if (gp.grouped && imm_conv64_group_launch(dtype, args, n, gp.bm, gp.bn, (hipStream_t)stream)) {
     IMM_CHECK_LAUNCH("imm_conv2d_group");
     return 0;
   }
+  row0 = 0;
   for (int i = 0; i < n; ++i) {
-    const int rc = imm_conv2d(descs + i, dtype, x, wts[i], nullptr, y, nullptr, nullptr, stream);
+    float* st = (descs[i].flags & IMM_CONV_STATS) ? stats_partial + (int64_t)row0 * 2 * descs[i].co : nullptr;
+    const int rc = imm_conv2d(descs + i, dtype, x, wts[i], nullptr, y, st, mask_ref, stream);
     if (rc) return rc;
+    row0 += gp.rows[i];
   }
   return 0;
 }
