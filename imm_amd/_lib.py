@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get('IMM_HIP_LIB') or os.path.join(_HERE, 'libimm_hip.so')
 IMM_BF16, IMM_F16 = 0, 1
 CONV_BIAS, CONV_RELU, CONV_STATS, CONV_MASK, CONV_OUT_F32 = 1, 2, 4, 8, 16
 SSE_BLOCKS = 512
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class ImmHipError(RuntimeError):
@@ -59,7 +59,7 @@ _SIGS = {
     'imm_bn_apply_relu': [_P, _I, _L, _I, _I, _P, _P, _I, _P, _I, _P],
     'imm_bn_bwd_reduce': [_P, _I, _P, _I, _I, _L, _I, _P, _P, _P, _P, _I, _P, _P],
     'imm_bn_bwd_blocks': [_L, _I],
-    'imm_bn_bwd_finalize': [_P, _I, _I, _L, _P, _P, _P, _P, _P, _P],
+    'imm_bn_bwd_finalize': [_P, _I, _I, _I, _L, _P, _P, _P, _I, _P, _P, _P, _P],
     'imm_bn_bwd_apply': [_P, _I, _P, _I, _I, _L, _I, _P, _P, _P, _P, _I, _P, _P, _I, _P],
     'imm_upsample2x_fwd': [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     'imm_upsample2x_bwd': [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
@@ -75,7 +75,10 @@ _SIGS = {
     'imm_vgg_conv1_1_fwd': [_P, _P, _I, _I, _I, _P, _P, _P, _I, _I, _P],
     'imm_vgg_conv1_1_bwd': [_P, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P, _I, _P],
     'imm_tps_warp': [_P, _I, _I, _I, _I, _I, _P, _I, _P, _P, _I, _P, _P, _I, _P],
-    'imm_conv2d_group': [_P, _I, _I, _P, _P, _P, _P],
+    'imm_conv2d_group': [_P, _I, _I, _P, _P, _P, _P, _P, _P],
+    'imm_conv2d_group_stats_blocks': [_P, _I],
+    'imm_upsample2x_bwd_bn': [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P],
+    'imm_upsample2x_bwd_bn_blocks': [_I, _I, _I, _I],
     'imm_crc32c': [_P, C.c_uint64, C.POINTER(C.c_uint32)],
     'imm_resize_crop_u8': [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P],
     'imm_unpool_tap_grad': [_P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _P, _I, _P],

@@ -85,7 +85,8 @@ extern "C" int imm_pack_image_taps(const float* src, void* dst, int dtype, int b
 // fixed-order LDS reduction over the row lanes.  c % 4 == 0 takes the vector path.
 template <int NS, int CPB = 32>
 __device__ __forceinline__ void reduce_partials_32x32(const float* __restrict__ partial, int nblk, int c, int ch,
-                                                      double (&out)[NS]) {
+                                                      double (&out)[NS], int ldp = 0) {
+  if (ldp == 0) ldp = c;                       // row layout [NS][ldp]: ldp > c when the producer wrote wider rows
   constexpr int QPB = CPB / 4;                 // float4 columns per sum
   constexpr int COLS = QPB * NS;               // float4 columns of this block's CPB channels x NS sums
   constexpr int RL = 1024 / COLS;              // row lanes
@@ -102,12 +103,12 @@ __device__ __forceinline__ void reduce_partials_32x32(const float* __restrict__ 
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc[u][e] = 0.0;
     if (live) {
-      const float* base = partial + (int64_t)sidx * c + ch0 + q4;
+      const float* base = partial + (int64_t)sidx * ldp + ch0 + q4;
       int b = rl;
       for (; b + 7 * RL < nblk; b += 8 * RL) {        // 8 loads in flight: the pass is a chain of L2 round trips
         float4 v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = *(const float4*)(base + (int64_t)(b + u * RL) * NS * c);
+        for (int u = 0; u < 8; ++u) v[u] = *(const float4*)(base + (int64_t)(b + u * RL) * NS * ldp);
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
           acc[u & 3][0] += (double)v[u].x; acc[u & 3][1] += (double)v[u].y; acc[u & 3][2] += (double)v[u].z; acc[u & 3][3] += (double)v[u].w;
@@ -116,14 +117,14 @@ __device__ __forceinline__ void reduce_partials_32x32(const float* __restrict__ 
       for (; b + 3 * RL < nblk; b += 4 * RL) {
         float4 v[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = *(const float4*)(base + (int64_t)(b + u * RL) * NS * c);
+        for (int u = 0; u < 4; ++u) v[u] = *(const float4*)(base + (int64_t)(b + u * RL) * NS * ldp);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           acc[u][0] += (double)v[u].x; acc[u][1] += (double)v[u].y; acc[u][2] += (double)v[u].z; acc[u][3] += (double)v[u].w;
         }
       }
       for (; b < nblk; b += RL) {
-        const float4 v = *(const float4*)(base + (int64_t)b * NS * c);
+        const float4 v = *(const float4*)(base + (int64_t)b * NS * ldp);
         acc[0][0] += (double)v.x; acc[0][1] += (double)v.y; acc[0][2] += (double)v.z; acc[0][3] += (double)v.w;
       }
     }
@@ -137,7 +138,7 @@ __device__ __forceinline__ void reduce_partials_32x32(const float* __restrict__ 
     if (ch < c && threadIdx.x < CPB) {
       for (int b = threadIdx.y; b < nblk; b += 32) {
 #pragma unroll
-        for (int s = 0; s < NS; ++s) acc[s] += (double)partial[((int64_t)b * NS + s) * c + ch];
+        for (int s = 0; s < NS; ++s) acc[s] += (double)partial[((int64_t)b * NS + s) * ldp + ch];
       }
     }
     if (threadIdx.x < CPB) {
@@ -333,14 +334,22 @@ extern "C" int imm_bn_bwd_reduce(const void* dout, int lddo, const void* y, int 
   return 0;
 }
 
+// from_out != 0: the partial sums come from the epilogue of the data gradient that produced dz (conv STATS|MASK, or
+// imm_upsample2x_bwd_bn): row = (sum dz, sum dz*out) with out = relu(gamma*xhat + beta) the layer's stored activation.
+// dz is non-zero only where out > 0, and there xhat = (out - beta)/gamma, so  sum dz*xhat = (sum dz*out - beta*sum dz)/gamma.
 template <int CPB>
-__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int c, double count,
-                                       const float* __restrict__ gamma, const float* __restrict__ rstd,
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int c, int ldp, double count,
+                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                       const float* __restrict__ rstd, int from_out,
                                        float* dgamma, float* dbeta, float* coef) {
   const int ch = blockIdx.x * CPB + threadIdx.x;
   double s[2] = {0.0, 0.0};
-  reduce_partials_32x32<2, CPB>(partial, nblk, c, ch, s);
+  reduce_partials_32x32<2, CPB>(partial, nblk, c, ch, s, ldp);
   if (threadIdx.y != 0 || threadIdx.x >= CPB || ch >= c) return;
+  if (from_out) {
+    const double g = (double)gamma[ch];
+    s[1] = (g != 0.0) ? (s[1] - (double)beta[ch] * s[0]) / g : 0.0;
+  }
   dbeta[ch] = (float)s[0];
   dgamma[ch] = (float)s[1];
   coef[ch] = gamma[ch] * rstd[ch];
@@ -348,15 +357,17 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
   coef[2 * c + ch] = (float)(s[1] / count);
 }
 
-extern "C" int imm_bn_bwd_finalize(const float* partial, int nblk, int c, int64_t count, const float* gamma,
-                                   const float* rstd, float* dgamma, float* dbeta, float* coef, void* stream) {
-  IMM_REQUIRE(partial && gamma && rstd && dgamma && dbeta && coef && nblk > 0 && c > 0 && count > 0, "bn_bwd_finalize: args");
+extern "C" int imm_bn_bwd_finalize(const float* partial, int nblk, int c, int ldp, int64_t count, const float* gamma,
+                                   const float* beta, const float* rstd, int from_out, float* dgamma, float* dbeta,
+                                   float* coef, void* stream) {
+  IMM_REQUIRE(partial && gamma && beta && rstd && dgamma && dbeta && coef && nblk > 0 && c > 0 && count > 0, "bn_bwd_finalize: args");
+  IMM_REQUIRE(ldp >= c && (ldp % 4 == 0 || ldp == c), "bn_bwd_finalize: ldp=%d (c=%d)", ldp, c);
   if (nblk >= 1024 && c % 8 == 0)
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel<8>, dim3(c / 8), dim3(32, 32), 0, (hipStream_t)stream, partial, nblk, c,
-                       (double)count, gamma, rstd, dgamma, dbeta, coef);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel<8>, dim3(c / 8), dim3(32, 32), 0, (hipStream_t)stream, partial, nblk, c, ldp,
+                       (double)count, gamma, beta, rstd, from_out, dgamma, dbeta, coef);
   else
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel<32>, dim3((c + 31) / 32), dim3(32, 32), 0, (hipStream_t)stream, partial, nblk, c,
-                       (double)count, gamma, rstd, dgamma, dbeta, coef);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel<32>, dim3((c + 31) / 32), dim3(32, 32), 0, (hipStream_t)stream, partial, nblk, c, ldp,
+                       (double)count, gamma, beta, rstd, from_out, dgamma, dbeta, coef);
   IMM_CHECK_LAUNCH("imm_bn_bwd_finalize");
   return 0;
 }
@@ -553,6 +564,87 @@ extern "C" int imm_upsample2x_bwd(const void* dy, void* dx, int dtype, int batch
                                                (hipStream_t)stream, (const uint16_t*)dy, (uint16_t*)dx, batch, h, w,
                                                c / 8, lddy, lddx));
   IMM_CHECK_LAUNCH("imm_upsample2x_bwd");
+  return 0;
+}
+
+// The same adjoint fused with what follows it when dx is the output gradient of a conv+BN+ReLU block (renderer conv_2/4/6,
+// imm_model.py:166-175): dz = dx * [out > 0] is what gets stored, and every workgroup writes the partial sums
+// (sum dz, sum dz*out) per channel — the pass imm_bn_bwd_reduce would otherwise make over dx and the conv output.
+template <typename ET>
+__global__ __launch_bounds__(EW_THREADS) void upsample2x_bwd_bn_kernel(
+    const uint16_t* __restrict__ dy, uint16_t* __restrict__ dx, int batch, int h, int w, int c8n, int lddy, int lddx,
+    const uint16_t* __restrict__ out, int ldo, float* __restrict__ partial) {
+  const int H = 2 * h, W = 2 * w;
+  const int64_t total = (int64_t)batch * h * w * c8n;
+  float acc[2][8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { acc[0][e] = 0.f; acc[1][e] = 0.f; }
+  // gridDim.x * blockDim.x is a multiple of c8n (c8n | 256): a thread keeps its channel group over the grid-stride loop
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int cg = (int)(idx % c8n);
+    int64_t t = idx / c8n;
+    const int j = (int)(t % w); t /= w;
+    const int i = (int)(t % h);
+    const int b = (int)(t / h);
+    int Ys[3], Xs[3]; float wy[3], wx[3];
+    Ys[0] = 2 * i - 1; wy[0] = (i >= 1) ? 0.5f : 0.f;
+    Ys[1] = 2 * i;     wy[1] = 1.f;
+    Ys[2] = 2 * i + 1; wy[2] = (i == h - 1) ? 1.f : 0.5f;
+    Xs[0] = 2 * j - 1; wx[0] = (j >= 1) ? 0.5f : 0.f;
+    Xs[1] = 2 * j;     wx[1] = 1.f;
+    Xs[2] = 2 * j + 1; wx[2] = (j == w - 1) ? 1.f : 0.5f;
+    float o[8], m[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = 0.f;
+    const uint16_t* base = dy + (int64_t)b * H * W * lddy + cg * 8;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      if (wy[a] == 0.f) continue;
+#pragma unroll
+      for (int bb = 0; bb < 3; ++bb) {
+        if (wx[bb] == 0.f) continue;
+        float d[8];
+        unpack8<ET>(*(const uint4*)(base + ((int64_t)Ys[a] * W + Xs[bb]) * lddy), d);
+        const float wgt = wy[a] * wx[bb];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] += wgt * d[e];
+      }
+    }
+    const int64_t p = ((int64_t)b * h + i) * w + j;
+    unpack8<ET>(*(const uint4*)(out + p * ldo + cg * 8), m);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      if (!(m[e] > 0.f)) o[e] = 0.f;
+      acc[0][e] += o[e];
+      acc[1][e] += o[e] * m[e];
+    }
+    *(uint4*)(dx + p * lddx + cg * 8) = pack8<ET>(o);
+  }
+  col_reduce_tail<2>(acc, c8n * 8, c8n, EW_THREADS / c8n, partial + (int64_t)blockIdx.x * 2 * c8n * 8);
+}
+
+extern "C" int imm_upsample2x_bwd_bn_blocks(int batch, int h, int w, int c) {
+  if (c <= 0 || c % 8 || c / 8 > EW_THREADS || EW_THREADS % (c / 8) || batch <= 0 || h <= 0 || w <= 0) return IMM_E_UNSUPPORTED;
+  const int64_t total = (int64_t)batch * h * w * (c / 8);
+  int64_t b = (total + EW_THREADS * 4 - 1) / (EW_THREADS * 4);      // >= 4 pixels-groups per thread
+  if (b < 1) b = 1;
+  if (b > 512) b = 512;
+  return (int)b;
+}
+
+extern "C" int imm_upsample2x_bwd_bn(const void* dy, void* dx, int dtype, int batch, int h, int w, int c, int lddy, int lddx,
+                                     const void* out, int ldo, float* partial, void* stream) {
+  IMM_REQUIRE(dy && dx && out && partial && batch > 0 && h > 0 && w > 0, "upsample2x_bwd_bn: args");
+  EW_REQUIRE_VEC(c, lddy, "upsample2x_bwd_bn(dy)");
+  EW_REQUIRE_VEC(c, lddx, "upsample2x_bwd_bn(dx)");
+  EW_REQUIRE_VEC(c, ldo, "upsample2x_bwd_bn(out)");
+  const int nblk = imm_upsample2x_bwd_bn_blocks(batch, h, w, c);
+  if (nblk < 0) return imm_fail(IMM_E_UNSUPPORTED, "upsample2x_bwd_bn: C=%d unsupported (C/8 must divide 256)", c);
+  IMM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((upsample2x_bwd_bn_kernel<ET>), dim3(nblk), dim3(EW_THREADS), 0,
+                                               (hipStream_t)stream, (const uint16_t*)dy, (uint16_t*)dx, batch, h, w,
+                                               c / 8, lddy, lddx, (const uint16_t*)out, ldo, partial));
+  IMM_CHECK_LAUNCH("imm_upsample2x_bwd_bn");
   return 0;
 }
 

@@ -196,6 +196,9 @@ class IMMEngine:
         self.reduce_per_layer = os.environ.get('IMM_REDUCE_PER_LAYER', '0') != '0'
         self._skip_tags = set(t for t in os.environ.get('IMM_DEBUG_SKIP_TAGS', '').split(',') if t)
         self.wgrad_lane = int(os.environ.get('IMM_WGRAD_LANE', '0')) if self.two_streams else 0
+        # batch-norm backward sums (sum dz, sum dz*out) taken in the epilogue of whatever produces dz (data gradient of the
+        # next layer, up-sampling adjoint) instead of a separate pass over dz and the conv output (IMM_BN_FUSE_BWD=0: A/B)
+        self.bn_fuse_bwd = os.environ.get('IMM_BN_FUSE_BWD', '1') != '0'
         self._side = None
         self._pack_jobs, self._reduce_jobs = [], []
         self._training = True
@@ -370,17 +373,27 @@ class IMMEngine:
         lay.nsplit = nsplit
         lay.slab = self._zeros(nsplit, fd.kpad, co)
         if bn:
-            lay.bwd_nblk = ops.bn_bwd_blocks(npix, co)
-            lay.bwd_partial = self._zeros(lay.bwd_nblk, 2, co)
+            lay.bwd_fused = False          # set by the producer of this block's output gradient (_fuse_bn_sums)
+            lay.bwd_nblk, lay.bwd_partial, lay.bwd_ldp = 0, None, co
             lay.coef = self._zeros(3, co)
             lay.dy = self._act(B, fd.ho, fd.wo, ldy)
         else:
             lay.cs_partial = self._zeros(ops.colsum_blocks(npix, lay.lddy), lay.lddy)
         return lay
 
-    def _conv_backward(self, lay, d_out, ldd, dx, lddx, dx_mask=None):
+    def _fuse_bn_sums(self, bn_lay, rows, ldp):
+        """The producer of bn_lay's output gradient writes `rows` rows of (sum dz, sum dz*out)[ldp] and stores dz already
+        masked by [out > 0]: bn_lay's backward then needs no reduction pass (and no ReLU mask in its apply pass)."""
+        bn_lay.bwd_fused, bn_lay.bwd_nblk, bn_lay.bwd_ldp = True, rows, ldp
+        bn_lay.bwd_partial = self._zeros(rows, 2, ldp)
+        return bn_lay.bwd_partial
+
+    def _conv_backward(self, lay, d_out, ldd, dx, lddx, dx_bn=None):
         """d_out: gradient w.r.t. the block output (post BN/ReLU for BN blocks; w.r.t. the conv output,
-        16-bit with stride lay.lddy, otherwise).  dx: buffer receiving the input gradient (or None)."""
+        16-bit with stride lay.lddy, otherwise).  dx: buffer receiving the input gradient (or None).
+        dx_bn: the conv+BN+ReLU block whose OUTPUT gradient dx is (the layer in front of this one), when dx feeds its
+        batch-norm backward directly: the data gradient's epilogue then applies that block's ReLU mask and takes its
+        batch-norm sums."""
         B, co, k = self.B, lay.co, lay.k
         npix = lay.npix
         scope = lay.scope
@@ -388,14 +401,20 @@ class IMMEngine:
         gw, gb = self.gview[scope + '/w'], self.gview[scope + '/b']
         if lay.bn:
             gg, gbeta = self.gview[scope + '/gamma'], self.gview[scope + '/beta']
-            gamma = self.pview[scope + '/gamma']
-            self._add(self.prog_bwd, lambda: ops.bn_bwd_reduce(d_out, ldd, lay.y, lay.ldy, npix, co, lay.scale, lay.shift,
-                                                               lay.mean, lay.rstd, lay.relu, lay.bwd_partial),
-                      'bn_bwd_reduce', 0.0, npix * co * 4.0)
-            self._add(self.prog_bwd, lambda: ops.bn_bwd_finalize(lay.bwd_partial, lay.bwd_nblk, co, npix, gamma, lay.rstd,
-                                                                 gg, gbeta, lay.coef), 'bn_bwd_finalize')
+            gamma, beta = self.pview[scope + '/gamma'], self.pview[scope + '/beta']
+            fused = lay.bwd_fused and lay.relu
+            if not fused:
+                lay.bwd_nblk, lay.bwd_ldp = ops.bn_bwd_blocks(npix, co), co
+                lay.bwd_partial = self._zeros(lay.bwd_nblk, 2, co)
+                self._add(self.prog_bwd, lambda: ops.bn_bwd_reduce(d_out, ldd, lay.y, lay.ldy, npix, co, lay.scale, lay.shift,
+                                                                   lay.mean, lay.rstd, lay.relu, lay.bwd_partial),
+                          'bn_bwd_reduce', 0.0, npix * co * 4.0)
+            self._add(self.prog_bwd, lambda: ops.bn_bwd_finalize(lay.bwd_partial, lay.bwd_nblk, co, npix, gamma, beta, lay.rstd,
+                                                                 gg, gbeta, lay.coef, from_out=fused, ldp=lay.bwd_ldp),
+                      'bn_bwd_finalize')
+            # fused: d_out already is dz (ReLU mask applied by its producer)
             self._add(self.prog_bwd, lambda: ops.bn_bwd_apply(d_out, ldd, lay.y, lay.ldy, npix, co, lay.scale, lay.shift,
-                                                              lay.mean, lay.rstd, lay.relu, lay.coef, lay.dy, lay.ldy),
+                                                              lay.mean, lay.rstd, lay.relu and not fused, lay.coef, lay.dy, lay.ldy),
                       'bn_bwd_apply', 0.0, npix * co * 6.0)
             dy, lddy = lay.dy, lay.ldy
             # conv bias feeds a batch norm: its gradient is analytically zero (sum of dy == 0); the
@@ -429,14 +448,21 @@ class IMMEngine:
             self._add(self.prog_bwd, (lambda tab1=tab1: ops.wgrad_reduce_multi(tab1)), 'wgrad_reduce')
         else:
             self._reduce_jobs.append((job, k * lay.kw * lay.ci_real * co))
+        fuse = self.bn_fuse_bwd and dx_bn is not None and dx_bn.bn and dx_bn.relu
+        mflags = (L.CONV_MASK | L.CONV_STATS) if fuse else 0
+        mask, ldmask = (dx_bn.out, dx_bn.ldo) if fuse else (None, 0)
         if lay.needs_dgrad and dx is not None and getattr(lay, 's2', None) is not None:
-            classes = ops.dgrad_s2_class_descs(B, lay.H, lay.W, lay.ci_real, lddx, lddy, lddy, k)
-            if os.environ.get('IMM_S2_GROUP', '1') != '0':
+            grouped = os.environ.get('IMM_S2_GROUP', '1') != '0'
+            if not grouped:
+                mflags, mask, ldmask, fuse = 0, None, 0, False
+            classes = ops.dgrad_s2_class_descs(B, lay.H, lay.W, lay.ci_real, lddx, lddy, lddy, k, flags=mflags, ldmask=ldmask)
+            if grouped:
                 # the four parity classes as one grouped launch (falls back to four launches inside the library when the
                 # members do not take the deep-K 64x64 tile)
                 grp = ops.ConvGroup([dd0 for dd0, _m in classes], list(lay.wt_s2))
                 ntaps = sum(dd0.kh * dd0.kw for dd0, _m in classes)
-                self._add(self.prog_bwd, (lambda grp=grp: ops.conv2d_group(grp, dy, dx)), 'conv_dgrad',
+                stats = self._fuse_bn_sums(dx_bn, ops.conv2d_group_stats_blocks(grp), lay.ci_real) if fuse else None
+                self._add(self.prog_bwd, (lambda grp=grp, stats=stats, mask=mask: ops.conv2d_group(grp, dy, dx, stats, mask)), 'conv_dgrad',
                           2.0 * npix * ntaps * lay.ci_real * co,
                           2.0 * (4 * npix * lddy + 4 * npix * lay.ci_real + sum(dd0.kpad for dd0, _m in classes) * lay.ci_real))
             else:
@@ -446,9 +472,14 @@ class IMMEngine:
                               2.0 * npix * ntap * lay.ci_real * co,
                               2.0 * (npix * lddy + npix * lay.ci_real + dd0.kpad * lay.ci_real))
         elif lay.needs_dgrad and dx is not None:
-            dd = ops.dgrad_desc(B, lay.H, lay.W, lay.ci_real, lddx, lddy, lddy, k, lay.stride, 0)
+            # output channels: the padded count when that makes whole 64-channel blocks (the concat layer: 266 -> 320, its
+            # packed filter rows beyond ci_real are zeros) — the deep-K kernels need co % 64 == 0
+            co_dx = lay.ci_pad if (lay.ci_pad != lay.ci_real and lay.ci_pad % 64 == 0 and lddx >= lay.ci_pad
+                                   and lay.wt_d.shape[0] >= lay.ci_pad) else lay.ci_real
+            dd = ops.dgrad_desc(B, lay.H, lay.W, co_dx, lddx, lddy, lddy, k, lay.stride, mflags, ldmask=ldmask)
             assert dd.kpad == lay.wt_d.shape[1], (dd.kpad, lay.wt_d.shape)
-            self._add(self.prog_bwd, lambda: ops.conv2d(dd, dy, lay.wt_d, None, dx), 'conv_dgrad', flops,
+            stats = self._fuse_bn_sums(dx_bn, ops.conv_stats_blocks(dd), co_dx) if fuse else None
+            self._add(self.prog_bwd, lambda: ops.conv2d(dd, dy, lay.wt_d, None, dx, stats, mask), 'conv_dgrad', flops,
                       2.0 * (npix * lddy + B * lay.H * lay.W * lay.ci_real + dd.kpad * lay.ci_real))
 
     def _build_network(self):
@@ -754,8 +785,11 @@ class IMMEngine:
         self._defer_wgrad = [] if defer else None
         for i in range(len(self.ren) - 1, -1, -1):
             lay = self.ren[i]
+            dx_bn = None
             if i == 0:
                 dx, lddx = self.d_joint, Cj
+                if self.He == 16:      # channels 0..8nf-1 of d_joint ARE the output gradient of the image encoder's conv_8
+                    dx_bn = self.enc_im[-1]   # (whose `out` is the joint buffer: the Gaussian / pad channels behind it are >= 0)
             else:
                 prev = self.ren[i - 1]
                 if (i - 1) in ups:     # this conv's input is the upsampled output of conv i-1
@@ -764,14 +798,22 @@ class IMMEngine:
                     dx, lddx = d_up, cp
                 else:
                     dx, lddx = self._act(B, prev.Ho, prev.Wo, prev.co), prev.co
-            self._conv_backward(lay, d_out, ldd, dx, lddx)
+                    dx_bn = prev
+            self._conv_backward(lay, d_out, ldd, dx, lddx, dx_bn=dx_bn)
             if i > 0:
                 if (i - 1) in ups:
                     _ub, Hp, cp = ups[i - 1]
                     d_prev = self._act(B, Hp, Hp, cp)
-                    self._add(self.prog_bwd, (lambda dx=dx, d_prev=d_prev, Hp=Hp, cp=cp:
-                                              ops.upsample2x_bwd(dx, d_prev, B, Hp, Hp, cp, cp, cp)), 'upsample_bwd',
-                              0.0, B * Hp * Hp * cp * 10.0)
+                    if self.bn_fuse_bwd and prev.bn and prev.relu:
+                        # adjoint of the up-sampling + ReLU mask + batch-norm sums of conv i-1 in one pass
+                        part = self._fuse_bn_sums(prev, ops.upsample2x_bwd_bn_blocks(B, Hp, Hp, cp), cp)
+                        self._add(self.prog_bwd, (lambda dx=dx, d_prev=d_prev, Hp=Hp, cp=cp, prev=prev, part=part:
+                                                  ops.upsample2x_bwd_bn(dx, d_prev, B, Hp, Hp, cp, cp, cp, prev.out, prev.ldo, part)),
+                                  'upsample_bwd', 0.0, B * Hp * Hp * cp * 12.0)
+                    else:
+                        self._add(self.prog_bwd, (lambda dx=dx, d_prev=d_prev, Hp=Hp, cp=cp:
+                                                  ops.upsample2x_bwd(dx, d_prev, B, Hp, Hp, cp, cp, cp)), 'upsample_bwd',
+                                  0.0, B * Hp * Hp * cp * 10.0)
                     d_out, ldd = d_prev, cp
                 else:
                     d_out, ldd = dx, lddx
@@ -804,7 +846,7 @@ class IMMEngine:
         self._add(self.prog_bwd, lambda: ops.softargmax_gauss_bwd(dg, Cj, B, He, He, K, self.inv_std, 16, self.mu, self.py,
                                                                   self.px, self.d_heat, ph.lddy), 'bottleneck_bwd')
         d_feat = self._act(B, He, He, nf8)
-        self._conv_backward(ph, self.d_heat, ph.lddy, d_feat, nf8)
+        self._conv_backward(ph, self.d_heat, ph.lddy, d_feat, nf8, dx_bn=self.enc_pose[-1])
         self._encoder_backward(self.enc_pose, d_feat, nf8)
 
         # ---- image encoder backward ----------------------------------------------------------------------------
@@ -836,8 +878,8 @@ class IMMEngine:
                 prev = layers[i - 1]
                 dx, lddx = self._act(B, prev.Ho, prev.Wo, prev.co), prev.co
             else:
-                dx, lddx = None, 0
-            self._conv_backward(lay, d_out, ldd, dx, lddx)
+                prev, dx, lddx = None, None, 0
+            self._conv_backward(lay, d_out, ldd, dx, lddx, dx_bn=prev)
             d_out, ldd = dx, lddx
 
     # ------------------------------------------------------------------------------------------

@@ -57,7 +57,7 @@ def dgrad_desc(batch, hi, wi, ci_out, lddx, co_pad, lddy, k, stride, flags, ldma
                     flags=flags, ldmask=ldmask)
 
 
-def dgrad_s2_class_descs(batch, hi, wi, ci_out, lddx, co_pad, lddy, k, flags=0):
+def dgrad_s2_class_descs(batch, hi, wi, ci_out, lddx, co_pad, lddy, k, flags=0, ldmask=0):
     """Stride-2 data gradient as 4 dense stride-1 convolutions, one per input-pixel parity class (py,px):
         dx[2a+py][2b+px] = sum_{ty,tx} dy[a-ty][b-tx] * W[py+2ty][px+2tx]
     (TF SAME on an even side with k=3 pads 0 before, so ky = iy - 2*oy has the parity of iy).  Returns
@@ -72,7 +72,7 @@ def dgrad_s2_class_descs(batch, hi, wi, ci_out, lddx, co_pad, lddy, k, flags=0):
             ny, nx = (k - py + 1) // 2, (k - px + 1) // 2
             d = ConvDesc(batch=batch, hi=ho, wi=wo, ci=co_pad, ldx=lddy, ho=ho, wo=wo, co=ci_out, ldy=lddx, kh=ny, kw=nx,
                          stride=1, pad_t=ny - 1, pad_l=nx - 1, updiv=1, kpad=round_up(ny * nx * co_pad, 32), flags=flags,
-                         ldmask=0, out_scale=2, out_off_y=py, out_off_x=px)
+                         ldmask=ldmask, out_scale=2, out_off_y=py, out_off_x=px)
             out.append((d, 4 + 2 * py + px))
     return out
 
@@ -192,8 +192,9 @@ def bn_bwd_reduce(dout, lddo, y, ldy, npix, c, scale, shift, mean, rstd, relu, p
          _p(rstd), int(relu), _p(partial), _s())
 
 
-def bn_bwd_finalize(partial, nblk, c, count, gamma, rstd, dgamma, dbeta, coef):
-    call('imm_bn_bwd_finalize', _p(partial), nblk, c, count, _p(gamma), _p(rstd), _p(dgamma), _p(dbeta), _p(coef), _s())
+def bn_bwd_finalize(partial, nblk, c, count, gamma, beta, rstd, dgamma, dbeta, coef, from_out=False, ldp=None):
+    call('imm_bn_bwd_finalize', _p(partial), nblk, c, c if ldp is None else ldp, count, _p(gamma), _p(beta), _p(rstd),
+         int(from_out), _p(dgamma), _p(dbeta), _p(coef), _s())
 
 
 def bn_bwd_apply(dout, lddo, y, ldy, npix, c, scale, shift, mean, rstd, relu, coef, dy_out, lddy):
@@ -208,6 +209,17 @@ def upsample2x_fwd(x, y, batch, h, w, c, ldx, ldy):
 
 def upsample2x_bwd(dy, dx, batch, h, w, c, lddy, lddx):
     call('imm_upsample2x_bwd', _p(dy), _p(dx), dtype_enum(dy.dtype), batch, h, w, c, lddy, lddx, _s())
+
+
+def upsample2x_bwd_bn_blocks(batch, h, w, c):
+    n = L.load().imm_upsample2x_bwd_bn_blocks(batch, h, w, c)
+    if n <= 0:
+        raise L.ImmHipError('imm_upsample2x_bwd_bn_blocks(%d,%d,%d,%d) unsupported' % (batch, h, w, c))
+    return n
+
+
+def upsample2x_bwd_bn(dy, dx, batch, h, w, c, lddy, lddx, out, ldo, partial):
+    call('imm_upsample2x_bwd_bn', _p(dy), _p(dx), dtype_enum(dy.dtype), batch, h, w, c, lddy, lddx, _p(out), ldo, _p(partial), _s())
 
 
 def resize_ac_fwd(x, y, batch, hi, wi, ho, wo, c, ldx, ldy):
@@ -348,6 +360,13 @@ class ConvGroup(object):
         self.ptrs = (C.c_void_p * self.n)(*[w.data_ptr() for w in wts])
 
 
-def conv2d_group(group, x, y):
+def conv2d_group(group, x, y, stats=None, mask=None):
     call('imm_conv2d_group', C.cast(group.descs, C.c_void_p), group.n, dtype_enum(x.dtype), _p(x), C.cast(group.ptrs, C.c_void_p),
-         _p(y), _s())
+         _p(y), _p(stats), _p(mask), _s())
+
+
+def conv2d_group_stats_blocks(group):
+    n = L.load().imm_conv2d_group_stats_blocks(C.cast(group.descs, C.c_void_p), group.n)
+    if n <= 0:
+        raise L.ImmHipError('imm_conv2d_group_stats_blocks: ' + L.load().imm_last_error().decode())
+    return n

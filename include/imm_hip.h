@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define IMM_ABI_VERSION 5   /* 2: imm_vgg_conv1_1_fwd gained `halves` */
+#define IMM_ABI_VERSION 6   /* 2: imm_vgg_conv1_1_fwd gained `halves` */
 
 enum imm_dtype { IMM_BF16 = 0, IMM_F16 = 1 };
 
@@ -98,12 +98,21 @@ int imm_wgrad_reduce_multi(const int64_t* jobs, const int32_t* blk_first, int n_
 /* ---- convolution (implicit GEMM on MFMA) ----------------------------------------------------- */
 /* n <= 4 convolutions that read the same x and write (disjoint pixels of) the same y, issued as ONE launch when every member
  * takes the deep-K 64x64-tile kernel, else one after the other (identical results): the four parity classes of a stride-2
- * data gradient (tf.nn.conv2d_backprop_input at nn_utils.py:100 call sites with stride 2).  Members carry no bias / stats /
- * mask; descs is an array of n descriptors, wts an array of n packed filter images. */
-int imm_conv2d_group(const imm_conv_desc* descs, int n, int dtype, const void* x, const void* const* wts, void* y, void* stream);
+ * data gradient (tf.nn.conv2d_backprop_input at nn_utils.py:100 call sites with stride 2).  Members carry no bias;
+ * descs is an array of n descriptors, wts an array of n packed filter images.  With IMM_CONV_STATS | IMM_CONV_MASK on the
+ * members, stats_partial holds imm_conv2d_group_stats_blocks(descs, n) rows of [2][co]: member i's rows follow member
+ * i-1's (mask_ref has the geometry of y). */
+int imm_conv2d_group(const imm_conv_desc* descs, int n, int dtype, const void* x, const void* const* wts, void* y,
+                     float* stats_partial, const void* mask_ref, void* stream);
+int imm_conv2d_group_stats_blocks(const imm_conv_desc* descs, int n);
 /* y[m][n] = epilogue( sum_k gather(x)[m][k] * wt[n][k] ).  stats_partial: [n_mblocks][2][co] f32
  * with n_mblocks = imm_conv_stats_blocks(desc).  Replaces tf.nn.conv2d+bias_add (nn_utils.py:100,108),
- * vgg conv+bias+relu (vgg16.py:182-189,230) and their data gradients. */
+ * vgg conv+bias+relu (vgg16.py:182-189,230) and their data gradients.
+ * Epilogue order: + bias, ReLU, mask (IMM_CONV_MASK: v = 0 where mask_ref <= 0, mask_ref 16-bit [pixels][ldmask] with the
+ * geometry of y), store, partial sums.  IMM_CONV_STATS alone: rows of (sum v, sum v^2) — the batch statistics of a forward
+ * convolution.  IMM_CONV_STATS | IMM_CONV_MASK: rows of (sum v, sum v * mask_ref) — the batch-norm BACKWARD sums (sum dz,
+ * sum dz * out) of the conv+BN+ReLU block whose output gradient this data gradient produces (mask_ref = that block's stored
+ * activation `out`), which replaces a separate reduction pass over dz (tf.gradients of nn_utils.py:201-209). */
 int imm_conv2d(const imm_conv_desc* desc_host, int dtype, const void* x, const void* wt, const float* bias,
                void* y, float* stats_partial, const void* mask_ref, void* stream);
 int imm_conv_stats_blocks(const imm_conv_desc* desc_host);
@@ -137,8 +146,11 @@ int imm_bn_bwd_reduce(const void* dout, int lddo, const void* y, int ldy, int dt
                       const float* scale, const float* shift, const float* mean, const float* rstd, int relu,
                       float* partial, void* stream);
 int imm_bn_bwd_blocks(int64_t npix, int c);
-int imm_bn_bwd_finalize(const float* partial, int nblk, int c, int64_t count, const float* gamma,
-                        const float* rstd, float* dgamma, float* dbeta, float* coef, void* stream);
+/* partial rows [2][ldp] (ldp >= c: rows written by a producer with more channels than this layer).  from_out = 0: rows of
+ * (sum dz, sum dz*xhat) from imm_bn_bwd_reduce; from_out = 1: rows of (sum dz, sum dz*out) from a data-gradient epilogue
+ * (IMM_CONV_STATS | IMM_CONV_MASK) or imm_upsample2x_bwd_bn: sum dz*xhat = (sum dz*out - beta * sum dz) / gamma. */
+int imm_bn_bwd_finalize(const float* partial, int nblk, int c, int ldp, int64_t count, const float* gamma, const float* beta,
+                        const float* rstd, int from_out, float* dgamma, float* dbeta, float* coef, void* stream);
 int imm_bn_bwd_apply(const void* dout, int lddo, const void* y, int ldy, int dtype, int64_t npix, int c,
                      const float* scale, const float* shift, const float* mean, const float* rstd, int relu,
                      const float* coef, void* dy_out, int lddy, void* stream);
@@ -149,6 +161,12 @@ int imm_upsample2x_fwd(const void* x, void* y, int dtype, int batch, int h, int 
                        void* stream);
 int imm_upsample2x_bwd(const void* dy, void* dx, int dtype, int batch, int h, int w, int c, int lddy, int lddx,
                        void* stream);
+/* the adjoint fused with the ReLU backward of the block that produced the up-sampled tensor and with the batch-norm
+ * backward sums: dx = adjoint(dy) * [out > 0]; partial [nblk][2][c] = per-workgroup (sum dx, sum dx*out),
+ * nblk = imm_upsample2x_bwd_bn_blocks(batch, h, w, c); out 16-bit [batch,h,w] with pixel stride ldo. */
+int imm_upsample2x_bwd_bn(const void* dy, void* dx, int dtype, int batch, int h, int w, int c, int lddy, int lddx,
+                          const void* out, int ldo, float* partial, void* stream);
+int imm_upsample2x_bwd_bn_blocks(int batch, int h, int w, int c);
 /* tf.image.resize_bilinear(align_corners=True) (imm_model.py:334) and its adjoint (dx must be zeroed
  * by the kernel itself: it is, via a gather formulation) */
 int imm_resize_ac_fwd(const void* x, void* y, int dtype, int batch, int hi, int wi, int ho, int wo, int c,

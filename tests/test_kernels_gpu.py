@@ -356,13 +356,134 @@ def test_batch_norm_fwd_bwd(ops, c, npix):
     dod = dout.to(DEV)
     ops.bn_bwd_reduce(dod, c, yd, c, npix, c, scale, shift, mean, rstd, True, part)
     dg, db, coef = torch.empty(c, device=DEV), torch.empty(c, device=DEV), torch.empty(3, c, device=DEV)
-    ops.bn_bwd_finalize(part, nblk, c, npix, gamma.to(DEV), rstd, dg, db, coef)
+    ops.bn_bwd_finalize(part, nblk, c, npix, gamma.to(DEV), beta.to(DEV), rstd, dg, db, coef)
     dyo = torch.empty(npix, c, dtype=dt, device=DEV)
     ops.bn_bwd_apply(dod, c, yd, c, npix, c, scale, shift, mean, rstd, True, coef, dyo, c)
     torch.cuda.synchronize()
     close(dg, gg, 2e-3, 1e-3, 'bn_dgamma')
     close(db, gb, 2e-3, 1e-3, 'bn_dbeta')
     close(dyo, gy.reshape(npix, c), 2e-2, 4e-3, 'bn_dy')
+
+
+@pytest.mark.parametrize('c,ldp,npix', [(32, 32, 4096), (256, 320, 512), (64, 64, 1000)])
+def test_batch_norm_bwd_from_producer_sums(ops, c, ldp, npix):
+    """The fused backward: the producer of dz hands over rows of (sum dz, sum dz*out) (out = the block's stored
+    ReLU output, rows possibly wider than the layer: ldp > c) and dz already masked; imm_bn_bwd_finalize(from_out=1)
+    recovers sum dz*xhat = (sum dz*out - beta sum dz)/gamma and imm_bn_bwd_apply runs without the ReLU mask.  Must equal
+    autograd of relu(batch_norm(y))."""
+    dt = torch.bfloat16
+    y = (rnd((npix, c), 141) * 2 + 0.5).to(dt)
+    gamma = rnd((c,), 142, 0.5, torch.float32) + 1.0
+    beta = rnd((c,), 143, 0.5, torch.float32)
+    yf = y.float()
+    partial = torch.stack([yf.sum(0), (yf * yf).sum(0)]).reshape(1, 2, c).to(DEV).contiguous()
+    mm, mv = torch.zeros(c, device=DEV), torch.ones(c, device=DEV)
+    scale, shift, mean, rstd = (torch.empty(c, device=DEV) for _ in range(4))
+    ops.bn_finalize(partial, 1, c, npix, gamma.to(DEV), beta.to(DEV), 1e-3, 0.99, True, mm, mv, scale, shift, mean, rstd)
+    yd = y.to(DEV)
+    out = torch.empty(npix, c, dtype=dt, device=DEV)
+    ops.bn_apply_relu(yd, npix, c, c, scale, shift, True, out, c)
+    torch.cuda.synchronize()
+    yr = yf.reshape(1, 1, npix, c).clone().requires_grad_(True)
+    g_, b_ = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    ref, _ = O.batch_norm(yr, g_, b_, torch.zeros(c), torch.ones(c), True)
+    ref = torch.relu(ref)
+    dout = rnd((npix, c), 144)
+    gy, gg, gb = torch.autograd.grad(ref, [yr, g_, b_], dout.float().reshape(1, 1, npix, c))
+    # what a producer epilogue leaves: dz = dout * [out > 0] (16-bit) and 3 rows of partial sums, ldp floats wide
+    of = out.float().cpu()
+    dz = dout.float() * (of > 0)
+    rows = torch.zeros(3, 2, ldp)
+    for r in range(3):
+        sl = slice(r * npix // 3, (r + 1) * npix // 3)
+        rows[r, 0, :c] = dz[sl].sum(0); rows[r, 1, :c] = (dz[sl] * of[sl]).sum(0)
+    rows[:, :, c:] = 123.0                     # columns of the producer's other channels: must be ignored
+    dg, db, coef = torch.empty(c, device=DEV), torch.empty(c, device=DEV), torch.empty(3, c, device=DEV)
+    ops.bn_bwd_finalize(rows.to(DEV), 3, c, npix, gamma.to(DEV), beta.to(DEV), rstd, dg, db, coef, from_out=True, ldp=ldp)
+    dyo = torch.empty(npix, c, dtype=dt, device=DEV)
+    ops.bn_bwd_apply(dz.to(dt).to(DEV), c, yd, c, npix, c, scale, shift, mean, rstd, False, coef, dyo, c)
+    torch.cuda.synchronize()
+    close(dg, gg, 1e-2, 2e-3, 'bn_dgamma(from_out)')     # xhat recovered from the 16-bit `out`: one more rounding than from y
+    close(db, gb, 2e-3, 1e-3, 'bn_dbeta(from_out)')
+    close(dyo, gy.reshape(npix, c), 2e-2, 4e-3, 'bn_dy(from_out)')
+
+
+@pytest.mark.parametrize('B,H,ci,co,dt', [(2, 32, 32, 64, torch.bfloat16), (40, 64, 64, 64, torch.bfloat16),
+                                          (36, 64, 32, 32, torch.float16), (9, 128, 32, 32, torch.bfloat16),
+                                          (14, 32, 128, 256, torch.bfloat16), (24, 16, 128, 256, torch.bfloat16),
+                                          (32, 16, 256, 320, torch.bfloat16), (51, 8, 128, 256, torch.bfloat16)],
+                         ids=['igemm', 'halo64_persistent', 'halo32_f16_persistent', 'halo32_128px', 'hdeep', 'hdeep_small_patch',
+                              'hdeep_co320', 'hdeep_map8_odd'])
+def test_conv_mask_with_bn_backward_sums(ops, B, H, ci, co, dt):
+    """IMM_CONV_STATS | IMM_CONV_MASK: same output as the mask alone, partial sums = (sum v, sum v*mask_ref) of the masked
+    f32 values (every kernel family that produces the output gradient of a conv+BN+ReLU block)."""
+    from imm_amd import _lib as L
+    x = rnd((B, H, H, ci), 4, 1.0, dt)
+    w = rnd((3, 3, ci, co), 5, 0.1, dt)
+    mref = rnd((B, H, H, co), 7, 1.0, dt).to(DEV).contiguous()
+    ref = O.conv2d_same(x.float(), w.float(), None, 1)
+    y3, _, _ = run_conv(ops, x, w, None, 3, 1, co, ci, False, extra_flags=L.CONV_MASK, mask=mref)
+    y4, stats, _ = run_conv(ops, x, w, None, 3, 1, co, ci, False, extra_flags=L.CONV_MASK | L.CONV_STATS, mask=mref)
+    assert torch.equal(y3, y4), 'the stats flag must not change the output'
+    mf = mref.float().cpu()
+    v = ref * (mf > 0)
+    close(y4, v, 1e-2, 2e-3, 'conv+mask+stats/y')
+    s = stats.sum(dim=0).cpu()
+    close(s[0], v.sum(dim=(0, 1, 2)), 2e-3, 2e-3, 'bn-bwd sums/sum dz')
+    close(s[1], (v * mf).sum(dim=(0, 1, 2)), 2e-3, 2e-3, 'bn-bwd sums/sum dz*out')
+
+
+@pytest.mark.parametrize('H,ci,co', [(32, 64, 128), (64, 128, 256), (16, 32, 64)], ids=['grouped_64x64', 'grouped_deep', 'fallback_bk32'])
+def test_conv_group_mask_with_bn_backward_sums(ops, H, ci, co):
+    """The stride-2 data gradient (four parity classes, scattered output) with the mask + sums epilogue: output = masked
+    sequential result; the rows of all members together sum to (sum dz, sum dz*out)."""
+    from imm_amd import _lib as L
+    B, k, dt = 8, 3, torch.bfloat16
+    w = rnd((k, k, ci, co), 401, 0.05)
+    dy = rnd((B, H // 2, H // 2, co), 402).to(DEV).contiguous()
+    mref = rnd((B, H, H, ci), 403).to(DEV).contiguous()
+    plain = ops.dgrad_s2_class_descs(B, H, H, ci, ci, co, co, k)
+    classes = ops.dgrad_s2_class_descs(B, H, H, ci, ci, co, co, k, flags=L.CONV_MASK | L.CONV_STATS, ldmask=ci)
+    rows = ops.round_up(ci, 128)
+    wts = []
+    for d, mode in classes:
+        wt = torch.zeros(rows, d.kpad, dtype=dt, device=DEV)
+        ops.pack_weights(w.float().to(DEV).contiguous(), wt, mode, k, k, ci, co, co, rows, d.kpad)
+        wts.append(wt)
+    ref = torch.full((B, H, H, ci), float('nan'), dtype=dt, device=DEV)
+    for (d, _m), wt in zip(plain, wts):
+        ops.conv2d(d, dy, wt, None, ref)
+    grp = ops.ConvGroup([d for d, _m in classes], wts)
+    nrows = ops.conv2d_group_stats_blocks(grp)
+    stats = torch.full((nrows, 2, ci), float('nan'), dtype=torch.float32, device=DEV)
+    got = torch.full((B, H, H, ci), float('nan'), dtype=dt, device=DEV)
+    ops.conv2d_group(grp, dy, got, stats, mref)
+    torch.cuda.synchronize()
+    mf = mref.float()
+    want = ref.float() * (mf > 0)
+    assert torch.equal(got.float(), want)                 # masking a value that was rounded to 16 bits first or after: same bits
+    s = stats.sum(dim=0).cpu()
+    close(s[0], want.sum(dim=(0, 1, 2)).cpu(), 5e-3, 5e-3, 'group sums/sum dz')          # sums of the f32 accumulators vs of
+    close(s[1], (want * mf).sum(dim=(0, 1, 2)).cpu(), 5e-3, 5e-3, 'group sums/sum dz*out')   # the 16-bit rounded values
+
+
+@pytest.mark.parametrize('B,h,c', [(2, 8, 16), (3, 16, 64), (32, 16, 256), (5, 64, 64)])
+def test_upsample2x_bwd_with_bn_backward_sums(ops, B, h, c):
+    dt = torch.bfloat16
+    dy = rnd((B, 2 * h, 2 * h, c), 52).to(DEV)
+    out = rnd((B, h, h, c), 55).to(DEV)
+    plain = torch.empty(B, h, h, c, dtype=dt, device=DEV)
+    ops.upsample2x_bwd(dy, plain, B, h, h, c, c, c)
+    nblk = ops.upsample2x_bwd_bn_blocks(B, h, h, c)
+    part = torch.full((nblk, 2, c), float('nan'), dtype=torch.float32, device=DEV)
+    dx = torch.empty(B, h, h, c, dtype=dt, device=DEV)
+    ops.upsample2x_bwd_bn(dy, dx, B, h, h, c, c, c, out, c, part)
+    torch.cuda.synchronize()
+    want = plain.float() * (out.float() > 0)
+    assert torch.equal(dx.float(), want)
+    s = part.sum(dim=0)
+    close(s[0], want.sum(dim=(0, 1, 2)), 5e-3, 5e-3, 'upsample_bwd_bn/sum dz')
+    close(s[1], (want * out.float()).sum(dim=(0, 1, 2)), 5e-3, 5e-3, 'upsample_bwd_bn/sum dz*out')
 
 
 # ----------------------------------------------------------------------------------------------
