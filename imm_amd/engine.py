@@ -196,9 +196,12 @@ class IMMEngine:
         self.reduce_per_layer = os.environ.get('IMM_REDUCE_PER_LAYER', '0') != '0'
         self._skip_tags = set(t for t in os.environ.get('IMM_DEBUG_SKIP_TAGS', '').split(',') if t)
         self.wgrad_lane = int(os.environ.get('IMM_WGRAD_LANE', '0')) if self.two_streams else 0
-        # batch-norm backward sums (sum dz, sum dz*out) taken in the epilogue of whatever produces dz (data gradient of the
-        # next layer, up-sampling adjoint) instead of a separate pass over dz and the conv output (IMM_BN_FUSE_BWD=0: A/B)
-        self.bn_fuse_bwd = os.environ.get('IMM_BN_FUSE_BWD', '1') != '0'
+        # IMM_BN_FUSE_BWD=1: batch-norm backward sums (sum dz, sum dz*out) taken in the epilogue of whatever produces dz (data
+        # gradient of the next layer, up-sampling adjoint) instead of a separate pass over dz and the conv output.  MEASURED
+        # (round 2, same box): 23 reduce launches (0.25 ms of kernel time) disappear, but the mask loads + sum reductions make
+        # the data-gradient epilogues 0.14 ms and the up-sampling adjoints 0.03 ms slower; step 3.841 -> 3.828 ms, and
+        # recovering xhat from the 16-bit `out` costs gradient precision (trained-model parity 0.095 -> 0.13 worst) => OFF.
+        self.bn_fuse_bwd = os.environ.get('IMM_BN_FUSE_BWD', '0') != '0'
         self._side = None
         self._pack_jobs, self._reduce_jobs = [], []
         self._training = True
