@@ -18,7 +18,9 @@ LIB_PATH = os.environ.get('IMM_HIP_LIB') or os.path.join(_HERE, 'libimm_hip.so')
 IMM_BF16, IMM_F16 = 0, 1
 CONV_BIAS, CONV_RELU, CONV_STATS, CONV_MASK, CONV_OUT_F32 = 1, 2, 4, 8, 16
 SSE_BLOCKS = 512
-ABI_VERSION = 6
+OPTIMIZERS = {'adam': 0, 'adadelta': 1, 'adagrad': 2}      # IMM_OPT_* (scripts/train.py:97-104)
+GAUSS_MODES = {'rot': 0, 'flat': 1, 'ankush': 2}     # IMM_GAUSS_* (config key gauss_mode, imm_model.py:48-72)
+ABI_VERSION = 7
 
 
 class ImmHipError(RuntimeError):
@@ -34,7 +36,7 @@ class ConvDesc(C.Structure):
 class OptHParams(C.Structure):
     _fields_ = [('lr_start', C.c_float), ('lr_decay', C.c_float), ('lr_step', C.c_int32), ('lr_multiple', C.c_float),
                 ('beta1', C.c_float), ('beta2', C.c_float), ('eps', C.c_float), ('clip', C.c_float),
-                ('grad_scale', C.c_float)]
+                ('grad_scale', C.c_float), ('optim', C.c_int32)]
 
 
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
@@ -69,11 +71,12 @@ _SIGS = {
     'imm_maxpool2_bwd': [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     'imm_pack_image': [_P, _P, _I, _L, _P],
     'imm_pack_image_taps': [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
-    'imm_softargmax_gauss_fwd': [_P, _I, _I, _I, _I, _I, _F, _I, _P, _P, _P, _P, _I, _I, _P],
-    'imm_softargmax_gauss_bwd': [_P, _I, _I, _I, _I, _I, _I, _F, _I, _P, _P, _P, _P, _I, _P],
-    'imm_gauss_render_f32': [_P, _I, _I, _F, _I, _P, _P],
+    'imm_softargmax_gauss_fwd': [_P, _I, _I, _I, _I, _I, _F, _I, _P, _P, _P, _P, _I, _I, _I, _P],
+    'imm_softargmax_gauss_bwd': [_P, _I, _I, _I, _I, _I, _I, _F, _I, _P, _P, _P, _P, _I, _I, _P],
+    'imm_gauss_render_f32': [_P, _I, _I, _F, _I, _P, _I, _P],
     'imm_vgg_conv1_1_fwd': [_P, _P, _I, _I, _I, _P, _P, _P, _I, _I, _P],
-    'imm_vgg_conv1_1_bwd': [_P, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P, _I, _P],
+    'imm_vgg_conv1_1_bwd': [_P, _I, _I, _I, _P, _P, _P, _I, _P, _P, _I, _I, _P, _I, _P],
+    'imm_image_loss_grad': [_P, _P, _I, _I, _I, _P, _P, _I, _I, _P, _I, _I, _P],
     'imm_tps_warp': [_P, _I, _I, _I, _I, _I, _P, _I, _P, _P, _I, _P, _P, _I, _P],
     'imm_conv2d_group': [_P, _I, _I, _P, _P, _P, _P, _P, _P],
     'imm_conv2d_group_stats_blocks': [_P, _I],
@@ -83,10 +86,10 @@ _SIGS = {
     'imm_resize_crop_u8': [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P],
     'imm_unpool_tap_grad': [_P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _P, _I, _P],
     'imm_masked_sse_pool': [_P, _P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P],
-    'imm_masked_sse': [_P, _P, _I, _I, _I, _I, _P, _I, _P, _P],
-    'imm_masked_sse_f32': [_P, _I, _P, _I, _I, _I, _I, _P, _P, _P],
-    'imm_perceptual_finalize': [_P, _I, _P, _P, _I, _P, _P, _P],
-    'imm_tap_grad': [_P, _I, _P, _P, _I, _I, _I, _I, _P, _I, _P, _I, _I, _P],
+    'imm_masked_sse': [_P, _P, _I, _I, _I, _I, _P, _I, _I, _P, _P],
+    'imm_masked_sse_f32': [_P, _I, _P, _I, _I, _I, _I, _P, _I, _P, _P],
+    'imm_perceptual_finalize': [_P, _I, _P, _P, _I, _P, _I, _I, _P, _P],
+    'imm_tap_grad': [_P, _I, _P, _P, _I, _I, _I, _I, _P, _I, _P, _I, _I, _I, _P],
     'imm_weight_decay_loss': [_P, _P, _P, _P, _I, _P, _P, _P, _P],
     'imm_clip_adam_step': [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, C.POINTER(OptHParams), _P],
 }

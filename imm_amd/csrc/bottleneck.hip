@@ -4,7 +4,8 @@
 // Reference: imm/models/imm_model.py:252-264 (reduce_mean over the other axis, softmax over this
 // axis, expectation against linspace(-1,1,n)) and :34-78 get_gaussian_maps mode 'rot'
 // (exp(-((y-mu_y)^2+(x-mu_x)^2)*inv_std^2), the mode every shipped config uses,
-// configs/experiments/celeba-10pts.yaml:27).  Modes 'flat' / 'ankush' are rejected loudly by the host.
+// configs/experiments/celeba-10pts.yaml:27), 'flat' (:61, exp(-(d + 1e-5)^(1/4))) and 'ankush' (:63-72, the outer
+// product of exp(-sqrt(1e-4 + |mu - coord| * inv_std)) along y and x): gauss_mode 0 / 1 / 2 (IMM_GAUSS_*).
 //
 // The whole heat-map of a sample (h*w*K f32: 10 KB at 16x16xK=10, 120 KB at 32x32x30) is staged in
 // the CU's 160 KB LDS once; row/column means, the two softmaxes and the render then run out of LDS.
@@ -16,10 +17,38 @@
 
 __device__ __forceinline__ float lin_pm1(int i, int n) { return n > 1 ? -1.f + 2.f * (float)i / (float)(n - 1) : -1.f; }
 
+// Gaussian-like map value at offset (dy, dx) = (coord - mu) and its derivative w.r.t. (mu_y, mu_x)
+// (imm_model.py:48-72; d|u|/du = sign(u) with sign(0) = 0, as TF / autograd define it).
+__device__ __forceinline__ float gauss_value(int mode, float dy, float dx, float inv_std) {
+  const float i2 = inv_std * inv_std;
+  if (mode == IMM_GAUSS_ROT) return expf(-(dy * dy + dx * dx) * i2);
+  if (mode == IMM_GAUSS_FLAT) return expf(-powf((dy * dy + dx * dx) * i2 + 1e-5f, 0.25f));
+  return expf(-sqrtf(1e-4f + fabsf(dy) * inv_std)) * expf(-sqrtf(1e-4f + fabsf(dx) * inv_std));
+}
+__device__ __forceinline__ void gauss_grad(int mode, float dy, float dx, float inv_std, float& g, float& dg_dmy, float& dg_dmx) {
+  const float i2 = inv_std * inv_std;
+  if (mode == IMM_GAUSS_ROT) {
+    g = expf(-(dy * dy + dx * dx) * i2);
+    dg_dmy = g * 2.f * i2 * dy; dg_dmx = g * 2.f * i2 * dx;
+  } else if (mode == IMM_GAUSS_FLAT) {
+    const float d = (dy * dy + dx * dx) * i2 + 1e-5f;
+    g = expf(-powf(d, 0.25f));
+    const float c = g * 0.25f * powf(d, -0.75f) * 2.f * i2;       // -dg/dd * dd/d(coord - mu)
+    dg_dmy = c * dy; dg_dmx = c * dx;
+  } else {
+    const float ry = sqrtf(1e-4f + fabsf(dy) * inv_std), rx = sqrtf(1e-4f + fabsf(dx) * inv_std);
+    const float gy = expf(-ry), gx = expf(-rx);
+    g = gy * gx;
+    const float sy = dy > 0.f ? 1.f : (dy < 0.f ? -1.f : 0.f), sx = dx > 0.f ? 1.f : (dx < 0.f ? -1.f : 0.f);
+    dg_dmy = gx * gy * inv_std * sy / (2.f * ry);
+    dg_dmx = gy * gx * inv_std * sx / (2.f * rx);
+  }
+}
+
 template <typename ET>
 __global__ __launch_bounds__(BT_THREADS) void softargmax_gauss_fwd_kernel(
     const float* __restrict__ heat, int ldh, int h, int w, int K, float inv_std, int s, float* __restrict__ mu,
-    float* __restrict__ py, float* __restrict__ px, uint16_t* __restrict__ gauss, int ldg) {
+    float* __restrict__ py, float* __restrict__ px, uint16_t* __restrict__ gauss, int ldg, int mode) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* sheat = sm;                      // [h*w][K]
   float* rmean = sheat + h * w * K;       // [h][K] row means -> probabilities
@@ -70,12 +99,11 @@ __global__ __launch_bounds__(BT_THREADS) void softargmax_gauss_fwd_kernel(
   __syncthreads();
   // render (imm_model.py:48-59, transposed to NHWC at :77)
   if (gauss != nullptr) {
-    const float i2 = inv_std * inv_std;
     for (int i = tid; i < s * s * K; i += BT_THREADS) {
       const int p = i / K, k = i - p * K;
       const int yy = p / s, xx = p - yy * s;
       const float dy = lin_pm1(yy, s) - smu[k * 2], dx = lin_pm1(xx, s) - smu[k * 2 + 1];
-      gauss[((int64_t)b * s * s + p) * ldg + k] = ET::from_f32(expf(-(dy * dy + dx * dx) * i2));
+      gauss[((int64_t)b * s * s + p) * ldg + k] = ET::from_f32(gauss_value(mode, dy, dx, inv_std));
     }
   }
 }
@@ -85,25 +113,25 @@ template <typename ET>
 __global__ __launch_bounds__(BT_THREADS) void softargmax_gauss_bwd_kernel(
     const uint16_t* __restrict__ dgauss, int ldg, int h, int w, int K, float inv_std, int s,
     const float* __restrict__ mu, const float* __restrict__ py, const float* __restrict__ px,
-    uint16_t* __restrict__ dheat, int lddh) {
+    uint16_t* __restrict__ dheat, int lddh, int mode) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* dmu = sm;              // [K][2]
   float* drow = dmu + 2 * K;    // [h][K]  d loss / d row-mean
   float* dcol = drow + h * K;   // [w][K]
   __shared__ float red[4];
   const int b = blockIdx.x, tid = threadIdx.x;
-  const float i2 = inv_std * inv_std;
-  // dmu[k][axis] = sum_p dG*G*2*inv_std^2*(coord - mu)
+  // dmu[k][axis] = sum_p dG * dG/dmu  ('rot': G*2*inv_std^2*(coord - mu))
   for (int k = 0; k < K; ++k) {
     const float my = mu[((int64_t)b * K + k) * 2], mx = mu[((int64_t)b * K + k) * 2 + 1];
     float ay = 0.f, ax = 0.f;
     for (int p = tid; p < s * s; p += BT_THREADS) {
       const int yy = p / s, xx = p - yy * s;
       const float dy = lin_pm1(yy, s) - my, dx = lin_pm1(xx, s) - mx;
-      const float g = expf(-(dy * dy + dx * dx) * i2);
-      const float dg = ET::to_f32(dgauss[((int64_t)b * s * s + p) * ldg + k]) * g * 2.f * i2;
-      ay += dg * dy;
-      ax += dg * dx;
+      float g, gmy, gmx;
+      gauss_grad(mode, dy, dx, inv_std, g, gmy, gmx);
+      const float dg = ET::to_f32(dgauss[((int64_t)b * s * s + p) * ldg + k]);
+      ay += dg * gmy;
+      ax += dg * gmx;
     }
     ay = block_sum_256(ay, red);
     ax = block_sum_256(ax, red);
@@ -137,8 +165,7 @@ __global__ __launch_bounds__(BT_THREADS) void softargmax_gauss_bwd_kernel(
 }
 
 __global__ void gauss_render_f32_kernel(const float* __restrict__ mu, int K, float inv_std, int s, float* __restrict__ out,
-                                        int64_t total) {
-  const float i2 = inv_std * inv_std;
+                                        int64_t total, int mode) {
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (int64_t)gridDim.x * blockDim.x) {
     const int k = (int)(idx % K);
@@ -147,7 +174,7 @@ __global__ void gauss_render_f32_kernel(const float* __restrict__ mu, int K, flo
     const int yy = (int)(t % s);
     const int64_t b = t / s;
     const float dy = lin_pm1(yy, s) - mu[(b * K + k) * 2], dx = lin_pm1(xx, s) - mu[(b * K + k) * 2 + 1];
-    out[idx] = expf(-(dy * dy + dx * dx) * i2);
+    out[idx] = gauss_value(mode, dy, dx, inv_std);
   }
 }
 
@@ -164,8 +191,9 @@ static int set_dyn_lds(K_ kernel, size_t bytes) {
 
 extern "C" int imm_softargmax_gauss_fwd(const float* heat, int ldh, int batch, int h, int w, int k, float inv_std, int s,
                                         float* mu, float* py, float* px, void* gauss_out, int ldg, int dtype,
-                                        void* stream) {
+                                        int gauss_mode, void* stream) {
   IMM_REQUIRE(heat && mu && py && px, "softargmax_fwd: null");
+  IMM_REQUIRE(gauss_mode >= IMM_GAUSS_ROT && gauss_mode <= IMM_GAUSS_ANKUSH, "softargmax_fwd: gauss_mode %d", gauss_mode);
   IMM_REQUIRE(batch > 0 && h > 0 && w > 0 && k > 0 && ldh >= k && s > 0, "softargmax_fwd: dims");
   IMM_REQUIRE(gauss_out == nullptr || ldg >= k, "softargmax_fwd: ldg");
   const size_t lds = sizeof(float) * ((size_t)h * w * k + (size_t)(h + w) * k + 2 * (size_t)k);
@@ -173,7 +201,7 @@ extern "C" int imm_softargmax_gauss_fwd(const float* heat, int ldh, int batch, i
   IMM_DISPATCH_DTYPE(dtype, {
     if (set_dyn_lds(softargmax_gauss_fwd_kernel<ET>, lds)) return IMM_E_HIP;
     hipLaunchKernelGGL((softargmax_gauss_fwd_kernel<ET>), dim3(batch), dim3(BT_THREADS), lds, (hipStream_t)stream, heat,
-                       ldh, h, w, k, inv_std, s, mu, py, px, (uint16_t*)gauss_out, ldg);
+                       ldh, h, w, k, inv_std, s, mu, py, px, (uint16_t*)gauss_out, ldg, gauss_mode);
   });
   IMM_CHECK_LAUNCH("imm_softargmax_gauss_fwd");
   return 0;
@@ -181,23 +209,26 @@ extern "C" int imm_softargmax_gauss_fwd(const float* heat, int ldh, int batch, i
 
 extern "C" int imm_softargmax_gauss_bwd(const void* dgauss, int ldg, int dtype, int batch, int h, int w, int k,
                                         float inv_std, int s, const float* mu, const float* py, const float* px,
-                                        void* dheat, int lddh, void* stream) {
+                                        void* dheat, int lddh, int gauss_mode, void* stream) {
   IMM_REQUIRE(dgauss && mu && py && px && dheat, "softargmax_bwd: null");
+  IMM_REQUIRE(gauss_mode >= IMM_GAUSS_ROT && gauss_mode <= IMM_GAUSS_ANKUSH, "softargmax_bwd: gauss_mode %d", gauss_mode);
   IMM_REQUIRE(batch > 0 && h > 0 && w > 0 && k > 0 && ldg >= k && lddh >= k && s > 0, "softargmax_bwd: dims");
   const size_t lds = sizeof(float) * (2 * (size_t)k + (size_t)(h + w) * k);
   IMM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((softargmax_gauss_bwd_kernel<ET>), dim3(batch), dim3(BT_THREADS), lds,
                                                (hipStream_t)stream, (const uint16_t*)dgauss, ldg, h, w, k, inv_std, s, mu,
-                                               py, px, (uint16_t*)dheat, lddh));
+                                               py, px, (uint16_t*)dheat, lddh, gauss_mode));
   IMM_CHECK_LAUNCH("imm_softargmax_gauss_bwd");
   return 0;
 }
 
-extern "C" int imm_gauss_render_f32(const float* mu, int batch, int k, float inv_std, int s, float* out, void* stream) {
+extern "C" int imm_gauss_render_f32(const float* mu, int batch, int k, float inv_std, int s, float* out, int gauss_mode,
+                                    void* stream) {
   IMM_REQUIRE(mu && out && batch > 0 && k > 0 && s > 0, "gauss_render: args");
+  IMM_REQUIRE(gauss_mode >= IMM_GAUSS_ROT && gauss_mode <= IMM_GAUSS_ANKUSH, "gauss_render: gauss_mode %d", gauss_mode);
   const int64_t total = (int64_t)batch * s * s * k;
   int64_t blocks = (total + 255) / 256;
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(gauss_render_f32_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, mu, k, inv_std, s, out, total);
+  hipLaunchKernelGGL(gauss_render_f32_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, mu, k, inv_std, s, out, total, gauss_mode);
   IMM_CHECK_LAUNCH("imm_gauss_render_f32");
   return 0;
 }

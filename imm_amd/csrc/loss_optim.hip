@@ -18,7 +18,7 @@
 template <typename ET>
 __global__ __launch_bounds__(LO_THREADS) void masked_sse_kernel(const uint16_t* __restrict__ a, const uint16_t* __restrict__ b,
                                                                 int batch, int s, int c8n, const float* __restrict__ mask,
-                                                                int S, float* __restrict__ partial) {
+                                                                int S, int l1, float* __restrict__ partial) {
   __shared__ float red[4];
   const int r = S / s;
   const int64_t total = (int64_t)batch * s * s * c8n;
@@ -39,7 +39,7 @@ __global__ __launch_bounds__(LO_THREADS) void masked_sse_kernel(const uint16_t* 
     unpack8<ET>(*(const uint4*)(b + idx * 8), fb);
     float sq = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { const float d = fa[i] - fb[i]; sq += d * d; }
+    for (int i = 0; i < 8; ++i) { const float d = fa[i] - fb[i]; sq += l1 ? fabsf(d) : d * d; }   // perceptual.l2 (imm_model.py:132)
     acc += mk * sq;
   }
   acc = block_sum_256(acc, red);
@@ -97,13 +97,13 @@ __global__ __launch_bounds__(LO_THREADS) void masked_sse_pool_kernel(const uint1
 
 __global__ __launch_bounds__(LO_THREADS) void masked_sse_f32_kernel(const float* __restrict__ a, int lda,
                                                                     const float* __restrict__ b, int ldb, int64_t npix,
-                                                                    int c, const float* __restrict__ mask,
+                                                                    int c, const float* __restrict__ mask, int l1,
                                                                     float* __restrict__ partial) {
   __shared__ float red[4];
   float acc = 0.f;
   for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (int64_t)gridDim.x * blockDim.x) {
     float sq = 0.f;
-    for (int ch = 0; ch < c; ++ch) { const float d = a[p * lda + ch] - b[p * ldb + ch]; sq += d * d; }
+    for (int ch = 0; ch < c; ++ch) { const float d = a[p * lda + ch] - b[p * ldb + ch]; sq += l1 ? fabsf(d) : d * d; }
     acc += (mask ? mask[p] : 1.f) * sq;
   }
   acc = block_sum_256(acc, red);
@@ -111,12 +111,12 @@ __global__ __launch_bounds__(LO_THREADS) void masked_sse_f32_kernel(const float*
 }
 
 extern "C" int imm_masked_sse(const void* a, const void* b, int dtype, int batch, int s, int c, const float* mask, int S,
-                              float* partial, void* stream) {
+                              int l1, float* partial, void* stream) {
   IMM_REQUIRE(a && b && partial && batch > 0 && s > 0 && c > 0 && c % 8 == 0, "masked_sse: args");
   IMM_REQUIRE(mask == nullptr || (S >= s && S % s == 0), "masked_sse: mask side %d not a multiple of feature side %d", S, s);
   IMM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((masked_sse_kernel<ET>), dim3(IMM_SSE_BLOCKS), dim3(LO_THREADS), 0,
                                                (hipStream_t)stream, (const uint16_t*)a, (const uint16_t*)b, batch, s, c / 8,
-                                               mask, S, partial));
+                                               mask, S, l1, partial));
   IMM_CHECK_LAUNCH("imm_masked_sse");
   return 0;
 }
@@ -133,20 +133,23 @@ extern "C" int imm_masked_sse_pool(const void* a, const void* b, int dtype, int 
 }
 
 extern "C" int imm_masked_sse_f32(const float* a, int lda, const float* b, int ldb, int batch, int s, int c,
-                                  const float* mask, float* partial, void* stream) {
+                                  const float* mask, int l1, float* partial, void* stream) {
   IMM_REQUIRE(a && b && partial && batch > 0 && s > 0 && c > 0 && lda >= c && ldb >= c, "masked_sse_f32: args");
   hipLaunchKernelGGL(masked_sse_f32_kernel, dim3(IMM_SSE_BLOCKS), dim3(LO_THREADS), 0, (hipStream_t)stream, a, lda, b, ldb,
-                     (int64_t)batch * s * s, c, mask, partial);
+                     (int64_t)batch * s * s, c, mask, l1, partial);
   IMM_CHECK_LAUNCH("imm_masked_sse_f32");
   return 0;
 }
 
 // m_k = SSE_k / nel_k ; wl_k = a_k + 0.01 (m_k - a_k) ; term_k = m_k / wl_k
 // d(1000*sum term)/d a_pred = c_k * mask * (a_pred - a_gt),  c_k = 1000 * (1/wl - 0.01 m/wl^2) * 2/nel
+// l1 (perceptual.l2: False, imm_model.py:132): the sums are of |d|, c_k = 1000 * (1/wl - 0.01 m/wl^2) / nel multiplies sign(d).
+// mode IMM_LOSS_L2 (reconstruction_loss: 'l2', imm_model.py:385-387,399): one feature (the image), no normaliser:
+//   reconstruction = 1000 * m, total = reconstruction / 255 + weight decay, c_0 = (1000/255) * 2/nel.
 __global__ __launch_bounds__(LO_THREADS) void perceptual_finalize_kernel(const float* __restrict__ partial, int nfeat,
                                                                          const float* __restrict__ nel, float* agg,
                                                                          int training, const float* __restrict__ wd_loss,
-                                                                         float* __restrict__ out) {
+                                                                         int l1, int mode, float* __restrict__ out) {
   __shared__ double dred[LO_THREADS];
   __shared__ double sse[16];
   const int tid = threadIdx.x;
@@ -163,6 +166,16 @@ __global__ __launch_bounds__(LO_THREADS) void perceptual_finalize_kernel(const f
     __syncthreads();
   }
   if (tid == 0) {
+    const float wd = wd_loss ? wd_loss[0] : 0.f;
+    if (mode == IMM_LOSS_L2) {
+      const float m = (float)(sse[0] / (double)nel[0]);
+      out[0] = m; out[nfeat] = m;
+      out[2 * nfeat] = (1000.f / 255.f) * 2.f / nel[0];
+      out[3 * nfeat] = 1000.f * m;
+      out[3 * nfeat + 1] = wd;
+      out[3 * nfeat + 2] = 1000.f * m / 255.f + wd;
+      return;
+    }
     float rec = 0.f;
     for (int f = 0; f < nfeat; ++f) {
       const float m = (float)(sse[f] / (double)nel[f]);
@@ -171,12 +184,11 @@ __global__ __launch_bounds__(LO_THREADS) void perceptual_finalize_kernel(const f
       const float term = m / wl;
       out[f] = term;
       out[nfeat + f] = m;
-      out[2 * nfeat + f] = 1000.f * (1.f / wl - 0.01f * m / (wl * wl)) * 2.f / nel[f];
+      out[2 * nfeat + f] = 1000.f * (1.f / wl - 0.01f * m / (wl * wl)) * (l1 ? 1.f : 2.f) / nel[f];
       if (training) agg[f] = wl;
       rec += term;
     }
     rec *= 1000.f;
-    const float wd = wd_loss ? wd_loss[0] : 0.f;
     out[3 * nfeat] = rec;
     out[3 * nfeat + 1] = wd;
     out[3 * nfeat + 2] = rec + wd;
@@ -184,10 +196,11 @@ __global__ __launch_bounds__(LO_THREADS) void perceptual_finalize_kernel(const f
 }
 
 extern "C" int imm_perceptual_finalize(const float* partial, int nfeat, const float* nel, float* agg, int training,
-                                       const float* wd_loss, float* out, void* stream) {
+                                       const float* wd_loss, int l1, int mode, float* out, void* stream) {
   IMM_REQUIRE(partial && nel && agg && out && nfeat > 0 && nfeat <= 16, "perceptual_finalize: args");
+  IMM_REQUIRE(mode == IMM_LOSS_PERCEPTUAL || (mode == IMM_LOSS_L2 && nfeat == 1 && !l1), "perceptual_finalize: mode");
   hipLaunchKernelGGL(perceptual_finalize_kernel, dim3(1), dim3(LO_THREADS), 0, (hipStream_t)stream, partial, nfeat, nel,
-                     agg, training, wd_loss, out);
+                     agg, training, wd_loss, l1, mode, out);
   IMM_CHECK_LAUNCH("imm_perceptual_finalize");
   return 0;
 }
@@ -198,7 +211,7 @@ extern "C" int imm_perceptual_finalize(const float* partial, int nfeat, const fl
 template <typename ET>
 __global__ void tap_grad_kernel(uint16_t* __restrict__ da, int has_in, const uint16_t* __restrict__ ap,
                                 const uint16_t* __restrict__ ag, int batch, int s, int c8n, const float* __restrict__ mask,
-                                int S, const float* __restrict__ coef, int idx_coef, int relu) {
+                                int S, const float* __restrict__ coef, int idx_coef, int relu, int l1) {
   const int r = S / s;
   const float ck = coef[idx_coef];
   const int64_t total = (int64_t)batch * s * s * c8n;
@@ -220,7 +233,9 @@ __global__ void tap_grad_kernel(uint16_t* __restrict__ da, int has_in, const uin
     const float cm = ck * mk;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      float v = (has_in ? d[i] : 0.f) + cm * (fp[i] - fg[i]);
+      float e = fp[i] - fg[i];
+      if (l1) e = e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f);
+      float v = (has_in ? d[i] : 0.f) + cm * e;
       if (relu && !(fp[i] > 0.f)) v = 0.f;
       d[i] = v;
     }
@@ -290,7 +305,7 @@ extern "C" int imm_unpool_tap_grad(void* da, const void* dpool, const void* a_pr
 }
 
 extern "C" int imm_tap_grad(void* da, int has_in, const void* a_pred, const void* a_gt, int dtype, int batch, int s, int c,
-                            const float* mask, int S, const float* coef, int idx, int relu, void* stream) {
+                            const float* mask, int S, const float* coef, int idx, int relu, int l1, void* stream) {
   IMM_REQUIRE(da && a_pred && a_gt && coef && batch > 0 && s > 0 && c > 0 && c % 8 == 0 && idx >= 0, "tap_grad: args");
   IMM_REQUIRE(mask == nullptr || (S >= s && S % s == 0), "tap_grad: mask side");
   const int64_t total = (int64_t)batch * s * s * (c / 8);
@@ -298,8 +313,48 @@ extern "C" int imm_tap_grad(void* da, int has_in, const void* a_pred, const void
   if (blocks > 16384) blocks = 16384;
   IMM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((tap_grad_kernel<ET>), dim3((int)blocks), dim3(LO_THREADS), 0,
                                                (hipStream_t)stream, (uint16_t*)da, has_in, (const uint16_t*)a_pred,
-                                               (const uint16_t*)a_gt, batch, s, c / 8, mask, S, coef, idx, relu));
+                                               (const uint16_t*)a_gt, batch, s, c / 8, mask, S, coef, idx, relu, l1));
   IMM_CHECK_LAUNCH("imm_tap_grad");
+  return 0;
+}
+
+// Gradient of an image-space loss term w.r.t. the prediction, when no VGG feature is tapped (reconstruction_loss: 'l2',
+// imm_model.py:385-387, or perceptual.comp == ['input']): dpred[p][ch] = coef[idx] * mask[p] * (pred - gt) (sign(.) with
+// l1) for ch < 3, zero for the other lddp - 3 channels of the 16-bit gradient image.
+template <typename ET>
+__global__ void image_loss_grad_kernel(const float* __restrict__ gt, const float* __restrict__ pred, int ldp, int64_t npix,
+                                       const float* __restrict__ mask, const float* __restrict__ coef, int idx, int l1,
+                                       uint16_t* __restrict__ dpred, int lddp) {
+  const int nvec = lddp / 8;
+  const float ck = coef[idx];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix * nvec; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p = i / nvec;
+    const int cg = (int)(i - p * nvec);
+    float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (cg == 0) {
+      const float cm = ck * (mask ? mask[p] : 1.f);
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        float d = pred[p * ldp + ch] - gt[p * 3 + ch];
+        if (l1) d = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+        o[ch] = cm * d;
+      }
+    }
+    *(uint4*)(dpred + p * lddp + cg * 8) = pack8<ET>(o);
+  }
+}
+
+extern "C" int imm_image_loss_grad(const float* gt, const float* pred, int ldp, int batch, int s, const float* mask,
+                                   const float* coef, int idx, int l1, void* dpred, int lddp, int dtype, void* stream) {
+  IMM_REQUIRE(gt && pred && coef && dpred && batch > 0 && s > 0 && ldp >= 3 && idx >= 0, "image_loss_grad: args");
+  IMM_REQUIRE(lddp >= 8 && lddp % 8 == 0, "image_loss_grad: lddp=%d must be a multiple of 8", lddp);
+  const int64_t npix = (int64_t)batch * s * s;
+  int64_t blocks = (npix * (lddp / 8) + LO_THREADS - 1) / LO_THREADS;
+  if (blocks > 8192) blocks = 8192;
+  IMM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((image_loss_grad_kernel<ET>), dim3((int)blocks), dim3(LO_THREADS), 0,
+                                               (hipStream_t)stream, gt, pred, ldp, npix, mask, coef, idx, l1,
+                                               (uint16_t*)dpred, lddp));
+  IMM_CHECK_LAUNCH("imm_image_loss_grad");
   return 0;
 }
 
@@ -410,12 +465,22 @@ __global__ __launch_bounds__(LO_THREADS) void clip_adam_kernel(float* __restrict
   const int blk = blockIdx.x;
   float factor = 1.f;
   if (hp.clip > 0.f) factor = hp.clip / fmaxf(sqrtf(seg_norm2[blk_seg[blk]]), hp.clip);
-  const float lr_t = lr_state[0];
+  const float lr_t = lr_state[0], lr = lr_state[1];
   auto one = [&](float g, float& mi, float& vi, float& w) {
     g *= factor;
-    mi = hp.beta1 * mi + (1.f - hp.beta1) * g;
-    vi = hp.beta2 * vi + (1.f - hp.beta2) * g * g;
-    w -= lr_t * mi / (sqrtf(vi) + hp.eps);
+    if (hp.optim == IMM_OPT_ADAM) {
+      mi = hp.beta1 * mi + (1.f - hp.beta1) * g;
+      vi = hp.beta2 * vi + (1.f - hp.beta2) * g * g;
+      w -= lr_t * mi / (sqrtf(vi) + hp.eps);
+    } else if (hp.optim == IMM_OPT_ADADELTA) {          // rho = beta1; vi = accum, mi = accum_update
+      vi = hp.beta1 * vi + (1.f - hp.beta1) * g * g;
+      const float u = sqrtf(mi + hp.eps) / sqrtf(vi + hp.eps) * g;
+      mi = hp.beta1 * mi + (1.f - hp.beta1) * u * u;
+      w -= lr * u;
+    } else {                                            // Adagrad: vi = accumulator
+      vi += g * g;
+      w -= lr * g / sqrtf(vi);
+    }
   };
   const int b0 = blk_begin[blk], b1 = blk_end[blk];
   const int a0 = min((b0 + 3) & ~3, b1), a1 = max(a0, b1 & ~3);
@@ -437,6 +502,7 @@ extern "C" int imm_clip_adam_step(float* params, float* grads, float* m, float* 
   IMM_REQUIRE(params && grads && m && v && blk_seg && blk_begin && blk_end && seg_first_blk && seg_wd && blk_partial &&
                   seg_norm2 && step_count && adam_t && lr_state && hp, "clip_adam_step: null");
   IMM_REQUIRE(nblk > 0 && nseg > 0 && hp->lr_step > 0, "clip_adam_step: dims");
+  IMM_REQUIRE(hp->optim >= IMM_OPT_ADAM && hp->optim <= IMM_OPT_ADAGRAD, "clip_adam_step: optim %d", hp->optim);
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(grad_prepare_kernel, dim3(nblk), dim3(LO_THREADS), 0, s, params, grads, blk_seg, blk_begin, blk_end,
                      seg_wd, hp->grad_scale, blk_partial);

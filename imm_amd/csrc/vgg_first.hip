@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void vgg_conv1_1_bwd_kernel(const uint16_t* __
                                                               const float* __restrict__ w, const float* __restrict__ gt,
                                                               const float* __restrict__ pred, int ldp,
                                                               const float* __restrict__ mask, const float* __restrict__ coef,
-                                                              uint16_t* __restrict__ dpred, int lddp) {
+                                                              int input_idx, int l1, uint16_t* __restrict__ dpred, int lddp) {
   constexpr int HT = VF_TILE + 2;
   __shared__ uint4 sdz[HT * HT * 8];          // dz tile + halo, 64 channels = 8 x 16 B per pixel (41 KB)
   const int tid = threadIdx.x;
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void vgg_conv1_1_bwd_kernel(const uint16_t* __
   for (int t = 0; t < 9; ++t)
 #pragma unroll
     for (int e = 0; e < 4; ++e) wr[t][e] = ET::pack2(w[t * 64 + cg * 8 + 2 * e], w[t * 64 + cg * 8 + 2 * e + 1]);
-  const float c0 = coef[0];
+  const float c0 = input_idx >= 0 ? coef[input_idx] : 0.f;      // 'input' feature not in perceptual.comp: no direct term
   __syncthreads();
 #pragma unroll 2
   for (int pass = 0; pass < 8; ++pass) {
@@ -132,7 +132,11 @@ __global__ __launch_bounds__(256) void vgg_conv1_1_bwd_kernel(const uint16_t* __
         const float cm = c0 * (mask ? mask[p] : 1.f);
         const float dg = part / (3.0f * 255.0f);
 #pragma unroll
-        for (int ch = 0; ch < 3; ++ch) o[ch] = dg + cm * (pred[p * ldp + ch] - gt[p * 3 + ch]);
+        for (int ch = 0; ch < 3; ++ch) {
+          float d = pred[p * ldp + ch] - gt[p * 3 + ch];
+          if (l1) d = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);       // perceptual.l2: False => |.|, gradient sign(d)
+          o[ch] = dg + cm * d;
+        }
       }
       *(uint4*)(dpred + p * lddp + cg * 8) = pack8<ET>(o);
     }
@@ -152,13 +156,13 @@ extern "C" int imm_vgg_conv1_1_fwd(const float* gt, const float* pred, int ldp, 
 }
 
 extern "C" int imm_vgg_conv1_1_bwd(const void* dz, int dtype, int batch, int s, const float* w9x64, const float* gt,
-                                   const float* pred, int ldp, const float* mask, const float* coef, void* dpred,
-                                   int lddp, void* stream) {
+                                   const float* pred, int ldp, const float* mask, const float* coef, int input_idx, int l1,
+                                   void* dpred, int lddp, void* stream) {
   IMM_REQUIRE(dz && w9x64 && gt && pred && coef && dpred, "vgg_conv1_1_bwd: null");
   IMM_REQUIRE(batch > 0 && s > 0 && ldp >= 3 && lddp >= 8 && lddp % 8 == 0 && lddp <= 64, "vgg_conv1_1_bwd: dims");
   const dim3 grid((s + VF_TILE - 1) / VF_TILE, (s + VF_TILE - 1) / VF_TILE, batch);
   IMM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((vgg_conv1_1_bwd_kernel<ET>), grid, dim3(256), 0, (hipStream_t)stream,
-                                               (const uint16_t*)dz, batch, s, w9x64, gt, pred, ldp, mask, coef,
+                                               (const uint16_t*)dz, batch, s, w9x64, gt, pred, ldp, mask, coef, input_idx, l1,
                                                (uint16_t*)dpred, lddp));
   IMM_CHECK_LAUNCH("imm_vgg_conv1_1_bwd");
   return 0;

@@ -138,17 +138,21 @@ class _ConvLayer:
 class IMMEngine:
     def __init__(self, cfg, batch, image_size, device='cuda:0', act_dtype=torch.bfloat16, seed=1, vgg_weights=None,
                  hparams=None, world_size=1):
-        if cfg.gauss_mode != 'rot':
-            if cfg.gauss_mode in ('flat', 'ankush'):
-                raise NotImplementedError("gauss_mode %r: only 'rot' (the mode of every shipped config) has HIP kernels"
-                                          % cfg.gauss_mode)
-            raise ValueError('Unknown mode: ' + str(cfg.gauss_mode))
+        if cfg.gauss_mode not in L.GAUSS_MODES:
+            raise ValueError('Unknown mode: ' + str(cfg.gauss_mode))       # imm_model.py:75
         if cfg.reconstruction_loss not in ('perceptual', 'l2'):
-            raise ValueError('Reconsutruction loss-type: ' + str(cfg.reconstruction_loss) + ' not understood')
-        if cfg.reconstruction_loss != 'perceptual':
-            raise NotImplementedError("reconstruction_loss 'l2' has no HIP path yet; shipped configs use 'perceptual'")
-        if list(cfg.perceptual.comp) != SUPPORTED_COMP or not cfg.perceptual.l2:
-            raise NotImplementedError('perceptual.comp must be %r with l2: True' % (SUPPORTED_COMP,))
+            raise ValueError('Reconsutruction loss-type: ' + str(cfg.reconstruction_loss) + ' not understood')   # imm_model.py:389
+        # loss features (imm_model.py:124-147): any ordered selection of the raw image and the five tapped VGG layers; the
+        # initial normalisers ws[k] go by POSITION in the list, as in the reference (:131,144)
+        self.loss_kind = cfg.reconstruction_loss
+        self.comp = list(cfg.perceptual.comp) if self.loss_kind == 'perceptual' else ['input']
+        if self.loss_kind == 'perceptual':
+            if not self.comp or len(set(self.comp)) != len(self.comp) or len(self.comp) > len(PERCEPTUAL_WS):
+                raise ValueError('perceptual.comp must name 1..%d distinct features, got %r' % (len(PERCEPTUAL_WS), self.comp))
+            if any(n not in SUPPORTED_COMP for n in self.comp):
+                raise NotImplementedError('perceptual.comp entries must come from %r (the layers the shipped configs tap), got %r'
+                                          % (SUPPORTED_COMP, self.comp))
+        self.l1 = self.loss_kind == 'perceptual' and not cfg.perceptual.l2       # f_e = tf.abs (imm_model.py:132)
         if image_size % 16 or image_size < 64:
             raise ValueError('image side must be a multiple of 16 and >= 64')
         L.load()   # fail loudly, now, if the HIP library is missing
@@ -179,13 +183,21 @@ class IMMEngine:
         self.lr_state = self._zeros(2)
         self.wd_loss = self._zeros(1)
         hp = dict(lr_start=1e-3, lr_decay=0.95, lr_step=100000, lr_multiple=1.0, beta1=0.9, beta2=0.999, eps=1e-8,
-                  clip=1.0, grad_scale=1.0 / world_size)
+                  clip=1.0, grad_scale=1.0 / world_size, optim='adam')
         hp.update(hparams or {})
+        # scripts/train.py:97-104: Adam | Adadelta(rho 0.95, eps 1e-6) | Adagrad(initial accumulator 0.1)
+        self.optim = str(hp['optim']).lower()
+        if self.optim not in L.OPTIMIZERS:
+            raise ValueError('Optimizer = %s not suppoerted' % hp['optim'])
+        if self.optim == 'adadelta':
+            hp.update(beta1=0.95, eps=1e-6)
+        hp['optim'] = L.OPTIMIZERS[self.optim]
         self.hp = ops.OptHParams(**hp)
 
         # ---- non-trainable state ------------------------------------------------------------------
         self.state = OrderedDict()           # BN moving statistics, loss normalisers
-        self.loss_agg = torch.tensor(PERCEPTUAL_WS, dtype=torch.float32, device=self.dev)
+        self.nfeat = len(self.comp)
+        self.loss_agg = torch.tensor(PERCEPTUAL_WS[:self.nfeat], dtype=torch.float32, device=self.dev)
         self.vgg_w = OrderedDict((k, v.to(self.dev).contiguous()) for k, v in (vgg_weights or synthetic_vgg_weights()).items())
 
         self.prog_pack, self.prog_fwd, self.prog_bwd, self.prog_opt = [], [], [], []
@@ -193,6 +205,8 @@ class IMMEngine:
         # timing experiment only (results become wrong): drop every launch whose tag is listed, to measure how much of the
         # step's critical path a kernel class occupies under graph replay / stream concurrency
         self.vgg_split = int(os.environ.get('IMM_VGG_SPLIT', '0')) if self.two_streams else 0
+        if self.loss_kind != 'perceptual' or all(n == 'input' for n in self.comp):
+            self.vgg_split = 0                   # no VGG feature is tapped: nothing to split
         self.reduce_per_layer = os.environ.get('IMM_REDUCE_PER_LAYER', '0') != '0'
         self._skip_tags = set(t for t in os.environ.get('IMM_DEBUG_SKIP_TAGS', '').split(',') if t)
         self.wgrad_lane = int(os.environ.get('IMM_WGRAD_LANE', '0')) if self.two_streams else 0
@@ -234,9 +248,16 @@ class IMMEngine:
                 self.pview[name].zero_()
         for k, v in self.state.items():
             v.fill_(1.0 if k.endswith('moving_variance') else 0.0)
-        self.loss_agg.copy_(torch.tensor(PERCEPTUAL_WS))
-        self.adam_m.zero_(); self.adam_v.zero_(); self.grads.zero_(); self.step_count.zero_(); self.adam_t.zero_()
+        self.loss_agg.copy_(torch.tensor(PERCEPTUAL_WS[:self.nfeat]))
+        self.reset_optimizer_slots(); self.grads.zero_(); self.step_count.zero_()
         self.run(self.prog_pack)
+
+    def reset_optimizer_slots(self):
+        """Fresh optimizer state: Adam m = v = 0, t = 0; Adadelta accumulators 0; Adagrad accumulator 0.1 (TF's
+        initial_accumulator_value).  Slot buffers: adam_m (m / accum_update), adam_v (v / accum)."""
+        self.adam_m.zero_()
+        self.adam_v.fill_(0.1 if self.optim == 'adagrad' else 0.0)
+        self.adam_t.zero_()
 
     def load_parameters(self, named, state=None):
         """named: {tf_variable_name: tensor}.  Missing names raise (no silent partial restore)."""
@@ -247,7 +268,8 @@ class IMMEngine:
                 if k in self.state:
                     self.state[k].copy_(v.to(self.dev))
                 elif k.startswith('loss/') and k.endswith('_agg'):
-                    self.loss_agg[list(self.cfg.perceptual.comp).index(k[5:-4])] = float(v)
+                    if self.loss_kind == 'perceptual' and k[5:-4] in self.comp:
+                        self.loss_agg[self.comp.index(k[5:-4])] = float(v)
                 elif k.startswith('vgg16/'):
                     self.vgg_w[k].copy_(v.to(self.dev))
                 else:
@@ -260,8 +282,9 @@ class IMMEngine:
 
     def named_state(self):
         out = OrderedDict((k, v.detach().clone()) for k, v in self.state.items())
-        for i, name in enumerate(self.cfg.perceptual.comp):
-            out['loss/%s_agg' % name] = self.loss_agg[i].detach().clone()
+        if self.loss_kind == 'perceptual':
+            for i, name in enumerate(self.comp):
+                out['loss/%s_agg' % name] = self.loss_agg[i].detach().clone()
         return out
 
     # ------------------------------------------------------------------------------------------
@@ -526,6 +549,10 @@ class IMMEngine:
 
         self._mark(self.prog_fwd, 'fork')
         self._cur_lane = 1                      # image encoder: side stream, concurrent with the pose encoder
+        # the weight-decay term of the loss depends on the parameters only: computed here, beside the (longer) pose branch,
+        # instead of in front of the loss where it sat on the critical path (23 us)
+        self._add(self.prog_fwd, lambda: ops.weight_decay_loss(self.params, self.tab, self.opt_blk_partial, self.wd_loss),
+                  'wd_loss', name='loss/weight_decay')
         self.enc_im = build_encoder('model/image_encoder', self.in_image)
         if He != 16:   # imm_model.py:324-335: align_corners resize of the 8f-channel embedding down to 16x16
             e = self.enc_im[-1]
@@ -544,7 +571,7 @@ class IMMEngine:
         self.inv_std = 1.0 / float(cfg.gauss_std)
         gview = self.joint[..., 8 * nf:]
         self._add(self.prog_fwd, lambda: ops.softargmax_gauss_fwd(self.heat, self.ldh, B, He, He, K, self.inv_std, 16,
-                                                                  self.mu, self.py, self.px, gview, Cj, dt), 'bottleneck')
+                                                                  self.mu, self.py, self.px, gview, Cj, dt, cfg.gauss_mode), 'bottleneck')
 
         if self.vgg_split == 2:
             # the image-encoder stream carries on with the VGG gt half while the main stream renders
@@ -580,14 +607,20 @@ class IMMEngine:
         # vgg_split the gt half -- which does not depend on the network -- is issued on a third stream at the very start
         # of the step and fills the CUs the low-resolution encoder/renderer layers leave idle; the main stream then
         # only runs the pred half before the loss.  Same kernels, same per-image arithmetic: results are bitwise equal.
+        # Only the layers up to the deepest tapped one are built; no tapped layer (perceptual.comp == ['input'] or
+        # reconstruction_loss 'l2') => no VGG at all.
         self.vgg_act, self.vgg_wt, self.vgg_wtd, self.vgg_desc, self.vgg_dd = OrderedDict(), {}, {}, {}, {}
         self.vgg_pool = {}
-        self.w11 = self._zeros(9, 64); self.b11 = self._zeros(64)
-        a = self._act(2 * B, S, S, 64)
-        self.vgg_act['conv1_1'] = (a, S)
-        split = self.vgg_split
+        self.tap_idx = {n: k for k, n in enumerate(self.comp)}          # feature name -> position in the loss
+        vnames = [n for n, _ci, _co in VGG_LAYERS]
+        taps = [n for n in self.comp if n != 'input'] if self.loss_kind == 'perceptual' else []
+        self.vgg_layers = VGG_LAYERS[:max(vnames.index(n) for n in taps) + 1] if taps else []
+        nfeat = self.nfeat
+        self.sse_partial = self._zeros(nfeat, L.SSE_BLOCKS)
+        split = self.vgg_split if self.vgg_layers else 0
         nimg = B if split else 2 * B
         gt_prog, pred_prog = [], self.prog_fwd
+        fuse_ok = not self.l1                    # the fused SSE+pool / unpool+tap passes exist for the squared error only
 
         def vadd(fn_for, tag, flops, nbytes, name=''):
             # fn_for(lo) -> launch closure over images [lo, lo + nimg)
@@ -599,15 +632,19 @@ class IMMEngine:
             else:
                 self._add(pred_prog, fn_for(0), tag, flops, nbytes, name)
 
-        if split:
-            vadd(lambda lo: (lambda: ops.vgg_conv1_1_fwd(self.in_future, self.pred, self.ldp, B, S, self.w11, self.b11, a,
-                                                         1 if lo == 0 else 2)),
-                 'vgg_conv1_1', 2.0 * B * S * S * 9 * 64, B * S * S * 128.0, 'vgg16/conv1_1')
-        else:
-            self._add(self.prog_fwd, lambda: ops.vgg_conv1_1_fwd(self.in_future, self.pred, self.ldp, B, S, self.w11, self.b11, a),
-                      'vgg_conv1_1', 2.0 * 2 * B * S * S * 9 * 64, 2 * B * S * S * 128.0)
-        x, H = a, S
-        for name, cin, cout in VGG_LAYERS[1:]:
+        if self.vgg_layers:
+            self.w11 = self._zeros(9, 64); self.b11 = self._zeros(64)
+            a = self._act(2 * B, S, S, 64)
+            self.vgg_act['conv1_1'] = (a, S)
+            if split:
+                vadd(lambda lo: (lambda: ops.vgg_conv1_1_fwd(self.in_future, self.pred, self.ldp, B, S, self.w11, self.b11, a,
+                                                             1 if lo == 0 else 2)),
+                     'vgg_conv1_1', 2.0 * B * S * S * 9 * 64, B * S * S * 128.0, 'vgg16/conv1_1')
+            else:
+                self._add(self.prog_fwd, lambda: ops.vgg_conv1_1_fwd(self.in_future, self.pred, self.ldp, B, S, self.w11, self.b11, a),
+                          'vgg_conv1_1', 2.0 * 2 * B * S * S * 9 * 64, 2 * B * S * S * 128.0)
+            x, H = a, S
+        for li, (name, cin, cout) in enumerate(self.vgg_layers[1:], start=1):
             fd = ops.fwd_desc(nimg, H, H, cin, cin, cout, cout, 3, 1, L.CONV_BIAS | L.CONV_RELU)
             wt = self._zeros(ops.round_up(cout, 128), fd.kpad, dtype=dt)
             wtd = self._zeros(ops.round_up(cin, 128), ops.round_up(9 * cout, 32), dtype=dt)
@@ -629,12 +666,12 @@ class IMMEngine:
                      'vgg16/' + name)
             self.vgg_act[name] = (y, H)
             x = y
-            if name in VGG_POOL_AFTER:
+            if name in VGG_POOL_AFTER and li < len(self.vgg_layers) - 1:      # the deepest layer is not pooled: nobody reads it
                 p = self._act(2 * B, H // 2, H // 2, cout)
-                if name in VGG_TAPS and not split and os.environ.get('IMM_SSE_POOL_FUSE', '1') != '0':
+                if name in taps and not split and fuse_ok and os.environ.get('IMM_SSE_POOL_FUSE', '1') != '0':
                     # the loss taps this layer AND it is pooled next: one pass computes the masked SSE of the two halves
                     # and both pooled halves (the feature map is read once instead of twice)
-                    idx = VGG_TAPS[name]
+                    idx = self.tap_idx[name]
                     self._fused_sse = getattr(self, '_fused_sse', set()) | {name}
                     self._add(self.prog_fwd, (lambda x=x, p=p, H=H, cout=cout, idx=idx: ops.masked_sse_pool(
                         x[:B], x[B:], B, H, cout, self.in_mask, S, self.sse_partial[idx], p[:B], p[B:])), 'sse',
@@ -660,32 +697,37 @@ class IMMEngine:
             self.prog_fwd[at:at] = head
             self.n_fwd_model += len(head)
             self._wait(self.prog_fwd, 'vgg_gt', lane=0)
-        self._pack_vgg()
+        if self.vgg_layers:
+            self._pack_vgg()
 
         # ---- loss -------------------------------------------------------------------------------------------
-        nfeat = 6
-        self.sse_partial = self._zeros(nfeat, L.SSE_BLOCKS)
-        nel = [float(B * S * S * 3)]
-        for name in SUPPORTED_COMP[1:]:
-            y, H = self.vgg_act[name]
-            nel.append(float(B * H * H * y.shape[-1]))
+        nel = []
+        for name in self.comp:
+            if name == 'input':
+                nel.append(float(B * S * S * 3))
+            else:
+                y, H = self.vgg_act[name]
+                nel.append(float(B * H * H * y.shape[-1]))
         self.nel = torch.tensor(nel, dtype=torch.float32, device=self.dev)
         self.loss_out = self._zeros(3 * nfeat + 3)
         mask = self.in_mask
-        self._add(self.prog_fwd, lambda: ops.masked_sse_f32(self.in_future, 3, self.pred, self.ldp, B, S, 3, mask,
-                                                            self.sse_partial[0]), 'sse')
-        for name, idx in VGG_TAPS.items():
+        l1 = self.l1
+        if 'input' in self.tap_idx:
+            idx0 = self.tap_idx['input']
+            self._add(self.prog_fwd, lambda: ops.masked_sse_f32(self.in_future, 3, self.pred, self.ldp, B, S, 3, mask,
+                                                                self.sse_partial[idx0], l1), 'sse')
+        for name in taps:
             if name in getattr(self, '_fused_sse', ()):
                 continue
+            idx = self.tap_idx[name]
             y, H = self.vgg_act[name]
             c = y.shape[-1]
             self._add(self.prog_fwd, (lambda y=y, H=H, c=c, idx=idx: ops.masked_sse(y[:B], y[B:], B, H, c, mask, S,
-                                                                                  self.sse_partial[idx])), 'sse',
+                                                                                  self.sse_partial[idx], l1)), 'sse',
                       0.0, 2 * B * H * H * c * 2.0)
-        self._add(self.prog_fwd, lambda: ops.weight_decay_loss(self.params, self.tab, self.opt_blk_partial, self.wd_loss),
-                  'wd_loss')
+        mode = ops.LOSS_L2 if self.loss_kind == 'l2' else ops.LOSS_PERCEPTUAL
         self._add(self.prog_fwd, lambda: ops.perceptual_finalize(self.sse_partial, nfeat, self.nel, self.loss_agg,
-                                                                 self._training, self.wd_loss, self.loss_out), 'loss_finalize')
+                                                                 self._training, self.wd_loss, self.loss_out, l1, mode), 'loss_finalize')
         self.coef = self.loss_out[2 * nfeat:3 * nfeat]
 
         self._build_backward()
@@ -700,10 +742,12 @@ class IMMEngine:
         self.prog_opt.extend(self.prog_pack)
 
     def _pack_vgg(self):
+        if not self.vgg_layers:
+            return
         w = self.vgg_w
         self.w11.copy_(w['vgg16/conv1_1/weights'].reshape(9, 64))
         self.b11.copy_(w['vgg16/conv1_1/biases'])
-        for name, cin, cout in VGG_LAYERS[1:]:
+        for name, cin, cout in self.vgg_layers[1:]:
             fd = self.vgg_desc[name]
             wm = w['vgg16/%s/weights' % name]
             ops.pack_weights(wm, self.vgg_wt[name], 0, 3, 3, cin, cout, cin, self.vgg_wt[name].shape[0], fd.kpad)
@@ -714,10 +758,12 @@ class IMMEngine:
         B, S, K, dt, Cj = self.B, self.S, self.K, self.dt, self.Cj
         mask = self.in_mask
         acts = self.vgg_act
-        names = [n for n, _ci, _co in VGG_LAYERS]
+        l1 = self.l1
+        names = [n for n, _ci, _co in self.vgg_layers]
+        taps = self.tap_idx
         # gradient buffers w.r.t. the (pred half of the) VGG activations, reused in place as dz after masking
         dbuf = {n: self._act(B, acts[n][1], acts[n][1], acts[n][0].shape[-1]) for n in names}
-        dpool = {n: self._act(B, acts[n][1] // 2, acts[n][1] // 2, acts[n][0].shape[-1]) for n in self.vgg_pool if n != 'conv5_3'}
+        dpool = {n: self._act(B, acts[n][1] // 2, acts[n][1] // 2, acts[n][0].shape[-1]) for n in self.vgg_pool}
 
         def pred_half(t):
             return t[B:]
@@ -726,7 +772,7 @@ class IMMEngine:
             y, H = acts[name]
             c = y.shape[-1]
             self._add(self.prog_bwd, lambda: ops.tap_grad(dbuf[name], has_in, y[B:], y[:B], B, H, c, mask, S, self.coef,
-                                                          VGG_TAPS[name], True), 'tap_grad', 0.0, B * H * H * c * 8.0)
+                                                          taps[name], True, l1), 'tap_grad', 0.0, B * H * H * c * 8.0)
 
         def dgrad(name, dst, mask_ref):
             """conv `name`: dz(name) -> gradient w.r.t. its input written to dst (masked by mask_ref>0 if given)."""
@@ -748,38 +794,43 @@ class IMMEngine:
 
         def unpool_tap(name, dy):
             """unpool(name, dy, 0) + tap(name, True) in one pass (the tapped layer is the pooled one)."""
-            if os.environ.get('IMM_UNPOOL_TAP_FUSE', '1') == '0':
+            if l1 or os.environ.get('IMM_UNPOOL_TAP_FUSE', '1') == '0':
                 unpool(name, dy, 0); tap(name, True)
                 return
             y, H = acts[name]
             c = y.shape[-1]
             self._add(self.prog_bwd, lambda: ops.unpool_tap_grad(dbuf[name], dy, y[B:], y[:B], B, H, c, mask, S, self.coef,
-                                                                 VGG_TAPS[name]), 'tap_grad', 0.0, B * H * H * c * 8.5)
+                                                                 taps[name]), 'tap_grad', 0.0, B * H * H * c * 8.5)
 
-        tap('conv5_2', False)
-        dgrad('conv5_2', dbuf['conv5_1'], pred_half(acts['conv5_1'][0]))
-        dgrad('conv5_1', dpool['conv4_3'], None)
-        unpool('conv4_3', dpool['conv4_3'], 1)
-        dgrad('conv4_3', dbuf['conv4_2'], None)
-        tap('conv4_2', True)
-        dgrad('conv4_2', dbuf['conv4_1'], pred_half(acts['conv4_1'][0]))
-        dgrad('conv4_1', dpool['conv3_3'], None)
-        unpool('conv3_3', dpool['conv3_3'], 1)
-        dgrad('conv3_3', dbuf['conv3_2'], None)
-        tap('conv3_2', True)
-        dgrad('conv3_2', dbuf['conv3_1'], pred_half(acts['conv3_1'][0]))
-        dgrad('conv3_1', dpool['conv2_2'], None)
-        unpool_tap('conv2_2', dpool['conv2_2'])
-        dgrad('conv2_2', dbuf['conv2_1'], pred_half(acts['conv2_1'][0]))
-        dgrad('conv2_1', dpool['conv1_2'], None)
-        unpool_tap('conv1_2', dpool['conv1_2'])
-        dgrad('conv1_2', dbuf['conv1_1'], pred_half(acts['conv1_1'][0]))
+        # Walk the frozen network back from the deepest tapped layer (vgg16.py:343-370 reversed).  At the top of iteration
+        # `name` the gradient w.r.t. its post-ReLU output is in dpool[name] (layer pooled next), or in dbuf[name] (already
+        # ReLU-masked by the epilogue of the data gradient that wrote it, unless the layer is tapped: then the tap pass adds
+        # the feature-loss term and applies the mask).
+        for i in range(len(names) - 1, 0, -1):
+            name, prev = names[i], names[i - 1]
+            deepest = i == len(names) - 1
+            if name in self.vgg_pool:
+                if name in taps:
+                    unpool_tap(name, dpool[name])
+                else:
+                    unpool(name, dpool[name], 1)
+            elif name in taps:
+                tap(name, not deepest)
+            if prev in self.vgg_pool:
+                dgrad(name, dpool[prev], None)
+            else:
+                dgrad(name, dbuf[prev], None if prev in taps else pred_half(acts[prev][0]))
         # first layer + 'input' feature -> gradient of the renderer's last convolution
         last = self.ren[-1]
         self.d_pred = self._act(B, S, S, last.lddy)
-        self._add(self.prog_bwd, lambda: ops.vgg_conv1_1_bwd(dbuf['conv1_1'], B, S, self.w11, self.in_future, self.pred,
-                                                             self.ldp, mask, self.coef, self.d_pred, last.lddy),
-                  'vgg_conv1_1_bwd', 2.0 * B * S * S * 9 * 64)
+        in_idx = taps.get('input', -1)
+        if names:
+            self._add(self.prog_bwd, lambda: ops.vgg_conv1_1_bwd(dbuf['conv1_1'], B, S, self.w11, self.in_future, self.pred,
+                                                                 self.ldp, mask, self.coef, self.d_pred, last.lddy, in_idx, l1),
+                      'vgg_conv1_1_bwd', 2.0 * B * S * S * 9 * 64)
+        else:       # image-space loss only: reconstruction_loss 'l2' (imm_model.py:385-387) or perceptual.comp == ['input']
+            self._add(self.prog_bwd, lambda: ops.image_loss_grad(self.in_future, self.pred, self.ldp, B, S, mask, self.coef, in_idx,
+                                                                 self.d_pred, last.lddy, l1), 'image_loss_grad')
 
         # ---- renderer backward -----------------------------------------------------------------------------
         ups = {idx: (ub, H, co) for idx, ub, H, co in self.ren_up}
@@ -847,7 +898,7 @@ class IMMEngine:
         self.d_heat = self._act(B, He, He, ph.lddy)
         dg = self.d_joint[..., nf8:]
         self._add(self.prog_bwd, lambda: ops.softargmax_gauss_bwd(dg, Cj, B, He, He, K, self.inv_std, 16, self.mu, self.py,
-                                                                  self.px, self.d_heat, ph.lddy), 'bottleneck_bwd')
+                                                                  self.px, self.d_heat, ph.lddy, self.cfg.gauss_mode), 'bottleneck_bwd')
         d_feat = self._act(B, He, He, nf8)
         self._conv_backward(ph, self.d_heat, ph.lddy, d_feat, nf8, dx_bn=self.enc_pose[-1])
         self._encoder_backward(self.enc_pose, d_feat, nf8)
@@ -988,11 +1039,11 @@ class IMMEngine:
     # convenience views -----------------------------------------------------------------------------
     @property
     def loss(self):
-        return self.loss_out[3 * 6 + 2]
+        return self.loss_out[3 * self.nfeat + 2]
 
     @property
     def loss_terms(self):
-        return self.loss_out[:6]
+        return self.loss_out[:self.nfeat]
 
     @property
     def future_im_pred(self):

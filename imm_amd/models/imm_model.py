@@ -133,7 +133,7 @@ class IMMModel(BaseModel):
         size = future_im_size[0]
         full_maps = torch.empty(eng.B, size, size, eng.K, device=eng.dev)
         from .. import ops
-        ops.gauss_render_f32(eng.mu, eng.B, eng.K, eng.inv_std, size, full_maps)
+        ops.gauss_render_f32(eng.mu, eng.B, eng.K, eng.inv_std, size, full_maps, eng.cfg.gauss_mode)
         tensors.update({'future_im': future_im, 'im': im,
                         'pose_embedding': colorize_landmark_maps(full_maps),
                         'future_im_pred': eng.future_im_pred,

@@ -247,18 +247,24 @@ def pack_image(src, dst, npix):
 
 
 # ---- bottleneck ------------------------------------------------------------------------------
-def softargmax_gauss_fwd(heat, ldh, batch, h, w, k, inv_std, s, mu, py, px, gauss_out, ldg, dtype):
+def gauss_mode_enum(mode):
+    if mode not in L.GAUSS_MODES:
+        raise ValueError('Unknown mode: ' + str(mode))       # imm_model.py:75
+    return L.GAUSS_MODES[mode]
+
+
+def softargmax_gauss_fwd(heat, ldh, batch, h, w, k, inv_std, s, mu, py, px, gauss_out, ldg, dtype, mode='rot'):
     call('imm_softargmax_gauss_fwd', _p(heat), ldh, batch, h, w, k, float(inv_std), s, _p(mu), _p(py), _p(px),
-         _p(gauss_out), ldg, dtype_enum(dtype), _s())
+         _p(gauss_out), ldg, dtype_enum(dtype), gauss_mode_enum(mode), _s())
 
 
-def softargmax_gauss_bwd(dgauss, ldg, batch, h, w, k, inv_std, s, mu, py, px, dheat, lddh):
+def softargmax_gauss_bwd(dgauss, ldg, batch, h, w, k, inv_std, s, mu, py, px, dheat, lddh, mode='rot'):
     call('imm_softargmax_gauss_bwd', _p(dgauss), ldg, dtype_enum(dheat.dtype), batch, h, w, k, float(inv_std), s, _p(mu),
-         _p(py), _p(px), _p(dheat), lddh, _s())
+         _p(py), _p(px), _p(dheat), lddh, gauss_mode_enum(mode), _s())
 
 
-def gauss_render_f32(mu, batch, k, inv_std, s, out):
-    call('imm_gauss_render_f32', _p(mu), batch, k, float(inv_std), s, _p(out), _s())
+def gauss_render_f32(mu, batch, k, inv_std, s, out, mode='rot'):
+    call('imm_gauss_render_f32', _p(mu), batch, k, float(inv_std), s, _p(out), gauss_mode_enum(mode), _s())
 
 
 # ---- VGG head / loss --------------------------------------------------------------------------
@@ -266,26 +272,35 @@ def vgg_conv1_1_fwd(gt, pred, ldp, batch, s, w, b, out, halves=3):
     call('imm_vgg_conv1_1_fwd', _p(gt), _p(pred), ldp, batch, s, _p(w), _p(b), _p(out), dtype_enum(out.dtype), halves, _s())
 
 
-def vgg_conv1_1_bwd(dz, batch, s, w, gt, pred, ldp, mask, coef, dpred, lddp):
+def vgg_conv1_1_bwd(dz, batch, s, w, gt, pred, ldp, mask, coef, dpred, lddp, input_idx=0, l1=False):
     call('imm_vgg_conv1_1_bwd', _p(dz), dtype_enum(dz.dtype), batch, s, _p(w), _p(gt), _p(pred), ldp, _p(mask), _p(coef),
-         _p(dpred), lddp, _s())
+         int(input_idx), int(l1), _p(dpred), lddp, _s())
 
 
-def masked_sse(a, b, batch, s, c, mask, S, partial):
-    call('imm_masked_sse', _p(a), _p(b), dtype_enum(a.dtype), batch, s, c, _p(mask), S, _p(partial), _s())
+def image_loss_grad(gt, pred, ldp, batch, s, mask, coef, idx, dpred, lddp, l1=False):
+    call('imm_image_loss_grad', _p(gt), _p(pred), ldp, batch, s, _p(mask), _p(coef), int(idx), int(l1), _p(dpred), lddp,
+         dtype_enum(dpred.dtype), _s())
 
 
-def masked_sse_f32(a, lda, b, ldb, batch, s, c, mask, partial):
-    call('imm_masked_sse_f32', _p(a), lda, _p(b), ldb, batch, s, c, _p(mask), _p(partial), _s())
+def masked_sse(a, b, batch, s, c, mask, S, partial, l1=False):
+    call('imm_masked_sse', _p(a), _p(b), dtype_enum(a.dtype), batch, s, c, _p(mask), S, int(l1), _p(partial), _s())
 
 
-def perceptual_finalize(partial, nfeat, nel, agg, training, wd_loss, out):
-    call('imm_perceptual_finalize', _p(partial), nfeat, _p(nel), _p(agg), int(training), _p(wd_loss), _p(out), _s())
+def masked_sse_f32(a, lda, b, ldb, batch, s, c, mask, partial, l1=False):
+    call('imm_masked_sse_f32', _p(a), lda, _p(b), ldb, batch, s, c, _p(mask), int(l1), _p(partial), _s())
 
 
-def tap_grad(da, has_in, a_pred, a_gt, batch, s, c, mask, S, coef, idx, relu):
+LOSS_PERCEPTUAL, LOSS_L2 = 0, 1
+
+
+def perceptual_finalize(partial, nfeat, nel, agg, training, wd_loss, out, l1=False, mode=LOSS_PERCEPTUAL):
+    call('imm_perceptual_finalize', _p(partial), nfeat, _p(nel), _p(agg), int(training), _p(wd_loss), int(l1), int(mode),
+         _p(out), _s())
+
+
+def tap_grad(da, has_in, a_pred, a_gt, batch, s, c, mask, S, coef, idx, relu, l1=False):
     call('imm_tap_grad', _p(da), int(has_in), _p(a_pred), _p(a_gt), dtype_enum(da.dtype), batch, s, c, _p(mask), S,
-         _p(coef), idx, int(relu), _s())
+         _p(coef), idx, int(relu), int(l1), _s())
 
 
 # ---- optimizer --------------------------------------------------------------------------------

@@ -230,7 +230,7 @@ def image_summaries(eng, max_outputs=3):
         return x.transpose(1, 0, 2, 3).reshape(S, n * S, 3)
 
     full = torch.empty(eng.B, S, S, eng.K, device=eng.dev)
-    ops.gauss_render_f32(eng.mu, eng.B, eng.K, eng.inv_std, S, full)
+    ops.gauss_render_f32(eng.mu, eng.B, eng.K, eng.inv_std, S, full, eng.cfg.gauss_mode)
     maps = colorize_landmark_maps(full[:n])
     maps = maps / maps.amax().clamp_min(1e-12) * 255.0
     return {'im': tile(eng.in_image), 'future_im': tile(eng.in_future), 'future_im_pred': tile(eng.future_im_pred),

@@ -366,6 +366,18 @@ def tf_variable_name(engine_name):
     return engine_name
 
 
+def optimizer_slots(engine):
+    """[(engine buffer name, TF slot-variable suffix)] of the engine's optimizer (scripts/train.py:97-104 names the TF
+    optimizers 'Adam', 'Adadelta', 'AdaGrad'; a second slot of one optimizer gets the suffix _1 in creation order:
+    Adam m, v; Adadelta accum, accum_update; Adagrad accumulator)."""
+    kind = getattr(engine, 'optim', 'adam')
+    if kind == 'adadelta':
+        return [('adam_v', '/Adadelta'), ('adam_m', '/Adadelta_1')]
+    if kind == 'adagrad':
+        return [('adam_v', '/AdaGrad')]
+    return [('adam_m', '/Adam'), ('adam_v', '/Adam_1')]
+
+
 def engine_to_tf(engine, with_optimizer=True):
     """{TF variable name: numpy array} of an engine: model variables, BN moving statistics, loss normalisers, global_step
     and (optionally) Adam's slots `<var>/Adam`, `<var>/Adam_1`, `beta1_power`, `beta2_power` (tf.train.AdamOptimizer)."""
@@ -377,11 +389,13 @@ def engine_to_tf(engine, with_optimizer=True):
     step = int(engine.step_count)
     out['global_step'] = np.asarray(step, dtype=np.float32)      # a float model_variable upstream (scripts/train.py:86-88)
     if with_optimizer:
-        m, v = engine.adam_m.cpu().numpy(), engine.adam_v.cpu().numpy()
-        for i, (name, shape, _wd) in enumerate(engine.spec):
-            o0, o1 = engine.tab.offsets[i], engine.tab.offsets[i + 1]
-            out[tf_variable_name(name) + '/Adam'] = m[o0:o1].reshape(shape)
-            out[tf_variable_name(name) + '/Adam_1'] = v[o0:o1].reshape(shape)
+        for buf, suffix in optimizer_slots(engine):
+            flat = getattr(engine, buf).cpu().numpy()
+            for i, (name, shape, _wd) in enumerate(engine.spec):
+                o0, o1 = engine.tab.offsets[i], engine.tab.offsets[i + 1]
+                out[tf_variable_name(name) + suffix] = flat[o0:o1].reshape(shape)
+        if getattr(engine, 'optim', 'adam') != 'adam':
+            return out
         # tf.train.AdamOptimizer: beta_power starts at beta and is multiplied by beta after every apply => beta^(t+1) after
         # t updates of these slots (NOT global_step: the two differ after a restore without the optimizer)
         t = int(engine.adam_t)
@@ -404,7 +418,7 @@ def load_tf_checkpoint(engine, prefix, restore_optim=False, ignore_missing_vars=
     want_state = OrderedDict((k, tf_variable_name(k)) for k in engine.named_state())
     needed = list(want_params.values()) + list(want_state.values())
     if restore_optim:
-        needed += [n + s for n in want_params.values() for s in ('/Adam', '/Adam_1')]
+        needed += [n + s for n in want_params.values() for _b, s in optimizer_slots(engine)]
     missing = [n for n in needed if n not in have]
     if missing and not ignore_missing_vars:
         raise KeyError('%s lacks %d variables (e.g. %s); pass ignore_missing_vars to skip them' % (prefix, len(missing), missing[0]))
@@ -418,14 +432,14 @@ def load_tf_checkpoint(engine, prefix, restore_optim=False, ignore_missing_vars=
     state = OrderedDict((k, torch.from_numpy(np.asarray(data[n], dtype=np.float32))) for k, n in want_state.items() if n in data)
     engine.load_parameters(params, state)
     if restore_optim:
-        m, v = engine.adam_m.cpu().numpy(), engine.adam_v.cpu().numpy()
-        for i, (name, _shape, _wd) in enumerate(engine.spec):
-            o0, o1 = engine.tab.offsets[i], engine.tab.offsets[i + 1]
-            n = want_params[name]
-            if n + '/Adam' in data:
-                m[o0:o1] = data[n + '/Adam'].reshape(-1)
-                v[o0:o1] = data[n + '/Adam_1'].reshape(-1)
-        engine.adam_m.copy_(torch.from_numpy(m)); engine.adam_v.copy_(torch.from_numpy(v))
+        for buf, suffix in optimizer_slots(engine):
+            flat = getattr(engine, buf).cpu().numpy()
+            for i, (name, _shape, _wd) in enumerate(engine.spec):
+                o0, o1 = engine.tab.offsets[i], engine.tab.offsets[i + 1]
+                n = want_params[name]
+                if n + suffix in data:
+                    flat[o0:o1] = data[n + suffix].reshape(-1)
+            getattr(engine, buf).copy_(torch.from_numpy(flat))
         # Adam's t from the saved accumulators beta^(t+1) (beta2_power first: it resolves t up to ~1e5 before float32
         # underflow, beta1_power only up to ~1e3); both underflown = the correction factors are 1 anyway: any large t
         t = 0
@@ -439,7 +453,7 @@ def load_tf_checkpoint(engine, prefix, restore_optim=False, ignore_missing_vars=
                     t = max(t, 1 << 20)
         engine.adam_t.fill_(t)
     else:
-        engine.adam_m.zero_(); engine.adam_v.zero_(); engine.adam_t.zero_()
+        engine.reset_optimizer_slots()
     if reset_global_step >= 0:
         engine.step_count.fill_(int(reset_global_step))
     elif 'global_step' in data:

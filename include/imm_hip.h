@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define IMM_ABI_VERSION 6   /* 2: imm_vgg_conv1_1_fwd gained `halves` */
+#define IMM_ABI_VERSION 7   /* 2: imm_vgg_conv1_1_fwd gained `halves` */
 
 enum imm_dtype { IMM_BF16 = 0, IMM_F16 = 1 };
 
@@ -188,17 +188,23 @@ int imm_pack_image(const float* src, void* dst, int dtype, int64_t npix, void* s
 int imm_pack_image_taps(const float* src, void* dst, int dtype, int batch, int h, int w, int kw, int pad_l, int ld,
                         void* stream);
 
-/* ---- landmark bottleneck (imm_model.py:252-264 soft-argmax, :34-78 Gaussian maps, mode 'rot') -- */
+/* ---- landmark bottleneck (imm_model.py:252-264 soft-argmax, :34-78 get_gaussian_maps) ---------- */
+/* gauss_mode (config key gauss_mode, imm_model.py:48-72): 'rot' exp(-((y-mu_y)^2+(x-mu_x)^2)*inv_std^2) (every shipped
+ * config), 'flat' exp(-(dist + 1e-5)^(1/4)), 'ankush' exp(-sqrt(1e-4+|mu_y-y|*inv_std)) * exp(-sqrt(1e-4+|mu_x-x|*inv_std)) */
+#define IMM_GAUSS_ROT 0
+#define IMM_GAUSS_FLAT 1
+#define IMM_GAUSS_ANKUSH 2
 /* heat f32 [B,h,w,ldh] (k<K) -> mu [B,K,2] (y,x), py [B,h,K], px [B,w,K];
  * gauss: 16-bit written at gauss_out[((b*s+y)*s+x)*ldg + k] for k<K. */
 int imm_softargmax_gauss_fwd(const float* heat, int ldh, int batch, int h, int w, int k, float inv_std, int s,
-                             float* mu, float* py, float* px, void* gauss_out, int ldg, int dtype, void* stream);
+                             float* mu, float* py, float* px, void* gauss_out, int ldg, int dtype, int gauss_mode,
+                             void* stream);
 /* dgauss 16-bit (same addressing as gauss_out) -> dheat 16-bit [B,h,w,lddh], channels >= K zeroed */
 int imm_softargmax_gauss_bwd(const void* dgauss, int ldg, int dtype, int batch, int h, int w, int k, float inv_std,
                              int s, const float* mu, const float* py, const float* px, void* dheat, int lddh,
-                             void* stream);
+                             int gauss_mode, void* stream);
 /* render only (pose_embedding summary maps at other sizes; f32 output [B,s,s,K]) */
-int imm_gauss_render_f32(const float* mu, int batch, int k, float inv_std, int s, float* out, void* stream);
+int imm_gauss_render_f32(const float* mu, int batch, int k, float inv_std, int s, float* out, int gauss_mode, void* stream);
 
 /* ---- frozen VGG16 first layer (build_vgg16.py:22-26 grayscale+normalise, vgg16.py:345 conv1_1) -- */
 /* images: gt f32 [B,S,S,3] and pred f32 [B,S,S,ldp] (first 3 ch) -> out 16-bit [2B,S,S,64] = concat([gt, pred], 0)
@@ -207,45 +213,68 @@ int imm_gauss_render_f32(const float* mu, int batch, int k, float inv_std, int s
 int imm_vgg_conv1_1_fwd(const float* gt, const float* pred, int ldp, int batch, int s, const float* w9x64,
                         const float* b64, void* out, int dtype, int halves, void* stream);
 /* dz 16-bit [B,S,S,64] (pred half, already ReLU-masked) -> dpred 16-bit [B,S,S,lddp]:
- * ch<3 = dgray/(3*255) + coef[0]*mask[p]*(pred-gt), ch>=3 = 0.  coef is a device scalar table. */
+ * ch<3 = dgray/(3*255) + coef[input_idx]*mask[p]*(pred-gt), ch>=3 = 0.  coef is a device scalar table; input_idx = the
+ * position of 'input' in perceptual.comp, or -1 when the raw image is not a loss feature; l1 != 0: sign(pred-gt)
+ * (perceptual.l2: False, imm_model.py:132). */
 int imm_vgg_conv1_1_bwd(const void* dz, int dtype, int batch, int s, const float* w9x64, const float* gt,
-                        const float* pred, int ldp, const float* mask, const float* coef, void* dpred, int lddp,
-                        void* stream);
+                        const float* pred, int ldp, const float* mask, const float* coef, int input_idx, int l1,
+                        void* dpred, int lddp, void* stream);
+/* the image-space term alone (no VGG feature tapped: reconstruction_loss 'l2', imm_model.py:385-387, or
+ * perceptual.comp == ['input']): dpred ch<3 = coef[idx]*mask[p]*(pred-gt) (sign with l1), ch>=3 = 0. */
+int imm_image_loss_grad(const float* gt, const float* pred, int ldp, int batch, int s, const float* mask,
+                        const float* coef, int idx, int l1, void* dpred, int lddp, int dtype, void* stream);
 
 /* ---- perceptual loss (imm_model.py:111-151; base_model.py:39-50) ----------------------------- */
 #define IMM_SSE_BLOCKS 512
-/* partial[IMM_SSE_BLOCKS] of sum mask[pixel/(s*s)...]*(a-b)^2; mask is the full-res f32 [B,S,S] mask,
- * sampled with stride S/s (legacy resize == strided pick, imm_model.py:408-410). a/b 16-bit [B,s,s,c]. */
-int imm_masked_sse(const void* a, const void* b, int dtype, int batch, int s, int c, const float* mask, int S,
+/* partial[IMM_SSE_BLOCKS] of sum mask[pixel/(s*s)...]*(a-b)^2 (l1 != 0: |a-b|, perceptual.l2: False, imm_model.py:132);
+ * mask is the full-res f32 [B,S,S] mask, sampled with stride S/s (legacy resize == strided pick, imm_model.py:408-410).
+ * a/b 16-bit [B,s,s,c]. */
+int imm_masked_sse(const void* a, const void* b, int dtype, int batch, int s, int c, const float* mask, int S, int l1,
                    float* partial, void* stream);
 /* imm_masked_sse fused with the 2x2/2 max-pool that follows the tapped VGG layer (conv1_2, conv2_2): reads the two feature
  * halves once, writes the SSE partials and both pooled halves [batch, s/2, s/2, c]. */
 int imm_masked_sse_pool(const void* a, const void* b, int dtype, int batch, int s, int c, const float* mask, int S,
                         float* partial, void* pool_a, void* pool_b, void* stream);
 int imm_masked_sse_f32(const float* a, int lda, const float* b, int ldb, int batch, int s, int c, const float* mask,
-                       float* partial, void* stream);
+                       int l1, float* partial, void* stream);
 /* nfeat features: partial [nfeat][IMM_SSE_BLOCKS], nel[nfeat] element counts, agg[nfeat] running
  * normalisers (updated when training).  Writes out[0..nfeat) loss terms, [nfeat..2nfeat) masked means,
- * [2nfeat..3nfeat) gradient coefficients c_k (d total / d (a_pred) = c_k*mask*(a_pred-a_gt)),
- * out[3nfeat] = 1000*sum terms, out[3nfeat+1] = wd_loss, out[3nfeat+2] = total. */
+ * [2nfeat..3nfeat) gradient coefficients c_k (d total / d (a_pred) = c_k*mask*(a_pred-a_gt), or c_k*mask*sign(.) with l1),
+ * out[3nfeat] = 1000*sum terms, out[3nfeat+1] = wd_loss, out[3nfeat+2] = total.
+ * mode IMM_LOSS_L2 (reconstruction_loss 'l2', imm_model.py:376,385-387,399): nfeat = 1 = the image, no normaliser:
+ * out[3] = 1000*mean(mask*(pred-gt)^2), total = out[3]/255 + wd_loss, c_0 = (1000/255)*2/nel. */
+#define IMM_LOSS_PERCEPTUAL 0
+#define IMM_LOSS_L2 1
 int imm_perceptual_finalize(const float* partial, int nfeat, const float* nel, float* agg, int training,
-                            const float* wd_loss, float* out, void* stream);
+                            const float* wd_loss, int l1, int mode, float* out, void* stream);
 /* imm_maxpool2_bwd (no ReLU mask) followed by imm_tap_grad (has_in, relu) in one pass, for tapped layers that are pooled
  * next (conv1_2, conv2_2); dpool [batch, s/2, s/2, c] is the gradient of the pooled tensor.  Bitwise equal to the sequence. */
 int imm_unpool_tap_grad(void* da, const void* dpool, const void* a_pred, const void* a_gt, int dtype, int batch, int s, int c,
                         const float* mask, int S, const float* coef, int idx, void* stream);
-/* da = (has_in ? da : 0) + coef[idx]*mask*(a_pred-a_gt), then *= (a_pred>0) if relu. 16-bit [B,s,s,c] */
+/* da = (has_in ? da : 0) + coef[idx]*mask*(a_pred-a_gt) (sign(a_pred-a_gt) with l1), then *= (a_pred>0) if relu.
+ * 16-bit [B,s,s,c] */
 int imm_tap_grad(void* da, int has_in, const void* a_pred, const void* a_gt, int dtype, int batch, int s, int c,
-                 const float* mask, int S, const float* coef, int idx, int relu, void* stream);
+                 const float* mask, int S, const float* coef, int idx, int relu, int l1, void* stream);
 
 /* ---- optimizer (cnn_train_multi.py:86-98 mean+clip_by_norm; scripts/train.py:92-98 Adam) ------ */
 /* segment table: nseg tensors, seg_off[nseg+1] element offsets into the flat f32 buffers,
  * seg_wd[nseg] = weight-decay coefficient of that tensor (1e-5 for conv kernels, else 0).
  * All tables are device int32/f32 arrays built once by the host. */
+/* optimizer (scripts/train.py:97-104, config key training.optim): the update after the tower mean and the per-tensor clip
+ *   IMM_OPT_ADAM      tf.train.AdamOptimizer(lr): beta1 .9, beta2 .999, eps 1e-8; slots m, v
+ *   IMM_OPT_ADADELTA  tf.train.AdadeltaOptimizer(lr, rho=0.95, epsilon=1e-6): slot v = accum, slot m = accum_update (both 0):
+ *                     accum = rho accum + (1-rho) g^2; u = sqrt(accum_update + eps) / sqrt(accum + eps) * g;
+ *                     accum_update = rho accum_update + (1-rho) u^2; w -= lr u          (rho = beta1, eps = eps)
+ *   IMM_OPT_ADAGRAD   tf.train.AdagradOptimizer(lr): slot v = accumulator (initial value 0.1, set by the caller):
+ *                     accum += g^2; w -= lr g / sqrt(accum) */
+#define IMM_OPT_ADAM 0
+#define IMM_OPT_ADADELTA 1
+#define IMM_OPT_ADAGRAD 2
 typedef struct imm_opt_hparams {
   float lr_start, lr_decay; int32_t lr_step; float lr_multiple;   /* staircase exponential decay */
   float beta1, beta2, eps, clip;                                   /* clip <= 0 disables clipping  */
   float grad_scale;                                                /* 1 / number of towers         */
+  int32_t optim;                                                   /* IMM_OPT_*                    */
 } imm_opt_hparams;
 /* wd_loss = sum_seg wd/2 * sum w^2  -> *out  (base_model.py:33-37) */
 int imm_weight_decay_loss(const float* params, const int32_t* blk_seg, const int32_t* blk_begin,

@@ -513,6 +513,35 @@ def adam_apply(P, grads, opt, lr, b1=0.9, b2=0.999, eps=1e-8):
     return newP
 
 
+def adadelta_apply(P, grads, opt, lr, rho=0.95, eps=1e-6):
+    """tf.train.AdadeltaOptimizer(lr, rho=0.95, epsilon=1e-06) (scripts/train.py:99-100; TF 1.10 ApplyAdadelta):
+    accum = rho accum + (1-rho) g^2; update = sqrt(accum_update + eps) * rsqrt(accum + eps) * g;
+    accum_update = rho accum_update + (1-rho) update^2; var -= lr * update.  opt['v'] = accum, opt['m'] = accum_update (zeros)."""
+    newP = OrderedDict()
+    for k, p in P.items():
+        g = grads[k]
+        opt['v'][k] = rho * opt['v'][k] + (1 - rho) * g * g
+        u = torch.sqrt(opt['m'][k] + eps) / torch.sqrt(opt['v'][k] + eps) * g
+        opt['m'][k] = rho * opt['m'][k] + (1 - rho) * u * u
+        newP[k] = p - lr * u
+    return newP
+
+
+def new_adagrad_state(P, initial_accumulator_value=0.1):
+    return {'v': OrderedDict((k, torch.full_like(v, initial_accumulator_value)) for k, v in P.items())}
+
+
+def adagrad_apply(P, grads, opt, lr):
+    """tf.train.AdagradOptimizer(lr) (scripts/train.py:101-102; initial_accumulator_value 0.1; TF 1.10 ApplyAdagrad):
+    accum += g^2; var -= lr * g * rsqrt(accum)."""
+    newP = OrderedDict()
+    for k, p in P.items():
+        g = grads[k]
+        opt['v'][k] = opt['v'][k] + g * g
+        newP[k] = p - lr * g / torch.sqrt(opt['v'][k])
+    return newP
+
+
 def loss_and_grads(P, S, inputs, cfg, act_round=None):
     """One tower: loss + d loss / d trainable (tf.gradients through everything, incl. `wl`)."""
     Pg = OrderedDict((k, v.detach().clone().requires_grad_(True)) for k, v in P.items())

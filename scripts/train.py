@@ -116,12 +116,11 @@ def main(args):
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         torch.distributed.init_process_group('nccl', device_id=torch.device(dev))
 
-    if train_config.optim.lower() != 'adam':
-        if train_config.optim.lower() in ('adadelta', 'adagrad'):
-            raise NotImplementedError('optimizer %s: only Adam (every shipped config) has a fused HIP kernel' % train_config.optim)
+    if train_config.optim.lower() not in ('adam', 'adadelta', 'adagrad'):        # scripts/train.py:97-104
         raise ValueError('Optimizer = %s not suppoerted' % train_config.optim)
     hparams = dict(lr_start=float(train_config.lr.start_val), lr_decay=float(train_config.lr.decay),
-                   lr_step=int(train_config.lr.step), lr_multiple=float(args.lr_multiple), clip=float(train_config.gradclip))
+                   lr_step=int(train_config.lr.step), lr_multiple=float(args.lr_multiple), clip=float(train_config.gradclip),
+                   optim=train_config.optim.lower())
     batch_size = int(train_config.batch)
     size = int(args.image_size)
     factory = model_factory(IMMModel, config=config.model, global_step=None, device=dev, hparams=hparams, world_size=world)
@@ -147,7 +146,7 @@ def main(args):
             eng.adam_m.copy_(ck['adam_m']); eng.adam_v.copy_(ck['adam_v'])
             eng.adam_t.fill_(int(ck.get('adam_t', ck.get('step', 0))))
         else:
-            eng.adam_m.zero_(); eng.adam_v.zero_(); eng.adam_t.zero_()
+            eng.reset_optimizer_slots()
     elif args.checkpoint is not None:
         print('No checkpoint at %s. Initializing randomly.' % args.checkpoint)
     if args.reset_global_step >= 0:

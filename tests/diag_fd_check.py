@@ -38,7 +38,7 @@ def directional(eng, direction_flat, eps, agg0):
         eng.loss_agg.copy_(agg0)
         eng.forward(True)
         torch.cuda.synchronize()
-        vals.append(float(eng.loss_out[3 * 6 + 2].double()))
+        vals.append(float(eng.loss.double()))
     eng.params.copy_(p0)
     eng.run(eng.prog_pack)
     eng.loss_agg.copy_(agg0)

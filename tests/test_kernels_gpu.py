@@ -604,16 +604,20 @@ def test_pack_image(ops):
 # ----------------------------------------------------------------------------------------------
 # bottleneck
 # ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('mode', ['rot', 'flat', 'ankush'])
 @pytest.mark.parametrize('h,K,s', [(16, 10, 16), (16, 50, 16), (32, 30, 16)])
-def test_softargmax_gauss(ops, h, K, s):
+def test_softargmax_gauss(ops, h, K, s, mode):
+    """All three get_gaussian_maps modes (imm_model.py:48-72), forward and backward, against the oracle + autograd.  'flat'
+    and 'ankush' have a kink at the landmark (|.|, ^1/4): the gradient tolerance is wider where a grid point sits within
+    1e-3 of mu, which the seeded heat-maps never produce."""
     B, ldh, ldg = 3, ops.round_up(K, 4), ops.round_up(256 + K, 32)
     heat = rnd((B, h, h, K), 61, 2.0, torch.float32)
     hr = heat.clone().requires_grad_(True)
     mu_r, py_r, px_r = O.soft_argmax(hr)
-    g_r = O.gaussian_maps(mu_r, [s, s], 10.0, 'rot')
+    g_r = O.gaussian_maps(mu_r, [s, s], 10.0, mode)
     mu = torch.empty(B, K, 2, device=DEV); py = torch.empty(B, h, K, device=DEV); px = torch.empty(B, h, K, device=DEV)
     joint = torch.zeros(B, s, s, ldg, dtype=torch.bfloat16, device=DEV)
-    ops.softargmax_gauss_fwd(padded(heat, ldh), ldh, B, h, h, K, 10.0, s, mu, py, px, joint[..., 256:], ldg, torch.bfloat16)
+    ops.softargmax_gauss_fwd(padded(heat, ldh), ldh, B, h, h, K, 10.0, s, mu, py, px, joint[..., 256:], ldg, torch.bfloat16, mode)
     torch.cuda.synchronize()
     close(mu, mu_r, 1e-4, 1e-5, 'mu')                     # f32 math: landmarks to ~1e-6
     assert float((mu.cpu() - mu_r.detach()).abs().max()) < 1e-5
@@ -625,14 +629,14 @@ def test_softargmax_gauss(ops, h, K, s):
     dj = torch.zeros(B, s, s, ldg, dtype=torch.bfloat16, device=DEV)
     dj[..., 256:256 + K] = dg.to(DEV)
     dheat = torch.full((B, h, h, 64), float('nan'), dtype=torch.bfloat16, device=DEV)
-    ops.softargmax_gauss_bwd(dj[..., 256:], ldg, B, h, h, K, 10.0, s, mu, py, px, dheat, 64)
+    ops.softargmax_gauss_bwd(dj[..., 256:], ldg, B, h, h, K, 10.0, s, mu, py, px, dheat, 64, mode)
     torch.cuda.synchronize()
     close(dheat[..., :K], gh, 1e-2, 2e-3, 'dheat')
     assert float(dheat[..., K:].float().abs().max()) == 0.0
     out = torch.empty(B, 128, 128, K, device=DEV)
-    ops.gauss_render_f32(mu, B, K, 10.0, 128, out)
+    ops.gauss_render_f32(mu, B, K, 10.0, 128, out, mode)
     torch.cuda.synchronize()
-    close(out, O.gaussian_maps(mu_r.detach(), [128, 128], 10.0, 'rot'), 1e-4, 1e-5, 'render128')
+    close(out, O.gaussian_maps(mu_r.detach(), [128, 128], 10.0, mode), 1e-4, 1e-5, 'render128')
 
 
 # ----------------------------------------------------------------------------------------------
@@ -767,6 +771,39 @@ def test_clip_adam_and_weight_decay(ops):
     assert int(step) == 250001 and int(adam_t) == 1
     big = grads.abs() > 1e-4          # first bias-corrected step: |dw| = lr * |g| / (|g| + eps') ~ lr
     np.testing.assert_allclose((params - p0).abs()[big].max().item(), lr, rtol=1e-3)
+
+
+@pytest.mark.parametrize('optim', ['adadelta', 'adagrad'])
+def test_clip_adadelta_adagrad(ops, optim):
+    """The other two optimizers scripts/train.py:99-102 offers, behind the same mean -> per-tensor clip front end."""
+    from imm_amd import _lib as L
+    sizes = [9 * 32 * 32, 32, 7, 20000]
+    wds = [1e-5, 0.0, 0.0, 1e-5]
+    tab = ops.SegmentTable(sizes, wds, DEV)
+    g = torch.Generator().manual_seed(6)
+    P = {('t%d/w' % i if wds[i] else 't%d/b' % i): torch.randn(n, generator=g) * 0.3 for i, n in enumerate(sizes)}
+    G = {k: torch.randn(v.shape, generator=g) * (3.0 if i % 2 == 0 else 1e-3) for i, (k, v) in enumerate(P.items())}
+    flat = lambda d: torch.cat([v.reshape(-1) for v in d.values()]).to(DEV)
+    params = flat(P)
+    m = torch.zeros_like(params)
+    v = torch.full_like(params, 0.1) if optim == 'adagrad' else torch.zeros_like(params)
+    part = torch.empty(tab.nblk, device=DEV); norm2 = torch.empty(tab.nseg, device=DEV)
+    step = torch.zeros(1, dtype=torch.int32, device=DEV); adam_t = torch.zeros(1, dtype=torch.int32, device=DEV)
+    lrs = torch.zeros(2, device=DEV)
+    hp = ops.OptHParams(lr_start=1e-2, lr_decay=0.95, lr_step=100000, lr_multiple=1.0, beta1=0.95 if optim == 'adadelta' else 0.9,
+                        beta2=0.999, eps=1e-6 if optim == 'adadelta' else 1e-8, clip=1.0, grad_scale=0.5, optim=L.OPTIMIZERS[optim])
+    opt = {'m': {k: torch.zeros_like(x) for k, x in P.items()}, 'v': {k: torch.zeros_like(x) for k, x in P.items()}} \
+        if optim == 'adadelta' else O.new_adagrad_state(P)
+    Pref = P
+    for it in range(3):
+        gref = {k: G[k] + (1e-5 * Pref[k] if k.endswith('/w') else 0) for k in P}
+        gref = {k: O.clip_by_norm(x, 1.0) for k, x in gref.items()}
+        Pref = O.adadelta_apply(Pref, gref, opt, lr=1e-2) if optim == 'adadelta' else O.adagrad_apply(Pref, gref, opt, lr=1e-2)
+        grads = flat(G) * 2.0
+        ops.clip_adam_step(params, grads, m, v, tab, part, norm2, step, adam_t, lrs, hp)
+        torch.cuda.synchronize()
+        close(params, flat(Pref), 1e-5, 1e-6, '%s params step %d' % (optim, it))
+    close(v, flat(opt['v']), 1e-5, 1e-6, optim + ' accumulator')
 
 
 def test_graph_capture_replay(ops):

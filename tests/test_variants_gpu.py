@@ -1,0 +1,152 @@
+"""Configuration branches of the hot path that no shipped config uses but the reference implements
+(/root/reference/imm/models/imm_model.py): Gaussian-map modes 'flat' / 'ankush' (:60-72), the absolute-value
+perceptual loss `perceptual.l2: False` (:132), feature subsets / orders in `perceptual.comp` (:125,131 — the initial
+normalisers go by POSITION in the list; :348-355 the renderer emits 3 + len(comp) channels), and
+`reconstruction_loss: 'l2'` (:376,385-387,399).  Each variant: forward + backward on the MI355X against the oracle on the same
+seeded inputs (landmarks 1e-3, loss 1e-3, well-conditioned gradients), then a few training steps that must run and reduce
+the loss."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import imm_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+bf = lambda t: t.to(torch.bfloat16).to(torch.float32)
+
+
+def rel(a, b):
+    a, b = a.detach().float().cpu().double(), b.detach().float().cpu().double()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def build(cfg, batch=2, S=128, dtype=torch.bfloat16):
+    from imm_amd.models.imm_model import IMMModel
+    from imm_amd.utils.box import Box
+    d = dict(cfg)
+    d['perceptual'] = dict(cfg['perceptual'])
+    model = IMMModel(Box(d), dtype=dtype, device=DEV)
+    inputs = O.synthetic_inputs(batch, S, seed=0)
+    _, loss, _, tens = model.build(inputs, True, output_tensors=True)
+    eng = model.engine
+    eng.backward()
+    torch.cuda.synchronize()
+    return model, eng, inputs, loss, tens
+
+
+def emul(P, St):
+    Pe = type(P)((k, bf(v) if k.endswith('/w') else v) for k, v in P.items())
+    Se = type(St)((k, bf(v) if (k.startswith('vgg16/') and k.endswith('/weights') and 'conv1_1' not in k) else v) for k, v in St.items())
+    return Pe, Se
+
+
+def check_against_oracle(cfg, eng, inputs, loss, tens, grad_tol=2e-2, tight=('model/renderer/conv_8/w',)):
+    P, St = O.init_params(cfg, 128)
+    for k, v in eng.named_parameters().items():
+        assert torch.equal(v.cpu(), P[k]), k                       # same seeded initialisation, same shapes
+    Pe, Se = emul(P, St)
+    out, g = O.loss_and_grads(Pe, Se, inputs, cfg, act_round=bf)
+    mu_err = float((tens['gauss_yx'].cpu() - out['gauss_yx'].detach()).abs().max())
+    loss_rel = abs(float(loss) - float(out['loss'])) / abs(float(out['loss']))
+    print('\nVARIANT mu %.3g loss %.6g (oracle %.6g, rel %.3g)' % (mu_err, float(loss), float(out['loss']), loss_rel))
+    assert mu_err < 1e-3 and loss_rel < 1e-3, (mu_err, loss_rel)
+    for k in tight:
+        e = rel(eng.gview[k], g[k])
+        print('VARIANT grad %-40s rel %.4g' % (k, e))
+        assert e < grad_tol, (k, e)
+    return out, g
+
+
+def train_a_little(model, inputs, steps=8):
+    from imm_amd.train.cnn_train_multi import TrainStep
+    B = inputs['image'].shape[0]
+    ts = TrainStep(model, B, 128, world_size=1, use_graph=True)
+    losses = [float(ts.step(inputs if i == 0 else None).clone()) for i in range(steps)]
+    ts.synchronize()
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+    assert bool(torch.isfinite(ts.engine.params).all())
+    return losses
+
+
+@pytest.mark.parametrize('mode', ['flat', 'ankush'])
+def test_gaussian_map_modes(mode):
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    cfg = O.default_model_config(10)
+    cfg['gauss_mode'] = mode
+    model, eng, inputs, loss, tens = build(cfg)
+    out, g = check_against_oracle(cfg, eng, inputs, loss, tens)
+    # the maps the renderer sees (16x16, channels behind the image encoder's 256) and the pose path's gradient
+    maps = eng.joint[..., 256:256 + 10]
+    assert rel(maps, out['pose_embeddings'][-1] if isinstance(out['pose_embeddings'], (list, tuple)) else out['pose_embeddings']) < 2e-2
+    k = 'model/pose_encoder/conv_1/w'
+    P, St = O.init_params(cfg, 128)
+    _of, gf = O.loss_and_grads(P, St, inputs, cfg)
+    e_eng, e_emul = rel(eng.gview[k], gf[k]), rel(g[k], gf[k])
+    print('VARIANT %s pose-head grad: engine-vs-fp32 %.3g emul-vs-fp32 %.3g' % (mode, e_eng, e_emul))
+    assert e_eng < 1.5 * e_emul + 0.05
+    train_a_little(model, inputs)
+
+
+def test_absolute_value_perceptual_loss():
+    """perceptual.l2: False -> f_e = tf.abs (imm_model.py:132): sums of |d|, gradients c_k * mask * sign(d)."""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    cfg = O.default_model_config(10)
+    cfg['perceptual'] = dict(cfg['perceptual'], l2=False)
+    model, eng, inputs, loss, tens = build(cfg)
+    assert eng.l1
+    # sign(d) flips wherever storage rounding moves a feature difference across zero: the gradient bound is wider than
+    # for the squared error; the loss itself is as exact as ever
+    out, g = check_against_oracle(cfg, eng, inputs, loss, tens, grad_tol=0.15)
+    terms_rel = max(abs(float(a) - float(b)) / abs(float(b)) for a, b in zip(eng.loss_terms.cpu(), out['loss_terms']))
+    assert terms_rel < 1e-2, terms_rel
+    train_a_little(model, inputs)
+
+
+@pytest.mark.parametrize('comp', [['conv2_2', 'input', 'conv4_2'], ['input'], ['conv3_2']], ids=['reordered_subset', 'input_only', 'one_layer'])
+def test_perceptual_feature_subsets(comp):
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    cfg = O.default_model_config(10)
+    cfg['perceptual'] = dict(cfg['perceptual'], comp=list(comp))
+    model, eng, inputs, loss, tens = build(cfg)
+    assert eng.ren[-1].co == 3 + len(comp)                       # workaround channels = len(perceptual.comp) (:348-355)
+    assert [n for n, _c, _o in eng.vgg_layers][-1:] == ([max((c for c in comp if c != 'input'))] if any(c != 'input' for c in comp) else [])
+    out, g = check_against_oracle(cfg, eng, inputs, loss, tens)
+    got_terms = eng.loss_terms.cpu().numpy()
+    np.testing.assert_allclose(got_terms, [float(t) for t in out['loss_terms']], rtol=1e-2)
+    st = eng.named_state()
+    assert sorted(k for k in st if k.startswith('loss/')) == sorted('loss/%s_agg' % n for n in comp)
+    for i, n in enumerate(comp):                                  # normalisers start at ws[POSITION] and follow the 0.99 average
+        np.testing.assert_allclose(float(st['loss/%s_agg' % n]), float(out['new_state']['loss/%s_agg' % n]), rtol=1e-2)
+    train_a_little(model, inputs)
+
+
+def test_l2_reconstruction_loss():
+    """reconstruction_loss: 'l2' -> loss = 1000 * mean(mask * (pred - gt)^2) / 255 + weight decay; no VGG at all."""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    cfg = O.default_model_config(10)
+    cfg['reconstruction_loss'] = 'l2'
+    model, eng, inputs, loss, tens = build(cfg)
+    assert eng.vgg_layers == [] and eng.nfeat == 1
+    out, g = check_against_oracle(cfg, eng, inputs, loss, tens, grad_tol=1e-2,
+                                  tight=('model/renderer/conv_8/w', 'model/renderer/conv_8/b'))
+    np.testing.assert_allclose(float(eng.loss_out[3]), float(out['reconstruction_loss']), rtol=1e-4)
+    train_a_little(model, inputs)
+
+
+def test_unknown_variants_fail_like_the_reference():
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    from imm_amd.models.imm_model import IMMModel
+    from imm_amd.utils.box import Box
+    inp = O.synthetic_inputs(1, 128)
+    c = dict(O.default_model_config()); c['perceptual'] = dict(c['perceptual'], comp=['conv1_1'])
+    with pytest.raises(NotImplementedError):
+        IMMModel(Box(c), device=DEV).build(inp, True)
+    c = dict(O.default_model_config()); c['perceptual'] = dict(c['perceptual'], comp=[])
+    with pytest.raises(ValueError):
+        IMMModel(Box(c), device=DEV).build(inp, True)
