@@ -83,6 +83,10 @@ _SIGS = {
     'imm_upsample2x_bwd_bn': [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P],
     'imm_upsample2x_bwd_bn_blocks': [_I, _I, _I, _I],
     'imm_crc32c': [_P, C.c_uint64, C.POINTER(C.c_uint32)],
+    'imm_rccl_unique_id': [_P],
+    'imm_rccl_init': [_I, _I, _P, C.POINTER(C.c_void_p)],
+    'imm_rccl_allreduce': [_P, _P, _L, _P],
+    'imm_rccl_destroy': [_P],
     'imm_resize_crop_u8': [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P],
     'imm_unpool_tap_grad': [_P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _P, _I, _P],
     'imm_masked_sse_pool': [_P, _P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P],
@@ -94,11 +98,22 @@ _SIGS = {
     'imm_clip_adam_step': [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, C.POINTER(OptHParams), _P],
 }
 
+# byte-size twins of the row-count queries (int64 result; < 0 = unsupported)
+_SIGS64 = {
+    'imm_conv2d_workspace_bytes': [C.POINTER(ConvDesc)],
+    'imm_conv2d_group_workspace_bytes': [_P, _I],
+    'imm_conv2d_wgrad_workspace_bytes': [C.POINTER(ConvDesc), _I, _I],
+    'imm_colsum_workspace_bytes': [_L, _I],
+    'imm_bn_bwd_workspace_bytes': [_L, _I],
+    'imm_upsample2x_bwd_bn_workspace_bytes': [_I, _I, _I, _I],
+    'imm_masked_sse_workspace_bytes': [_I],
+}
+
 _lib = None
 
 
 def declared_symbols():
-    return sorted(list(_SIGS) + ['imm_last_error', 'imm_source_digest'])
+    return sorted(list(_SIGS) + list(_SIGS64) + ['imm_last_error', 'imm_source_digest'])
 
 
 def load():
@@ -127,6 +142,10 @@ def load():
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = C.c_int
+    for name, args in _SIGS64.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = C.c_int64
     v = lib.imm_abi_version()
     if v != ABI_VERSION:
         raise ImmHipError('libimm_hip.so ABI %d != expected %d' % (v, ABI_VERSION))

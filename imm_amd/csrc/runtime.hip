@@ -110,3 +110,46 @@ extern "C" int imm_crc32c(const void* data, uint64_t n, uint32_t* crc_inout) {
   *crc_inout = ~c;
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// workspace sizes (bytes) of the caller-allocated scratch buffers: thin twins of the row-count queries
+// ---------------------------------------------------------------------------------------------
+extern "C" int imm_conv_stats_blocks(const imm_conv_desc* d);
+extern "C" int imm_conv2d_group_stats_blocks(const imm_conv_desc* descs, int n);
+extern "C" int imm_conv2d_wgrad_splits(const imm_conv_desc* d, int lddy);
+extern "C" int imm_colsum_blocks(int64_t npix, int c);
+extern "C" int imm_bn_bwd_blocks(int64_t npix, int c);
+extern "C" int imm_upsample2x_bwd_bn_blocks(int batch, int h, int w, int c);
+
+extern "C" int64_t imm_conv2d_workspace_bytes(const imm_conv_desc* d) {
+  if (!d) return IMM_E_INVALID;
+  if (!(d->flags & IMM_CONV_STATS)) return 0;
+  const int rows = imm_conv_stats_blocks(d);
+  return rows < 0 ? rows : (int64_t)rows * 2 * d->co * 4;
+}
+extern "C" int64_t imm_conv2d_group_workspace_bytes(const imm_conv_desc* descs, int n) {
+  if (!descs || n < 1) return IMM_E_INVALID;
+  if (!(descs[0].flags & IMM_CONV_STATS)) return 0;
+  const int rows = imm_conv2d_group_stats_blocks(descs, n);
+  return rows < 0 ? rows : (int64_t)rows * 2 * descs[0].co * 4;
+}
+extern "C" int64_t imm_conv2d_wgrad_workspace_bytes(const imm_conv_desc* d, int lddy, int nsplit) {
+  if (!d) return IMM_E_INVALID;
+  const int forced = imm_conv2d_wgrad_splits(d, lddy);
+  if (forced < 0) return forced;
+  const int ns = forced > 0 ? forced : (nsplit > 0 ? nsplit : 1);
+  return (int64_t)ns * d->kpad * d->co * 4;
+}
+extern "C" int64_t imm_colsum_workspace_bytes(int64_t npix, int c) {
+  const int rows = imm_colsum_blocks(npix, c);
+  return rows < 0 ? rows : (int64_t)rows * c * 4;
+}
+extern "C" int64_t imm_bn_bwd_workspace_bytes(int64_t npix, int c) {
+  const int rows = imm_bn_bwd_blocks(npix, c);
+  return rows < 0 ? rows : (int64_t)rows * 2 * c * 4;
+}
+extern "C" int64_t imm_upsample2x_bwd_bn_workspace_bytes(int batch, int h, int w, int c) {
+  const int rows = imm_upsample2x_bwd_bn_blocks(batch, h, w, c);
+  return rows < 0 ? rows : (int64_t)rows * 2 * c * 4;
+}
+extern "C" int64_t imm_masked_sse_workspace_bytes(int nfeat) { return nfeat > 0 ? (int64_t)nfeat * IMM_SSE_BLOCKS * 4 : IMM_E_INVALID; }

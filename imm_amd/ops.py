@@ -385,3 +385,35 @@ def conv2d_group_stats_blocks(group):
     if n <= 0:
         raise L.ImmHipError('imm_conv2d_group_stats_blocks: ' + L.load().imm_last_error().decode())
     return n
+
+
+# ---- RCCL through the C-ABI (imm_rccl_*): the data-parallel gradient exchange without torch.distributed in the loop ----------
+class RcclComm:
+    """Communicator for the current device.  The 128-byte unique id is made by rank 0 and exchanged over the (already
+    initialised) torch.distributed process group, used here as the host-side side channel only."""
+
+    def __init__(self, rank, world, group=None):
+        import torch.distributed as dist
+        uid = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            buf = (C.c_ubyte * 128)()
+            call('imm_rccl_unique_id', C.cast(buf, C.c_void_p))
+            uid = torch.tensor(list(buf), dtype=torch.uint8)
+        if world > 1:
+            obj = [uid]
+            dist.broadcast_object_list(obj, src=0, group=group)
+            uid = obj[0]
+        self._uid = (C.c_ubyte * 128)(*[int(x) for x in uid])
+        self._comm = C.c_void_p()
+        call('imm_rccl_init', rank, world, C.cast(self._uid, C.c_void_p), C.byref(self._comm))
+        self.world = world
+
+    def all_reduce_sum(self, flat_f32):
+        """In-place sum over ranks, enqueued on torch's current stream (capturable into a HIP graph)."""
+        assert flat_f32.dtype == torch.float32 and flat_f32.is_contiguous()
+        call('imm_rccl_allreduce', self._comm, _p(flat_f32), flat_f32.numel(), _s())
+
+    def destroy(self):
+        if self._comm:
+            call('imm_rccl_destroy', self._comm)
+            self._comm = C.c_void_p()

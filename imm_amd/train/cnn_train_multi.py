@@ -85,6 +85,15 @@ class TrainStep:
         if abs(self.engine.hp.grad_scale - 1.0 / world_size) > 1e-9:
             raise ValueError('engine was built for world_size %g' % (1.0 / self.engine.hp.grad_scale))
         self.use_graph = use_graph
+        # IMM_RCCL_NATIVE=1: the collective goes through the C-ABI (imm_rccl_allreduce, include/imm_hip.h) on a stream of
+        # this object instead of through torch.distributed's process group (which then only carries the 128-byte
+        # unique id at start-up).  Same sums; default off until it has run on a multi-GPU box.
+        self.native_comm = None
+        if self.split and os.environ.get('IMM_RCCL_NATIVE', '0') != '0':
+            rank = dist.get_rank(group) if dist.is_initialized() else 0
+            with torch.cuda.device(self.engine.dev):
+                self.native_comm = ops.RcclComm(rank, world_size, group)
+            self.comm_stream = torch.cuda.Stream(device=self.engine.dev)
         self.stream = torch.cuda.Stream(device=self.engine.dev, priority=int(os.environ.get('IMM_MAIN_PRIO', '0')))
         self._graphs = None
         torch.cuda.synchronize(self.engine.dev)   # engine construction ran on the default stream
@@ -149,7 +158,9 @@ class TrainStep:
                 if self._graphs is None:
                     self._capture()
                 self._graphs[0].launch()
-                if self.split and self.buckets < 2:
+                if self.split and self.native_comm is not None:
+                    self._native_exchange(eng)
+                elif self.split and self.buckets < 2:
                     average_gradients(eng.grads, self.world_size, self.group, force=True)
                     self._graphs[1].launch()
                 elif self.split:
@@ -167,6 +178,26 @@ class TrainStep:
                 average_gradients(eng.grads, self.world_size, self.group)
                 eng.optimizer_step()
         return eng.loss
+
+    def _native_exchange(self, eng):
+        """graphs[0] has been launched on self.stream: the gradient exchange through imm_rccl_allreduce on self.comm_stream
+        (ordered by events, no host wait), then the remaining graphs.  Two buckets: the renderer's gradients travel while
+        the encoders' backward graph runs."""
+        def on_comm(flat):
+            ev = torch.cuda.Event(); ev.record(self.stream)
+            self.comm_stream.wait_event(ev)
+            with torch.cuda.stream(self.comm_stream):
+                self.native_comm.all_reduce_sum(flat)
+        if self.buckets < 2:
+            on_comm(eng.grads)
+        else:
+            off = eng.bucket0_offset
+            on_comm(eng.grads[off:])
+            self._graphs[1].launch()              # encoder backward, concurrent with the first bucket's all-reduce
+            on_comm(eng.grads[:off])
+        done = torch.cuda.Event(); done.record(self.comm_stream)
+        self.stream.wait_event(done)
+        self._graphs[-1].launch()
 
     def synchronize(self):
         self.stream.synchronize()

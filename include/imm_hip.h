@@ -291,6 +291,26 @@ int imm_clip_adam_step(float* params, float* grads, float* m, float* v, const in
                        const int32_t* seg_first_blk, const float* seg_wd, float* blk_partial, float* seg_norm2,
                        int32_t* step_count, int32_t* adam_t, float* lr_state, const imm_opt_hparams* hp_host, void* stream);
 
+/* ---- data-parallel gradient exchange (cnn_train_multi.py:66-106 average_gradients) ------------------------------------ */
+/* One process per GPU; ONE sum all-reduce of (a bucket of) the flat f32 gradient buffer over RCCL / xGMI on the caller's
+ * stream (capturable into the step's HIP graph); the division by the number of towers is imm_clip_adam_step's grad_scale, so
+ * the reference's order "mean, then per-tensor clip" holds.  RCCL is bound at run time (the librccl already in the process,
+ * else the system one).  unique id: 128 bytes made by rank 0, handed to every rank by any host-side channel. */
+int imm_rccl_unique_id(void* out128_host);
+int imm_rccl_init(int rank, int world, const void* unique_id128_host, void** comm_out_host);
+int imm_rccl_allreduce(void* comm, float* buf, int64_t count, void* stream);
+int imm_rccl_destroy(void* comm);
+
+/* ---- workspace sizes: every scratch buffer is caller-allocated; these return its size in BYTES (< 0: unsupported shape) -- */
+int64_t imm_conv2d_workspace_bytes(const imm_conv_desc* desc_host);                /* stats_partial of imm_conv2d            */
+int64_t imm_conv2d_group_workspace_bytes(const imm_conv_desc* descs, int n);      /* stats_partial of imm_conv2d_group      */
+int64_t imm_conv2d_wgrad_workspace_bytes(const imm_conv_desc* desc_host, int lddy, int nsplit);  /* slab (nsplit <= 0: the
+                                                                                      forced / minimal split count)        */
+int64_t imm_colsum_workspace_bytes(int64_t npix, int c);                          /* partial of imm_colsum                  */
+int64_t imm_bn_bwd_workspace_bytes(int64_t npix, int c);                          /* partial of imm_bn_bwd_reduce           */
+int64_t imm_upsample2x_bwd_bn_workspace_bytes(int batch, int h, int w, int c);    /* partial of imm_upsample2x_bwd_bn       */
+int64_t imm_masked_sse_workspace_bytes(int nfeat);                                /* partial of imm_masked_sse* (per loss)  */
+
 /* ---- thin-plate-spline augmentation (imm/utils/tps_sampler.py:76-99,142-157; imm/datasets/tps_dataset.py:70-96) ---- */
 /* dst[b][p] = bilinear(src[b], sum_j basis_t[j][p] * w_tps[b][j][0..1]) with F.grid_sample's align_corners=True mapping and
  * zero padding.  src f32 NHWC [B,h,w,ld_src] (first c <= 8 channels), basis_t f32 [m3][h*w] (TPSGridGen's L matrix

@@ -17,7 +17,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     B.build()
     lib = L.load()
     header = open(os.path.join(ROOT, 'include', 'imm_hip.h')).read()
-    declared = sorted(set(re.findall(r'^(?:int|const char\*)\s+(imm_[a-z0-9_]+)\s*\(', header, flags=re.M)))
+    declared = sorted(set(re.findall(r'^(?:int|int64_t|const char\*)\s+(imm_[a-z0-9_]+)\s*\(', header, flags=re.M)))
     assert declared == L.declared_symbols(), set(declared) ^ set(L.declared_symbols())
     for name in declared:
         assert getattr(lib, name) is not None

