@@ -411,10 +411,10 @@ def test_gradient_parity_on_a_trained_model():
     ill conditioned (test_gradient_parity); after 60 Adam steps on a smooth batch the fp32 oracle agrees with an fp64 run of
     itself to 1.3e-4 on every tensor (tests/diag_grad_conditioning.py), so a mis-scaled or mis-wired gradient anywhere in
     the backward chain would show.  Bound for the bf16 engine against the fp32 oracle at the SAME trained parameters and
-    state: EVERY trainable tensor within 0.25 relative L2, cosine >= 0.97 and no further from the fp32 oracle than 1.5 x the
-    oracle's own bf16-storage emulation + 0.02; at least 85 % of the tensors within 0.10.  (Measured over builds whose
-    summation orders differ, i.e. over different trained states: worst 0.095 .. 0.18 — always at the level of the emulation
-    — worst cosine 0.985 .. 0.9955, typical tensor 0.06.)"""
+    state: EVERY trainable tensor within 0.25 relative L2, cosine >= 0.97 and no further from the fp32 oracle than 1.25 x the
+    oracle's own bf16-storage emulation + 0.02; median over the tensors <= 0.10.  (Measured over builds whose summation
+    orders differ, i.e. over different trained states: worst 0.095 .. 0.18, median 0.06 .. 0.07, worst cosine 0.985 .. 0.9955;
+    tensor by tensor the engine sits within +-10 % of the emulation: what is left is bf16 storage, not wiring.)"""
     if not torch.cuda.is_available():
         pytest.skip('no GPU')
     from imm_amd.models.imm_model import IMMModel
@@ -455,12 +455,12 @@ def test_gradient_parity_on_a_trained_model():
         rels.append(e)
         worst = (max(worst[0], e), min(worst[1], cos))
         print('TRAINED_GRAD %-48s rel %.4f cos %.5f  emul %.4f' % (k, e, cos, e_emul))
-        if e > 0.25 or cos < 0.97 or e > 1.5 * e_emul + 0.02:
+        if e > 0.25 or cos < 0.97 or e > 1.25 * e_emul + 0.02:
             bad.append((k, e, cos, e_emul))
-    frac_tight = float(np.mean(np.array(rels) <= 0.10))
-    print('TRAINED_GRAD worst rel %.4f, worst cos %.5f, %.0f %% of the tensors within 0.10' % (worst + (100 * frac_tight,)))
+    med = float(np.median(np.array(rels)))
+    print('TRAINED_GRAD worst rel %.4f, worst cos %.5f, median rel %.4f' % (worst + (med,)))
     assert not bad, bad
-    assert frac_tight >= 0.85, frac_tight
+    assert med <= 0.10, med
 
 
 def test_backward_is_the_derivative_of_the_forward():
