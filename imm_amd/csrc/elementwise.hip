@@ -246,6 +246,122 @@ extern "C" int imm_bn_apply_relu(const void* y, int dtype, int64_t npix, int c, 
 }
 
 // ---------------------------------------------------------------------------------------------
+// finalize + apply in ONE launch, for layers with few partial rows (the 16x16 .. 64x64 maps: rows <= 256)
+// ---------------------------------------------------------------------------------------------
+// Every workgroup owns a 32-channel slice x a pixel range and FIRST redoes the (tiny) finalize for its slice: nblk rows of
+// 2 x 32 floats = nblk * 256 B from L2 (same rows, same fixed summation order in every workgroup => bit-identical
+// scale / shift everywhere), then streams its pixels.  One launch and one kernel boundary less per layer than
+// imm_bn_finalize + imm_bn_apply_relu, whose finalize is a 6-9 us latency chain for a microsecond of arithmetic.
+// Workgroup (0, slice) also publishes scale / shift / mean / rstd for the backward pass and updates the moving statistics.
+// Shared with the backward twin below: reduce NS sums of this workgroup's 32 channels over the partial rows.
+template <int NS>
+__device__ __forceinline__ void slice32_reduce(const float* __restrict__ partial, int nblk, int ldp, int ch0, double* out /*[NS*32] LDS*/) {
+  constexpr int COLS = 8 * NS, RL = EW_THREADS / COLS;       // float4 columns x row lanes
+  __shared__ double red[RL][NS * 32 + 1];
+  const int tid = threadIdx.x, col = tid % COLS, rl = tid / COLS;
+  const int sidx = col / 8, q4 = (col % 8) * 4;
+  double a0[4] = {0.0, 0.0, 0.0, 0.0}, a1[4] = {0.0, 0.0, 0.0, 0.0};
+  const float* base = partial + (int64_t)sidx * ldp + ch0 + q4;
+  int b = rl;
+  for (; b + RL < nblk; b += 2 * RL) {
+    const float4 v0 = *(const float4*)(base + (int64_t)b * NS * ldp), v1 = *(const float4*)(base + (int64_t)(b + RL) * NS * ldp);
+    a0[0] += (double)v0.x; a0[1] += (double)v0.y; a0[2] += (double)v0.z; a0[3] += (double)v0.w;
+    a1[0] += (double)v1.x; a1[1] += (double)v1.y; a1[2] += (double)v1.z; a1[3] += (double)v1.w;
+  }
+  if (b < nblk) {
+    const float4 v0 = *(const float4*)(base + (int64_t)b * NS * ldp);
+    a0[0] += (double)v0.x; a0[1] += (double)v0.y; a0[2] += (double)v0.z; a0[3] += (double)v0.w;
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) red[rl][sidx * 32 + q4 + e] = a0[e] + a1[e];
+  __syncthreads();
+  if (tid < NS * 32) {
+    double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+    for (int r = 0; r < RL; r += 2) { t0 += red[r][tid]; t1 += red[r + 1][tid]; }
+    out[tid] = t0 + t1;
+  }
+  __syncthreads();
+}
+
+template <typename ET>
+__global__ __launch_bounds__(EW_THREADS) void bn_apply_fused_kernel(
+    const float* __restrict__ partial, int nblk, int c, double count, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float eps, float momentum, int training, float* moving_mean, float* moving_var,
+    float* scale, float* shift, float* mean_out, float* rstd_out, const uint16_t* __restrict__ y, int64_t npix, int ldy,
+    int relu, uint16_t* __restrict__ x, int ldx, int px_per_blk) {
+  __shared__ double sums[64];
+  __shared__ float ssc[32], ssh[32];
+  const int tid = threadIdx.x, ch0 = blockIdx.y * 32;
+  if (training) slice32_reduce<2>(partial, nblk, c, ch0, sums);
+  if (tid < 32) {
+    const int ch = ch0 + tid;
+    float mean, var;
+    if (training) {
+      const double m = sums[tid] / count;
+      double v = sums[32 + tid] / count - m * m;
+      if (v < 0.0) v = 0.0;
+      mean = (float)m; var = (float)v;
+      if (blockIdx.x == 0) {
+        const double unbiased = count > 1.0 ? v * count / (count - 1.0) : v;
+        moving_mean[ch] = moving_mean[ch] * momentum + mean * (1.f - momentum);
+        moving_var[ch] = moving_var[ch] * momentum + (float)unbiased * (1.f - momentum);
+      }
+    } else {
+      mean = moving_mean[ch]; var = moving_var[ch];
+    }
+    const float rstd = rsqrtf(var + eps);
+    const float sc = gamma[ch] * rstd, sh = beta[ch] - mean * sc;
+    ssc[tid] = sc; ssh[tid] = sh;
+    if (blockIdx.x == 0) { scale[ch] = sc; shift[ch] = sh; mean_out[ch] = mean; rstd_out[ch] = rstd; }
+  }
+  __syncthreads();
+  const int q = tid & 3;                         // 16-byte chunk of the 64-byte slice of a pixel
+  float sc[8], sh[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { sc[i] = ssc[q * 8 + i]; sh[i] = ssh[q * 8 + i]; }
+  const int64_t p0 = (int64_t)blockIdx.x * px_per_blk;
+  const int64_t p1 = p0 + px_per_blk < npix ? p0 + px_per_blk : npix;
+  for (int64_t p = p0 + (tid >> 2); p < p1; p += EW_THREADS / 4) {
+    float f[8];
+    unpack8<ET>(*(const uint4*)(y + p * ldy + ch0 + q * 8), f);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      f[i] = f[i] * sc[i] + sh[i];
+      if (relu) f[i] = fmaxf(f[i], 0.f);
+    }
+    *(uint4*)(x + p * ldx + ch0 + q * 8) = pack8<ET>(f);
+  }
+}
+
+static int fused_px_per_blk(int64_t npix, int c) {
+  // ~512 workgroups, at least 256 pixels each (the per-workgroup finalize must stay small next to the streamed bytes)
+  int64_t chunks = 512 / (c / 32);
+  if (chunks < 1) chunks = 1;
+  int64_t ppb = (npix + chunks - 1) / chunks;
+  if (ppb < 256) ppb = 256;
+  return (int)((ppb + 63) / 64 * 64);
+}
+
+extern "C" int imm_bn_apply_fused(const float* partial, int nblk, int c, int64_t count, const float* gamma, const float* beta,
+                                  float eps, float momentum, int training, float* moving_mean, float* moving_var, float* scale,
+                                  float* shift, float* mean, float* rstd, const void* y, int dtype, int ldy, int relu,
+                                  void* x_out, int ldx, void* stream) {
+  IMM_REQUIRE(gamma && beta && moving_mean && moving_var && scale && shift && mean && rstd && y && x_out, "bn_apply_fused: null");
+  IMM_REQUIRE(!training || (partial && nblk > 0), "bn_apply_fused: training needs partial sums");
+  IMM_REQUIRE(c > 0 && c % 32 == 0 && count > 0, "bn_apply_fused: C=%d must be a multiple of 32", c);
+  EW_REQUIRE_VEC(c, ldy, "bn_apply_fused(y)");
+  EW_REQUIRE_VEC(c, ldx, "bn_apply_fused(x)");
+  const int ppb = fused_px_per_blk(count, c);
+  const dim3 grid((unsigned)((count + ppb - 1) / ppb), (unsigned)(c / 32));
+  IMM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_apply_fused_kernel<ET>), grid, dim3(EW_THREADS), 0, (hipStream_t)stream, partial,
+                                               nblk, c, (double)count, gamma, beta, eps, momentum, training, moving_mean, moving_var,
+                                               scale, shift, mean, rstd, (const uint16_t*)y, count, ldy, relu, (uint16_t*)x_out, ldx, ppb));
+  IMM_CHECK_LAUNCH("imm_bn_apply_fused");
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
 // batch norm backward (+ fused ReLU backward):  dz = dout * [scale*y+shift > 0]
 //   s1 = sum dz, s2 = sum dz*xhat;  dgamma = s2, dbeta = s1
 //   dy = gamma*rstd * (dz - s1/N - xhat*s2/N)
@@ -257,7 +373,9 @@ static int col_reduce_blocks(int64_t npix, int c) {
   // capped at 1024 workgroups (= partial rows the finalize kernel has to sum)
   int64_t b = (npix + (int64_t)rows * 4 - 1) / ((int64_t)rows * 4);
   if (b < 1) b = 1;
-  if (b > 1024) b = 1024;
+  // <= 256 rows for the small tensors (<= 4M elements): imm_bn_bwd_apply_fused re-reduces the rows in every workgroup
+  const int64_t cap = (npix * c <= (1LL << 22)) ? 256 : 1024;
+  if (b > cap) b = cap;
   return (int)b;
 }
 
@@ -417,6 +535,62 @@ extern "C" int imm_bn_bwd_apply(const void* dout, int lddo, const void* y, int l
                                                (const uint16_t*)y, ldy, npix, c / 8, c, scale, shift, mean, rstd, relu,
                                                coef, (uint16_t*)dy_out, lddy));
   IMM_CHECK_LAUNCH("imm_bn_bwd_apply");
+  return 0;
+}
+
+// finalize + apply of the backward pass in one launch (see bn_apply_fused_kernel): every workgroup re-reduces the
+// (sum dz, sum dz*xhat) rows of its 32-channel slice, workgroup (0, slice) writes dgamma / dbeta.
+template <typename ET>
+__global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_fused_kernel(
+    const float* __restrict__ partial, int nblk, int c, double count, const float* __restrict__ gamma,
+    const uint16_t* __restrict__ dout, int lddo, const uint16_t* __restrict__ y, int ldy, int64_t npix,
+    const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
+    const float* __restrict__ rstd, int relu, float* dgamma, float* dbeta, uint16_t* __restrict__ dy, int lddy, int px_per_blk) {
+  __shared__ double sums[64];
+  const int tid = threadIdx.x, ch0 = blockIdx.y * 32;
+  slice32_reduce<2>(partial, nblk, c, ch0, sums);
+  if (blockIdx.x == 0 && tid < 32) { dbeta[ch0 + tid] = (float)sums[tid]; dgamma[ch0 + tid] = (float)sums[32 + tid]; }
+  const int q = tid & 3;
+  float sc[8], sh[8], mu[8], rs[8], k0[8], k1[8], k2[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int l = q * 8 + i, ch = ch0 + l;
+    sc[i] = scale[ch]; sh[i] = shift[ch]; mu[i] = mean[ch]; rs[i] = rstd[ch];
+    k0[i] = gamma[ch] * rs[i]; k1[i] = (float)(sums[l] / count); k2[i] = (float)(sums[32 + l] / count);
+  }
+  const int64_t p0 = (int64_t)blockIdx.x * px_per_blk;
+  const int64_t p1 = p0 + px_per_blk < npix ? p0 + px_per_blk : npix;
+  for (int64_t p = p0 + (tid >> 2); p < p1; p += EW_THREADS / 4) {
+    float d[8], v[8], o[8];
+    unpack8<ET>(*(const uint4*)(dout + p * lddo + ch0 + q * 8), d);
+    unpack8<ET>(*(const uint4*)(y + p * ldy + ch0 + q * 8), v);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float dz = d[i];
+      if (relu && !(v[i] * sc[i] + sh[i] > 0.f)) dz = 0.f;
+      const float xhat = (v[i] - mu[i]) * rs[i];
+      o[i] = k0[i] * (dz - k1[i] - xhat * k2[i]);
+    }
+    *(uint4*)(dy + p * lddy + ch0 + q * 8) = pack8<ET>(o);
+  }
+}
+
+extern "C" int imm_bn_bwd_apply_fused(const float* partial, int nblk, int c, int64_t count, const float* gamma, const void* dout,
+                                      int lddo, const void* y, int ldy, int dtype, const float* scale, const float* shift,
+                                      const float* mean, const float* rstd, int relu, float* dgamma, float* dbeta, void* dy_out,
+                                      int lddy, void* stream) {
+  IMM_REQUIRE(partial && gamma && dout && y && scale && shift && mean && rstd && dgamma && dbeta && dy_out && nblk > 0 && count > 0,
+              "bn_bwd_apply_fused: args");
+  IMM_REQUIRE(c > 0 && c % 32 == 0, "bn_bwd_apply_fused: C=%d must be a multiple of 32", c);
+  EW_REQUIRE_VEC(c, lddo, "bn_bwd_apply_fused(dout)");
+  EW_REQUIRE_VEC(c, ldy, "bn_bwd_apply_fused(y)");
+  EW_REQUIRE_VEC(c, lddy, "bn_bwd_apply_fused(dy)");
+  const int ppb = fused_px_per_blk(count, c);
+  const dim3 grid((unsigned)((count + ppb - 1) / ppb), (unsigned)(c / 32));
+  IMM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_bwd_apply_fused_kernel<ET>), grid, dim3(EW_THREADS), 0, (hipStream_t)stream, partial,
+                                               nblk, c, (double)count, gamma, (const uint16_t*)dout, lddo, (const uint16_t*)y, ldy,
+                                               count, scale, shift, mean, rstd, relu, dgamma, dbeta, (uint16_t*)dy_out, lddy, ppb));
+  IMM_CHECK_LAUNCH("imm_bn_bwd_apply_fused");
   return 0;
 }
 

@@ -216,6 +216,8 @@ class IMMEngine:
         # the data-gradient epilogues 0.14 ms and the up-sampling adjoints 0.03 ms slower; step 3.841 -> 3.828 ms, and
         # recovering xhat from the 16-bit `out` costs gradient precision (trained-model parity 0.095 -> 0.13 worst) => OFF.
         self.bn_fuse_bwd = os.environ.get('IMM_BN_FUSE_BWD', '0') != '0'
+        # finalize + apply of a batch norm in one launch where the partial rows are few (IMM_BN_FUSE_FINALIZE=0: A/B)
+        self.bn_fuse_finalize = os.environ.get('IMM_BN_FUSE_FINALIZE', '1') != '0'
         self._side = None
         self._pack_jobs, self._reduce_jobs = [], []
         self._training = True
@@ -350,9 +352,16 @@ class IMMEngine:
                                 lay.scale, lay.shift, lay.mean, lay.rstd)
             cbytes = 2.0 * (B * H * W * ci_pad + npix * co + fd.kpad * co)
             self._add(self.prog_fwd, f_conv, 'conv_fwd', flops, cbytes)
-            self._add(self.prog_fwd, f_fin, 'bn_finalize')
-            self._add(self.prog_fwd, lambda: ops.bn_apply_relu(lay.y, npix, co, ldy, lay.scale, lay.shift, relu, out, ldo),
-                      'bn_apply', 0.0, npix * co * 4.0)
+            if self.bn_fuse_finalize and nblk <= 256 and co % 32 == 0:
+                # few partial rows: the finalize is redone by every workgroup of the apply pass (one launch, one kernel
+                # boundary and a 6-9 us latency chain less per layer)
+                self._add(self.prog_fwd, lambda: ops.bn_apply_fused(lay.stats, nblk, co, npix, gamma, beta, BN_EPS, BN_MOMENTUM,
+                                                                    self._training, mm, mv, lay.scale, lay.shift, lay.mean, lay.rstd,
+                                                                    lay.y, ldy, relu, out, ldo), 'bn_apply', 0.0, npix * co * 4.0)
+            else:
+                self._add(self.prog_fwd, f_fin, 'bn_finalize')
+                self._add(self.prog_fwd, lambda: ops.bn_apply_relu(lay.y, npix, co, ldy, lay.scale, lay.shift, relu, out, ldo),
+                          'bn_apply', 0.0, npix * co * 4.0)
         else:
             lay.out, lay.ldo = lay.y, ldy
             self._add(self.prog_fwd, lambda: ops.conv2d(fd_eval, x, lay.wt, b, lay.y), 'conv_fwd', flops,
@@ -435,13 +444,19 @@ class IMMEngine:
                 self._add(self.prog_bwd, lambda: ops.bn_bwd_reduce(d_out, ldd, lay.y, lay.ldy, npix, co, lay.scale, lay.shift,
                                                                    lay.mean, lay.rstd, lay.relu, lay.bwd_partial),
                           'bn_bwd_reduce', 0.0, npix * co * 4.0)
-            self._add(self.prog_bwd, lambda: ops.bn_bwd_finalize(lay.bwd_partial, lay.bwd_nblk, co, npix, gamma, beta, lay.rstd,
-                                                                 gg, gbeta, lay.coef, from_out=fused, ldp=lay.bwd_ldp),
-                      'bn_bwd_finalize')
-            # fused: d_out already is dz (ReLU mask applied by its producer)
-            self._add(self.prog_bwd, lambda: ops.bn_bwd_apply(d_out, ldd, lay.y, lay.ldy, npix, co, lay.scale, lay.shift,
-                                                              lay.mean, lay.rstd, lay.relu and not fused, lay.coef, lay.dy, lay.ldy),
-                      'bn_bwd_apply', 0.0, npix * co * 6.0)
+            if self.bn_fuse_finalize and not fused and lay.bwd_nblk <= 256 and co % 32 == 0:
+                self._add(self.prog_bwd, lambda: ops.bn_bwd_apply_fused(lay.bwd_partial, lay.bwd_nblk, co, npix, gamma, d_out, ldd,
+                                                                        lay.y, lay.ldy, lay.scale, lay.shift, lay.mean, lay.rstd,
+                                                                        lay.relu, gg, gbeta, lay.dy, lay.ldy),
+                          'bn_bwd_apply', 0.0, npix * co * 6.0)
+            else:
+                self._add(self.prog_bwd, lambda: ops.bn_bwd_finalize(lay.bwd_partial, lay.bwd_nblk, co, npix, gamma, beta, lay.rstd,
+                                                                     gg, gbeta, lay.coef, from_out=fused, ldp=lay.bwd_ldp),
+                          'bn_bwd_finalize')
+                # fused: d_out already is dz (ReLU mask applied by its producer)
+                self._add(self.prog_bwd, lambda: ops.bn_bwd_apply(d_out, ldd, lay.y, lay.ldy, npix, co, lay.scale, lay.shift,
+                                                                  lay.mean, lay.rstd, lay.relu and not fused, lay.coef, lay.dy, lay.ldy),
+                          'bn_bwd_apply', 0.0, npix * co * 6.0)
             dy, lddy = lay.dy, lay.ldy
             # conv bias feeds a batch norm: its gradient is analytically zero (sum of dy == 0); the
             # reference computes rounding noise there.  The flat gradient slice stays 0.

@@ -180,6 +180,18 @@ def bn_apply_relu(y, npix, c, ldy, scale, shift, relu, x_out, ldx):
     call('imm_bn_apply_relu', _p(y), dtype_enum(y.dtype), npix, c, ldy, _p(scale), _p(shift), int(relu), _p(x_out), ldx, _s())
 
 
+def bn_apply_fused(partial, nblk, c, count, gamma, beta, eps, momentum, training, mm, mv, scale, shift, mean, rstd, y, ldy,
+                   relu, x_out, ldx):
+    call('imm_bn_apply_fused', _p(partial), nblk, c, count, _p(gamma), _p(beta), eps, momentum, int(training), _p(mm), _p(mv),
+         _p(scale), _p(shift), _p(mean), _p(rstd), _p(y), dtype_enum(y.dtype), ldy, int(relu), _p(x_out), ldx, _s())
+
+
+def bn_bwd_apply_fused(partial, nblk, c, count, gamma, dout, lddo, y, ldy, scale, shift, mean, rstd, relu, dgamma, dbeta,
+                       dy_out, lddy):
+    call('imm_bn_bwd_apply_fused', _p(partial), nblk, c, count, _p(gamma), _p(dout), lddo, _p(y), ldy, dtype_enum(y.dtype),
+         _p(scale), _p(shift), _p(mean), _p(rstd), int(relu), _p(dgamma), _p(dbeta), _p(dy_out), lddy, _s())
+
+
 def bn_bwd_blocks(npix, c):
     n = L.load().imm_bn_bwd_blocks(npix, c)
     if n <= 0:

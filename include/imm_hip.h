@@ -141,6 +141,12 @@ int imm_bn_finalize(const float* partial, int nblk, int c, int64_t count, const 
                     float* scale, float* shift, float* mean, float* rstd, void* stream);
 int imm_bn_apply_relu(const void* y, int dtype, int64_t npix, int c, int ldy, const float* scale,
                       const float* shift, int relu, void* x_out, int ldx, void* stream);
+/* imm_bn_finalize + imm_bn_apply_relu in ONE launch, for layers with few partial rows (nblk <= ~256; c % 32 == 0): every
+ * workgroup owns a 32-channel slice x a pixel range and redoes the finalize of its slice from the rows (fixed order: the same
+ * scale / shift in every workgroup), workgroup (0, slice) writes scale / shift / mean / rstd and the moving statistics. */
+int imm_bn_apply_fused(const float* partial, int nblk, int c, int64_t count, const float* gamma, const float* beta, float eps,
+                       float momentum, int training, float* moving_mean, float* moving_var, float* scale, float* shift,
+                       float* mean, float* rstd, const void* y, int dtype, int ldy, int relu, void* x_out, int ldx, void* stream);
 /* backward: reduce -> finalize (writes dgamma, dbeta, coef[3][c]) -> apply (dy_conv = ...) */
 int imm_bn_bwd_reduce(const void* dout, int lddo, const void* y, int ldy, int dtype, int64_t npix, int c,
                       const float* scale, const float* shift, const float* mean, const float* rstd, int relu,
@@ -154,6 +160,10 @@ int imm_bn_bwd_finalize(const float* partial, int nblk, int c, int ldp, int64_t 
 int imm_bn_bwd_apply(const void* dout, int lddo, const void* y, int ldy, int dtype, int64_t npix, int c,
                      const float* scale, const float* shift, const float* mean, const float* rstd, int relu,
                      const float* coef, void* dy_out, int lddy, void* stream);
+/* imm_bn_bwd_finalize (rows of imm_bn_bwd_reduce, [2][c]) + imm_bn_bwd_apply in ONE launch (same scheme as imm_bn_apply_fused) */
+int imm_bn_bwd_apply_fused(const float* partial, int nblk, int c, int64_t count, const float* gamma, const void* dout, int lddo,
+                           const void* y, int ldy, int dtype, const float* scale, const float* shift, const float* mean,
+                           const float* rstd, int relu, float* dgamma, float* dbeta, void* dy_out, int lddy, void* stream);
 
 /* ---- resampling / pooling -------------------------------------------------------------------- */
 /* tf.image.resize_images x2, bilinear, legacy align_corners=False (imm_model.py:175) and its adjoint */

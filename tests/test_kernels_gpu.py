@@ -365,6 +365,62 @@ def test_batch_norm_fwd_bwd(ops, c, npix):
     close(dyo, gy.reshape(npix, c), 2e-2, 4e-3, 'bn_dy')
 
 
+@pytest.mark.parametrize('c,npix,nrows', [(32, 4096, 7), (256, 8192, 64), (64, 1000, 256), (128, 32768, 33)])
+def test_batch_norm_finalize_fused_into_apply(ops, c, npix, nrows):
+    """imm_bn_apply_fused / imm_bn_bwd_apply_fused == the finalize + apply pairs (same arithmetic; the partial rows are
+    summed in a different but fixed order: f64 sums, so the f32 results agree to the last bits), in training and eval mode."""
+    dt = torch.bfloat16
+    y = (rnd((npix, c), 241) * 2 + 0.5).to(dt).to(DEV)
+    gamma = (rnd((c,), 242, 0.5, torch.float32) + 1.0).to(DEV)
+    beta = rnd((c,), 243, 0.5, torch.float32).to(DEV)
+    yf = y.float()
+    # nrows partial rows: split the pixels into nrows ranges
+    idx = torch.linspace(0, npix, nrows + 1).long()
+    part = torch.stack([torch.stack([yf[idx[r]:idx[r + 1]].sum(0), (yf[idx[r]:idx[r + 1]] ** 2).sum(0)]) for r in range(nrows)]).contiguous()
+    res = {}
+    for fused in (False, True):
+        mm, mv = torch.full((c,), 0.3, device=DEV), torch.full((c,), 1.7, device=DEV)
+        scale, shift, mean, rstd = (torch.full((c,), float('nan'), device=DEV) for _ in range(4))
+        xo = torch.full((npix, c), float('nan'), dtype=dt, device=DEV)
+        if fused:
+            ops.bn_apply_fused(part, nrows, c, npix, gamma, beta, 1e-3, 0.99, True, mm, mv, scale, shift, mean, rstd, y, c, True, xo, c)
+        else:
+            ops.bn_finalize(part, nrows, c, npix, gamma, beta, 1e-3, 0.99, True, mm, mv, scale, shift, mean, rstd)
+            ops.bn_apply_relu(y, npix, c, c, scale, shift, True, xo, c)
+        torch.cuda.synchronize()
+        res[fused] = (xo, mm, mv, scale, shift, mean, rstd)
+    for a, b, what in zip(res[True], res[False], ('out', 'moving_mean', 'moving_var', 'scale', 'shift', 'mean', 'rstd')):
+        close(a, b, 1e-6 if what != 'out' else 8e-3, 1e-6 if what != 'out' else 1e-3, 'bn_apply_fused/' + what)
+    assert float((res[True][0].float() != res[False][0].float()).float().mean()) < 1e-3       # 16-bit outputs: (almost) all identical
+    # eval mode: moving statistics, untouched
+    scale, shift, mean, rstd = res[False][3:]
+    mm, mv = res[False][1].clone(), res[False][2].clone()
+    xo_e = torch.empty(npix, c, dtype=dt, device=DEV); xo_r = torch.empty_like(xo_e)
+    s2, h2, m2, r2 = (torch.empty(c, device=DEV) for _ in range(4))
+    ops.bn_apply_fused(None, 0, c, npix, gamma, beta, 1e-3, 0.99, False, mm, mv, s2, h2, m2, r2, y, c, True, xo_e, c)
+    ops.bn_finalize(None, 0, c, npix, gamma, beta, 1e-3, 0.99, False, mm, mv, scale, shift, mean, rstd)
+    ops.bn_apply_relu(y, npix, c, c, scale, shift, True, xo_r, c)
+    torch.cuda.synchronize()
+    assert torch.equal(xo_e, xo_r) and torch.equal(mm, res[False][1]) and torch.equal(mv, res[False][2])
+    # backward
+    dout = rnd((npix, c), 244).to(DEV)
+    nblk = ops.bn_bwd_blocks(npix, c)
+    assert nblk <= 256
+    bpart = torch.empty(nblk, 2, c, dtype=torch.float32, device=DEV)
+    ops.bn_bwd_reduce(dout, c, y, c, npix, c, scale, shift, mean, rstd, True, bpart)
+    dg, db, coef = torch.empty(c, device=DEV), torch.empty(c, device=DEV), torch.empty(3, c, device=DEV)
+    ops.bn_bwd_finalize(bpart, nblk, c, npix, gamma, beta, rstd, dg, db, coef)
+    dy_ref = torch.empty(npix, c, dtype=dt, device=DEV)
+    ops.bn_bwd_apply(dout, c, y, c, npix, c, scale, shift, mean, rstd, True, coef, dy_ref, c)
+    dg2, db2 = torch.empty(c, device=DEV), torch.empty(c, device=DEV)
+    dy_f = torch.full((npix, c), float('nan'), dtype=dt, device=DEV)
+    ops.bn_bwd_apply_fused(bpart, nblk, c, npix, gamma, dout, c, y, c, scale, shift, mean, rstd, True, dg2, db2, dy_f, c)
+    torch.cuda.synchronize()
+    close(dg2, dg, 1e-6, 1e-6, 'bn_bwd_fused/dgamma'); close(db2, db, 1e-6, 1e-6, 'bn_bwd_fused/dbeta')
+    close(dy_f, dy_ref, 8e-3, 1e-3, 'bn_bwd_fused/dy')
+    assert float((dy_f.float() != dy_ref.float()).float().mean()) < 1e-3
+
+
 @pytest.mark.parametrize('c,ldp,npix', [(32, 32, 4096), (256, 320, 512), (64, 64, 1000)])
 def test_batch_norm_bwd_from_producer_sums(ops, c, ldp, npix):
     """The fused backward: the producer of dz hands over rows of (sum dz, sum dz*out) (out = the block's stored
