@@ -59,7 +59,7 @@ _SIGS = {
     'imm_colsum_blocks': [_L, _I],
     'imm_bn_finalize': [_P, _I, _I, _L, _P, _P, _F, _F, _I, _P, _P, _P, _P, _P, _P, _P],
     'imm_bn_apply_relu': [_P, _I, _L, _I, _I, _P, _P, _I, _P, _I, _P],
-    'imm_bn_apply_fused': [_P, _I, _I, _L, _P, _P, _F, _F, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _I, _P],
+    'imm_bn_apply_fused': [_P, _I, _I, _L, _P, _P, _F, _F, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _I, _P, _I, _I, _I, _P],
     'imm_bn_bwd_apply_fused': [_P, _I, _I, _L, _P, _P, _I, _P, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _I, _P],
     'imm_bn_bwd_reduce': [_P, _I, _P, _I, _I, _L, _I, _P, _P, _P, _P, _I, _P, _P],
     'imm_bn_bwd_blocks': [_L, _I],

@@ -289,7 +289,7 @@ __global__ __launch_bounds__(EW_THREADS) void bn_apply_fused_kernel(
     const float* __restrict__ partial, int nblk, int c, double count, const float* __restrict__ gamma,
     const float* __restrict__ beta, float eps, float momentum, int training, float* moving_mean, float* moving_var,
     float* scale, float* shift, float* mean_out, float* rstd_out, const uint16_t* __restrict__ y, int64_t npix, int ldy,
-    int relu, uint16_t* __restrict__ x, int ldx, int px_per_blk) {
+    int relu, uint16_t* __restrict__ x, int ldx, int px_per_blk, uint16_t* __restrict__ up, int ldu, int h, int w) {
   __shared__ double sums[64];
   __shared__ float ssc[32], ssh[32];
   const int tid = threadIdx.x, ch0 = blockIdx.y * 32;
@@ -322,15 +322,44 @@ __global__ __launch_bounds__(EW_THREADS) void bn_apply_fused_kernel(
   for (int i = 0; i < 8; ++i) { sc[i] = ssc[q * 8 + i]; sh[i] = ssh[q * 8 + i]; }
   const int64_t p0 = (int64_t)blockIdx.x * px_per_blk;
   const int64_t p1 = p0 + px_per_blk < npix ? p0 + px_per_blk : npix;
-  for (int64_t p = p0 + (tid >> 2); p < p1; p += EW_THREADS / 4) {
-    float f[8];
-    unpack8<ET>(*(const uint4*)(y + p * ldy + ch0 + q * 8), f);
+  auto norm = [&](int64_t pp, float (&f)[8]) {
+    unpack8<ET>(*(const uint4*)(y + pp * ldy + ch0 + q * 8), f);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       f[i] = f[i] * sc[i] + sh[i];
       if (relu) f[i] = fmaxf(f[i], 0.f);
     }
+  };
+  for (int64_t p = p0 + (tid >> 2); p < p1; p += EW_THREADS / 4) {
+    float f[8];
+    norm(p, f);
     *(uint4*)(x + p * ldx + ch0 + q * 8) = pack8<ET>(f);
+    if (up != nullptr) {
+      // x2 bilinear up-sampling of the normalised activation in the same pass (tf.image.resize_images, legacy
+      // align_corners=False, imm_model.py:175: out[2i] = in[i], out[2i+1] = (in[i] + in[min(i+1, n-1)]) / 2), from the
+      // 16-bit values the separate kernel would read back (same arithmetic, same results)
+      const int j = (int)(p % w);
+      const int64_t t = p / w;
+      const int i = (int)(t % h);
+      const int64_t b = t / h;
+      float c00[8], c01[8], c10[8], c11[8], g[8];
+      { const uint4 u = pack8<ET>(f); unpack8<ET>(u, c00); }
+      const int64_t pr = p + (j + 1 < w ? 1 : 0), pd = p + (i + 1 < h ? w : 0), pdr = pd + (j + 1 < w ? 1 : 0);
+      norm(pr, g); { const uint4 u = pack8<ET>(g); unpack8<ET>(u, c01); }
+      norm(pd, g); { const uint4 u = pack8<ET>(g); unpack8<ET>(u, c10); }
+      norm(pdr, g); { const uint4 u = pack8<ET>(g); unpack8<ET>(u, c11); }
+      uint16_t* o = up + (((b * 2 * h + 2 * i) * (int64_t)(2 * w)) + 2 * j) * ldu + ch0 + q * 8;
+      float r01[8], r10[8], r11[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float top = c00[e] + (c01[e] - c00[e]) * 0.5f, bot = c10[e] + (c11[e] - c10[e]) * 0.5f;
+        r01[e] = top; r10[e] = c00[e] + (c10[e] - c00[e]) * 0.5f; r11[e] = top + (bot - top) * 0.5f;
+      }
+      *(uint4*)o = pack8<ET>(c00);
+      *(uint4*)(o + ldu) = pack8<ET>(r01);
+      *(uint4*)(o + (int64_t)2 * w * ldu) = pack8<ET>(r10);
+      *(uint4*)(o + (int64_t)2 * w * ldu + ldu) = pack8<ET>(r11);
+    }
   }
 }
 
@@ -346,17 +375,22 @@ static int fused_px_per_blk(int64_t npix, int c) {
 extern "C" int imm_bn_apply_fused(const float* partial, int nblk, int c, int64_t count, const float* gamma, const float* beta,
                                   float eps, float momentum, int training, float* moving_mean, float* moving_var, float* scale,
                                   float* shift, float* mean, float* rstd, const void* y, int dtype, int ldy, int relu,
-                                  void* x_out, int ldx, void* stream) {
+                                  void* x_out, int ldx, void* up2x_out, int ldu, int h, int w, void* stream) {
   IMM_REQUIRE(gamma && beta && moving_mean && moving_var && scale && shift && mean && rstd && y && x_out, "bn_apply_fused: null");
   IMM_REQUIRE(!training || (partial && nblk > 0), "bn_apply_fused: training needs partial sums");
   IMM_REQUIRE(c > 0 && c % 32 == 0 && count > 0, "bn_apply_fused: C=%d must be a multiple of 32", c);
   EW_REQUIRE_VEC(c, ldy, "bn_apply_fused(y)");
   EW_REQUIRE_VEC(c, ldx, "bn_apply_fused(x)");
+  if (up2x_out) {
+    EW_REQUIRE_VEC(c, ldu, "bn_apply_fused(up2x)");
+    IMM_REQUIRE(h > 0 && w > 0 && count % ((int64_t)h * w) == 0, "bn_apply_fused: up-sampling needs the map size (h=%d w=%d)", h, w);
+  }
   const int ppb = fused_px_per_blk(count, c);
   const dim3 grid((unsigned)((count + ppb - 1) / ppb), (unsigned)(c / 32));
   IMM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_apply_fused_kernel<ET>), grid, dim3(EW_THREADS), 0, (hipStream_t)stream, partial,
                                                nblk, c, (double)count, gamma, beta, eps, momentum, training, moving_mean, moving_var,
-                                               scale, shift, mean, rstd, (const uint16_t*)y, count, ldy, relu, (uint16_t*)x_out, ldx, ppb));
+                                               scale, shift, mean, rstd, (const uint16_t*)y, count, ldy, relu, (uint16_t*)x_out, ldx, ppb,
+                                               (uint16_t*)up2x_out, ldu, h, w));
   IMM_CHECK_LAUNCH("imm_bn_apply_fused");
   return 0;
 }

@@ -309,7 +309,7 @@ class IMMEngine:
         prog.append(_Launch(None, what))
 
     def _conv_block(self, scope, x, H, W, ci_real, ci_pad, ldx, co, k, stride, bn, relu, needs_dgrad,
-                    out=None, ldo=None, out_f32=False, kw=None):
+                    out=None, ldo=None, out_f32=False, kw=None, up2x=False):
         """Registers forward launches now and returns a layer record whose .backward(d_out, dx) registers the
         backward launches later (in reverse order)."""
         B, dt, dev = self.B, self.dt, self.dev
@@ -352,12 +352,16 @@ class IMMEngine:
                                 lay.scale, lay.shift, lay.mean, lay.rstd)
             cbytes = 2.0 * (B * H * W * ci_pad + npix * co + fd.kpad * co)
             self._add(self.prog_fwd, f_conv, 'conv_fwd', flops, cbytes)
+            lay.up = None
             if self.bn_fuse_finalize and nblk <= 256 and co % 32 == 0:
                 # few partial rows: the finalize is redone by every workgroup of the apply pass (one launch, one kernel
-                # boundary and a 6-9 us latency chain less per layer)
+                # boundary and a 6-9 us latency chain less per layer); the renderer's x2 up-sampling rides along
+                if up2x and os.environ.get('IMM_BN_FUSE_UPSAMPLE', '1') != '0':
+                    lay.up = self._act(B, 2 * fd.ho, 2 * fd.wo, co)
                 self._add(self.prog_fwd, lambda: ops.bn_apply_fused(lay.stats, nblk, co, npix, gamma, beta, BN_EPS, BN_MOMENTUM,
                                                                     self._training, mm, mv, lay.scale, lay.shift, lay.mean, lay.rstd,
-                                                                    lay.y, ldy, relu, out, ldo), 'bn_apply', 0.0, npix * co * 4.0)
+                                                                    lay.y, ldy, relu, out, ldo, lay.up, co, fd.ho, fd.wo),
+                          'bn_apply', 0.0, npix * co * (4.0 + (8.0 if lay.up is not None else 0.0)))
             else:
                 self._add(self.prog_fwd, f_fin, 'bn_finalize')
                 self._add(self.prog_fwd, lambda: ops.bn_apply_relu(lay.y, npix, co, ldy, lay.scale, lay.shift, relu, out, ldo),
@@ -602,14 +606,16 @@ class IMMEngine:
         for i, (k, ci, co, bn, up) in enumerate(rspec):
             assert ci == ci_real, (ci, ci_real)
             lay = self._conv_block('model/renderer/conv_%d' % (i + 1), x, H, H, ci_real, ci_pad, ldx, co, k, 1, bn, bn,
-                                   needs_dgrad=True, out_f32=not bn)
+                                   needs_dgrad=True, out_f32=not bn, up2x=bool(up and bn))
             self.ren.append(lay)
             x, ci_real, ci_pad, ldx = lay.out, co, co, lay.ldo
             if up:
-                ub = self._act(B, 2 * H, 2 * H, co)
-                src = lay.out
-                self._add(self.prog_fwd, (lambda src=src, ub=ub, H=H, co=co: ops.upsample2x_fwd(src, ub, B, H, H, co, co, co)),
-                          'upsample', 0.0, B * H * H * co * 10.0)
+                ub = getattr(lay, 'up', None)
+                if ub is None:       # not taken by the fused finalize + apply + up-sample pass
+                    ub = self._act(B, 2 * H, 2 * H, co)
+                    src = lay.out
+                    self._add(self.prog_fwd, (lambda src=src, ub=ub, H=H, co=co: ops.upsample2x_fwd(src, ub, B, H, H, co, co, co)),
+                              'upsample', 0.0, B * H * H * co * 10.0)
                 self.ren_up.append((len(self.ren) - 1, ub, H, co))
                 x, H = ub, 2 * H
         self.pred = self.ren[-1].y              # f32 [B,S,S,ldp]; channels 0..2 = future_im_pred

@@ -181,9 +181,10 @@ def bn_apply_relu(y, npix, c, ldy, scale, shift, relu, x_out, ldx):
 
 
 def bn_apply_fused(partial, nblk, c, count, gamma, beta, eps, momentum, training, mm, mv, scale, shift, mean, rstd, y, ldy,
-                   relu, x_out, ldx):
+                   relu, x_out, ldx, up2x=None, ldu=0, h=0, w=0):
     call('imm_bn_apply_fused', _p(partial), nblk, c, count, _p(gamma), _p(beta), eps, momentum, int(training), _p(mm), _p(mv),
-         _p(scale), _p(shift), _p(mean), _p(rstd), _p(y), dtype_enum(y.dtype), ldy, int(relu), _p(x_out), ldx, _s())
+         _p(scale), _p(shift), _p(mean), _p(rstd), _p(y), dtype_enum(y.dtype), ldy, int(relu), _p(x_out), ldx,
+         _p(up2x), ldu, h, w, _s())
 
 
 def bn_bwd_apply_fused(partial, nblk, c, count, gamma, dout, lddo, y, ldy, scale, shift, mean, rstd, relu, dgamma, dbeta,

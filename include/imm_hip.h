@@ -143,10 +143,13 @@ int imm_bn_apply_relu(const void* y, int dtype, int64_t npix, int c, int ldy, co
                       const float* shift, int relu, void* x_out, int ldx, void* stream);
 /* imm_bn_finalize + imm_bn_apply_relu in ONE launch, for layers with few partial rows (nblk <= ~256; c % 32 == 0): every
  * workgroup owns a 32-channel slice x a pixel range and redoes the finalize of its slice from the rows (fixed order: the same
- * scale / shift in every workgroup), workgroup (0, slice) writes scale / shift / mean / rstd and the moving statistics. */
+ * scale / shift in every workgroup), workgroup (0, slice) writes scale / shift / mean / rstd and the moving statistics.
+ * up2x_out != NULL: the x2 bilinear up-sampling that follows the block in the renderer (imm_model.py:175) is written in the
+ * same pass, [B, 2h, 2w] with pixel stride ldu, from the 16-bit values of x_out (bitwise = imm_upsample2x_fwd(x_out)). */
 int imm_bn_apply_fused(const float* partial, int nblk, int c, int64_t count, const float* gamma, const float* beta, float eps,
                        float momentum, int training, float* moving_mean, float* moving_var, float* scale, float* shift,
-                       float* mean, float* rstd, const void* y, int dtype, int ldy, int relu, void* x_out, int ldx, void* stream);
+                       float* mean, float* rstd, const void* y, int dtype, int ldy, int relu, void* x_out, int ldx,
+                       void* up2x_out, int ldu, int h, int w, void* stream);
 /* backward: reduce -> finalize (writes dgamma, dbeta, coef[3][c]) -> apply (dy_conv = ...) */
 int imm_bn_bwd_reduce(const void* dout, int lddo, const void* y, int ldy, int dtype, int64_t npix, int c,
                       const float* scale, const float* shift, const float* mean, const float* rstd, int relu,

@@ -402,6 +402,16 @@ def test_batch_norm_finalize_fused_into_apply(ops, c, npix, nrows):
     ops.bn_apply_relu(y, npix, c, c, scale, shift, True, xo_r, c)
     torch.cuda.synchronize()
     assert torch.equal(xo_e, xo_r) and torch.equal(mm, res[False][1]) and torch.equal(mv, res[False][2])
+    # with the renderer's x2 up-sampling written in the same pass: bitwise the separate kernel applied to the 16-bit output
+    if npix % 64 == 0:
+        Bq, hq = (npix // 64, 8) if npix <= 8192 else (npix // 1024, 32)
+        up_f = torch.full((Bq, 2 * hq, 2 * hq, c), float('nan'), dtype=dt, device=DEV)
+        xo_u = torch.empty(npix, c, dtype=dt, device=DEV)
+        ops.bn_apply_fused(None, 0, c, npix, gamma, beta, 1e-3, 0.99, False, mm, mv, s2, h2, m2, r2, y, c, True, xo_u, c, up_f, c, hq, hq)
+        up_r = torch.empty_like(up_f)
+        ops.upsample2x_fwd(xo_r.reshape(Bq, hq, hq, c), up_r, Bq, hq, hq, c, c, c)
+        torch.cuda.synchronize()
+        assert torch.equal(xo_u, xo_r) and torch.equal(up_f, up_r)
     # backward
     dout = rnd((npix, c), 244).to(DEV)
     nblk = ops.bn_bwd_blocks(npix, c)
