@@ -53,8 +53,12 @@ struct WgradHaloArgs {
   uint32_t x_bytes, dy_bytes;
 };
 
-// CI input channels, CO = channels of the dY rows that are staged (32 or 64; co <= CO real ones)
-template <typename ET, int CI, int CO>
+// CI input channels, CO = channels of the dY rows that are staged (32 or 64; co <= CO real ones).
+// NS-stage ring (round 2): a patch is ~20-40 KB of fresh HBM data for ~0.5 us of MFMA work, so with the two-stage ring of
+// round 1 (wait vmcnt(0), then prefetch ONE patch ahead) every patch exposed most of its fetch latency (renderer conv_5:
+// 1.5 us per patch for 0.55 us of matrix work).  Now NS-1 patches are in flight and the wait is counted: every wave issues
+// exactly LPP DMA instructions per patch, so "at most (NS-2)*LPP outstanding" == "this patch has landed".
+template <typename ET, int CI, int CO, int NS>
 __global__ __launch_bounds__(256) void conv_wgrad_halo_kernel(const WgradHaloArgs a) {
   constexpr int XC8 = CI / 8, YC8 = CO / 8;
   constexpr int NCT = CI / 16, NNT = CO / 16;          // 16-channel tiles
@@ -64,7 +68,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_halo_kernel(const WgradHaloArg
   constexpr int X_PIX_PER_DMA = 64 / XC8, Y_PIX_PER_DMA = 64 / YC8;
   constexpr int X_DMA = WH_HP / X_PIX_PER_DMA, Y_DMA = 128 / Y_PIX_PER_DMA;
   constexpr int X_BYTES = WH_HP * CI * 2, Y_BYTES = 128 * CO * 2, STAGE = X_BYTES + Y_BYTES;
-  extern __shared__ __attribute__((aligned(16))) uint4 smem[];   // 2 stages of [X halo | dY patch]
+  constexpr int LPP = X_DMA / 4 + Y_DMA / 4;           // DMA instructions per wave and patch
+  static_assert(X_DMA % 4 == 0 && Y_DMA % 4 == 0 && NS >= 2 && (NS - 2) * LPP < 64, "uniform per-wave DMA count");
+  extern __shared__ __attribute__((aligned(16))) uint4 smem[];   // NS stages of [X halo | dY patch]
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wc = wid % WC, wn = wid / WC;
@@ -111,12 +117,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_halo_kernel(const WgradHaloArg
   const int k_row = g >> 1, k_x = (g & 1) * 8 + (i16 >> 2), ch4 = (i16 & 3) * 4;
   const char* lds_c = (const char*)smem;
 
-  int patch = blockIdx.x, stage = 0;
-  if (patch < a.n_patches) issue(patch, 0);
-  for (; patch < a.n_patches; patch += gridDim.x) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const int G = gridDim.x;
+  const int n_mine = ((int)blockIdx.x < a.n_patches) ? (a.n_patches - (int)blockIdx.x + G - 1) / G : 0;
+#pragma unroll
+  for (int t = 0; t < NS - 1; ++t)
+    if (t < n_mine) issue(blockIdx.x + t * G, t);
+  int stage = 0;
+  for (int it = 0; it < n_mine; ++it) {
+    // patches it .. min(it+NS-2, n_mine-1) are in flight; patch `it` must have landed (this wave's share, then everyone's)
+    if (it + NS - 2 < n_mine) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * LPP) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (patch + (int)gridDim.x < a.n_patches) issue(patch + gridDim.x, stage ^ 1);
+    if (it + NS - 1 < n_mine) {      // into the stage patch it-1 occupied: every wave is past its reads (the barrier above)
+      int ns = stage + NS - 1; if (ns >= NS) ns -= NS;
+      issue(blockIdx.x + (it + NS - 1) * G, ns);
+    }
     const char* Xl = lds_c + stage * STAGE;
     const char* Yl = Xl + X_BYTES;
 
@@ -147,7 +162,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_halo_kernel(const WgradHaloArg
         for (int j = 0; j < TNT; ++j) acc[tap][j] = ET::mfma(bfr[ks][j], af, acc[tap][j]);   // D[n][c]
       }
     }
-    stage ^= 1;
+    if (++stage == NS) stage = 0;
   }
 
   // lane holds D[n = 4*(lane>>4)+r][c = lane&15] -> slab[split][kk = tap*ci + ci0 + wc*16 + c][co0 + n .. +3]
@@ -255,13 +270,20 @@ int imm_wgrad_halo_splits(const imm_conv_desc* d, int lddy) {
 
 template <typename ET, int CI, int CO>
 static void wh_launch_cfg(const WgradHaloArgs& a, dim3 grid, hipStream_t s) {
-  constexpr int lds = 2 * (WH_HP * CI * 2 + 128 * CO * 2);
+  constexpr int stage = WH_HP * CI * 2 + 128 * CO * 2;
+  constexpr int NS = stage > 36 * 1024 ? 3 : 4;         // 64x64 slices: 3 x 40 KB; the others 4 x 20..32 KB
+  constexpr int lds = NS * stage;
+  static const bool two_stage = getenv("IMM_WGRAD_HALO_NS2") != nullptr;    // A/B: the round-1 schedule
+  if (two_stage) {
+    hipLaunchKernelGGL((conv_wgrad_halo_kernel<ET, CI, CO, 2>), grid, dim3(256), 2 * stage, s, a);
+    return;
+  }
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {
-    (void)hipFuncSetAttribute((const void*)conv_wgrad_halo_kernel<ET, CI, CO>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_halo_kernel<ET, CI, CO, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_wgrad_halo_kernel<ET, CI, CO>), grid, dim3(256), lds, s, a);
+  hipLaunchKernelGGL((conv_wgrad_halo_kernel<ET, CI, CO, NS>), grid, dim3(256), lds, s, a);
 }
 
 void imm_wgrad_halo_launch(int dtype, const imm_conv_desc* d, const void* x, const void* dy, int lddy, float* slab,
