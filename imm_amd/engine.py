@@ -978,8 +978,14 @@ class IMMEngine:
             if i not in streams:
                 streams[i] = self._side_stream(i)
             return streams[i]
+        skip_lane = int(os.environ.get('IMM_DEBUG_SKIP_LANE', '-1'))      # timing experiment (wrong results): drop a whole lane
+        only = os.environ.get('IMM_DEBUG_SKIP_LANE_PROG', '')             # ... in the forward / backward program only,
+        if (only == 'fwd' and prog is not self.prog_fwd) or (only == 'bwd' and prog is not self.prog_bwd):
+            skip_lane = -1
+        skip_scopes = tuple(x for x in os.environ.get('IMM_DEBUG_SKIP_SCOPES', '').split(',') if x)   # ... or launches by scope
         for l in prog:
-            if l.fn is not None and l.tag in self._skip_tags:
+            if l.fn is not None and (l.tag in self._skip_tags or l.lane == skip_lane or
+                                     (skip_scopes and any(x in l.name for x in skip_scopes))):
                 continue
             if l.fn is not None:
                 if l.lane == 0:
