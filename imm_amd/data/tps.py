@@ -70,15 +70,26 @@ class TPSParamCache(object):
 
 
 class TPSRandomSampler(object):
-    """Random TPS warps of NHWC float32 device batches.  `pad=True` (replicate-pad by half the size, warp, crop) is not
-    used by the reference's datasets and is not implemented."""
+    """Random TPS warps of NHWC float32 device batches.
+
+    `pad=True` follows the reference's arithmetic to the letter (tps_sampler.py:24-29,89-92): h_pad = H//2, w_pad = W//2;
+    the sampling grid is (H + h_pad) x (W + w_pad); `F.pad(input, (h_pad, h_pad, w_pad, w_pad), 'replicate')` on an NCHW
+    tensor pads the COLUMNS by h_pad and the ROWS by w_pad; the negative pad afterwards crops the same amounts — so the
+    result is (H + h_pad - 2 w_pad) x (W + w_pad - 2 h_pad), e.g. 64x64 from 128x128.  (The datasets construct their
+    samplers with pad=False, imm/datasets/tps_dataset.py:35-41.)"""
 
     def __init__(self, height, width, vertical_points=10, horizontal_points=10, rotsd=0.0, scalesd=0.0, transsd=0.1,
                  warpsd=(0.001, 0.005), cache_size=1000, cache_evict_prob=0.01, pad=True, device='cuda:0', rng=None):
-        if pad:
-            raise NotImplementedError('TPSRandomSampler(pad=True) is not built; the datasets use pad=False '
-                                      '(imm/datasets/tps_dataset.py:35-41)')
-        self.height, self.width = int(height), int(width)
+        self.input_height, self.input_width = int(height), int(width)
+        self.pad = bool(pad)
+        self.h_pad = self.input_height // 2 if pad else 0
+        self.w_pad = self.input_width // 2 if pad else 0
+        self.height, self.width = self.input_height + self.h_pad, self.input_width + self.w_pad      # the sampling grid
+        self.out_height = self.height - 2 * self.w_pad
+        self.out_width = self.width - 2 * self.h_pad
+        if self.out_height < 1 or self.out_width < 1:
+            raise ValueError('TPSRandomSampler(pad=True) on %dx%d leaves no output (the reference crops %d rows / %d columns '
+                             'from a %dx%d grid)' % (height, width, 2 * self.w_pad, 2 * self.h_pad, self.height, self.width))
         self.vertical_points, self.horizontal_points = int(vertical_points), int(horizontal_points)
         self.rotsd, self.scalesd, self.transsd, self.warpsd = rotsd, scalesd, transsd, tuple(warpsd)
         self.cache_size, self.cache_evict_prob = int(cache_size), float(cache_evict_prob)
@@ -101,8 +112,16 @@ class TPSRandomSampler(object):
     def warp(self, x, w_tps, dst=None, dst_c0=None, dst_rest=None):
         """x [B,H,W,C] float32 NHWC on the device, w_tps [B, M+3, 2].  Writes any of: dst (all channels), dst_c0
         (channel 0, [B,H,W]), dst_rest (channels 1.., [B,H,W,C-1]); allocates and returns dst when none is given."""
-        assert x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == self.height and x.shape[2] == self.width
+        assert x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == self.input_height and x.shape[2] == self.input_width
         assert tuple(w_tps.shape) == (x.shape[0], self.m3, 2), w_tps.shape
+        if self.pad:
+            assert dst_c0 is None and dst_rest is None, 'pad=True writes one tensor'
+            if dst is None:
+                dst = torch.empty(x.shape[0], self.out_height, self.out_width, x.shape[3], dtype=torch.float32, device=x.device)
+            assert tuple(dst.shape[1:3]) == (self.out_height, self.out_width), dst.shape
+            ops.tps_warp_pad(x, self.basis_t, w_tps, (self.w_pad, self.h_pad), (self.height, self.width),
+                             (self.w_pad, self.h_pad), dst)
+            return dst
         if dst is None and dst_c0 is None and dst_rest is None:
             dst = torch.empty_like(x)
         ops.tps_warp(x, self.basis_t, w_tps, dst, dst_c0, dst_rest)

@@ -361,6 +361,14 @@ def tps_warp(src, basis_t, w_tps, dst=None, dst_c0=None, dst_rest=None):
          dst.stride(2) if dst is not None else 0, _p(dst_c0), _p(dst_rest), dst_rest.stride(2) if dst_rest is not None else 0, _s())
 
 
+def tps_warp_pad(src, basis_t, w_tps, pad_yx, grid_hw, crop_yx, dst):
+    """TPSRandomSampler(pad=True): src [B,H,W,C] f32 NHWC read as if replicate-padded by pad_yx, warped on a grid_hw grid
+    (basis_t [M+3, gh*gw]), window crop_yx + dst.shape[1:3] written to dst [B,oh,ow,C] (include/imm_hip.h: imm_tps_warp_pad)."""
+    b, h, w, c = src.shape
+    call('imm_tps_warp_pad', _p(src), src.stride(2), b, h, w, c, pad_yx[0], pad_yx[1], grid_hw[0], grid_hw[1], crop_yx[0], crop_yx[1],
+         dst.shape[1], dst.shape[2], _p(basis_t), basis_t.shape[0], _p(w_tps), _p(dst), dst.stride(2), _s())
+
+
 def resize_crop_u8(src_u8, offsets, hw, c, resize_hw, crop_yx, out_hw, dst, ld_dst=None):
     """src_u8: flat u8 device buffer of packed HWC images; offsets i64 [B]; hw i32 [B,2]; dst f32 view whose element
     (b,y,x,0) is dst.data_ptr() + ((b*oh+y)*ow+x)*ld_dst floats (include/imm_hip.h: imm_resize_crop_u8)."""

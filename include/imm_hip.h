@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define IMM_ABI_VERSION 7   /* 2: imm_vgg_conv1_1_fwd gained `halves` */
+#define IMM_ABI_VERSION 8   /* 2: imm_vgg_conv1_1_fwd gained `halves` */
 
 enum imm_dtype { IMM_BF16 = 0, IMM_F16 = 1 };
 
@@ -332,6 +332,16 @@ int64_t imm_masked_sse_workspace_bytes(int nfeat);                              
  * (the image, e.g. straight into the training step's input buffer). */
 int imm_tps_warp(const float* src, int ld_src, int batch, int h, int w, int c, const float* basis_t, int m3,
                  const float* w_tps, float* dst, int ld_dst, float* dst_c0, float* dst_rest, int ld_rest, void* stream);
+/* TPSRandomSampler(pad=True) (tps_sampler.py:24-29,89-92): the source is addressed as if replicate-padded by pad_y rows /
+ * pad_x columns on each side (coordinates are clamped; no padded copy), warped on a grid_h x grid_w sampling grid (basis_t
+ * f32 [m3][grid_h*grid_w]; normalised coordinates refer to the PADDED source, zero outside it), and the window
+ * [crop_y, crop_y+out_h) x [crop_x, crop_x+out_w) of the result is written to dst [B,out_h,out_w,ld_dst].  The reference's
+ * own arithmetic is pad_y = w/2, pad_x = h/2, grid = (h + h/2) x (w + w/2), crop = (w/2, h/2), out = (h + h/2 - 2(w/2)) x
+ * (w + w/2 - 2(h/2)) — F.pad's argument order makes it swap the two paddings, and the output is smaller than the input;
+ * imm_amd.data.tps.TPSRandomSampler reproduces exactly that. */
+int imm_tps_warp_pad(const float* src, int ld_src, int batch, int h, int w, int c, int pad_y, int pad_x, int grid_h, int grid_w,
+                     int crop_y, int crop_x, int out_h, int out_w, const float* basis_t, int m3, const float* w_tps,
+                     float* dst, int ld_dst, void* stream);
 
 /* ---- decoded-image ingest (imm/datasets/celeba_dataset.py:136-174, aflw_dataset.py:81-114: to_float -> bilinear
  *      align_corners=True resize -> central crop) ---- */

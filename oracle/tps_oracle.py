@@ -95,6 +95,20 @@ def warp(img, w_tps, hc=10, wc=10, basis=None):
     return grid_sample(img, tps_grid(basis, w_tps, h, wd), align_corners=True)
 
 
+def warp_pad(img, w_tps, hc=10, wc=10):
+    """TPSRandomSampler.forward with pad=True (tps_sampler.py:24-29,89-92), step by step as the reference does it on its
+    NCHW tensor: h_pad = H//2, w_pad = W//2; F.pad(x, (h_pad, h_pad, w_pad, w_pad), 'replicate') pads the last dimension
+    (columns) by h_pad and the rows by w_pad; the grid is (H + h_pad) x (W + w_pad); the negative pad crops h_pad columns and
+    w_pad rows from each side.  img [B,H,W,C] -> [B, H + h_pad - 2 w_pad, W + w_pad - 2 h_pad, C]."""
+    img = np.asarray(img, dtype=np.float32)
+    _b, h, w, _c = img.shape
+    h_pad, w_pad = h // 2, w // 2
+    gh, gw = h + h_pad, w + w_pad
+    padded = np.pad(img, ((0, 0), (w_pad, w_pad), (h_pad, h_pad), (0, 0)), mode='edge')
+    out = grid_sample(padded, tps_grid(tps_basis(gh, gw, hc, wc), w_tps, gh, gw), align_corners=True)
+    return out[:, w_pad:gh - w_pad, h_pad:gw - h_pad]
+
+
 def apply_pair(image, mask, w_target, w_source, hc=10, wc=10):
     """tps_dataset.py:70-96: the mask rides as channel 0 through both warps; future = target(mask||image),
     image = source(future); returns image [B,H,W,3], future_image [B,H,W,3], mask (= the FUTURE image's mask) [B,H,W,1]."""

@@ -57,6 +57,17 @@ def main():
     smp.cache[0] = torch.from_numpy(grid_t[:1])
     y = smp.forward_py(img[:1])
     out['sampler_forward_py_sub'] = y[:, ::5, ::3]
+    # (3b) pad=True (the constructor default; not used by the datasets): non-square so that the reference's swapped
+    # paddings show; 24x20 -> grid 36x30, output 16x6
+    np.random.seed(11)
+    w_p = np.stack([T.sample_tps_w(4, 5, (0.001, 0.01), 5.0, 0.1, 0.1) for _ in range(2)])
+    smp = T.TPSRandomSampler(24, 20, vertical_points=4, horizontal_points=5, pad=True, cache_size=1, cache_evict_prob=0.0)
+    img_p = (np.random.RandomState(8).rand(2, 24, 20, 3) * 255).astype(np.float32)
+    ys = []
+    for i in range(2):
+        smp.cache[0] = smp.tps(torch.from_numpy(w_p[i:i + 1].astype(np.float32)))
+        ys.append(smp.forward_py(img_p[i:i + 1]))
+    out['pad_w'] = w_p; out['pad_img'] = img_p; out['pad_out'] = np.concatenate(ys)
     # (4) sample_tps_w under a fixed seed (draw order)
     np.random.seed(5)
     out['w_seed5'] = T.sample_tps_w(4, 3, (0.01, 0.02), 10.0, 0.2, 0.3)

@@ -40,6 +40,13 @@ def test_grid_and_warp_match_reference():
     np.testing.assert_array_equal(out['image'], src[..., 1:])
 
 
+def test_padded_warp_matches_reference():
+    """TPSRandomSampler(pad=True).forward_py of the reference on a non-square input: swapped paddings, smaller output."""
+    out = T.warp_pad(G['pad_img'], G['pad_w'].astype(np.float32), 4, 5)
+    assert out.shape == G['pad_out'].shape == (2, 16, 6, 3)
+    np.testing.assert_allclose(out, G['pad_out'], rtol=0, atol=2e-3)
+
+
 def test_grid_sample_known_answers():
     img = np.arange(2 * 3 * 4, dtype=np.float32).reshape(1, 3, 4, 2)
     # identity grid reproduces the image (align_corners=True puts -1/+1 on the corner pixel centres)

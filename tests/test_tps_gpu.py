@@ -94,9 +94,33 @@ def test_pair_augmenter_fills_engine_inputs(tps):
     assert out['image'] is bufs[0] and out['future_image'] is bufs[1] and out['mask'] is bufs[2]
 
 
+def test_padded_warp_matches_reference_vectors(tps):
+    """pad=True against the reference's own TPSRandomSampler(pad=True).forward_py (tests/golden/make_tps_golden.py 3b)."""
+    s = tps.TPSRandomSampler(24, 20, 4, 5, pad=True, device=DEV)
+    assert (s.out_height, s.out_width) == (16, 6)
+    got = s.warp(torch.from_numpy(G['pad_img']).to(DEV), torch.from_numpy(G['pad_w'].astype(np.float32)).to(DEV))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(got.cpu().numpy(), G['pad_out'], rtol=0, atol=3e-3)
+
+
+@pytest.mark.parametrize('B,H,W,C,hc,wc', [(3, 16, 16, 1, 3, 3), (9, 40, 32, 4, 4, 5), (32, 128, 128, 4, 10, 10)], ids=['tiny', 'rect', 'dataset_shape'])
+def test_padded_warp_vs_oracle(tps, B, H, W, C, hc, wc):
+    rng = np.random.RandomState(100 + B)
+    img = (rng.rand(B, H, W, C) * 255).astype(np.float32)
+    w = np.stack([T.sample_tps_w(hc, wc, (0.01, 0.05), 20.0, 0.3, 0.8, rng) for _ in range(B)]).astype(np.float32)
+    ref = T.warp_pad(img, w, hc, wc)
+    s = tps.TPSRandomSampler(H, W, hc, wc, pad=True, device=DEV)
+    got = s.warp(torch.from_numpy(img).to(DEV), torch.from_numpy(w).to(DEV))
+    torch.cuda.synchronize()
+    got = got.cpu().numpy()
+    assert got.shape == ref.shape == (B, H + H // 2 - 2 * (W // 2), W + W // 2 - 2 * (H // 2), C)
+    np.testing.assert_allclose(got, ref, rtol=0, atol=2e-2)
+    assert float(np.mean(np.abs(got - ref))) < 3e-4
+
+
 def test_sampler_errors_and_cache(tps):
-    with pytest.raises(NotImplementedError):
-        tps.TPSRandomSampler(16, 16, pad=True, device=DEV)
+    with pytest.raises(ValueError):
+        tps.TPSRandomSampler(16, 64, pad=True, device=DEV)                  # 16 + 8 - 64 rows: nothing left
     s = tps.TPSRandomSampler(16, 16, pad=False, device=DEV, cache_size=2, cache_evict_prob=0.0, rng=np.random.RandomState(0))
     a = s.sample_params(64)
     assert len({a[i].cpu().numpy().tobytes() for i in range(64)}) <= 2       # only two cached parameter sets are reused
