@@ -244,6 +244,8 @@ static bool wh_plan(const imm_conv_desc* d, int lddy, WhPlan* pl) {
   // layers (64->64 at 64x64: 75 MB of slabs each); measured 3.83 -> 3.80 ms per step (round 2, same box)
   static const int per_cu = getenv("IMM_WGRAD_HALO_PER_CU") ? atoi(getenv("IMM_WGRAD_HALO_PER_CU")) : 1;
   int grid = per_cu * wh_num_cu();
+  static const int grid1 = getenv("IMM_WGRAD_HALO_GRID1") ? atoi(getenv("IMM_WGRAD_HALO_GRID1")) : 0;   // A/B: fewer, fatter workgroups
+  if (grid1 > 0) grid = grid1;
   if (blocks > 1) grid = wh_num_cu();                  // sliced layers: slab bytes = nsplit x |dW|, keep nsplit small
   static const int grid64 = getenv("IMM_WGRAD_HALO_GRID64") ? atoi(getenv("IMM_WGRAD_HALO_GRID64")) : 0;
   if (blocks > 1 && cs == 64 && grid64 > 0) grid = grid64;

@@ -24,6 +24,15 @@ extern "C" const char* imm_last_error(void) { return imm_err_buf; }
 static const char imm_digest_marker[] = "IMM_SOURCE_DIGEST=" IMM_SOURCE_DIGEST;
 extern "C" const char* imm_source_digest(void) { return imm_digest_marker + 18; }
 
+__global__ void debug_stamp_kernel(uint64_t* slots, int index) { slots[index] = wall_clock64(); }
+
+extern "C" int imm_debug_stamp(uint64_t* slots, int index, void* stream) {
+  IMM_REQUIRE(slots && index >= 0, "debug_stamp: null / negative slot");
+  hipLaunchKernelGGL(debug_stamp_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, slots, index);
+  IMM_CHECK_LAUNCH("imm_debug_stamp");
+  return 0;
+}
+
 extern "C" int imm_device_info(int32_t* out2) {
   IMM_REQUIRE(out2, "device_info: null");
   int dev = 0;

@@ -209,6 +209,11 @@ class IMMEngine:
             self.vgg_split = 0                   # no VGG feature is tapped: nothing to split
         self.reduce_per_layer = os.environ.get('IMM_REDUCE_PER_LAYER', '0') != '0'
         self._skip_tags = set(t for t in os.environ.get('IMM_DEBUG_SKIP_TAGS', '').split(',') if t)
+        # IMM_DEBUG_STAMPS=marks|all: device wall-clock probes between the launches (lane boundaries / every launch) -> a
+        # profiler-free timeline of a graph replay, read with stamp_report()
+        self._stamp_mode = os.environ.get('IMM_DEBUG_STAMPS', '')
+        self._stamp_buf = torch.zeros(8192, dtype=torch.int64, device=self.dev) if self._stamp_mode else None
+        self._stamp_names = []
         self.wgrad_lane = int(os.environ.get('IMM_WGRAD_LANE', '0')) if self.two_streams else 0
         # IMM_BN_FUSE_BWD=1: batch-norm backward sums (sum dz, sum dz*out) taken in the epilogue of whatever produces dz (data
         # gradient of the next layer, up-sampling adjoint) instead of a separate pass over dz and the conv output.  MEASURED
@@ -978,6 +983,17 @@ class IMMEngine:
             if i not in streams:
                 streams[i] = self._side_stream(i)
             return streams[i]
+        pname = 'fwd' if prog is self.prog_fwd else 'bwd' if prog is self.prog_bwd else 'opt'
+        if self._stamp_mode and prog is self.prog_fwd:
+            self._stamp_names = []
+
+        def stamp(lane, label):
+            if not self._stamp_mode or len(self._stamp_names) >= self._stamp_buf.numel():
+                return
+            with torch.cuda.stream(lane_stream(lane)):
+                ops.debug_stamp(self._stamp_buf, len(self._stamp_names))
+            self._stamp_names.append((lane, '%s:%s' % (pname, label)))
+        stamp(0, 'start')
         skip_lane = int(os.environ.get('IMM_DEBUG_SKIP_LANE', '-1'))      # timing experiment (wrong results): drop a whole lane
         only = os.environ.get('IMM_DEBUG_SKIP_LANE_PROG', '')             # ... in the forward / backward program only,
         if (only == 'fwd' and prog is not self.prog_fwd) or (only == 'bwd' and prog is not self.prog_bwd):
@@ -993,14 +1009,31 @@ class IMMEngine:
                 else:
                     with torch.cuda.stream(lane_stream(l.lane)):
                         l.fn()
+                if self._stamp_mode == 'all':
+                    stamp(l.lane, '%s %s' % (l.tag, l.name))
             elif l.tag == 'fork':
+                stamp(0, 'fork')
                 ev = torch.cuda.Event(); ev.record(main); lane_stream(1).wait_event(ev)
+                stamp(1, 'fork: lane 1 released')
             elif l.tag == 'join':
+                stamp(1, 'join: lane 1 done')
+                stamp(0, 'join: lane 0 arrives')
                 ev = torch.cuda.Event(); ev.record(lane_stream(1)); main.wait_event(ev)
+                stamp(0, 'join: lane 0 resumes')
             elif l.tag.startswith('record:'):
+                stamp(l.lane, l.tag)
                 ev = torch.cuda.Event(); ev.record(lane_stream(l.lane)); events[l.tag[7:]] = ev
             elif l.tag.startswith('wait:'):
+                stamp(l.lane, l.tag + ' arrives')
                 lane_stream(l.lane).wait_event(events[l.tag[5:]])
+                stamp(l.lane, l.tag + ' resumes')
+        stamp(0, 'end')
+
+    def stamp_report(self):
+        """[(microseconds since the first probe of the step, lane, label)] of the last step issued with IMM_DEBUG_STAMPS set."""
+        torch.cuda.synchronize(self.dev)
+        t = self._stamp_buf[:len(self._stamp_names)].cpu().tolist()
+        return [((v - t[0]) / 100.0, lane, label) for v, (lane, label) in zip(t, self._stamp_names)]
 
     def _side_stream(self, i=1):
         if self._side is None:

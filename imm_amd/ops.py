@@ -354,6 +354,11 @@ class SegmentTable:
         self.seg_wd = torch.tensor([float(w) for w in wds], dtype=torch.float32, device=device)
 
 
+def debug_stamp(slots, index):
+    """slots: int64 device tensor; slots[index] = device wall clock (100 MHz ticks) at this point of the current stream."""
+    call('imm_debug_stamp', _p(slots), int(index), _s())
+
+
 def tps_warp(src, basis_t, w_tps, dst=None, dst_c0=None, dst_rest=None):
     """src [B,H,W,C] f32 NHWC; basis_t [M+3, H*W]; w_tps [B, M+3, 2]; outputs as in include/imm_hip.h (imm_tps_warp)."""
     b, h, w, c = src.shape

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define IMM_ABI_VERSION 8   /* 2: imm_vgg_conv1_1_fwd gained `halves` */
+#define IMM_ABI_VERSION 9   /* 2: imm_vgg_conv1_1_fwd gained `halves` */
 
 enum imm_dtype { IMM_BF16 = 0, IMM_F16 = 1 };
 
@@ -69,6 +69,10 @@ const char* imm_last_error(void);
 const char* imm_source_digest(void);
 /* device properties the host needs to size launches: [0]=CU count, [1]=gfx arch number (950) */
 int imm_device_info(int32_t* out2_host);
+/* timeline probe: slots[index] = the device's constant-rate wall clock (100 MHz ticks) when this one-thread kernel runs on
+ * `stream`.  Placed between the launches of a captured program it gives a profiler-free timeline of a HIP-graph replay
+ * (IMM_DEBUG_STAMPS=1 in imm_amd/engine.py). */
+int imm_debug_stamp(uint64_t* slots, int index, void* stream);
 /* HIP-graph capture of a launch sequence on `stream` (replaces TF's session.run of a static graph,
  * imm/train/cnn_train_multi.py:459). */
 int imm_graph_begin(void* stream);
