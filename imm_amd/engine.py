@@ -447,21 +447,36 @@ class IMMEngine:
             gg, gbeta = self.gview[scope + '/gamma'], self.gview[scope + '/beta']
             gamma, beta = self.pview[scope + '/gamma'], self.pview[scope + '/beta']
             fused = lay.bwd_fused and lay.relu
-            if not fused:
-                lay.bwd_nblk, lay.bwd_ldp = ops.bn_bwd_blocks(npix, co), co
+            lay.bwd_nblk = lay.bwd_nblk if fused else ops.bn_bwd_blocks(npix, co)
+            small = self.bn_fuse_finalize and lay.bwd_nblk <= 256 and co % 32 == 0
+            # IMM_BN_BWD_TICKET=1: layers with too many partial rows for the fused apply pass finish their sums in the reduce
+            # kernel itself (last workgroup done, imm_bn_bwd_reduce_finalize) instead of a finalize launch.  MEASURED (round 2,
+            # 11 layers, same box): with device-scope fences 3.64 -> 5.44 ms (every fence writes back / invalidates a whole
+            # L2); with fence-free sc1 atomics 3.70 -> 3.80 ms — two cross-XCD hand-overs through memory cost more than the
+            # 9 us finalize launch they replace.  A kernel boundary is the cheapest device-wide barrier here => off.
+            ticket = not fused and not small and co <= 256 and os.environ.get('IMM_BN_BWD_TICKET', '0') != '0'
+            if ticket:
+                lay.bwd_ws = ops.bn_bwd_reduce_finalize_workspace(npix, co, self.dev)
+                self._add(self.prog_bwd, lambda: ops.bn_bwd_reduce_finalize(d_out, ldd, lay.y, lay.ldy, npix, co, lay.scale, lay.shift,
+                                                                            lay.mean, lay.rstd, lay.relu, npix, gamma, gg, gbeta,
+                                                                            lay.coef, lay.bwd_ws),
+                          'bn_bwd_reduce', 0.0, npix * co * 4.0)
+            elif not fused:
+                lay.bwd_ldp = co
                 lay.bwd_partial = self._zeros(lay.bwd_nblk, 2, co)
                 self._add(self.prog_bwd, lambda: ops.bn_bwd_reduce(d_out, ldd, lay.y, lay.ldy, npix, co, lay.scale, lay.shift,
                                                                    lay.mean, lay.rstd, lay.relu, lay.bwd_partial),
                           'bn_bwd_reduce', 0.0, npix * co * 4.0)
-            if self.bn_fuse_finalize and not fused and lay.bwd_nblk <= 256 and co % 32 == 0:
+            if small and not fused:
                 self._add(self.prog_bwd, lambda: ops.bn_bwd_apply_fused(lay.bwd_partial, lay.bwd_nblk, co, npix, gamma, d_out, ldd,
                                                                         lay.y, lay.ldy, lay.scale, lay.shift, lay.mean, lay.rstd,
                                                                         lay.relu, gg, gbeta, lay.dy, lay.ldy),
                           'bn_bwd_apply', 0.0, npix * co * 6.0)
             else:
-                self._add(self.prog_bwd, lambda: ops.bn_bwd_finalize(lay.bwd_partial, lay.bwd_nblk, co, npix, gamma, beta, lay.rstd,
-                                                                     gg, gbeta, lay.coef, from_out=fused, ldp=lay.bwd_ldp),
-                          'bn_bwd_finalize')
+                if not ticket:
+                    self._add(self.prog_bwd, lambda: ops.bn_bwd_finalize(lay.bwd_partial, lay.bwd_nblk, co, npix, gamma, beta, lay.rstd,
+                                                                         gg, gbeta, lay.coef, from_out=fused, ldp=lay.bwd_ldp),
+                              'bn_bwd_finalize')
                 # fused: d_out already is dz (ReLU mask applied by its producer)
                 self._add(self.prog_bwd, lambda: ops.bn_bwd_apply(d_out, ldd, lay.y, lay.ldy, npix, co, lay.scale, lay.shift,
                                                                   lay.mean, lay.rstd, lay.relu and not fused, lay.coef, lay.dy, lay.ldy),
@@ -647,6 +662,20 @@ class IMMEngine:
         nimg = B if split else 2 * B
         gt_prog, pred_prog = [], self.prog_fwd
         fuse_ok = not self.l1                    # the fused SSE+pool / unpool+tap passes exist for the squared error only
+        # IMM_SSE_SIDE=1: the error sums that nothing in the VGG chain waits for ('input', conv3_2, conv4_2) on the side lane.
+        # MEASURED (round 2, same box, A/B twice): 3.717 -> 3.757 ms — the three fork edges + one join of the HIP graph cost
+        # more than the 30 us of reductions taken off the chain => off.
+        sse_side = self.two_streams and not split and os.environ.get('IMM_SSE_SIDE', '0') != '0' and bool(self.vgg_layers)
+        side_sse = set()
+        if sse_side and 'input' in self.tap_idx:
+            idx0 = self.tap_idx['input']
+            self._signal(self.prog_fwd, 'pred_done', lane=0)
+            self._wait(self.prog_fwd, 'pred_done', lane=1)
+            self._cur_lane = 1
+            self._add(self.prog_fwd, lambda: ops.masked_sse_f32(self.in_future, 3, self.pred, self.ldp, B, S, 3, self.in_mask,
+                                                                self.sse_partial[idx0], self.l1), 'sse')
+            self._cur_lane = 0
+            side_sse.add('input')
 
         def vadd(fn_for, tag, flops, nbytes, name=''):
             # fn_for(lo) -> launch closure over images [lo, lo + nimg)
@@ -692,6 +721,19 @@ class IMMEngine:
                      'vgg16/' + name)
             self.vgg_act[name] = (y, H)
             x = y
+            pooled_next = name in VGG_POOL_AFTER and li < len(self.vgg_layers) - 1
+            if (sse_side and name in taps and li < len(self.vgg_layers) - 1 and
+                    not (pooled_next and fuse_ok and os.environ.get('IMM_SSE_POOL_FUSE', '1') != '0')):
+                # a tapped layer in the middle of the network: its masked error sum is off the critical chain (the next
+                # convolution does not need it) -> side lane, next to the matrix-bound convolutions that follow
+                idx = self.tap_idx[name]
+                self._signal(self.prog_fwd, 'tap:' + name, lane=0)
+                self._wait(self.prog_fwd, 'tap:' + name, lane=1)
+                self._cur_lane = 1
+                self._add(self.prog_fwd, (lambda y=y, H=H, cout=cout, idx=idx: ops.masked_sse(
+                    y[:B], y[B:], B, H, cout, self.in_mask, S, self.sse_partial[idx], self.l1)), 'sse', 0.0, 2 * B * H * H * cout * 2.0)
+                self._cur_lane = 0
+                side_sse.add(name)
             if name in VGG_POOL_AFTER and li < len(self.vgg_layers) - 1:      # the deepest layer is not pooled: nobody reads it
                 p = self._act(2 * B, H // 2, H // 2, cout)
                 if name in taps and not split and fuse_ok and os.environ.get('IMM_SSE_POOL_FUSE', '1') != '0':
@@ -738,12 +780,12 @@ class IMMEngine:
         self.loss_out = self._zeros(3 * nfeat + 3)
         mask = self.in_mask
         l1 = self.l1
-        if 'input' in self.tap_idx:
+        if 'input' in self.tap_idx and 'input' not in side_sse:
             idx0 = self.tap_idx['input']
             self._add(self.prog_fwd, lambda: ops.masked_sse_f32(self.in_future, 3, self.pred, self.ldp, B, S, 3, mask,
                                                                 self.sse_partial[idx0], l1), 'sse')
         for name in taps:
-            if name in getattr(self, '_fused_sse', ()):
+            if name in getattr(self, '_fused_sse', ()) or name in side_sse:
                 continue
             idx = self.tap_idx[name]
             y, H = self.vgg_act[name]
@@ -751,6 +793,9 @@ class IMMEngine:
             self._add(self.prog_fwd, (lambda y=y, H=H, c=c, idx=idx: ops.masked_sse(y[:B], y[B:], B, H, c, mask, S,
                                                                                   self.sse_partial[idx], l1)), 'sse',
                       0.0, 2 * B * H * H * c * 2.0)
+        if side_sse:
+            self._signal(self.prog_fwd, 'sse_side_done', lane=1)
+            self._wait(self.prog_fwd, 'sse_side_done', lane=0)
         mode = ops.LOSS_L2 if self.loss_kind == 'l2' else ops.LOSS_PERCEPTUAL
         self._add(self.prog_fwd, lambda: ops.perceptual_finalize(self.sse_partial, nfeat, self.nel, self.loss_agg,
                                                                  self._training, self.wd_loss, self.loss_out, l1, mode), 'loss_finalize')

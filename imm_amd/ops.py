@@ -210,6 +210,19 @@ def bn_bwd_finalize(partial, nblk, c, count, gamma, beta, rstd, dgamma, dbeta, c
          int(from_out), _p(dgamma), _p(dbeta), _p(coef), _s())
 
 
+def bn_bwd_reduce_finalize_workspace(npix, c, device):
+    """Zeroed workspace of bn_bwd_reduce_finalize (partial rows | group rows | ticket counters)."""
+    n = L.load().imm_bn_bwd_reduce_finalize_workspace_bytes(int(npix), int(c))
+    if n < 0:
+        raise L.ImmHipError('imm_bn_bwd_reduce_finalize_workspace_bytes(%d, %d) failed' % (npix, c))
+    return torch.zeros((n + 15) // 16 * 2, dtype=torch.float64, device=device)      # 16-byte aligned
+
+
+def bn_bwd_reduce_finalize(dout, lddo, y, ldy, npix, c, scale, shift, mean, rstd, relu, count, gamma, dgamma, dbeta, coef, workspace):
+    call('imm_bn_bwd_reduce_finalize', _p(dout), lddo, _p(y), ldy, dtype_enum(y.dtype), npix, c, _p(scale), _p(shift), _p(mean),
+         _p(rstd), int(relu), int(count), _p(gamma), _p(dgamma), _p(dbeta), _p(coef), _p(workspace), _s())
+
+
 def bn_bwd_apply(dout, lddo, y, ldy, npix, c, scale, shift, mean, rstd, relu, coef, dy_out, lddy):
     call('imm_bn_bwd_apply', _p(dout), lddo, _p(y), ldy, dtype_enum(y.dtype), npix, c, _p(scale), _p(shift), _p(mean),
          _p(rstd), int(relu), _p(coef), _p(dy_out), lddy, _s())

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define IMM_ABI_VERSION 9   /* 2: imm_vgg_conv1_1_fwd gained `halves` */
+#define IMM_ABI_VERSION 10   /* 2: imm_vgg_conv1_1_fwd gained `halves` */
 
 enum imm_dtype { IMM_BF16 = 0, IMM_F16 = 1 };
 
@@ -164,6 +164,14 @@ int imm_bn_bwd_blocks(int64_t npix, int c);
  * (IMM_CONV_STATS | IMM_CONV_MASK) or imm_upsample2x_bwd_bn: sum dz*xhat = (sum dz*out - beta * sum dz) / gamma. */
 int imm_bn_bwd_finalize(const float* partial, int nblk, int c, int ldp, int64_t count, const float* gamma, const float* beta,
                         const float* rstd, int from_out, float* dgamma, float* dbeta, float* coef, void* stream);
+/* imm_bn_bwd_reduce + imm_bn_bwd_finalize (from_out = 0) in ONE launch: the workgroup that finishes last does the finalize
+ * ("last block done", two levels of 32: fixed summation order, bitwise reproducible).  `workspace`:
+ * imm_bn_bwd_reduce_finalize_workspace_bytes(npix, c) bytes, 16-byte aligned, ZEROED ONCE by the caller before the first launch
+ * (it ends with ticket counters that every launch leaves at zero).  c <= 256. */
+int imm_bn_bwd_reduce_finalize(const void* dout, int lddo, const void* y, int ldy, int dtype, int64_t npix, int c,
+                               const float* scale, const float* shift, const float* mean, const float* rstd, int relu,
+                               int64_t count, const float* gamma, float* dgamma, float* dbeta, float* coef, void* workspace,
+                               void* stream);
 int imm_bn_bwd_apply(const void* dout, int lddo, const void* y, int ldy, int dtype, int64_t npix, int c,
                      const float* scale, const float* shift, const float* mean, const float* rstd, int relu,
                      const float* coef, void* dy_out, int lddy, void* stream);
@@ -325,6 +333,7 @@ int64_t imm_conv2d_wgrad_workspace_bytes(const imm_conv_desc* desc_host, int ldd
                                                                                       forced / minimal split count)        */
 int64_t imm_colsum_workspace_bytes(int64_t npix, int c);                          /* partial of imm_colsum                  */
 int64_t imm_bn_bwd_workspace_bytes(int64_t npix, int c);                          /* partial of imm_bn_bwd_reduce           */
+int64_t imm_bn_bwd_reduce_finalize_workspace_bytes(int64_t npix, int c);          /* workspace of imm_bn_bwd_reduce_finalize */
 int64_t imm_upsample2x_bwd_bn_workspace_bytes(int batch, int h, int w, int c);    /* partial of imm_upsample2x_bwd_bn       */
 int64_t imm_masked_sse_workspace_bytes(int nfeat);                                /* partial of imm_masked_sse* (per loss)  */
 

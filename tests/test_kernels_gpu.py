@@ -365,6 +365,43 @@ def test_batch_norm_fwd_bwd(ops, c, npix):
     close(dyo, gy.reshape(npix, c), 2e-2, 4e-3, 'bn_dy')
 
 
+@pytest.mark.parametrize('c,npix', [(32, 32 * 128 * 128), (64, 32 * 64 * 64), (32, 5000), (256, 700), (128, 33 * 1024 + 5)],
+                         ids=['1024_rows', '64x64', 'few_rows', 'one_group', 'ragged_group'])
+def test_batch_norm_bwd_reduce_finalize_in_one_launch(ops, c, npix):
+    """imm_bn_bwd_reduce_finalize (last workgroup done, two levels) against reduce + finalize: same rows, f64 sums in another
+    grouping -> equal to ~1 ulp of f32; launch after launch bitwise identical (the ticket counters reset themselves)."""
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(c + npix)
+    y = (torch.randn(npix, c, generator=g) * 2 + 0.5).to(dt).to(DEV)
+    dout = torch.randn(npix, c, generator=g).to(dt).to(DEV)
+    gamma = (torch.rand(c, generator=g) + 0.5).to(DEV)
+    beta = (torch.rand(c, generator=g) - 0.5).to(DEV)
+    yf = y.float()
+    mean = yf.mean(0); var = yf.var(0, unbiased=False)
+    rstd = torch.rsqrt(var + 1e-3); scale = gamma * rstd; shift = beta - mean * scale
+    nblk = ops.bn_bwd_blocks(npix, c)
+    part = torch.empty(nblk, 2, c, dtype=torch.float32, device=DEV)
+    ops.bn_bwd_reduce(dout, c, y, c, npix, c, scale, shift, mean, rstd, True, part)
+    dg0, db0, coef0 = torch.empty(c, device=DEV), torch.empty(c, device=DEV), torch.empty(3, c, device=DEV)
+    ops.bn_bwd_finalize(part, nblk, c, npix, gamma, beta, rstd, dg0, db0, coef0)
+    ws = ops.bn_bwd_reduce_finalize_workspace(npix, c, DEV)
+    outs = []
+    for _ in range(4):
+        dg, db, coef = (torch.full((c,), float('nan'), device=DEV), torch.full((c,), float('nan'), device=DEV),
+                        torch.full((3, c), float('nan'), device=DEV))
+        ops.bn_bwd_reduce_finalize(dout, c, y, c, npix, c, scale, shift, mean, rstd, True, npix, gamma, dg, db, coef, ws)
+        torch.cuda.synchronize()
+        outs.append((dg, db, coef))
+    for dg, db, coef in outs[1:]:
+        assert torch.equal(dg, outs[0][0]) and torch.equal(db, outs[0][1]) and torch.equal(coef, outs[0][2])
+    dg, db, coef = outs[0]
+    tol = dict(rtol=2e-6, atol=1e-6 * float(part.abs().sum(0).max()))
+    assert torch.allclose(dg, dg0, **tol) and torch.allclose(db, db0, **tol), (float((dg - dg0).abs().max()), float((db - db0).abs().max()))
+    assert torch.allclose(coef, coef0, rtol=2e-6, atol=tol['atol'] / npix)
+    # the partial rows the fused launch leaves behind are the reduce kernel's rows
+    assert torch.equal(ws.view(torch.float32)[:nblk * 2 * c].reshape(nblk, 2, c), part)
+
+
 @pytest.mark.parametrize('c,npix,nrows', [(32, 4096, 7), (256, 8192, 64), (64, 1000, 256), (128, 32768, 33)])
 def test_batch_norm_finalize_fused_into_apply(ops, c, npix, nrows):
     """imm_bn_apply_fused / imm_bn_bwd_apply_fused == the finalize + apply pairs (same arithmetic; the partial rows are
