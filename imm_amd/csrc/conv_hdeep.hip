@@ -15,6 +15,7 @@
 // taps 0-5, the rest are no-op pieces into a dump slot), so one counted s_waitcnt vmcnt per tap is exact.
 #include "conv_common.h"
 #include <stdlib.h>
+#include <stdio.h>
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
@@ -34,6 +35,7 @@ struct HdArgs {
   int n_patches, patches_x, patches_y;
   int n_wg;                              // n_patches * n_nblk
   int n_img;                             // batch (MAP8 tiles hold two images)
+  unsigned long long* prof;              // IMM_HDEEP_PROF=1: wall-clock stamps of workgroup 0 / wave 0 (diagnosis only)
 };
 
 __device__ __forceinline__ void hd_dma16(u32x4_t rsrc, uint32_t lds_addr, uint32_t voff, uint32_t soff) {
@@ -54,14 +56,33 @@ __device__ __forceinline__ int hd_bidx(int row, int chunk) { return row * 8 + (c
 
 template <int V> struct HdInt { static constexpr int value = V; };
 
+// total over each row of 16 lanes, in every lane: x += row_ror(x, 8), 4, 2, 1 — the rotation rides on the add (one VALU
+// instruction per step; s_nop 1 = the two wait states a DPP read needs after the VALU write of its source)
+__device__ __forceinline__ float hd_row_sum16(float x) {
+  float y;
+  asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+               "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+               "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+               "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1"
+               : "=&v"(y) : "v"(x));
+  return y;
+}
+
 // MAP8: the maps are 8x8 (VGG conv5 at 128x128 inputs): a workgroup tile is TWO whole images (each with its own 10x10
 // zero-padded halo), wave wm owns image wm, and an MFMA operand row of 16 pixels is two image rows of 8.
-template <typename ET, int BN, int NW, int PH, bool MAP8 = false>
+// PERSIST (round 2): the grid is one workgroup per CU and a workgroup walks tiles w = blockIdx.x, +gridDim.x, ...  The
+// loader simply keeps going across the tile boundary — during the last taps of a tile the ring receives the first filter
+// taps of the NEXT tile and the free halo stage its first slice — so the prologue burst (every CU fetching ~100 KB at once:
+// ~4 us, MI355X_MICROARCH.md "prologue HBM burst") and the store burst of the epilogue overlap with matrix work instead of
+// adding ~6 us per tile (conv2_2: 24 of 78 us).  The counted vmcnt waits stay exact for the DMA loads: the epilogue's stores
+// and mask loads only ADD to the counter (waits become conservative, never early).
+template <typename ET, int BN, int NW, int PH, bool MAP8 = false, int NSB_ = 0, bool PERSIST = false>
 __global__ __launch_bounds__(NW * 64) void conv_hdeep_kernel(const HdArgs ha) {
   const ConvArgs& a = ha.c;
   static_assert((NW == 8 && PH == 16) || (NW == 4 && PH == 8), "wave (wm, wn) owns patch rows 4wm..4wm+3 x BN/2 channels");
   static_assert(!MAP8 || NW == 4, "two 8x8 images per 4-wave workgroup");
-  constexpr int HD_NSB = MAP8 ? 3 : 4;                 // filter-slice ring depth (MAP8: 3 keeps two workgroups per CU)
+  static_assert(!(PERSIST && MAP8), "persistent tiles: 16x16 / 8x16 patches only");
+  constexpr int HD_NSB = NSB_ ? NSB_ : MAP8 ? 3 : 4;   // filter-slice ring depth (MAP8: 3 keeps two workgroups per CU)
   constexpr int NPIECE = MAP8 ? 7 : 6;                 // halo DMA pieces per wave and slice
   constexpr int TN = BN / 2, MT = 4, NT = TN / 16;
   constexpr int B_I = BN / (8 * NW);                   // filter DMA instructions per wave and tap (BN rows / 8 / NW waves)
@@ -79,86 +100,117 @@ __global__ __launch_bounds__(NW * 64) void conv_hdeep_kernel(const HdArgs ha) {
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid >> 1, wn = wid & 1;
   const int frow = lane & 15, q = lane >> 4;
-  int bid = blockIdx.x;
-  {   // XCD-contiguous order: the n-blocks of a patch and neighbouring patches share one L2
-    const int xq = ha.n_wg >> 3, xr = ha.n_wg & 7, xcd = bid & 7;
-    bid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
-  }
-  const int nblk = bid % a.n_nblk, patch = bid / a.n_nblk;
   const int per_img = ha.patches_x * ha.patches_y;
-  // MAP8: `patch` is a pair of images (2*patch, 2*patch + 1), origin (0, 0)
-  const int img = MAP8 ? 2 * patch : patch / per_img, pr = MAP8 ? 0 : patch - img * per_img;
-  const int y0 = MAP8 ? 0 : (pr / ha.patches_x) * PH, x0 = MAP8 ? 0 : (pr % ha.patches_x) * HD_PW;
-  const int n0 = nblk * BN;
-
   const uint64_t xa = (uint64_t)a.x, wa = (uint64_t)a.wt;
   const u32x4_t xr = {(uint32_t)xa, (uint32_t)(xa >> 32) & 0xffffu, a.x_bytes, 0x00020000u};
   const u32x4_t wr = {(uint32_t)wa, (uint32_t)(wa >> 32) & 0xffffu, a.wt_bytes, 0x00020000u};
   const uint32_t lds_base = (uint32_t)(size_t)(lds_void_t*)smem;
 
-  // ---- loader state ------------------------------------------------------------------------------------------
-  // halo piece k of this wave = instruction wid + NW*k (k < 6; instructions >= HINSTR do not exist -> dump slot)
-  uint32_t h_voff[NPIECE];
+  // ---- tile state ----------------------------------------------------------------------------------------------------
+  // ONE set of loader registers (the DMA offsets of the tile whose data is being fetched: the current tile, and from the
+  // last slice on the next one) + the coordinates of the tile being computed (e_*, for the epilogue) and of the next (n_*).
+  int e_patch, e_img, e_y0, e_x0, e_n0, n_patch = 0, n_img = 0, n_y0 = 0, n_x0 = 0, n_n0 = 0;
+  uint32_t h_voff[NPIECE];       // halo piece k of this wave = instruction wid + NW*k (instructions >= HINSTR: dump slot)
+  uint32_t h_soff;
+  uint32_t b_voff[B_I], nb_voff[B_I];
+  auto locate = [&](int w, int& patch, int& img, int& y0, int& x0, int& n0) {
+    int bid = w;
+    {   // XCD-contiguous order: the n-blocks of a patch and neighbouring patches share one L2
+      const int xq = ha.n_wg >> 3, xr_ = ha.n_wg & 7, xcd = bid & 7;
+      bid = (xcd < xr_ ? xcd * (xq + 1) : xr_ * (xq + 1) + (xcd - xr_) * xq) + (bid >> 3);
+    }
+    const int nblk = bid % a.n_nblk;
+    patch = bid / a.n_nblk;
+    // MAP8: `patch` is a pair of images (2*patch, 2*patch + 1), origin (0, 0)
+    img = MAP8 ? 2 * patch : patch / per_img;
+    const int pr = MAP8 ? 0 : patch - img * per_img;
+    y0 = MAP8 ? 0 : (pr / ha.patches_x) * PH; x0 = MAP8 ? 0 : (pr % ha.patches_x) * HD_PW;
+    n0 = nblk * BN;
+  };
+  auto halo_offsets = [&](int img, int y0, int x0) {
 #pragma unroll
-  for (int k = 0; k < NPIECE; ++k) {
-    const int hp = (wid + NW * k) * 8 + (lane >> 3);
-    int hy, hx, il = 0;                                // halo row / column (, image of the pair)
-    if (MAP8) { il = hp / 100; const int rr = hp - il * 100; hy = rr / 10; hx = rr - hy * 10; }
-    else { hy = hp / HD_HW; hx = hp - hy * HD_HW; }
-    const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
-    const bool ok = hp < SLOTS && (unsigned)iy < (unsigned)a.hi && (unsigned)ix < (unsigned)a.wi && (!MAP8 || img + il < ha.n_img);
-    h_voff[k] = ok ? (uint32_t)(((il * a.hi + iy) * a.wi + ix) * a.ldx * 2 + (((lane & 7) ^ hd_swz(hx)) * 16)) : HD_OOB;
-  }
-  const uint32_t img_soff = (uint32_t)(img * a.hi * a.wi) * (uint32_t)(a.ldx * 2);
-  uint32_t b_voff[B_I];
+    for (int k = 0; k < NPIECE; ++k) {
+      const int hp = (wid + NW * k) * 8 + (lane >> 3);
+      int hy, hx, il = 0;                                // halo row / column (, image of the pair)
+      if (MAP8) { il = hp / 100; const int rr = hp - il * 100; hy = rr / 10; hx = rr - hy * 10; }
+      else { hy = hp / HD_HW; hx = hp - hy * HD_HW; }
+      const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+      const bool ok = hp < SLOTS && (unsigned)iy < (unsigned)a.hi && (unsigned)ix < (unsigned)a.wi && (!MAP8 || img + il < ha.n_img);
+      h_voff[k] = ok ? (uint32_t)(((il * a.hi + iy) * a.wi + ix) * a.ldx * 2 + (((lane & 7) ^ hd_swz(hx)) * 16)) : HD_OOB;
+    }
+    h_soff = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(img * a.hi * a.wi) * (uint32_t)(a.ldx * 2)));
+  };
+  auto filter_offsets = [&](int n0, uint32_t (&bv)[B_I]) {
 #pragma unroll
-  for (int j = 0; j < B_I; ++j) {
-    const int r = (wid * B_I + j) * 8 + (lane >> 3);
-    b_voff[j] = (n0 + r < a.co) ? (uint32_t)((n0 + r) * a.kpad * 2 + (((lane & 7) ^ hd_bswz<NT>(r)) * 16)) : HD_OOB;
-  }
+    for (int j = 0; j < B_I; ++j) {
+      const int r = (wid * B_I + j) * 8 + (lane >> 3);
+      bv[j] = (n0 + r < a.co) ? (uint32_t)((n0 + r) * a.kpad * 2 + (((lane & 7) ^ hd_bswz<NT>(r)) * 16)) : HD_OOB;
+    }
+  };
   const int ncc = a.ci8 >> 3;                          // 64-channel slices
-  const int T = ncc * 9;                               // taps in total
-  auto issue_b = [&](int t, int stage) {
+  const int T = ncc * 9;                               // taps per tile
+  // filter tap t (< T) of the loader's tile -> ring stage; real = false: a no-op piece that keeps the per-tap DMA count exact
+  auto issue_b = [&](int t, int stage, bool real) {
     // tap t = slice cc, tap index tp: filter columns [tp*ci + cc*64, +64) of Wt[n][kpad]
     const int cc = t / 9, tp = t - cc * 9;
     const uint32_t soff = (uint32_t)((tp * (a.ci8 << 3) + cc * 64) * 2);
-    const bool real = t < T;
 #pragma unroll
     for (int j = 0; j < B_I; ++j)
       hd_dma16(wr, lds_base + (uint32_t)((BRING_U4 + stage * B_U4 + (wid * B_I + j) * 64) * 16), real ? b_voff[j] : HD_OOB, soff);
   };
-  auto issue_halo_piece = [&](int cc, int k, bool real) {
+  // halo piece k of slice cc of the loader's tile -> halo stage hs
+  auto issue_halo_piece = [&](int cc, int hs, int k, bool real) {
     const int i = wid + NW * k;
     const bool exists = real && i < HINSTR;
-    const uint32_t dst = exists ? (uint32_t)(((cc & 1) * HSTAGE + i * 64) * 16) : (uint32_t)(DUMP_U4 * 16);
-    hd_dma16(xr, lds_base + dst, exists ? h_voff[k < NPIECE ? k : 0] : HD_OOB, img_soff + (uint32_t)(cc * 128));
+    const uint32_t dst = exists ? (uint32_t)((hs * HSTAGE + i * 64) * 16) : (uint32_t)(DUMP_U4 * 16);
+    hd_dma16(xr, lds_base + dst, exists ? h_voff[k < NPIECE ? k : 0] : HD_OOB, h_soff + (uint32_t)(cc * 128));
   };
+
+  const int G = PERSIST ? (int)gridDim.x : 1;
+  const int n_mine = PERSIST ? (ha.n_wg - (int)blockIdx.x + G - 1) / G : 1;
+  locate(blockIdx.x, e_patch, e_img, e_y0, e_x0, e_n0);
+  halo_offsets(e_img, e_y0, e_x0);
+  filter_offsets(e_n0, b_voff);
 
   // ---- prologue: halo of slice 0, filter taps 0 .. NSB-1 (every ring stage) ---------------------------------------
 #pragma unroll
-  for (int k = 0; k < NPIECE; ++k) issue_halo_piece(0, k, true);
+  for (int k = 0; k < NPIECE; ++k) issue_halo_piece(0, 0, k, true);
 #pragma unroll
-  for (int t = 0; t < HD_NSB; ++t) issue_b(t, t);
+  for (int t = 0; t < HD_NSB; ++t) issue_b(t, t, true);
 
-  f32x4_t acc[MT][NT];
+  // The accumulators START at the bias: its loads are issued here, behind the prologue DMA (an epilogue that begins with a
+  // dependent global load costs its whole latency: ~0.6 us of the 2.2 us measured per tile), and the epilogue has no adds.
+  const bool f_bias = a.flags & IMM_CONV_BIAS;
+  f32x4_t acc[MT][NT], bias4[NT];
+  auto load_bias = [&](int n0_) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const float4 b4 = f_bias ? *(const float4*)(a.bias + n0_ + wn * TN + q * (4 * NT) + j * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      bias4[j] = f32x4_t{b4.x, b4.y, b4.z, b4.w};
+    }
+  };
+  load_bias(e_n0);
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
-    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NT; ++j) acc[i][j] = bias4[j];
 
-  // per-lane fragment offsets (uint4 units): A = halo pixel (row wm*4 + i + ky, col frow + kx), B = filter row
-  int aoff[3];
+  // per-lane fragment offsets (uint4 units): A = halo pixel (row wm*4 + i + ky, col frow + kx), B = filter row.  Persistent
+  // tiles recompute them after every epilogue (11 registers that need not live through it).
+  int aoff[3], boff[NT][2];
+  auto frag_offsets = [&]() {
 #pragma unroll
-  for (int kx = 0; kx < 3; ++kx) {
-    if (MAP8) aoff[kx] = (wm * 100 + (frow >> 3) * 10 + (frow & 7) + kx) * 8 + (q ^ hd_swz((frow & 7) + kx));
-    else aoff[kx] = (wm * 4 * HD_HW + frow + kx) * 8 + (q ^ hd_swz(frow + kx));
-  }
-  int boff[NT][2];
+    for (int kx = 0; kx < 3; ++kx) {
+      if (MAP8) aoff[kx] = (wm * 100 + (frow >> 3) * 10 + (frow & 7) + kx) * 8 + (q ^ hd_swz((frow & 7) + kx));
+      else aoff[kx] = (wm * 4 * HD_HW + frow + kx) * 8 + (q ^ hd_swz(frow + kx));
+    }
 #pragma unroll
-  for (int j = 0; j < NT; ++j)
+    for (int j = 0; j < NT; ++j)
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-      boff[j][ks] = hd_bidx<NT>(wn * TN + (frow >> 2) * (4 * NT) + j * 4 + (frow & 3), ks * 4 + q);
+      for (int ks = 0; ks < 2; ++ks)
+        boff[j][ks] = hd_bidx<NT>(wn * TN + (frow >> 2) * (4 * NT) + j * 4 + (frow & 3), ks * 4 + q);
+  };
+  frag_offsets();
 
   // Software pipeline at k-step granularity (a tap = two k-steps of 32 channels): the fragments of the next k-step are
   // read from LDS while the 16 MFMAs of the current one run, and a k-step's MFMAs are already queued when the wave
@@ -183,16 +235,36 @@ __global__ __launch_bounds__(NW * 64) void conv_hdeep_kernel(const HdArgs ha) {
   __builtin_amdgcn_s_barrier();
   read_frags(0, smem, smem + BRING_U4, 0, 0);
 
-  int t = 0, bs = 0;
-  for (int cc = 0; cc < ncc; ++cc) {
+  int bs = 0, gs = 0;                                  // ring stage of the current tap; slices done so far (halo stage = parity)
+  // -DIMM_HDEEP_PROFILE + IMM_HDEEP_PROF=1: workgroup 0 / wave 0 stamps the wall clock at tile / tap boundaries (how the
+  // 2.2 us epilogue, the 0.84 us tile setup and the 0.84 us taps of DESIGN.md were measured); compiled out otherwise
+#ifdef IMM_HDEEP_PROFILE
+  int pidx = 1;
+  const bool prof = ha.prof != nullptr && blockIdx.x == 0 && wid == 0;
+#define HD_STAMP(code) do { if (prof && pidx < 4000) { if (lane == 0) ha.prof[pidx] = ((unsigned long long)(code) << 56) | (wall_clock64() & 0xffffffffffffffull); ++pidx; } } while (0)
+#else
+#define HD_STAMP(code) do { } while (0)
+#endif
+  for (int it = 0; it < n_mine; ++it) {
+  const bool have_next = PERSIST && it + 1 < n_mine;
+  int t = 0;
+  for (int cc = 0; cc < ncc; ++cc, ++gs) {
     const bool next_slice = cc + 1 < ncc;
-    const uint4* Hc = smem + (cc & 1) * HSTAGE;
+    if (PERSIST && !next_slice && have_next) {         // the loader turns to the next tile during this slice: its halo now,
+      HD_STAMP(1);                                     // its filter rows once this tile's last tap has been requested
+      locate(blockIdx.x + (it + 1) * G, n_patch, n_img, n_y0, n_x0, n_n0);
+      halo_offsets(n_img, n_y0, n_x0);
+      filter_offsets(n_n0, nb_voff);
+      HD_STAMP(2);
+    }
+    const uint4* Hc = smem + (gs & 1) * HSTAGE;
+    const int hs_next = (gs + 1) & 1;
 #pragma unroll
     for (int tp = 0; tp < 9; ++tp) {
       const int ky = tp / 3, kx = tp % 3;
-      // next tap: (tp+1) of this slice, or tap 0 of the next slice (other halo stage)
+      // next tap: (tp+1) of this slice, or tap 0 of the next slice / the next tile's first slice (other halo stage)
       const int ntp = tp == 8 ? 0 : tp + 1;
-      const uint4* Hn = smem + ((tp == 8 ? cc + 1 : cc) & 1) * HSTAGE;
+      const uint4* Hn = smem + ((tp == 8 ? gs + 1 : gs) & 1) * HSTAGE;
       const uint4* Bc = smem + BRING_U4 + bs * B_U4;
       int nbs = bs + 1; if (nbs == HD_NSB) nbs = 0;
       const uint4* Bn = smem + BRING_U4 + nbs * B_U4;
@@ -214,14 +286,24 @@ __global__ __launch_bounds__(NW * 64) void conv_hdeep_kernel(const HdArgs ha) {
       }
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (t == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((HD_NSB - 2) * B_I) : "memory");          // prologue: taps 2.. in flight
-      else if (t == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((HD_NSB - 2) * B_I + 1) : "memory");
+      // first tile only: the prologue issued its filter taps back to back (no halo pieces in between)
+      if (it == 0 && t == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((HD_NSB - 2) * B_I) : "memory");          // taps 2.. in flight
+      else if (it == 0 && t == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((HD_NSB - 2) * B_I + 1) : "memory");
+      else if (it > 0 && t < HD_NSB - 1) { /* taps 1 .. NSB-1 landed before the previous tile's epilogue (drain below): no wait, so
+                                              that its output stores get NSB-1 taps to be acknowledged before a counted wait sees them */ }
       else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WN_STEADY) : "memory");
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
-      issue_b(t + HD_NSB, bs);
-      issue_halo_piece(cc + 1, tp, next_slice && tp < NPIECE);
-      read_frags(0, Hn, Bn, ntp / 3, ntp % 3);         // past the last tap: reads of landed no-op data, never used
+      HD_STAMP(3);
+      if (PERSIST && tp == 9 - HD_NSB && !next_slice && have_next) {          // t + NSB == T: the ring runs on into the next tile
+#pragma unroll
+        for (int j = 0; j < B_I; ++j) b_voff[j] = nb_voff[j];
+      }
+      if (t + HD_NSB < T) issue_b(t + HD_NSB, bs, true);
+      else issue_b(t + HD_NSB - T, bs, have_next);
+      issue_halo_piece(next_slice ? cc + 1 : 0, hs_next, tp, (next_slice || have_next) && tp < NPIECE);   // ... and so does the halo
+      // (k-step 0 of the next tap; not across a tile boundary: 32 fragment registers would stay live through the epilogue)
+      if (!(PERSIST && tp == 8 && !next_slice)) read_frags(0, Hn, Bn, ntp / 3, ntp % 3);
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -236,61 +318,119 @@ __global__ __launch_bounds__(NW * 64) void conv_hdeep_kernel(const HdArgs ha) {
       ++t;
     }
   }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // trailing no-op pieces: no LDS-DMA may outlive the workgroup
-  __syncthreads();
+  HD_STAMP(4);
+  if (!have_next) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // trailing no-op pieces: no LDS-DMA may outlive the workgroup
+    __syncthreads();
+  } else {
+    // the next tile's halo and first NSB filter taps (issued 0.5 .. NSB-0.5 taps ago) have landed: from here on only this
+    // tile's output stores are outstanding, and the next tile's first NSB-1 taps need no counted wait
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  HD_STAMP(5);
+  const int img = e_img, y0 = e_y0, x0 = e_x0, n0 = e_n0, patch = e_patch;
 
   // ---- epilogue: lane = pixel (row wm*4 + i, col frow), 4*NT consecutive channels (see hd_bswz) ----------------------
-  const bool f_bias = a.flags & IMM_CONV_BIAS, f_relu = a.flags & IMM_CONV_RELU;
-  const bool f_stats = a.flags & IMM_CONV_STATS, f_mask = a.flags & IMM_CONV_MASK;
+  // Two waves per SIMD run this at the same time with no matrix work to hide behind: it is VALU-bound (measured with the
+  // in-kernel clock: 2.2 us per tile for ~450 VALU instructions per wave in the generic form).  Hence one uniform branch per
+  // variant instead of per-value selects, packed f32 adds, ReLU and the ReLU-backward mask as PACKED 16-bit integer operations
+  // on the converted outputs (bf16 / f16 are sign-magnitude: max_i16(x, 0) == relu(x); (max_i16(mask, 0) != 0) == (mask > 0)).
+  const bool f_relu = a.flags & IMM_CONV_RELU;
+  // (persistent tiles: launches without batch-norm sums only — the host falls back to one workgroup per tile otherwise;
+  // the sums' 32 extra registers do not fit beside the loop state that stays live through this epilogue)
+  const bool f_stats = !PERSIST && (a.flags & IMM_CONV_STATS), f_mask = a.flags & IMM_CONV_MASK;
   const int nb = n0 + wn * TN + q * (4 * NT);          // first channel of this lane
-  float s1[NT][4], s2[NT][4], bv[NT][4];
+  float s1[NT][4], s2[NT][4];
 #pragma unroll
   for (int j = 0; j < NT; ++j)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { bv[j][r] = f_bias ? a.bias[nb + j * 4 + r] : 0.f; s1[j][r] = 0.f; s2[j][r] = 0.f; }
+    for (int r = 0; r < 4; ++r) { s1[j][r] = 0.f; s2[j][r] = 0.f; }
+  if (have_next) load_bias(n_n0);                      // the next tile's accumulators start from it (below)
+  const int64_t m_first = MAP8 ? ((int64_t)(img + wm) * 8 + (frow >> 3)) * 8 + (frow & 7)
+                               : ((int64_t)img * a.ho + y0 + wm * 4) * a.wo + x0 + frow;
+  const int64_t m_step = MAP8 ? 16 : a.wo;             // pixel index of tile row i = m_first + i * m_step
+  const bool rows_exist = !MAP8 || img + wm < ha.n_img;   // odd batch: the second image of the last pair does not exist
+  typedef short s16x2_t __attribute__((ext_vector_type(2)));
+  typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+  const s16x2_t zero2 = {0, 0}, one2 = {1, 1};
+  if (!f_stats && rows_exist) {
+    // ---- plain / masked store: ~12 (+12 with the mask) VALU per 8 outputs --------------------------------------------
 #pragma unroll
-  for (int i = 0; i < MT; ++i) {
-    const int64_t m = MAP8 ? ((int64_t)(img + wm) * 8 + 2 * i + (frow >> 3)) * 8 + (frow & 7)
-                           : ((int64_t)img * a.ho + y0 + wm * 4 + i) * a.wo + x0 + frow;
-    if (MAP8 && img + wm >= ha.n_img) continue;        // odd batch: the second image of the last pair does not exist
+    for (int i = 0; i < MT; ++i) {
+      const int64_t m = m_first + i * m_step;
 #pragma unroll
-    for (int h = 0; h < NT / 2; ++h) {                 // 8 channels = one 16-byte store
-      float v[8];
+      for (int h = 0; h < NT / 2; ++h) {               // 8 channels = one 16-byte store
+        uint32_t w[4];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        v[e] = acc[i][2 * h + (e >> 2)][e & 3] + bv[2 * h + (e >> 2)][e & 3];
-        if (f_relu) v[e] = fmaxf(v[e], 0.f);
-      }
-      float mf[8];
-      if (f_mask) {
-        unpack8<ET>(*(const uint4*)(a.mask + m * a.ldmask + nb + 8 * h), mf);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) if (!(mf[e] > 0.f)) v[e] = 0.f;
-      }
-      if (f_stats) {
-        // STATS | MASK: second sum = sum(v * mask_ref) — the batch-norm backward sums of the layer this gradient enters
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          s1[2 * h + (e >> 2)][e & 3] += v[e];
-          s2[2 * h + (e >> 2)][e & 3] += v[e] * (f_mask ? mf[e] : v[e]);
+        for (int e = 0; e < 4; ++e) {                  // pair e = channels 2e, 2e+1 of the eight
+          const int j = 2 * h + (e >> 1), r = (e & 1) * 2;
+          w[e] = ET::pack2(acc[i][j][r], acc[i][j][r + 1]);
         }
+        if (f_relu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            w[e] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2_t, w[e]), zero2));
+        }
+        if (f_mask) {
+          const uint4 mk = *(const uint4*)(a.mask + m * a.ldmask + nb + 8 * h);
+          const uint32_t mw[4] = {mk.x, mk.y, mk.z, mk.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const s16x2_t pos = __builtin_elementwise_min(__builtin_elementwise_max(__builtin_bit_cast(s16x2_t, mw[e]), zero2), one2);   // 1 where mask > 0
+            w[e] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2_t, w[e]) * __builtin_bit_cast(u16x2_t, pos));
+          }
+        }
+        *(uint4*)((uint16_t*)a.y + m * a.ldy + nb + 8 * h) = make_uint4(w[0], w[1], w[2], w[3]);
       }
-      *(uint4*)((uint16_t*)a.y + m * a.ldy + nb + 8 * h) = pack8<ET>(v);
+    }
+  } else if (rows_exist) {
+    // ---- batch-norm statistics (+ optional mask): the sums need the f32 values ----------------------------------------
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int64_t m = m_first + i * m_step;
+#pragma unroll
+      for (int h = 0; h < NT / 2; ++h) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int j = 2 * h + (e >> 1), r = (e & 1) * 2;
+          v[2 * e] = acc[i][j][r]; v[2 * e + 1] = acc[i][j][r + 1];
+        }
+        if (f_relu) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        if (f_mask) {
+          // STATS | MASK: second sum = sum(v * mask_ref) — the batch-norm backward sums of the layer this gradient enters
+          float mf[8];
+          unpack8<ET>(*(const uint4*)(a.mask + m * a.ldmask + nb + 8 * h), mf);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            if (!(mf[e] > 0.f)) v[e] = 0.f;
+            s1[2 * h + (e >> 2)][e & 3] += v[e];
+            s2[2 * h + (e >> 2)][e & 3] += v[e] * mf[e];
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            s1[2 * h + (e >> 2)][e & 3] += v[e];
+            s2[2 * h + (e >> 2)][e & 3] = fmaf(v[e], v[e], s2[2 * h + (e >> 2)][e & 3]);
+          }
+        }
+        *(uint4*)((uint16_t*)a.y + m * a.ldy + nb + 8 * h) = pack8<ET>(v);
+      }
     }
   }
   if (f_stats) {
-    float* red = (float*)smem;                         // [4 wm][2][BN]
+    // [NW/2 wm][2][BN]; persistent tiles: behind the filter ring (the halo stages are receiving the next tile's data)
+    // (the previous tile's sums were read at least a tile's worth of barriers ago)
+    float* red = (float*)(PERSIST ? smem + BRING_U4 + HD_NSB * B_U4 : smem);
+    // sum over the 16 pixel lanes of a row: DPP row rotations (plain VALU; the ds_bpermute shuffles went through the LDS)
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {
-          s1[j][r] += __shfl_xor(s1[j][r], o, 64);
-          s2[j][r] += __shfl_xor(s2[j][r], o, 64);
-        }
-      }
+      for (int r = 0; r < 4; ++r) { s1[j][r] = hd_row_sum16(s1[j][r]); s2[j][r] = hd_row_sum16(s2[j][r]); }
     if (frow == 0) {
 #pragma unroll
       for (int j = 0; j < NT; ++j)
@@ -301,7 +441,8 @@ __global__ __launch_bounds__(NW * 64) void conv_hdeep_kernel(const HdArgs ha) {
           red[(wm * 2 + 1) * BN + nl] = s2[j][r];
         }
     }
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // LDS only: a __syncthreads would also drain the next tile's DMA
+    __builtin_amdgcn_s_barrier();
     if (tid < BN) {
       float t1 = 0.f, t2 = 0.f;
 #pragma unroll
@@ -310,6 +451,21 @@ __global__ __launch_bounds__(NW * 64) void conv_hdeep_kernel(const HdArgs ha) {
       a.stats[((int64_t)patch * 2 + 1) * a.co + n0 + tid] = t2;
     }
   }
+  HD_STAMP(6);
+  if (have_next) {
+    frag_offsets();
+    read_frags(0, smem + (gs & 1) * HSTAGE, smem + BRING_U4 + bs * B_U4, 0, 0);   // next tile, tap 0 (landed before the epilogue)
+    e_patch = n_patch; e_img = n_img; e_y0 = n_y0; e_x0 = n_x0; e_n0 = n_n0;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] = bias4[j];
+  }
+  }   // tiles of this workgroup
+#ifdef IMM_HDEEP_PROFILE
+  if (prof && lane == 0) ha.prof[0] = (unsigned long long)pidx;
+#endif
+#undef HD_STAMP
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -331,7 +487,7 @@ static int hd_num_cu() {
 //   16 x 16 x 64 when THAT does;
 //   else 8 x 16 x 64 (4 waves, two workgroups per CU) when the map height allows — the small-grid layers (16x16 maps of
 //   a 32-image batch: 32 patches) otherwise leave half the chip idle.
-struct HdPlan { int ph, bn, n_patches, n_wg; bool map8; };
+struct HdPlan { int ph, bn, n_patches, n_wg; bool map8, persist; };
 
 static HdPlan hd_plan(const imm_conv_desc* d) {
   static const bool no_small = getenv("IMM_HDEEP_NO_SMALL") != nullptr;
@@ -339,7 +495,7 @@ static HdPlan hd_plan(const imm_conv_desc* d) {
   static const int small_below = getenv("IMM_HDEEP_SMALL_BELOW") ? atoi(getenv("IMM_HDEEP_SMALL_BELOW")) : 4;   // x CUs
   static const bool no_big = getenv("IMM_HDEEP_NO_BIG") != nullptr;
   HdPlan p;
-  p.map8 = false;
+  p.map8 = false; p.persist = false;
   if (d->ho == 8 && d->wo == 8) {                      // two whole 8x8 images per (4-wave) workgroup
     static const bool no_map8 = getenv("IMM_HDEEP_NO_MAP8") != nullptr;
     p.ph = 8; p.bn = 64; p.map8 = true;
@@ -353,6 +509,9 @@ static HdPlan hd_plan(const imm_conv_desc* d) {
   else if (!no_small) { p.ph = 8; p.bn = 64; p.n_patches = d->batch * (d->ho / 8) * (d->wo / HD_PW); }
   else { p.ph = 16; p.bn = 64; p.n_patches = np16; }
   p.n_wg = p.n_patches * (d->co / p.bn);
+  // more tiles than CUs: one persistent workgroup per CU walks them (IMM_HDEEP_PERSIST=0: one workgroup per tile)
+  static const bool persist = !(getenv("IMM_HDEEP_PERSIST") && atoi(getenv("IMM_HDEEP_PERSIST")) == 0);
+  p.persist = persist && p.ph == 16 && p.n_wg > cus && (cus % 8) == 0 && !(d->flags & IMM_CONV_STATS);
   return p;
 }
 
@@ -374,29 +533,52 @@ bool imm_hdeep_applicable(const imm_conv_desc* d) {
 
 int imm_hdeep_stats_blocks(const imm_conv_desc* d) { return hd_plan(d).n_patches; }
 
-template <typename ET, int BN, int NW, int PH, bool MAP8 = false>
+template <typename ET, int BN, int NW, int PH, bool MAP8 = false, int NSB_ = 0, bool PERSIST = false>
 static void hd_launch_cfg(const HdArgs& ha, hipStream_t s) {
-  constexpr int hstage = MAP8 ? 25 * 64 : HD_HSTAGE(PH), nsb = MAP8 ? 3 : 4;
-  constexpr int lds = (2 * hstage + 64 + nsb * BN * 8) * 16;
+  constexpr int hstage = MAP8 ? 25 * 64 : HD_HSTAGE(PH), nsb = NSB_ ? NSB_ : MAP8 ? 3 : 4;
+  constexpr int lds = (2 * hstage + 64 + nsb * BN * 8) * 16 + (PERSIST ? NW * BN * 4 : 0);   // + [NW/2][2][BN] f32 stats scratch
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)conv_hdeep_kernel<ET, BN, NW, PH, MAP8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)conv_hdeep_kernel<ET, BN, NW, PH, MAP8, NSB_, PERSIST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_hdeep_kernel<ET, BN, NW, PH, MAP8>), dim3(ha.n_wg), dim3(NW * 64), lds, s, ha);
+  const int grid = PERSIST ? (ha.n_wg < hd_num_cu() ? ha.n_wg : hd_num_cu()) : ha.n_wg;
+  hipLaunchKernelGGL((conv_hdeep_kernel<ET, BN, NW, PH, MAP8, NSB_, PERSIST>), dim3(grid), dim3(NW * 64), lds, s, ha);
 }
 
 template <typename ET>
 static void hd_launch(const HdPlan& p, const HdArgs& ha, hipStream_t s) {
   if (p.map8) hd_launch_cfg<ET, 64, 4, 8, true>(ha, s);
+  else if (p.ph == 16 && p.bn == 128 && p.persist) hd_launch_cfg<ET, 128, 8, 16, false, 0, true>(ha, s);
   else if (p.ph == 16 && p.bn == 128) hd_launch_cfg<ET, 128, 8, 16>(ha, s);
+  else if (p.ph == 16 && p.persist) hd_launch_cfg<ET, 64, 8, 16, false, 0, true>(ha, s);
   else if (p.ph == 16) hd_launch_cfg<ET, 64, 8, 16>(ha, s);
   else hd_launch_cfg<ET, 64, 4, 8>(ha, s);
+}
+
+// IMM_HDEEP_PROF=1: workgroup 0 / wave 0 of every hdeep launch stamps the device wall clock (100 MHz) at its tile / tap
+// boundaries into one buffer (the last launch wins); printed at process exit.  Diagnosis only.
+static unsigned long long* hd_prof_buf = nullptr;
+static void hd_prof_dump() {
+  if (!hd_prof_buf) return;
+  static unsigned long long host[4000];
+  if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(host, hd_prof_buf, sizeof(host), hipMemcpyDeviceToHost) != hipSuccess) return;
+  const int n = (int)host[0] < 4000 ? (int)host[0] : 4000;
+  const unsigned long long mask = 0xffffffffffffffull;
+  for (int i = 1; i < n; ++i)
+    fprintf(stderr, "HDPROF %4d code %d  t %9.2f us  (+%7.2f)\n", i, (int)(host[i] >> 56), (double)((host[i] & mask) - (host[1] & mask)) / 100.0,
+            i > 1 ? (double)((host[i] & mask) - (host[i - 1] & mask)) / 100.0 : 0.0);
 }
 
 void imm_conv_hdeep_launch(int dtype, const imm_conv_desc* d, const ConvArgs& a, hipStream_t s) {
   HdArgs ha;
   ha.c = a;
+  static const bool prof = getenv("IMM_HDEEP_PROF") != nullptr;
+  if (prof && !hd_prof_buf && hipMalloc((void**)&hd_prof_buf, 4000 * sizeof(unsigned long long)) == hipSuccess) {
+    (void)hipMemset(hd_prof_buf, 0, 4000 * sizeof(unsigned long long));
+    atexit(hd_prof_dump);
+  }
+  ha.prof = prof ? hd_prof_buf : nullptr;
   const HdPlan p = hd_plan(d);
   ha.patches_x = p.map8 ? 1 : d->wo / HD_PW; ha.patches_y = p.map8 ? 1 : d->ho / p.ph;
   ha.n_img = d->batch;

@@ -78,6 +78,10 @@ CONV_CASES = [
     (13, 32, 128, 128, 256, 3, 1, False, 'hdeep_bn64_two_slices'),
     (64, 16, 128, 128, 512, 3, 1, False, 'hdeep_bn128_whole_image_patches'),
     (7, 64, 192, 192, 128, 3, 1, False, 'hdeep_three_slices'),
+    # more tiles than CUs: one persistent workgroup per CU walks them (ragged: some take two tiles, some one; one / two slices)
+    (20, 64, 128, 128, 128, 3, 1, False, 'hdeep_persistent_ragged'),
+    (9, 64, 64, 64, 256, 3, 1, False, 'hdeep_persistent_one_slice_two_nblk'),
+    (70, 32, 128, 128, 64, 3, 1, False, 'hdeep_persistent_bn64'),
     # small grids: 8x16 patches, 4 waves, two workgroups per CU
     (32, 16, 128, 128, 256, 3, 1, False, 'hdeep_small_patch'),
     (5, 40, 64, 64, 64, 3, 1, False, 'hdeep_small_patch_h40'),
@@ -133,9 +137,11 @@ def test_conv_forward(ops, case, dt):
                                           (3, 64, 32, 64, torch.bfloat16), (40, 64, 64, 64, torch.bfloat16),
                                           (3, 128, 64, 64, torch.float16), (36, 64, 32, 32, torch.float16),
                                           (14, 32, 128, 256, torch.bfloat16), (64, 16, 256, 256, torch.float16),
-                                          (24, 16, 128, 256, torch.bfloat16), (51, 8, 128, 256, torch.bfloat16)],
+                                          (24, 16, 128, 256, torch.bfloat16), (51, 8, 128, 256, torch.bfloat16),
+                                          (20, 64, 128, 128, torch.bfloat16), (40, 32, 256, 128, torch.float16)],
                          ids=['igemm', 'halo64', 'halo32', 'halo64_32', 'halo32_64', 'halo64_persistent', 'halo64_f16',
-                              'halo32_f16_persistent', 'hdeep', 'hdeep_f16', 'hdeep_small_patch', 'hdeep_map8_odd'])
+                              'halo32_f16_persistent', 'hdeep', 'hdeep_f16', 'hdeep_small_patch', 'hdeep_map8_odd',
+                              'hdeep_persistent', 'hdeep_persistent_f16'])
 def test_conv_relu_stats_mask(ops, B, H, ci, co, dt):
     """Epilogue variants (BN partial sums, ReLU, ReLU-backward mask).  The halo cases run conv_halo2.hip (filter in
     registers, deferred epilogue); the *_persistent cases give every workgroup several patches, i.e. exercise the halo /

@@ -48,7 +48,15 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--ablate', action='store_true')
     ap.add_argument('--wgrad', action='store_true')
+    ap.add_argument('--layers', default='', help="probe shapes instead of the table: 'images,H,ci,co[,k[,stride]];...'")
     args = ap.parse_args()
+    global LAYERS
+    if args.layers:
+        LAYERS = []
+        for item in args.layers.split(';'):
+            v = [int(t) for t in item.split(',')]
+            n, H, ci, co = v[:4]
+            LAYERS.append(('probe %d x %d^2 %d->%d' % (n, H, ci, co), n, H, ci, co, v[4] if len(v) > 4 else 3, v[5] if len(v) > 5 else 1))
     torch.cuda.set_device(0)
     dt = torch.bfloat16
     variants = [('full', 0)]
