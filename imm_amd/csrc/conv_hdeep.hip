@@ -295,21 +295,31 @@ __global__ __launch_bounds__(NW * 64) void conv_hdeep_kernel(const HdArgs ha) {
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
       HD_STAMP(3);
+      // Both waves of a SIMD leave the barrier together: whatever comes first here runs with the matrix pipe idle.  The
+      // fragments of k-step 1 are in registers, so a quarter of its MFMAs goes first and the loader's scalar address
+      // arithmetic + DMA issue (~250 cycles when it led the block, measured as 0.77 us per tap against 0.51 us of MFMA
+      // time) rides in their shadow; the second quarter covers the halo piece, the rest the next tap's fragment reads.
+      constexpr int QM = MT * NT / 4;
+#pragma unroll
+      for (int m = 0; m < QM; ++m) acc[m % MT][m / MT] = ET::mfma(bf[1][m / MT], af[1][m % MT], acc[m % MT][m / MT]);
+      __builtin_amdgcn_sched_barrier(0);
       if (PERSIST && tp == 9 - HD_NSB && !next_slice && have_next) {          // t + NSB == T: the ring runs on into the next tile
 #pragma unroll
         for (int j = 0; j < B_I; ++j) b_voff[j] = nb_voff[j];
       }
       if (t + HD_NSB < T) issue_b(t + HD_NSB, bs, true);
       else issue_b(t + HD_NSB - T, bs, have_next);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int m = QM; m < 2 * QM; ++m) acc[m % MT][m / MT] = ET::mfma(bf[1][m / MT], af[1][m % MT], acc[m % MT][m / MT]);
+      __builtin_amdgcn_sched_barrier(0);
       issue_halo_piece(next_slice ? cc + 1 : 0, hs_next, tp, (next_slice || have_next) && tp < NPIECE);   // ... and so does the halo
       // (k-step 0 of the next tap; not across a tile boundary: 32 fragment registers would stay live through the epilogue)
       if (!(PERSIST && tp == 8 && !next_slice)) read_frags(0, Hn, Bn, ntp / 3, ntp % 3);
 #pragma unroll
-      for (int i = 0; i < MT; ++i)
+      for (int m = 2 * QM; m < MT * NT; ++m) acc[m % MT][m / MT] = ET::mfma(bf[1][m / MT], af[1][m % MT], acc[m % MT][m / MT]);
 #pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = ET::mfma(bf[1][j], af[1][i], acc[i][j]);
-#pragma unroll
-      for (int m = 0; m < MT * NT; ++m) {
+      for (int m = 0; m < 2 * QM; ++m) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x006, 2, 0);
