@@ -20,7 +20,7 @@ CONV_BIAS, CONV_RELU, CONV_STATS, CONV_MASK, CONV_OUT_F32 = 1, 2, 4, 8, 16
 SSE_BLOCKS = 512
 OPTIMIZERS = {'adam': 0, 'adadelta': 1, 'adagrad': 2}      # IMM_OPT_* (scripts/train.py:97-104)
 GAUSS_MODES = {'rot': 0, 'flat': 1, 'ankush': 2}     # IMM_GAUSS_* (config key gauss_mode, imm_model.py:48-72)
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 
 class ImmHipError(RuntimeError):
@@ -61,6 +61,7 @@ _SIGS = {
     'imm_bn_apply_relu': [_P, _I, _L, _I, _I, _P, _P, _I, _P, _I, _P],
     'imm_bn_apply_fused': [_P, _I, _I, _L, _P, _P, _F, _F, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _I, _P, _I, _I, _I, _P],
     'imm_bn_bwd_apply_fused': [_P, _I, _I, _L, _P, _P, _I, _P, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _I, _P],
+    'imm_rows_reduce': [_P, _I, _I, _I, _P, _P],
     'imm_bn_bwd_reduce': [_P, _I, _P, _I, _I, _L, _I, _P, _P, _P, _P, _I, _P, _P],
     'imm_bn_bwd_reduce_finalize': [_P, _I, _P, _I, _I, _L, _I, _P, _P, _P, _P, _I, _L, _P, _P, _P, _P, _P, _P],
     'imm_bn_bwd_blocks': [_L, _I],

@@ -396,6 +396,39 @@ extern "C" int imm_bn_apply_fused(const float* partial, int nblk, int c, int64_t
 }
 
 // ---------------------------------------------------------------------------------------------
+// Row pre-reduction: out[g][w] = sum of rows [g*group, (g+1)*group) of in[rows][width], f64 accumulation in row order.
+// The layers with more than 256 partial rows (128x128 / 64x64 maps) used a finalize launch whose single workgroup per 8..32
+// channels walks all rows (a 9-14 us latency chain per layer, 18 launches per step); 32-row groups reduced in parallel by
+// rows/32 workgroups leave <= 32 rows, which the fused apply passes (imm_bn_apply_fused / imm_bn_bwd_apply_fused) finish.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(EW_THREADS) void rows_reduce_kernel(const float* __restrict__ in, int rows, int width, int group,
+                                                                 float* __restrict__ out) {
+  const int w = blockIdx.y * EW_THREADS + threadIdx.x;
+  if (w >= width) return;
+  const int r0 = blockIdx.x * group, r1 = r0 + group < rows ? r0 + group : rows;
+  const float* col = in + w;
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  int r = r0;
+  for (; r + 7 < r1; r += 8) {                       // 8 loads in flight
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = col[(int64_t)(r + u) * width];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u & 3] += (double)v[u];
+  }
+  for (; r < r1; ++r) acc[0] += (double)col[(int64_t)r * width];
+  out[(int64_t)blockIdx.x * width + w] = (float)((acc[0] + acc[1]) + (acc[2] + acc[3]));
+}
+
+extern "C" int imm_rows_reduce(const float* in, int rows, int width, int group, float* out, void* stream) {
+  IMM_REQUIRE(in && out && rows > 0 && width > 0 && group > 0, "rows_reduce: args");
+  const dim3 grid((rows + group - 1) / group, (width + EW_THREADS - 1) / EW_THREADS);
+  hipLaunchKernelGGL(rows_reduce_kernel, grid, dim3(EW_THREADS), 0, (hipStream_t)stream, in, rows, width, group, out);
+  IMM_CHECK_LAUNCH("imm_rows_reduce");
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
 // batch norm backward (+ fused ReLU backward):  dz = dout * [scale*y+shift > 0]
 //   s1 = sum dz, s2 = sum dz*xhat;  dgamma = s2, dbeta = s1
 //   dy = gamma*rstd * (dz - s1/N - xhat*s2/N)

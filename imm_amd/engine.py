@@ -211,6 +211,9 @@ class IMMEngine:
         self._skip_tags = set(t for t in os.environ.get('IMM_DEBUG_SKIP_TAGS', '').split(',') if t)
         # IMM_DEBUG_STAMPS=marks|all: device wall-clock probes between the launches (lane boundaries / every launch) -> a
         # profiler-free timeline of a graph replay, read with stamp_report()
+        # IMM_BN_PREREDUCE (default 1): layers with > 256 partial rows: parallel 32-row pre-reduction + fused apply instead of a
+        # finalize launch (see imm_rows_reduce)
+        self.bn_prereduce = os.environ.get('IMM_BN_PREREDUCE', '1') != '0'
         self._stamp_mode = os.environ.get('IMM_DEBUG_STAMPS', '')
         self._stamp_buf = torch.zeros(8192, dtype=torch.int64, device=self.dev) if self._stamp_mode else None
         self._stamp_names = []
@@ -367,6 +370,21 @@ class IMMEngine:
                                                                     self._training, mm, mv, lay.scale, lay.shift, lay.mean, lay.rstd,
                                                                     lay.y, ldy, relu, out, ldo, lay.up, co, fd.ho, fd.wo),
                           'bn_apply', 0.0, npix * co * (4.0 + (8.0 if lay.up is not None else 0.0)))
+            elif self.bn_fuse_finalize and self.bn_prereduce and co % 32 == 0:
+                # many partial rows: 32-row groups are summed by rows/32 workgroups in parallel, the fused apply pass finishes
+                # the <= 32 group rows (instead of a finalize launch whose few workgroups walk every row)
+                g = max(32, -(-nblk // 32))
+                nred = -(-nblk // g)
+                lay.stats_red = self._zeros(nred, 2, co)
+
+                def f_red():
+                    if self._training:
+                        ops.rows_reduce(lay.stats, nblk, 2 * co, g, lay.stats_red)
+                self._add(self.prog_fwd, f_red, 'bn_finalize')
+                self._add(self.prog_fwd, lambda: ops.bn_apply_fused(lay.stats_red, nred, co, npix, gamma, beta, BN_EPS, BN_MOMENTUM,
+                                                                    self._training, mm, mv, lay.scale, lay.shift, lay.mean, lay.rstd,
+                                                                    lay.y, ldy, relu, out, ldo, None, co, fd.ho, fd.wo),
+                          'bn_apply', 0.0, npix * co * 4.0)
             else:
                 self._add(self.prog_fwd, f_fin, 'bn_finalize')
                 self._add(self.prog_fwd, lambda: ops.bn_apply_relu(lay.y, npix, co, ldy, lay.scale, lay.shift, relu, out, ldo),
@@ -467,7 +485,17 @@ class IMMEngine:
                 self._add(self.prog_bwd, lambda: ops.bn_bwd_reduce(d_out, ldd, lay.y, lay.ldy, npix, co, lay.scale, lay.shift,
                                                                    lay.mean, lay.rstd, lay.relu, lay.bwd_partial),
                           'bn_bwd_reduce', 0.0, npix * co * 4.0)
-            if small and not fused:
+            prered = (not fused and not small and not ticket and self.bn_fuse_finalize and self.bn_prereduce and co % 32 == 0)
+            if prered:
+                g = max(32, -(-lay.bwd_nblk // 32))
+                nred = -(-lay.bwd_nblk // g)
+                lay.bwd_red = self._zeros(nred, 2, co)
+                self._add(self.prog_bwd, lambda: ops.rows_reduce(lay.bwd_partial, lay.bwd_nblk, 2 * co, g, lay.bwd_red), 'bn_bwd_finalize')
+                self._add(self.prog_bwd, lambda: ops.bn_bwd_apply_fused(lay.bwd_red, nred, co, npix, gamma, d_out, ldd,
+                                                                        lay.y, lay.ldy, lay.scale, lay.shift, lay.mean, lay.rstd,
+                                                                        lay.relu, gg, gbeta, lay.dy, lay.ldy),
+                          'bn_bwd_apply', 0.0, npix * co * 6.0)
+            elif small and not fused:
                 self._add(self.prog_bwd, lambda: ops.bn_bwd_apply_fused(lay.bwd_partial, lay.bwd_nblk, co, npix, gamma, d_out, ldd,
                                                                         lay.y, lay.ldy, lay.scale, lay.shift, lay.mean, lay.rstd,
                                                                         lay.relu, gg, gbeta, lay.dy, lay.ldy),

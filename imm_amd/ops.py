@@ -200,6 +200,11 @@ def bn_bwd_blocks(npix, c):
     return n
 
 
+def rows_reduce(src, rows, width, group, dst):
+    """dst[g] = sum of rows [g*group, (g+1)*group) of src[rows][width] (include/imm_hip.h: imm_rows_reduce)."""
+    call('imm_rows_reduce', _p(src), rows, width, group, _p(dst), _s())
+
+
 def bn_bwd_reduce(dout, lddo, y, ldy, npix, c, scale, shift, mean, rstd, relu, partial):
     call('imm_bn_bwd_reduce', _p(dout), lddo, _p(y), ldy, dtype_enum(y.dtype), npix, c, _p(scale), _p(shift), _p(mean),
          _p(rstd), int(relu), _p(partial), _s())

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define IMM_ABI_VERSION 10   /* 2: imm_vgg_conv1_1_fwd gained `halves` */
+#define IMM_ABI_VERSION 11   /* 2: imm_vgg_conv1_1_fwd gained `halves` */
 
 enum imm_dtype { IMM_BF16 = 0, IMM_F16 = 1 };
 
@@ -154,6 +154,9 @@ int imm_bn_apply_fused(const float* partial, int nblk, int c, int64_t count, con
                        float momentum, int training, float* moving_mean, float* moving_var, float* scale, float* shift,
                        float* mean, float* rstd, const void* y, int dtype, int ldy, int relu, void* x_out, int ldx,
                        void* up2x_out, int ldu, int h, int w, void* stream);
+/* out[g][0..width) = sum of rows [g*group, (g+1)*group) of in[rows][width] (f64 accumulation, row order): brings the partial rows
+ * of a large layer (conv statistics, imm_bn_bwd_reduce) down to ceil(rows/group) rows that the fused apply passes finish. */
+int imm_rows_reduce(const float* in, int rows, int width, int group, float* out, void* stream);
 /* backward: reduce -> finalize (writes dgamma, dbeta, coef[3][c]) -> apply (dy_conv = ...) */
 int imm_bn_bwd_reduce(const void* dout, int lddo, const void* y, int ldy, int dtype, int64_t npix, int c,
                       const float* scale, const float* shift, const float* mean, const float* rstd, int relu,

@@ -371,6 +371,25 @@ def test_batch_norm_fwd_bwd(ops, c, npix):
     close(dyo, gy.reshape(npix, c), 2e-2, 4e-3, 'bn_dy')
 
 
+@pytest.mark.parametrize('rows,width,group', [(1024, 64, 32), (512, 128, 32), (700, 64, 32), (33, 512, 32), (2048, 64, 64)])
+def test_rows_reduce(ops, rows, width, group):
+    """imm_rows_reduce: group sums of partial rows (f64 accumulation); bitwise repeatable."""
+    g = torch.Generator().manual_seed(rows + width)
+    src = (torch.randn(rows, width, generator=g) * 100).to(DEV)
+    n = -(-rows // group)
+    outs = []
+    for _ in range(2):
+        dst = torch.full((n, width), float('nan'), device=DEV)
+        ops.rows_reduce(src, rows, width, group, dst)
+        torch.cuda.synchronize()
+        outs.append(dst)
+    assert torch.equal(outs[0], outs[1])
+    pad = torch.zeros(n * group, width, dtype=torch.float64)
+    pad[:rows] = src.cpu().double()
+    ref = pad.reshape(n, group, width).sum(1)
+    assert torch.allclose(outs[0].cpu().double(), ref, rtol=2e-7, atol=1e-4)
+
+
 @pytest.mark.parametrize('c,npix', [(32, 32 * 128 * 128), (64, 32 * 64 * 64), (32, 5000), (256, 700), (128, 33 * 1024 + 5)],
                          ids=['1024_rows', '64x64', 'few_rows', 'one_group', 'ragged_group'])
 def test_batch_norm_bwd_reduce_finalize_in_one_launch(ops, c, npix):
