@@ -118,26 +118,54 @@ __global__ __launch_bounds__(BT_THREADS) void softargmax_gauss_bwd_kernel(
   float* dmu = sm;              // [K][2]
   float* drow = dmu + 2 * K;    // [h][K]  d loss / d row-mean
   float* dcol = drow + h * K;   // [w][K]
-  __shared__ float red[4];
-  const int b = blockIdx.x, tid = threadIdx.x;
-  // dmu[k][axis] = sum_p dG * dG/dmu  ('rot': G*2*inv_std^2*(coord - mu))
-  for (int k = 0; k < K; ++k) {
-    const float my = mu[((int64_t)b * K + k) * 2], mx = mu[((int64_t)b * K + k) * 2 + 1];
-    float ay = 0.f, ax = 0.f;
+  constexpr int KC = 10;                       // landmarks per pass: 2*KC partial sums per thread, reduced together
+  __shared__ float red[BT_THREADS / 64][2 * KC];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  // dmu[k][axis] = sum_p dG * dG/dmu  ('rot': G*2*inv_std^2*(coord - mu)).  A thread walks its pixels once per pass and
+  // keeps the sums of KC landmarks (their dG values are adjacent in memory); the 2*KC sums then go through ONE reduction
+  // (wave butterflies + a 4-row LDS stage) instead of two block reductions per landmark (20 for K = 10: most of the
+  // kernel's 22 us on the critical path of the pose encoder's backward).
+  for (int k0 = 0; k0 < K; k0 += KC) {
+    float ay[KC], ax[KC], my[KC], mx[KC];
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+      ay[c] = 0.f; ax[c] = 0.f;
+      const int k = k0 + c < K ? k0 + c : K - 1;
+      my[c] = mu[((int64_t)b * K + k) * 2]; mx[c] = mu[((int64_t)b * K + k) * 2 + 1];
+    }
     for (int p = tid; p < s * s; p += BT_THREADS) {
       const int yy = p / s, xx = p - yy * s;
-      const float dy = lin_pm1(yy, s) - my, dx = lin_pm1(xx, s) - mx;
-      float g, gmy, gmx;
-      gauss_grad(mode, dy, dx, inv_std, g, gmy, gmx);
-      const float dg = ET::to_f32(dgauss[((int64_t)b * s * s + p) * ldg + k]);
-      ay += dg * gmy;
-      ax += dg * gmx;
+      const float ly = lin_pm1(yy, s), lx = lin_pm1(xx, s);
+      const uint16_t* dgp = dgauss + ((int64_t)b * s * s + p) * ldg + k0;
+#pragma unroll
+      for (int c = 0; c < KC; ++c) {
+        if (k0 + c < K) {
+          float g, gmy, gmx;
+          gauss_grad(mode, ly - my[c], lx - mx[c], inv_std, g, gmy, gmx);
+          const float dg = ET::to_f32(dgp[c]);
+          ay[c] += dg * gmy;
+          ax[c] += dg * gmx;
+        }
+      }
     }
-    ay = block_sum_256(ay, red);
-    ax = block_sum_256(ax, red);
-    if (tid == 0) { dmu[k * 2] = ay; dmu[k * 2 + 1] = ax; }
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) { ay[c] += __shfl_xor(ay[c], o, 64); ax[c] += __shfl_xor(ax[c], o, 64); }
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int c = 0; c < KC; ++c) { red[wv][2 * c] = ay[c]; red[wv][2 * c + 1] = ax[c]; }
+    }
+    __syncthreads();
+    if (tid < 2 * KC && k0 + tid / 2 < K) {
+      float t = 0.f;
+#pragma unroll
+      for (int wq = 0; wq < BT_THREADS / 64; ++wq) t += red[wq][tid];
+      dmu[(k0 + tid / 2) * 2 + (tid & 1)] = t;
+    }
+    __syncthreads();
   }
-  __syncthreads();
   // mu = sum_j p_j lin_j, p = softmax(r):  dr_j = p_j (lin_j - mu) dmu
   for (int i = tid; i < (h + w) * K; i += BT_THREADS) {
     if (i < h * K) {
