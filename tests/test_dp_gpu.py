@@ -103,7 +103,11 @@ def test_two_engines_equal_the_two_tower_reference(emu):
         du_got = (got[k].cpu() - P[k]).flatten().double()
         if float(info['grads'][k].norm()) < 1e-6:
             continue                     # pose 1x1 bias: |g| ~ 3e-8, cancellation noise in every implementation
-        cos = float((du_ref * du_got).sum() / (du_ref.norm() * du_got.norm() + 1e-30))
+        # the first Adam update is lr * sign(g) element by element: elements whose gradient is rounding noise (the
+        # 0.01-std initialisation is ill conditioned, DESIGN.md numerics) flip sign with any change of summation order,
+        # so the agreement is weighted by the oracle's |g|
+        wgt = info['grads'][k].flatten().double().abs()
+        cos = float((wgt * du_ref * du_got).sum() / (((wgt * du_ref * du_ref).sum() * (wgt * du_got * du_got).sum()).sqrt() + 1e-30))
         lim = 0.97 if k in ('model/renderer/conv_8/w', 'model/renderer/conv_7/gamma', 'model/renderer/conv_7/beta') else 0.5
         if cos < lim:
             worst.append((k, cos))
