@@ -831,7 +831,7 @@ class IMMEngine:
 
         self._build_backward()
         # one table-driven launch re-packs every trainable kernel (forward + dgrad layouts) after an update
-        self.pack_tab = ops.JobTable([j for j, _n in self._pack_jobs], [n for _j, n in self._pack_jobs], 2048, self.dev)
+        self.pack_tab = ops.pack_table([j for j, _n in self._pack_jobs], self.dev)
         self._add(self.prog_pack, lambda: ops.pack_weights_multi(self.pack_tab, dt), 'pack')
 
         # ---- optimizer --------------------------------------------------------------------------------------

@@ -115,14 +115,27 @@ def pack_weights(w, wt, mode, kh, kw, ci_real, co_real, c_pad, rows, kpad):
 class JobTable:
     """Device job table for the table-driven launches (imm_pack_weights_multi / imm_wgrad_reduce_multi)."""
 
-    def __init__(self, jobs, items_per_job, items_per_block, device):
+    def __init__(self, jobs, items_per_job, items_per_block, device, blocks_per_job=None):
         first = [0]
-        for n in items_per_job:
-            first.append(first[-1] + max(1, -(-int(n) // items_per_block)))
+        if blocks_per_job is None:
+            blocks_per_job = [max(1, -(-int(n) // items_per_block)) for n in items_per_job]
+        for n in blocks_per_job:
+            first.append(first[-1] + int(n))
         rows = [list(j) + [0] * (12 - len(j)) for j in jobs]
         self.jobs = torch.tensor(rows, dtype=torch.int64, device=device)
         self.blk_first = torch.tensor(first, dtype=torch.int32, device=device)
         self.n_jobs, self.n_blocks = len(jobs), first[-1]
+
+
+def pack_table(jobs, device):
+    """Job table of imm_pack_weights_multi: jobs = (w, wt, mode, kh, kw, ci_real, co_real, c_pad, rows, kpad) tuples."""
+    blocks = []
+    for j in jobs:
+        n = L.load().imm_pack_weights_multi_blocks(int(j[2]), int(j[8]), int(j[9]))
+        if n <= 0:
+            raise L.ImmHipError('imm_pack_weights_multi_blocks(%d, %d, %d) failed' % (j[2], j[8], j[9]))
+        blocks.append(n)
+    return JobTable(jobs, None, None, device, blocks_per_job=blocks)
 
 
 def pack_weights_multi(tab, dtype):

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define IMM_ABI_VERSION 11   /* 2: imm_vgg_conv1_1_fwd gained `halves` */
+#define IMM_ABI_VERSION 12   /* 2: imm_vgg_conv1_1_fwd gained `halves` */
 
 enum imm_dtype { IMM_BF16 = 0, IMM_F16 = 1 };
 
@@ -92,9 +92,11 @@ int imm_pack_weights(const float* w, void* wt, int dtype, int mode, int kh, int 
                      int c_pad, int rows, int kpad, void* stream);
 
 /* Table-driven variants: ONE launch re-packs / reduces every tensor of a step.  jobs: device int64[n_jobs][12];
- * pack job  = {w, wt, mode, kh, kw, ci_real, co_real, c_pad, rows, kpad, 0, 0}  (256*8 elements per workgroup)
+ * pack job  = {w, wt, mode, kh, kw, ci_real, co_real, c_pad, rows, kpad, 0, 0}  (imm_pack_weights_multi_blocks workgroups:
+ *             mode 0 = 32 x 64 tiles transposed through LDS, the other modes 256*8 consecutive elements per workgroup)
  * reduce job = {slab, dw, nsplit, kh*kw, ci_pad, ci_real, co, kpad, 0, 0, 0, 0}   (64 outputs per workgroup)
  * blk_first: device int32[n_jobs+1] prefix sums of workgroups per job; n_blocks = blk_first[n_jobs]. */
+int imm_pack_weights_multi_blocks(int mode, int rows, int kpad);
 int imm_pack_weights_multi(const int64_t* jobs, const int32_t* blk_first, int n_jobs, int n_blocks, int dtype,
                            void* stream);
 int imm_wgrad_reduce_multi(const int64_t* jobs, const int32_t* blk_first, int n_jobs, int n_blocks, void* stream);

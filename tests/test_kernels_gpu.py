@@ -279,7 +279,8 @@ def test_conv_wgrad_halo(ops, case):
 def test_table_driven_pack_and_reduce(ops):
     """imm_pack_weights_multi (bit for bit) / imm_wgrad_reduce_multi (to f32 rounding) vs their single-tensor counterparts."""
     dt = torch.bfloat16
-    layers = [(3, 3, 8, 32, 0), (3, 32, 32, 64, 0), (3, 266, 288, 256, 0), (3, 32, 16, 9, 1), (1, 256, 16, 10, 1)]
+    layers = [(3, 3, 8, 32, 0), (3, 32, 32, 64, 0), (3, 266, 288, 256, 0), (3, 32, 16, 9, 1), (1, 256, 16, 10, 1), (7, 3, 8, 32, 0),
+              (1, 256, 256, 10, 0), (3, 64, 128, 128, 4), (3, 64, 128, 128, 7)]
     jobs, items, refs = [], [], []
     for k, ci_real, c_pad, co, mode in layers:
         w = rnd((k, k, ci_real, co), 100 + ci_real, 0.1, torch.float32).to(DEV).contiguous()
@@ -292,7 +293,7 @@ def test_table_driven_pack_and_reduce(ops):
         ops.pack_weights(w, wt_ref, mode, k, k, ci_real, co, c_pad, rows, kpad)
         jobs.append((w.data_ptr(), wt.data_ptr(), mode, k, k, ci_real, co, c_pad, rows, kpad)); items.append(rows * kpad)
         refs.append((w, wt, wt_ref))
-    tab = ops.JobTable(jobs, items, 2048, DEV)
+    tab = ops.pack_table(jobs, DEV)
     ops.pack_weights_multi(tab, dt)
     torch.cuda.synchronize()
     for _w, wt, wt_ref in refs:
