@@ -60,8 +60,9 @@ def build(force=False, verbose=True):
     for src in _sources():
         obj = os.path.join(objdir, os.path.basename(src) + '.o')
         objs.append(obj)
+        # IMM_HIPCC_FLAGS: extra compile flags for diagnosis builds (e.g. -DIMM_HDEEP_PROFILE), never set in normal use
         cmd = [hipcc, '--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function',
-               '-DIMM_SOURCE_DIGEST="%s"' % dig, '-c', src, '-o', obj]
+               '-DIMM_SOURCE_DIGEST="%s"' % dig] + os.environ.get('IMM_HIPCC_FLAGS', '').split() + ['-c', src, '-o', obj]
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     for cmd, p in procs:
         out, _ = p.communicate()

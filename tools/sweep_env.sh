@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of engine switches on one box: each line of the here-doc is an environment (possibly empty) for one bench run.
-#   gpurun -- 'bash tools/sweep_env.sh <tag> <<< "..."'   or edit the default list below.  Output: gpurun_out/<tag>/sweep.txt
+#   gpurun -- 'bash tools/sweep_env.sh <tag> < tools/sweeps/<file>'   or edit the default list below.  Output: gpurun_out/<tag>/sweep.txt
 TAG=${1:-sweep}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
