@@ -8,6 +8,7 @@
 // tf.image.resize_images imm/models/imm_model.py:175; resize_bilinear(align_corners=True) :334;
 // tf.nn.max_pool imm/models/selfsup/ops.py:16-26; tf.nn.bias_add gradient nn_utils.py:108.
 #include "common.h"
+#include <stdlib.h>
 
 #define EW_THREADS 256
 
@@ -440,8 +441,11 @@ static int col_reduce_blocks(int64_t npix, int c) {
   // capped at 1024 workgroups (= partial rows the finalize kernel has to sum)
   int64_t b = (npix + (int64_t)rows * 4 - 1) / ((int64_t)rows * 4);
   if (b < 1) b = 1;
-  // <= 256 rows for the small tensors (<= 4M elements): imm_bn_bwd_apply_fused re-reduces the rows in every workgroup
-  const int64_t cap = (npix * c <= (1LL << 22)) ? 256 : 1024;
+  // <= 256 rows for the small tensors (<= 4M elements): imm_bn_bwd_apply_fused re-reduces the rows in every workgroup.  The
+  // large ones keep up to 1024 workgroups (IMM_COL_REDUCE_CAP): MEASURED 256 (one per CU, 8 loads in flight per thread) 3.594 ->
+  // 3.631 ms per step, 512 3.587 — the pre-reduction of the rows (imm_rows_reduce) is cheaper than a thinner grid
+  static const int64_t cap_env = getenv("IMM_COL_REDUCE_CAP") ? atoi(getenv("IMM_COL_REDUCE_CAP")) : 1024;
+  const int64_t cap = (npix * c <= (1LL << 22)) ? 256 : cap_env;
   if (b > cap) b = cap;
   return (int)b;
 }
@@ -492,10 +496,10 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_reduce_kernel(
   float acc[2][8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
-  for (int64_t p = p0 + r; p < p1; p += rows) {
+  auto take = [&](const uint4& dq, const uint4& yq) {
     float d[8], v[8];
-    unpack8<ET>(*(const uint4*)(dout + p * lddo + cg * 8), d);
-    unpack8<ET>(*(const uint4*)(y + p * ldy + cg * 8), v);
+    unpack8<ET>(dq, d);
+    unpack8<ET>(yq, v);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       float dz = d[i];
@@ -503,7 +507,20 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_reduce_kernel(
       acc[0][i] += dz;
       acc[1][i] += dz * ((v[i] - mu[i]) * rs[i]);
     }
+  };
+  // 4 pixels (8 x 16-byte loads) in flight per thread
+  int64_t p = p0 + r;
+  for (; p + 3 * (int64_t)rows < p1; p += 4 * (int64_t)rows) {
+    uint4 dq[4], yq[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      dq[u] = *(const uint4*)(dout + (p + u * (int64_t)rows) * lddo + cg * 8);
+      yq[u] = *(const uint4*)(y + (p + u * (int64_t)rows) * ldy + cg * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) take(dq[u], yq[u]);
   }
+  for (; p < p1; p += rows) take(*(const uint4*)(dout + p * lddo + cg * 8), *(const uint4*)(y + p * ldy + cg * 8));
   col_reduce_tail<2>(acc, c, tpp, rows, partial + (int64_t)blockIdx.x * 2 * c);
 }
 
