@@ -20,6 +20,15 @@ struct ConvArgs {
 };
 
 
+// Several convolutions of the same tile shape in ONE launch (conv_igemm64.hip / conv_igemm.hip group kernels): workgroup b
+// belongs to member g with first[g] <= b < first[g+1] and runs that member's argument block unchanged.
+#define IMM_CONV_GROUP_MAX 4
+struct ConvArgsGroup {
+  ConvArgs a[IMM_CONV_GROUP_MAX];
+  int first[IMM_CONV_GROUP_MAX + 1];
+  int n;
+};
+
 // Epilogue of one BM x BN tile: bias, ReLU, ReLU-backward mask, NHWC store (lane = 4 consecutive channels of one
 // pixel), deterministic per-M-block batch-norm partial sums.  `red` = >= WGM*2*BN floats of LDS, free to overwrite
 // (all waves are past their last LDS read).

@@ -34,7 +34,7 @@ __device__ __forceinline__ int lds_chunk_idx(int row, int chunk) {
 // per-lane gather offsets are recomputed once per tap and the channel slice rides in the buffer
 // instruction's scalar offset -> a handful of VALU instructions per K step instead of ~150.
 template <typename ET, int BM, int BN, int WGM, int WGN, bool FAST>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
+__device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int block) {
   constexpr int TM = BM / WGM, TN = BN / WGN;
   constexpr int MT = TM / 16, NT = TN / 16;
   constexpr int A_PASSES = BM / 64;
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
   // XCD-aware remap (workgroup id -> XCD id%8 is the observed dispatch rule; speed only): give every
   // XCD a contiguous run of logical tiles so the N-blocks of one pixel tile and its halo neighbours
   // share that XCD's L2.  Bijective for any grid size.
-  int bid = blockIdx.x;
+  int bid = block;
   {
     const int q = a.n_blocks >> 3, r = a.n_blocks & 7, xcd = bid & 7;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
@@ -207,6 +207,22 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
   conv_epilogue<ET, BM, BN, WGM, WGN, MT, NT>(a, acc, tid, wm, wn, m0, n0, mblk, (float*)smem);
 }
 
+template <typename ET, int BM, int BN, int WGM, int WGN, bool FAST>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
+  conv_igemm_body<ET, BM, BN, WGM, WGN, FAST>(a, blockIdx.x);
+}
+
+// The four parity classes of a stride-2 data gradient with <= 32 output channels (encoder conv_3: 64 -> 32 at 128x128) in
+// ONE launch of the 128x32 tile: four launches of 8-14 us each otherwise.
+template <typename ET, int BM, int BN, int WGM, int WGN>
+__global__ __launch_bounds__(256) void conv_igemm_group_kernel(const ConvArgsGroup g) {
+  int m = 0;
+#pragma unroll
+  for (int i = 1; i < IMM_CONV_GROUP_MAX; ++i)
+    if (i < g.n && (int)blockIdx.x >= g.first[i]) m = i;
+  conv_igemm_body<ET, BM, BN, WGM, WGN, true>(g.a[m], (int)blockIdx.x - g.first[m]);
+}
+
 // ---------------------------------------------------------------------------------------------
 // host side: tile selection + launch
 // ---------------------------------------------------------------------------------------------
@@ -345,28 +361,32 @@ extern "C" int imm_conv2d(const imm_conv_desc* d, int dtype, const void* x, cons
 // 64x64-tile kernel to share a launch, otherwise they are launched one after the other (same results either way).
 // With IMM_CONV_STATS | IMM_CONV_MASK on the members (batch-norm backward sums of the layer the gradient enters) the
 // partial-sum rows of member i follow those of members 0..i-1; imm_conv2d_group_stats_blocks = total row count.
-struct GroupPlan { bool grouped; int bm, bn; int rows[4]; int total_rows; };
+struct GroupPlan { bool grouped, grouped32; int bm, bn; int rows[4]; int total_rows; };
 
 static int group_plan(const imm_conv_desc* descs, int n, GroupPlan* gp) {
   static const bool off = getenv("IMM_NO_CONV_GROUP") != nullptr;
-  gp->grouped = !off; gp->bm = gp->bn = 0; gp->total_rows = 0;
+  gp->grouped = !off; gp->grouped32 = !off && !getenv("IMM_NO_CONV_GROUP32"); gp->bm = gp->bn = 0; gp->total_rows = 0;
   for (int i = 0; i < n; ++i) {
     const imm_conv_desc* d = descs + i;
     if (validate_desc(d)) return IMM_E_INVALID;
     IMM_REQUIRE(!(d->flags & IMM_CONV_BIAS), "conv_group: members carry no bias");
-    if (imm_halo2_applicable(d) || imm_halo_applicable(d) || imm_hdeep_applicable(d)) gp->grouped = false;
+    if (imm_halo2_applicable(d) || imm_halo_applicable(d) || imm_hdeep_applicable(d)) gp->grouped = gp->grouped32 = false;
     const int64_t M = (int64_t)d->batch * d->ho * d->wo;
     const TileCfg t = pick_tile(M, d->co);
     const int64_t xb = (int64_t)d->batch * d->hi * d->wi * d->ldx * 2, wb = (int64_t)d->co * d->kpad * 2;
     const bool deep = (d->ci % 64 == 0) && xb < (1LL << 31) && wb < (1LL << 31) && t.bn >= 64 && !(d->flags & 0xf00) &&
                       !getenv("IMM_NO_DEEPK");
     if (!deep || (i > 0 && (t.bm != gp->bm || t.bn != gp->bn))) gp->grouped = false;
+    // the general kernel's 128x32 tile, one tap x 32 channels per K tile (ci % 32 == 0)
+    const bool fast32 = (d->ci % 32 == 0) && xb < (1LL << 31) && wb < (1LL << 31) && t.bm == 128 && t.bn == 32 && !(d->flags & 0xf00);
+    if (!fast32) gp->grouped32 = false;
     gp->bm = t.bm; gp->bn = t.bn;
   }
+  if (gp->grouped) gp->grouped32 = false;
   if (gp->grouped && !(gp->bm == 64 && gp->bn == 64)) gp->grouped = false;   // the grouped kernel exists for the 64x64 tile only
   for (int i = 0; i < n; ++i) {
     const int64_t M = (int64_t)descs[i].batch * descs[i].ho * descs[i].wo;
-    gp->rows[i] = gp->grouped ? (int)((M + 63) / 64) : imm_conv_stats_blocks(descs + i);
+    gp->rows[i] = gp->grouped ? (int)((M + 63) / 64) : gp->grouped32 ? (int)((M + 127) / 128) : imm_conv_stats_blocks(descs + i);
     gp->total_rows += gp->rows[i];
   }
   return 0;
@@ -401,6 +421,22 @@ extern "C" int imm_conv2d_group(const imm_conv_desc* descs, int n, int dtype, co
   }
   if (gp.grouped && imm_conv64_group_launch(dtype, args, n, gp.bm, gp.bn, (hipStream_t)stream)) {
     IMM_CHECK_LAUNCH("imm_conv2d_group");
+    return 0;
+  }
+  if (gp.grouped32) {
+    ConvArgsGroup g;
+    g.n = n;
+    int total = 0;
+    for (int i = 0; i < n; ++i) {
+      args[i].n_blocks = ((args[i].M + 127) / 128) * args[i].n_nblk;
+      g.a[i] = args[i];
+      g.first[i] = total;
+      total += args[i].n_blocks;
+    }
+    for (int i = n; i <= IMM_CONV_GROUP_MAX; ++i) g.first[i] = total;
+    if (dtype == IMM_BF16) hipLaunchKernelGGL((conv_igemm_group_kernel<BF16, 128, 32, 4, 1>), dim3(total), dim3(256), 0, (hipStream_t)stream, g);
+    else hipLaunchKernelGGL((conv_igemm_group_kernel<F16, 128, 32, 4, 1>), dim3(total), dim3(256), 0, (hipStream_t)stream, g);
+    IMM_CHECK_LAUNCH("imm_conv2d_group(128x32)");
     return 0;
   }
   row0 = 0;

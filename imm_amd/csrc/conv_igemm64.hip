@@ -166,12 +166,6 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm64_kernel(const ConvArgs a)
 // Several convolutions of the same tile shape in ONE launch (the four parity classes of a stride-2 data gradient: each
 // alone is a grid of 64-512 workgroups a few microseconds long).  Workgroup b belongs to member g with
 // first[g] <= b < first[g+1] and runs that member's argument block unchanged.
-#define IMM_CONV_GROUP_MAX 4
-struct ConvArgsGroup {
-  ConvArgs a[IMM_CONV_GROUP_MAX];
-  int first[IMM_CONV_GROUP_MAX + 1];
-  int n;
-};
 
 template <typename ET, int BM, int BN, int NS, int NW>
 __global__ __launch_bounds__(NW * 64) void conv_igemm64_group_kernel(const ConvArgsGroup g) {

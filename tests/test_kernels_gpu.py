@@ -193,7 +193,7 @@ def test_conv_dgrad(ops, case):
     close(dx[..., :ci_real], gx, 1e-2, 2e-3, 'dgrad/' + tag)
 
 
-@pytest.mark.parametrize('H,ci,co', [(16, 32, 64), (32, 64, 128), (64, 128, 256)])
+@pytest.mark.parametrize('H,ci,co', [(16, 32, 64), (32, 64, 128), (64, 128, 256), (64, 32, 64)])
 def test_conv_dgrad_stride2_parity_classes(ops, H, ci, co):
     """Stride-2 data gradient as four dense sub-convolutions (one per input-pixel parity class) scattered into dx."""
     B, k, dt = 2, 3, torch.bfloat16
@@ -564,7 +564,7 @@ def test_conv_mask_with_bn_backward_sums(ops, B, H, ci, co, dt):
     close(s[1], (v * mf).sum(dim=(0, 1, 2)), 2e-3, 2e-3, 'bn-bwd sums/sum dz*out')
 
 
-@pytest.mark.parametrize('H,ci,co', [(32, 64, 128), (64, 128, 256), (16, 32, 64)], ids=['grouped_64x64', 'grouped_deep', 'fallback_bk32'])
+@pytest.mark.parametrize('H,ci,co', [(32, 64, 128), (64, 128, 256), (16, 32, 64)], ids=['grouped_64x64', 'grouped_deep', 'grouped_128x32'])
 def test_conv_group_mask_with_bn_backward_sums(ops, H, ci, co):
     """The stride-2 data gradient (four parity classes, scattered output) with the mask + sums epilogue: output = masked
     sequential result; the rows of all members together sum to (sum dz, sum dz*out)."""
@@ -997,7 +997,7 @@ def test_unpool_fused_with_tap_grad(ops):
         assert torch.equal(got, ref)
 
 
-@pytest.mark.parametrize('H,ci,co', [(32, 64, 128), (64, 128, 256), (16, 32, 64)], ids=['grouped_64x64', 'grouped_deep', 'fallback_bk32'])
+@pytest.mark.parametrize('H,ci,co', [(32, 64, 128), (64, 128, 256), (16, 32, 64)], ids=['grouped_64x64', 'grouped_deep', 'grouped_128x32'])
 def test_conv_group_equals_sequential(ops, H, ci, co):
     """imm_conv2d_group (stride-2 dgrad parity classes in one launch) == the four launches, bit for bit."""
     B, k, dt = 8, 3, torch.bfloat16
