@@ -72,10 +72,28 @@ __global__ __launch_bounds__(256) void vgg_conv1_1_bwd_kernel(const uint16_t* __
                                                               int input_idx, int l1, uint16_t* __restrict__ dpred, int lddp) {
   constexpr int HT = VF_TILE + 2;
   __shared__ uint4 sdz[HT * HT * 8];          // dz tile + halo, 64 channels = 8 x 16 B per pixel (41 KB)
+  __shared__ float sdir[VF_TILE * VF_TILE][3]; // the 'input' feature's direct term c0 * mask * (pred - gt) of the tile's pixels
   const int tid = threadIdx.x;
   const int img = blockIdx.z;
   const int ty0 = blockIdx.y * VF_TILE, tx0 = blockIdx.x * VF_TILE;
+  const float c0 = input_idx >= 0 ? coef[input_idx] : 0.f;      // 'input' feature not in perceptual.comp: no direct term
   {
+    // thread t = pixel t of the tile: its pred / gt / mask values are requested HERE, together with the dz tile (they were 7
+    // dependent 4-byte loads per pixel at the end of every pass of the loop below, by one lane in eight: a chain of HBM
+    // latencies; 44 -> 35 us.  A GEMM + gather formulation on the matrix cores was no faster: with the 64-byte gradient
+    // pixels of the renderer head and the strided pred reads the kernel moves ~150 MB, it is HBM-bound)
+    const int yy = ty0 + tid / VF_TILE, xx = tx0 + tid % VF_TILE;
+    float dir[3] = {0.f, 0.f, 0.f};
+    if (yy < s && xx < s) {
+      const int64_t p = ((int64_t)img * s + yy) * s + xx;
+      const float cm = c0 * (mask ? mask[p] : 1.f);
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        float d = pred[p * ldp + ch] - gt[p * 3 + ch];
+        if (l1) d = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);       // perceptual.l2: False => |.|, gradient sign(d)
+        dir[ch] = cm * d;
+      }
+    }
     // all 11 loads of a thread in flight before the first LDS store (the tile load is a chain of HBM latencies otherwise)
     constexpr int NL = (HT * HT * 8 + 255) / 256;
     uint4 v[NL];
@@ -93,6 +111,7 @@ __global__ __launch_bounds__(256) void vgg_conv1_1_bwd_kernel(const uint16_t* __
       const int i = tid + k * 256;
       if (i < HT * HT * 8) sdz[i] = v[k];
     }
+    sdir[tid][0] = dir[0]; sdir[tid][1] = dir[1]; sdir[tid][2] = dir[2];
   }
   const int cg = tid & 7, pl = tid >> 3;
   // filter taps of this lane's 8 channels as packed 16-bit pairs: the contraction runs on v_dot2c (2 MACs per issue;
@@ -102,7 +121,6 @@ __global__ __launch_bounds__(256) void vgg_conv1_1_bwd_kernel(const uint16_t* __
   for (int t = 0; t < 9; ++t)
 #pragma unroll
     for (int e = 0; e < 4; ++e) wr[t][e] = ET::pack2(w[t * 64 + cg * 8 + 2 * e], w[t * 64 + cg * 8 + 2 * e + 1]);
-  const float c0 = input_idx >= 0 ? coef[input_idx] : 0.f;      // 'input' feature not in perceptual.comp: no direct term
   __syncthreads();
 #pragma unroll 2
   for (int pass = 0; pass < 8; ++pass) {
@@ -129,14 +147,9 @@ __global__ __launch_bounds__(256) void vgg_conv1_1_bwd_kernel(const uint16_t* __
       float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       const int64_t p = ((int64_t)img * s + yy) * s + xx;
       if (cg == 0) {
-        const float cm = c0 * (mask ? mask[p] : 1.f);
         const float dg = part / (3.0f * 255.0f);
 #pragma unroll
-        for (int ch = 0; ch < 3; ++ch) {
-          float d = pred[p * ldp + ch] - gt[p * 3 + ch];
-          if (l1) d = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);       // perceptual.l2: False => |.|, gradient sign(d)
-          o[ch] = dg + cm * d;
-        }
+        for (int ch = 0; ch < 3; ++ch) o[ch] = dg + sdir[pix][ch];
       }
       *(uint4*)(dpred + p * lddp + cg * 8) = pack8<ET>(o);
     }
