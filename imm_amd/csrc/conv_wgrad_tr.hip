@@ -163,7 +163,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(const WgradTrArgs a)
   const char* lds_c = (const char*)smem;
   // (Round 2, measured: reading the fragments of step st+1 under the MFMAs of step st — which costs one step of DMA look-ahead,
   // the wait then being for step st+1 — is SLOWER, 3.543 -> 3.561 ms per training step, 39.9 -> 44.8 us on the 32x32 256->128
-  // layer: the steps are bound by the global->LDS latency of their 16 KB, not by the LDS round trip.)
+  // layer: the steps are bound by the global->LDS latency of their 16 KB, not by the LDS round trip.  A deeper ring does not
+  // help either: NS = 6 / 8 instead of 4: 3.555 -> 3.655 ms, 38.7 -> 54 us on that layer.)
   int stage = 0;
   for (int st = 0; st < nsteps; ++st) {
     if (st + NS - 2 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * LPT) : "memory");
