@@ -76,19 +76,27 @@ __device__ __forceinline__ float hd_row_sum16(float x) {
 // ~4 us, MI355X_MICROARCH.md "prologue HBM burst") and the store burst of the epilogue overlap with matrix work instead of
 // adding ~6 us per tile (conv2_2: 24 of 78 us).  The counted vmcnt waits stay exact for the DMA loads: the epilogue's stores
 // and mask loads only ADD to the counter (waits become conservative, never early).
-template <typename ET, int BN, int NW, int PH, bool MAP8 = false, int NSB_ = 0, bool PERSIST = false>
+//
+// ROW3 (round 2, the 4-wave variants on small grids): a barrier interval is one FILTER ROW (3 taps x 64 channels = 6 k-steps,
+// 48 MFMAs per wave) instead of one tap.  Measured from inside: a tap of the 4-wave variant costs 0.30 us for 0.11 us of MFMA
+// time — 0.19 us of barrier, DMA issue and exposed LDS round trip per interval with one wave per SIMD — and 16 more MFMAs in
+// the same interval cost only their own 0.11 us.  The ring is the nine tap stages of a slice (tap (ky, kx) of every slice lands
+// in stage 3 ky + kx; a row's three stages are refilled for the next slice right after the row's barrier), the next slice's halo
+// is requested after the FIRST row's barrier so that it has landed when the last row's barrier is passed.
+template <typename ET, int BN, int NW, int PH, bool MAP8 = false, int NSB_ = 0, bool PERSIST = false, bool ROW3 = false>
 __global__ __launch_bounds__(NW * 64) void conv_hdeep_kernel(const HdArgs ha) {
   const ConvArgs& a = ha.c;
   static_assert((NW == 8 && PH == 16) || (NW == 4 && PH == 8), "wave (wm, wn) owns patch rows 4wm..4wm+3 x BN/2 channels");
   static_assert(!MAP8 || NW == 4, "two 8x8 images per 4-wave workgroup");
   static_assert(!(PERSIST && MAP8), "persistent tiles: 16x16 / 8x16 patches only");
+  static_assert(!ROW3 || (NSB_ == 9 && !PERSIST), "row-at-a-time schedule: nine tap stages, one tile per workgroup");
   constexpr int HD_NSB = NSB_ ? NSB_ : MAP8 ? 3 : 4;   // filter-slice ring depth (MAP8: 3 keeps two workgroups per CU)
   constexpr int NPIECE = MAP8 ? 7 : 6;                 // halo DMA pieces per wave and slice
   constexpr int TN = BN / 2, MT = 4, NT = TN / 16;
   constexpr int B_I = BN / (8 * NW);                   // filter DMA instructions per wave and tap (BN rows / 8 / NW waves)
   constexpr int SLOTS = MAP8 ? 200 : HD_SLOTS(PH);     // halo pixels
   constexpr int HINSTR = (SLOTS + 7) / 8, HSTAGE = HINSTR * 64;
-  static_assert(B_I >= 1 && NPIECE * NW >= HINSTR && NPIECE <= 11 - HD_NSB, "halo pieces per wave cover the halo and land in time");
+  static_assert(B_I >= 1 && NPIECE * NW >= HINSTR && (ROW3 || NPIECE <= 11 - HD_NSB), "halo pieces per wave cover the halo and land in time");
   // fragment row strides (uint4 units): output tile row i, vertical tap ky
   constexpr int STEP_I = MAP8 ? 160 : (HD_HW * 128) / 16, STEP_KY = MAP8 ? 80 : (HD_HW * 128) / 16;
   constexpr int B_U4 = BN * 8;                         // uint4 per filter stage
@@ -231,7 +239,7 @@ __global__ __launch_bounds__(NW * 64) void conv_hdeep_kernel(const HdArgs ha) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) bf[ks][j] = Bs[boff[j][ks]];
   };
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"((HD_NSB - 1) * B_I) : "memory");   // halo(0) and filter tap 0
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"((ROW3 ? 6 : HD_NSB - 1) * B_I) : "memory");   // halo(0) and filter tap 0 (ROW3: row 0)
   __builtin_amdgcn_s_barrier();
   read_frags(0, smem, smem + BRING_U4, 0, 0);
 
@@ -248,6 +256,52 @@ __global__ __launch_bounds__(NW * 64) void conv_hdeep_kernel(const HdArgs ha) {
   for (int it = 0; it < n_mine; ++it) {
   const bool have_next = PERSIST && it + 1 < n_mine;
   int t = 0;
+  if constexpr (ROW3) {
+    for (int cc = 0; cc < ncc; ++cc, ++gs) {
+      const bool next_slice = cc + 1 < ncc;
+      const uint4* Hc = smem + (gs & 1) * HSTAGE;
+      const uint4* Hnx = smem + ((gs + 1) & 1) * HSTAGE;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {                  // k-step j of the row: tap (ky, kx = j / 2), channels 32 (j & 1) ..
+          const int cur = j & 1;                      // tap (ky, j >> 1), channel half j & 1 = fragment buffer
+          __builtin_amdgcn_sched_barrier(0);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // fragments of k-step j are in registers
+          __builtin_amdgcn_sched_barrier(0);
+          if (j < 5) {
+            const int nkx = (j + 1) >> 1;
+            read_frags(cur ^ 1, Hc, smem + BRING_U4 + (ky * 3 + nkx) * B_U4, ky, nkx);
+          } else {
+            // every fragment of this row has been read: its three stages are free; the next row's taps (requested one
+            // slice = three rows ago) and, before the last row, the next slice's halo (requested after the first) must be in
+            if (ky == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * B_I + NPIECE) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * B_I) : "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int x3 = 0; x3 < 3; ++x3) issue_b((cc + 1) * 9 + ky * 3 + x3, ky * 3 + x3, next_slice);
+            if (ky == 0) {
+#pragma unroll
+              for (int k = 0; k < NPIECE; ++k) issue_halo_piece(cc + 1, (gs + 1) & 1, k, next_slice);
+            }
+            if (ky < 2) read_frags(0, Hc, smem + BRING_U4 + ((ky + 1) * 3) * B_U4, ky + 1, 0);
+            else read_frags(0, Hnx, smem + BRING_U4, 0, 0);           // past the last slice: landed no-op data, never used
+          }
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int jj = 0; jj < NT; ++jj) acc[i][jj] = ET::mfma(bf[cur][jj], af[cur][i], acc[i][jj]);
+#pragma unroll
+          for (int m = 0; m < MT * NT; ++m) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x006, 2, 0);
+          }
+        }
+      }
+    }
+  } else
   for (int cc = 0; cc < ncc; ++cc, ++gs) {
     const bool next_slice = cc + 1 < ncc;
     if (PERSIST && !next_slice && have_next) {         // the loader turns to the next tile during this slice: its halo now,
@@ -543,22 +597,28 @@ bool imm_hdeep_applicable(const imm_conv_desc* d) {
 
 int imm_hdeep_stats_blocks(const imm_conv_desc* d) { return hd_plan(d).n_patches; }
 
-template <typename ET, int BN, int NW, int PH, bool MAP8 = false, int NSB_ = 0, bool PERSIST = false>
+template <typename ET, int BN, int NW, int PH, bool MAP8 = false, int NSB_ = 0, bool PERSIST = false, bool ROW3 = false>
 static void hd_launch_cfg(const HdArgs& ha, hipStream_t s) {
   constexpr int hstage = MAP8 ? 25 * 64 : HD_HSTAGE(PH), nsb = NSB_ ? NSB_ : MAP8 ? 3 : 4;
   constexpr int lds = (2 * hstage + 64 + nsb * BN * 8) * 16 + (PERSIST ? NW * BN * 4 : 0);   // + [NW/2][2][BN] f32 stats scratch
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)conv_hdeep_kernel<ET, BN, NW, PH, MAP8, NSB_, PERSIST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)conv_hdeep_kernel<ET, BN, NW, PH, MAP8, NSB_, PERSIST, ROW3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
   const int grid = PERSIST ? (ha.n_wg < hd_num_cu() ? ha.n_wg : hd_num_cu()) : ha.n_wg;
-  hipLaunchKernelGGL((conv_hdeep_kernel<ET, BN, NW, PH, MAP8, NSB_, PERSIST>), dim3(grid), dim3(NW * 64), lds, s, ha);
+  hipLaunchKernelGGL((conv_hdeep_kernel<ET, BN, NW, PH, MAP8, NSB_, PERSIST, ROW3>), dim3(grid), dim3(NW * 64), lds, s, ha);
 }
 
 template <typename ET>
 static void hd_launch(const HdPlan& p, const HdArgs& ha, hipStream_t s) {
-  if (p.map8) hd_launch_cfg<ET, 64, 4, 8, true>(ha, s);
+  static const bool row3 = !(getenv("IMM_HDEEP_ROW3") && atoi(getenv("IMM_HDEEP_ROW3")) == 0);   // A/B: one barrier per filter row
+  // (119 KB of LDS: one workgroup per CU — only where the grid leaves it at one per CU anyway; with more tiles than CUs the
+  // 78 KB tap-at-a-time form keeps two co-resident: 32x32 128->128, 512 tiles, 14.2 vs 17.1 us)
+  const bool one_wave = p.n_wg <= hd_num_cu();
+  if (p.map8 && row3 && one_wave) hd_launch_cfg<ET, 64, 4, 8, true, 9, false, true>(ha, s);
+  else if (p.ph == 8 && p.bn == 64 && !p.map8 && row3 && one_wave) hd_launch_cfg<ET, 64, 4, 8, false, 9, false, true>(ha, s);
+  else if (p.map8) hd_launch_cfg<ET, 64, 4, 8, true>(ha, s);
   else if (p.ph == 16 && p.bn == 128 && p.persist) hd_launch_cfg<ET, 128, 8, 16, false, 0, true>(ha, s);
   else if (p.ph == 16 && p.bn == 128) hd_launch_cfg<ET, 128, 8, 16>(ha, s);
   else if (p.ph == 16 && p.persist) hd_launch_cfg<ET, 64, 8, 16, false, 0, true>(ha, s);
