@@ -551,7 +551,7 @@ static int hd_num_cu() {
 //   16 x 16 x 64 when THAT does;
 //   else 8 x 16 x 64 (4 waves, two workgroups per CU) when the map height allows — the small-grid layers (16x16 maps of
 //   a 32-image batch: 32 patches) otherwise leave half the chip idle.
-struct HdPlan { int ph, bn, n_patches, n_wg; bool map8, persist; };
+struct HdPlan { int ph, bn, n_patches, n_wg; bool map8, persist, row3; };
 
 static HdPlan hd_plan(const imm_conv_desc* d) {
   static const bool no_small = getenv("IMM_HDEEP_NO_SMALL") != nullptr;
@@ -559,7 +559,7 @@ static HdPlan hd_plan(const imm_conv_desc* d) {
   static const int small_below = getenv("IMM_HDEEP_SMALL_BELOW") ? atoi(getenv("IMM_HDEEP_SMALL_BELOW")) : 4;   // x CUs
   static const bool no_big = getenv("IMM_HDEEP_NO_BIG") != nullptr;
   HdPlan p;
-  p.map8 = false; p.persist = false;
+  p.map8 = false; p.persist = false; p.row3 = false;
   if (d->ho == 8 && d->wo == 8) {                      // two whole 8x8 images per (4-wave) workgroup
     static const bool no_map8 = getenv("IMM_HDEEP_NO_MAP8") != nullptr;
     p.ph = 8; p.bn = 64; p.map8 = true;
@@ -573,6 +573,13 @@ static HdPlan hd_plan(const imm_conv_desc* d) {
   else if (!no_small) { p.ph = 8; p.bn = 64; p.n_patches = d->batch * (d->ho / 8) * (d->wo / HD_PW); }
   else { p.ph = 16; p.bn = 64; p.n_patches = np16; }
   p.n_wg = p.n_patches * (d->co / p.bn);
+  // 8x16 tiles that would be two rounds of 4-wave workgroups (e.g. 32x32 maps, 128 channels: 512) as ONE round of 8-wave
+  // 16x16x64 workgroups with the row-at-a-time schedule (IMM_HDEEP_ROW3_BIG=0: off)
+  static const bool row3_big = !(getenv("IMM_HDEEP_ROW3_BIG") && atoi(getenv("IMM_HDEEP_ROW3_BIG")) == 0);
+  if (row3_big && !no_small && p.ph == 8 && p.bn == 64 && p.n_wg > cus && np16 > 0 && np16 * (d->co / 64) <= cus &&
+      np16 * (d->co / 64) >= cus / 2) {
+    p.ph = 16; p.n_patches = np16; p.n_wg = np16 * (d->co / 64); p.row3 = true;
+  }
   // more tiles than CUs: one persistent workgroup per CU walks them (IMM_HDEEP_PERSIST=0: one workgroup per tile)
   static const bool persist = !(getenv("IMM_HDEEP_PERSIST") && atoi(getenv("IMM_HDEEP_PERSIST")) == 0);
   p.persist = persist && p.ph == 16 && p.n_wg > cus && (cus % 8) == 0 && !(d->flags & IMM_CONV_STATS);
@@ -621,6 +628,7 @@ static void hd_launch(const HdPlan& p, const HdArgs& ha, hipStream_t s) {
   else if (p.map8) hd_launch_cfg<ET, 64, 4, 8, true>(ha, s);
   else if (p.ph == 16 && p.bn == 128 && p.persist) hd_launch_cfg<ET, 128, 8, 16, false, 0, true>(ha, s);
   else if (p.ph == 16 && p.bn == 128) hd_launch_cfg<ET, 128, 8, 16>(ha, s);
+  else if (p.ph == 16 && p.bn == 64 && p.row3) hd_launch_cfg<ET, 64, 8, 16, false, 9, false, true>(ha, s);
   else if (p.ph == 16 && p.persist) hd_launch_cfg<ET, 64, 8, 16, false, 0, true>(ha, s);
   else if (p.ph == 16) hd_launch_cfg<ET, 64, 8, 16>(ha, s);
   else hd_launch_cfg<ET, 64, 4, 8>(ha, s);
