@@ -46,6 +46,47 @@ __global__ __launch_bounds__(LO_THREADS) void masked_sse_kernel(const uint16_t* 
   if (threadIdx.x == 0) partial[blockIdx.x] = acc;
 }
 
+// Several features in ONE launch (blockIdx.y = feature): the error sums of the deep tapped layers (conv3_2, conv4_2, conv5_2)
+// sit back to back on the one-lane critical path in front of the loss; each is a 5-11 us launch.
+struct SseMultiArgs {
+  const uint16_t* a[8]; const uint16_t* b[8];
+  int s[8], c8n[8];
+  float* partial[8];
+};
+template <typename ET>
+__global__ __launch_bounds__(LO_THREADS) void masked_sse_multi_kernel(const SseMultiArgs g, int batch, const float* __restrict__ mask,
+                                                                      int S, int l1) {
+  __shared__ float red[4];
+  const int f = blockIdx.y;
+  const uint16_t* __restrict__ a = g.a[f];
+  const uint16_t* __restrict__ b = g.b[f];
+  const int s = g.s[f], c8n = g.c8n[f];
+  const int r = S / s;
+  const int64_t total = (int64_t)batch * s * s * c8n;
+  float acc = 0.f;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p = idx / c8n;
+    float mk = 1.f;
+    if (mask) {
+      const int xx = (int)(p % s);
+      const int64_t t = p / s;
+      const int yy = (int)(t % s);
+      const int64_t bi = t / s;
+      mk = mask[(bi * S + (int64_t)yy * r) * S + (int64_t)xx * r];
+    }
+    float fa[8], fb[8];
+    unpack8<ET>(*(const uint4*)(a + idx * 8), fa);
+    unpack8<ET>(*(const uint4*)(b + idx * 8), fb);
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { const float d = fa[i] - fb[i]; sq += l1 ? fabsf(d) : d * d; }
+    acc += mk * sq;
+  }
+  acc = block_sum_256(acc, red);
+  if (threadIdx.x == 0) g.partial[f][blockIdx.x] = acc;
+}
+
 // The same sum fused with the 2x2 max-pool that follows the tapped layer (conv1_2, conv2_2: imm/models/selfsup/vgg16.py
 // pool1 / pool2 right after the feature the loss reads): one pass over the two feature halves instead of two.
 // a = ground-truth half, b = prediction half [batch,s,s,c]; pool_a / pool_b [batch,s/2,s/2,c].
@@ -121,6 +162,22 @@ extern "C" int imm_masked_sse(const void* a, const void* b, int dtype, int batch
   return 0;
 }
 
+extern "C" int imm_masked_sse_multi(int n, const void* const* a, const void* const* b, const int32_t* s_host, const int32_t* c_host,
+                                    float* const* partial, int dtype, int batch, const float* mask, int S, int l1, void* stream) {
+  IMM_REQUIRE(n >= 1 && n <= 8 && a && b && s_host && c_host && partial && batch > 0, "masked_sse_multi: args");
+  SseMultiArgs g;
+  for (int i = 0; i < 8; ++i) {
+    const int k = i < n ? i : 0;
+    IMM_REQUIRE(a[k] && b[k] && partial[k] && s_host[k] > 0 && c_host[k] > 0 && c_host[k] % 8 == 0, "masked_sse_multi: feature %d", k);
+    IMM_REQUIRE(mask == nullptr || (S >= s_host[k] && S % s_host[k] == 0), "masked_sse_multi: mask side %d vs feature side %d", S, s_host[k]);
+    g.a[i] = (const uint16_t*)a[k]; g.b[i] = (const uint16_t*)b[k]; g.s[i] = s_host[k]; g.c8n[i] = c_host[k] / 8; g.partial[i] = partial[k];
+  }
+  IMM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((masked_sse_multi_kernel<ET>), dim3(IMM_SSE_BLOCKS, n), dim3(LO_THREADS), 0,
+                                               (hipStream_t)stream, g, batch, mask, S, l1));
+  IMM_CHECK_LAUNCH("imm_masked_sse_multi");
+  return 0;
+}
+
 extern "C" int imm_masked_sse_pool(const void* a, const void* b, int dtype, int batch, int s, int c, const float* mask, int S,
                                    float* partial, void* pool_a, void* pool_b, void* stream) {
   IMM_REQUIRE(a && b && partial && pool_a && pool_b && batch > 0 && s > 0 && s % 2 == 0 && c > 0 && c % 8 == 0, "masked_sse_pool: args");
@@ -150,21 +207,34 @@ __global__ __launch_bounds__(LO_THREADS) void perceptual_finalize_kernel(const f
                                                                          const float* __restrict__ nel, float* agg,
                                                                          int training, const float* __restrict__ wd_loss,
                                                                          int l1, int mode, float* __restrict__ out) {
-  __shared__ double dred[LO_THREADS];
   __shared__ double sse[16];
+  __shared__ double wsum[LO_THREADS / 64][16];
   const int tid = threadIdx.x;
-  for (int f = 0; f < nfeat; ++f) {
-    double v = 0.0;
-    for (int i = tid; i < IMM_SSE_BLOCKS; i += LO_THREADS) v += (double)partial[f * IMM_SSE_BLOCKS + i];
-    dred[tid] = v;
-    __syncthreads();
-    for (int o = LO_THREADS / 2; o > 0; o >>= 1) {
-      if (tid < o) dred[tid] += dred[tid + o];
-      __syncthreads();
-    }
-    if (tid == 0) sse[f] = dred[0];
-    __syncthreads();
+  // every feature's partials in flight at once, one wave butterfly per feature, one barrier in all (was a load + an
+  // 8-barrier tree per feature in sequence: 10.5 us on the critical path between the last error sum and the first gradient)
+  double v[16];
+#pragma unroll
+  for (int f = 0; f < 16; ++f) {
+    v[f] = 0.0;
+    if (f < nfeat)
+      for (int i = tid; i < IMM_SSE_BLOCKS; i += LO_THREADS) v[f] += (double)partial[f * IMM_SSE_BLOCKS + i];
   }
+#pragma unroll
+  for (int f = 0; f < 16; ++f) {
+    if (f < nfeat) {
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) v[f] += __shfl_xor(v[f], o, 64);
+      if ((tid & 63) == 0) wsum[tid >> 6][f] = v[f];
+    }
+  }
+  __syncthreads();
+  if (tid < nfeat) {
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < LO_THREADS / 64; ++w) t += wsum[w][tid];
+    sse[tid] = t;
+  }
+  __syncthreads();
   if (tid == 0) {
     const float wd = wd_loss ? wd_loss[0] : 0.f;
     if (mode == IMM_LOSS_L2) {

@@ -812,9 +812,18 @@ class IMMEngine:
             idx0 = self.tap_idx['input']
             self._add(self.prog_fwd, lambda: ops.masked_sse_f32(self.in_future, 3, self.pred, self.ldp, B, S, 3, mask,
                                                                 self.sse_partial[idx0], l1), 'sse')
-        for name in taps:
-            if name in getattr(self, '_fused_sse', ()) or name in side_sse:
-                continue
+        tail = [name for name in taps if name not in getattr(self, '_fused_sse', ()) and name not in side_sse]
+        if len(tail) > 1 and os.environ.get('IMM_SSE_MULTI', '1') != '0':
+            # the deep tapped layers' error sums in one launch (they sit back to back in front of the loss)
+            feats = []
+            for name in tail:
+                y, H = self.vgg_act[name]
+                feats.append((y[:B], y[B:], H, y.shape[-1], self.sse_partial[self.tap_idx[name]]))
+            self.sse_multi = ops.SseMulti(feats)
+            self._add(self.prog_fwd, lambda: ops.masked_sse_multi(self.sse_multi, B, mask, S, l1), 'sse', 0.0,
+                      sum(2 * B * f[2] * f[2] * f[3] * 2.0 for f in feats))
+            tail = []
+        for name in tail:
             idx = self.tap_idx[name]
             y, H = self.vgg_act[name]
             c = y.shape[-1]

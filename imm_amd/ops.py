@@ -330,6 +330,26 @@ def masked_sse(a, b, batch, s, c, mask, S, partial, l1=False):
     call('imm_masked_sse', _p(a), _p(b), dtype_enum(a.dtype), batch, s, c, _p(mask), S, int(l1), _p(partial), _s())
 
 
+class SseMulti:
+    """Argument block of imm_masked_sse_multi: feats = [(a, b, s, c, partial_row)], built once, launched every step."""
+
+    def __init__(self, feats):
+        n = len(feats)
+        self.n = n
+        self.keep = feats
+        self.a = (C.c_void_p * n)(*[f[0].data_ptr() for f in feats])
+        self.b = (C.c_void_p * n)(*[f[1].data_ptr() for f in feats])
+        self.s = (C.c_int32 * n)(*[int(f[2]) for f in feats])
+        self.c = (C.c_int32 * n)(*[int(f[3]) for f in feats])
+        self.p = (C.c_void_p * n)(*[f[4].data_ptr() for f in feats])
+        self.dtype = feats[0][0].dtype
+
+
+def masked_sse_multi(g, batch, mask, S, l1=False):
+    call('imm_masked_sse_multi', g.n, C.cast(g.a, C.c_void_p), C.cast(g.b, C.c_void_p), C.cast(g.s, C.c_void_p), C.cast(g.c, C.c_void_p),
+         C.cast(g.p, C.c_void_p), dtype_enum(g.dtype), batch, _p(mask), S, int(l1), _s())
+
+
 def masked_sse_f32(a, lda, b, ldb, batch, s, c, mask, partial, l1=False):
     call('imm_masked_sse_f32', _p(a), lda, _p(b), ldb, batch, s, c, _p(mask), int(l1), _p(partial), _s())
 

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define IMM_ABI_VERSION 12   /* 2: imm_vgg_conv1_1_fwd gained `halves` */
+#define IMM_ABI_VERSION 13   /* 2: imm_vgg_conv1_1_fwd gained `halves` */
 
 enum imm_dtype { IMM_BF16 = 0, IMM_F16 = 1 };
 
@@ -259,6 +259,10 @@ int imm_image_loss_grad(const float* gt, const float* pred, int ldp, int batch, 
 /* partial[IMM_SSE_BLOCKS] of sum mask[pixel/(s*s)...]*(a-b)^2 (l1 != 0: |a-b|, perceptual.l2: False, imm_model.py:132);
  * mask is the full-res f32 [B,S,S] mask, sampled with stride S/s (legacy resize == strided pick, imm_model.py:408-410).
  * a/b 16-bit [B,s,s,c]. */
+/* imm_masked_sse of n <= 8 features in ONE launch: a[i]/b[i] 16-bit [B,s[i],s[i],c[i]] -> partial[i][IMM_SSE_BLOCKS]; the pointer and
+ * size arrays are HOST arrays (copied into the kernel arguments). */
+int imm_masked_sse_multi(int n, const void* const* a, const void* const* b, const int32_t* s_host, const int32_t* c_host,
+                         float* const* partial, int dtype, int batch, const float* mask, int S, int l1, void* stream);
 int imm_masked_sse(const void* a, const void* b, int dtype, int batch, int s, int c, const float* mask, int S, int l1,
                    float* partial, void* stream);
 /* imm_masked_sse fused with the 2x2/2 max-pool that follows the tapped VGG layer (conv1_2, conv2_2): reads the two feature

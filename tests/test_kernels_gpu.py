@@ -372,6 +372,29 @@ def test_batch_norm_fwd_bwd(ops, c, npix):
     close(dyo, gy.reshape(npix, c), 2e-2, 4e-3, 'bn_dy')
 
 
+def test_masked_sse_multi_equals_single_launches(ops):
+    """imm_masked_sse_multi: several features in one launch, partial sums bit for bit those of imm_masked_sse."""
+    from imm_amd import _lib as L
+    B, S = 3, 64
+    g = torch.Generator().manual_seed(5)
+    mask = torch.rand(B, S, S, generator=g).to(DEV)
+    feats, single = [], []
+    for s_, c in ((32, 256), (16, 512), (8, 64)):
+        y = torch.randn(2 * B, s_, s_, c, generator=g).to(torch.bfloat16).to(DEV)
+        part = torch.full((L.SSE_BLOCKS,), float('nan'), device=DEV)
+        ref = torch.empty(L.SSE_BLOCKS, device=DEV)
+        ops.masked_sse(y[:B], y[B:], B, s_, c, mask, S, ref)
+        feats.append((y[:B], y[B:], s_, c, part)); single.append(ref)
+    for l1 in (False, True):
+        if l1:
+            for (a, b, s_, c, _p), ref in zip(feats, single):
+                ops.masked_sse(a, b, B, s_, c, mask, S, ref, l1=True)
+        ops.masked_sse_multi(ops.SseMulti(feats), B, mask, S, l1=l1)
+        torch.cuda.synchronize()
+        for (_a, _b, _s, _c, part), ref in zip(feats, single):
+            assert torch.equal(part, ref)
+
+
 @pytest.mark.parametrize('rows,width,group', [(1024, 64, 32), (512, 128, 32), (700, 64, 32), (33, 512, 32), (2048, 64, 64)])
 def test_rows_reduce(ops, rows, width, group):
     """imm_rows_reduce: group sums of partial rows (f64 accumulation); bitwise repeatable."""
