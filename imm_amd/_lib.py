@@ -20,7 +20,7 @@ CONV_BIAS, CONV_RELU, CONV_STATS, CONV_MASK, CONV_OUT_F32 = 1, 2, 4, 8, 16
 SSE_BLOCKS = 512
 OPTIMIZERS = {'adam': 0, 'adadelta': 1, 'adagrad': 2}      # IMM_OPT_* (scripts/train.py:97-104)
 GAUSS_MODES = {'rot': 0, 'flat': 1, 'ankush': 2}     # IMM_GAUSS_* (config key gauss_mode, imm_model.py:48-72)
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 
 class ImmHipError(RuntimeError):
@@ -36,7 +36,8 @@ class ConvDesc(C.Structure):
 class OptHParams(C.Structure):
     _fields_ = [('lr_start', C.c_float), ('lr_decay', C.c_float), ('lr_step', C.c_int32), ('lr_multiple', C.c_float),
                 ('beta1', C.c_float), ('beta2', C.c_float), ('eps', C.c_float), ('clip', C.c_float),
-                ('grad_scale', C.c_float), ('optim', C.c_int32)]
+                ('grad_scale', C.c_float), ('optim', C.c_int32),
+                ('scale_growth_interval', C.c_int32), ('scale_max', C.c_float)]
 
 
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
@@ -100,10 +101,10 @@ _SIGS = {
     'imm_masked_sse_multi': [_I, _P, _P, _P, _P, _P, _I, _I, _P, _I, _I, _P],
     'imm_masked_sse': [_P, _P, _I, _I, _I, _I, _P, _I, _I, _P, _P],
     'imm_masked_sse_f32': [_P, _I, _P, _I, _I, _I, _I, _P, _I, _P, _P],
-    'imm_perceptual_finalize': [_P, _I, _P, _P, _I, _P, _I, _I, _P, _P],
+    'imm_perceptual_finalize': [_P, _I, _P, _P, _I, _P, _I, _I, _P, _P, _P],
     'imm_tap_grad': [_P, _I, _P, _P, _I, _I, _I, _I, _P, _I, _P, _I, _I, _I, _P],
     'imm_weight_decay_loss': [_P, _P, _P, _P, _I, _P, _P, _P, _P],
-    'imm_clip_adam_step': [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, C.POINTER(OptHParams), _P],
+    'imm_clip_adam_step': [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, C.POINTER(OptHParams), _P, _P],
 }
 
 # byte-size twins of the row-count queries (int64 result; < 0 = unsupported)

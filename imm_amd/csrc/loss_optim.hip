@@ -206,7 +206,8 @@ extern "C" int imm_masked_sse_f32(const float* a, int lda, const float* b, int l
 __global__ __launch_bounds__(LO_THREADS) void perceptual_finalize_kernel(const float* __restrict__ partial, int nfeat,
                                                                          const float* __restrict__ nel, float* agg,
                                                                          int training, const float* __restrict__ wd_loss,
-                                                                         int l1, int mode, float* __restrict__ out) {
+                                                                         int l1, int mode, const float* __restrict__ loss_scale,
+                                                                         float* __restrict__ out) {
   __shared__ double sse[16];
   __shared__ double wsum[LO_THREADS / 64][16];
   const int tid = threadIdx.x;
@@ -237,10 +238,13 @@ __global__ __launch_bounds__(LO_THREADS) void perceptual_finalize_kernel(const f
   __syncthreads();
   if (tid == 0) {
     const float wd = wd_loss ? wd_loss[0] : 0.f;
+    // loss scaling (16-bit gradient storage with f16's range): every seed of the backward pass carries the factor S; the
+    // backward chain is linear in its seeds, imm_clip_adam_step divides the flat gradients by S again
+    const float ls = loss_scale ? loss_scale[0] : 1.f;
     if (mode == IMM_LOSS_L2) {
       const float m = (float)(sse[0] / (double)nel[0]);
       out[0] = m; out[nfeat] = m;
-      out[2 * nfeat] = (1000.f / 255.f) * 2.f / nel[0];
+      out[2 * nfeat] = ls * ((1000.f / 255.f) * 2.f / nel[0]);
       out[3 * nfeat] = 1000.f * m;
       out[3 * nfeat + 1] = wd;
       out[3 * nfeat + 2] = 1000.f * m / 255.f + wd;
@@ -254,7 +258,7 @@ __global__ __launch_bounds__(LO_THREADS) void perceptual_finalize_kernel(const f
       const float term = m / wl;
       out[f] = term;
       out[nfeat + f] = m;
-      out[2 * nfeat + f] = 1000.f * (1.f / wl - 0.01f * m / (wl * wl)) * (l1 ? 1.f : 2.f) / nel[f];
+      out[2 * nfeat + f] = ls * (1000.f * (1.f / wl - 0.01f * m / (wl * wl)) * (l1 ? 1.f : 2.f) / nel[f]);
       if (training) agg[f] = wl;
       rec += term;
     }
@@ -266,11 +270,12 @@ __global__ __launch_bounds__(LO_THREADS) void perceptual_finalize_kernel(const f
 }
 
 extern "C" int imm_perceptual_finalize(const float* partial, int nfeat, const float* nel, float* agg, int training,
-                                       const float* wd_loss, int l1, int mode, float* out, void* stream) {
+                                       const float* wd_loss, int l1, int mode, const float* loss_scale, float* out,
+                                       void* stream) {
   IMM_REQUIRE(partial && nel && agg && out && nfeat > 0 && nfeat <= 16, "perceptual_finalize: args");
   IMM_REQUIRE(mode == IMM_LOSS_PERCEPTUAL || (mode == IMM_LOSS_L2 && nfeat == 1 && !l1), "perceptual_finalize: mode");
   hipLaunchKernelGGL(perceptual_finalize_kernel, dim3(1), dim3(LO_THREADS), 0, (hipStream_t)stream, partial, nfeat, nel,
-                     agg, training, wd_loss, l1, mode, out);
+                     agg, training, wd_loss, l1, mode, loss_scale, out);
   IMM_CHECK_LAUNCH("imm_perceptual_finalize");
   return 0;
 }
@@ -476,9 +481,11 @@ __global__ __launch_bounds__(LO_THREADS) void grad_prepare_kernel(const float* _
                                                                   const int32_t* __restrict__ blk_begin,
                                                                   const int32_t* __restrict__ blk_end,
                                                                   const float* __restrict__ seg_wd, float grad_scale,
+                                                                  const float* __restrict__ loss_scale,
                                                                   float* __restrict__ blk_partial) {
   __shared__ float red[4];
   const int blk = blockIdx.x;
+  if (loss_scale) grad_scale *= 1.f / loss_scale[0];     // S is a power of two: exact
   const float wd = seg_wd[blk_seg[blk]];
   float acc = 0.f;
   // 16-byte accesses over the aligned body of the chunk, scalars on the (<= 3 element) head and tail
@@ -504,24 +511,44 @@ __global__ __launch_bounds__(LO_THREADS) void grad_prepare_kernel(const float* _
   if (threadIdx.x == 0) blk_partial[blk] = acc;
 }
 
-__global__ void opt_tick_kernel(const float* __restrict__ blk_partial, const int32_t* __restrict__ seg_first_blk, int nseg,
-                                float* __restrict__ seg_norm2, int32_t* step_count, int32_t* adam_t, float* lr_state,
-                                imm_opt_hparams hp) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < nseg) {
+// One workgroup: per-tensor squared norms from the block partials, the step counters, the learning rate — and, with loss
+// scaling (ls != NULL: {S, clean steps in a row, steps skipped so far, this step overflowed}), the decision to skip the update
+// when any tensor's norm is not finite (an f16 gradient overflowed somewhere in the backward chain) and the dynamic scale:
+// halved on overflow, doubled after hp.scale_growth_interval clean steps (0: static), kept within [1, hp.scale_max].
+__global__ __launch_bounds__(LO_THREADS) void opt_tick_kernel(const float* __restrict__ blk_partial,
+                                                              const int32_t* __restrict__ seg_first_blk, int nseg,
+                                                              float* __restrict__ seg_norm2, int32_t* step_count, int32_t* adam_t,
+                                                              float* lr_state, float* ls, imm_opt_hparams hp) {
+  __shared__ int bad;
+  if (threadIdx.x == 0) bad = 0;
+  __syncthreads();
+  for (int t = threadIdx.x; t < nseg; t += LO_THREADS) {
     double s = 0.0;
     for (int b = seg_first_blk[t]; b < seg_first_blk[t + 1]; ++b) s += (double)blk_partial[b];
     seg_norm2[t] = (float)s;
+    if (!isfinite((float)s)) atomicOr(&bad, 1);
   }
-  if (t == 0) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const bool skip = ls != nullptr && bad != 0;
+    if (ls) {
+      float S = ls[0], clean = ls[1];
+      if (skip) { S = fmaxf(S * 0.5f, 1.f); clean = 0.f; ls[2] += 1.f; }
+      else if (hp.scale_growth_interval > 0 && clean + 1.f >= (float)hp.scale_growth_interval) {
+        S = fminf(S * 2.f, hp.scale_max > 0.f ? hp.scale_max : S * 2.f); clean = 0.f;
+      } else clean += 1.f;
+      ls[0] = S; ls[1] = clean; ls[3] = skip ? 1.f : 0.f;
+    }
     const int gs = step_count[0];           // TF global_step before this apply: learning-rate schedule only
     const int tt = adam_t[0] + 1;           // Adam's t (TF: beta1_power / beta2_power, independent of global_step)
     const double lr = (double)hp.lr_multiple * (double)hp.lr_start * pow((double)hp.lr_decay, (double)(gs / hp.lr_step));
     const double lr_t = lr * sqrt(1.0 - pow((double)hp.beta2, (double)tt)) / (1.0 - pow((double)hp.beta1, (double)tt));
     lr_state[0] = (float)lr_t;
     lr_state[1] = (float)lr;
-    step_count[0] = gs + 1;
-    adam_t[0] = tt;
+    if (!skip) {                            // a skipped step leaves the weights, the slots and both counters untouched
+      step_count[0] = gs + 1;
+      adam_t[0] = tt;
+    }
   }
 }
 
@@ -531,8 +558,10 @@ __global__ __launch_bounds__(LO_THREADS) void clip_adam_kernel(float* __restrict
                                                                const int32_t* __restrict__ blk_begin,
                                                                const int32_t* __restrict__ blk_end,
                                                                const float* __restrict__ seg_norm2,
-                                                               const float* __restrict__ lr_state, imm_opt_hparams hp) {
+                                                               const float* __restrict__ lr_state,
+                                                               const float* __restrict__ ls, imm_opt_hparams hp) {
   const int blk = blockIdx.x;
+  if (ls && ls[3] != 0.f) return;      // overflow in this step's gradients: no update (opt_tick_kernel)
   float factor = 1.f;
   if (hp.clip > 0.f) factor = hp.clip / fmaxf(sqrtf(seg_norm2[blk_seg[blk]]), hp.clip);
   const float lr_t = lr_state[0], lr = lr_state[1];
@@ -568,18 +597,18 @@ extern "C" int imm_clip_adam_step(float* params, float* grads, float* m, float* 
                                   const int32_t* blk_begin, const int32_t* blk_end, int nblk, int nseg,
                                   const int32_t* seg_first_blk, const float* seg_wd, float* blk_partial, float* seg_norm2,
                                   int32_t* step_count, int32_t* adam_t, float* lr_state, const imm_opt_hparams* hp,
-                                  void* stream) {
+                                  float* loss_scale_state, void* stream) {
   IMM_REQUIRE(params && grads && m && v && blk_seg && blk_begin && blk_end && seg_first_blk && seg_wd && blk_partial &&
                   seg_norm2 && step_count && adam_t && lr_state && hp, "clip_adam_step: null");
   IMM_REQUIRE(nblk > 0 && nseg > 0 && hp->lr_step > 0, "clip_adam_step: dims");
   IMM_REQUIRE(hp->optim >= IMM_OPT_ADAM && hp->optim <= IMM_OPT_ADAGRAD, "clip_adam_step: optim %d", hp->optim);
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(grad_prepare_kernel, dim3(nblk), dim3(LO_THREADS), 0, s, params, grads, blk_seg, blk_begin, blk_end,
-                     seg_wd, hp->grad_scale, blk_partial);
-  hipLaunchKernelGGL(opt_tick_kernel, dim3((nseg + 63) / 64), dim3(64), 0, s, blk_partial, seg_first_blk, nseg, seg_norm2,
-                     step_count, adam_t, lr_state, *hp);
+                     seg_wd, hp->grad_scale, loss_scale_state, blk_partial);
+  hipLaunchKernelGGL(opt_tick_kernel, dim3(1), dim3(LO_THREADS), 0, s, blk_partial, seg_first_blk, nseg, seg_norm2,
+                     step_count, adam_t, lr_state, loss_scale_state, *hp);
   hipLaunchKernelGGL(clip_adam_kernel, dim3(nblk), dim3(LO_THREADS), 0, s, params, grads, m, v, blk_seg, blk_begin, blk_end,
-                     seg_norm2, lr_state, *hp);
+                     seg_norm2, lr_state, loss_scale_state, *hp);
   IMM_CHECK_LAUNCH("imm_clip_adam_step");
   return 0;
 }

@@ -183,8 +183,22 @@ class IMMEngine:
         self.lr_state = self._zeros(2)
         self.wd_loss = self._zeros(1)
         hp = dict(lr_start=1e-3, lr_decay=0.95, lr_step=100000, lr_multiple=1.0, beta1=0.9, beta2=0.999, eps=1e-8,
-                  clip=1.0, grad_scale=1.0 / world_size, optim='adam')
+                  clip=1.0, grad_scale=1.0 / world_size, optim='adam', scale_growth_interval=1000, scale_max=2.0 ** 24)
         hp.update(hparams or {})
+        # Loss scaling.  The reference computes in fp32 (imm_model.py:97); with f16 storage the gradient tensors of a trained
+        # model (|dy| down to 1e-8) fall below f16's range, so the seeds of the backward pass are multiplied by a power of two
+        # S (imm_perceptual_finalize) and the flat gradients divided by it inside imm_clip_adam_step, which also skips the
+        # update and halves S when a gradient overflowed, and doubles S after `scale_growth_interval` clean steps.  All of it
+        # lives in device memory (graph replay needs no host value).  bf16 has f32's range: no scaling.
+        # hparams['loss_scale']: initial S (power of two), 0 / None = off; default 2^12 for f16, off for bf16.
+        ls0 = hp.pop('loss_scale', 4096.0 if act_dtype == torch.float16 else 0.0) or 0.0
+        if ls0 and (ls0 < 1.0 or math.log2(ls0) != int(math.log2(ls0))):
+            raise ValueError('loss_scale must be a power of two >= 1, got %r' % (ls0,))
+        self.loss_scale_state = None
+        if ls0:
+            self.loss_scale_state = self._zeros(4)      # {S, clean steps in a row, skipped steps, last step overflowed}
+            self.loss_scale_state[0] = float(ls0)
+        self._loss_scale_init = float(ls0)
         # scripts/train.py:97-104: Adam | Adadelta(rho 0.95, eps 1e-6) | Adagrad(initial accumulator 0.1)
         self.optim = str(hp['optim']).lower()
         if self.optim not in L.OPTIMIZERS:
@@ -268,6 +282,9 @@ class IMMEngine:
         self.adam_m.zero_()
         self.adam_v.fill_(0.1 if self.optim == 'adagrad' else 0.0)
         self.adam_t.zero_()
+        if self.loss_scale_state is not None:
+            self.loss_scale_state.zero_()
+            self.loss_scale_state[0] = self._loss_scale_init
 
     def load_parameters(self, named, state=None):
         """named: {tf_variable_name: tensor}.  Missing names raise (no silent partial restore)."""
@@ -835,7 +852,8 @@ class IMMEngine:
             self._wait(self.prog_fwd, 'sse_side_done', lane=0)
         mode = ops.LOSS_L2 if self.loss_kind == 'l2' else ops.LOSS_PERCEPTUAL
         self._add(self.prog_fwd, lambda: ops.perceptual_finalize(self.sse_partial, nfeat, self.nel, self.loss_agg,
-                                                                 self._training, self.wd_loss, self.loss_out, l1, mode), 'loss_finalize')
+                                                                 self._training, self.wd_loss, self.loss_out, l1, mode,
+                                                                 self.loss_scale_state), 'loss_finalize')
         self.coef = self.loss_out[2 * nfeat:3 * nfeat]
 
         self._build_backward()
@@ -846,7 +864,8 @@ class IMMEngine:
         # ---- optimizer --------------------------------------------------------------------------------------
         self._add(self.prog_opt, lambda: ops.clip_adam_step(self.params, self.grads, self.adam_m, self.adam_v, self.tab,
                                                             self.opt_blk_partial, self.seg_norm2, self.step_count,
-                                                            self.adam_t, self.lr_state, self.hp), 'clip_adam', 0.0, self.tab.total * 36.0)
+                                                            self.adam_t, self.lr_state, self.hp, self.loss_scale_state),
+                  'clip_adam', 0.0, self.tab.total * 36.0)
         self.prog_opt.extend(self.prog_pack)
 
     def _pack_vgg(self):
@@ -1166,13 +1185,16 @@ class IMMEngine:
         """Everything a step mutates (used to warm kernels up before graph capture without side effects)."""
         return {'params': self.params.clone(), 'm': self.adam_m.clone(), 'v': self.adam_v.clone(),
                 'step': self.step_count.clone(), 'adam_t': self.adam_t.clone(), 'agg': self.loss_agg.clone(), 'grads': self.grads.clone(),
-                'state': {k: v.clone() for k, v in self.state.items()}}
+                'state': {k: v.clone() for k, v in self.state.items()},
+                'loss_scale': None if self.loss_scale_state is None else self.loss_scale_state.clone()}
 
     def restore(self, snap):
         self.params.copy_(snap['params']); self.adam_m.copy_(snap['m']); self.adam_v.copy_(snap['v'])
         self.step_count.copy_(snap['step']); self.adam_t.copy_(snap['adam_t']); self.loss_agg.copy_(snap['agg']); self.grads.copy_(snap['grads'])
         for k, v in snap['state'].items():
             self.state[k].copy_(v)
+        if self.loss_scale_state is not None:
+            self.loss_scale_state.copy_(snap['loss_scale'])
         self.run(self.prog_pack)
 
     def optimizer_step(self):
@@ -1186,6 +1208,17 @@ class IMMEngine:
     @property
     def loss_terms(self):
         return self.loss_out[:self.nfeat]
+
+    @property
+    def loss_scale(self):
+        """Current loss scale S (1.0 when loss scaling is off): `grads` / `gview` hold S x the gradient between backward()
+        and optimizer_step().  Reads the device scalar (synchronises)."""
+        return 1.0 if self.loss_scale_state is None else float(self.loss_scale_state[0])
+
+    def named_gradients(self):
+        """{tf variable name: gradient of the loss (weight decay excluded), loss scale divided out} after backward()."""
+        inv = 1.0 / self.loss_scale
+        return OrderedDict((k, v.detach() * inv) for k, v in self.gview.items())
 
     @property
     def future_im_pred(self):

@@ -69,6 +69,10 @@ class IMMModel(BaseModel):
     def require_vgg(self):
         """The loss needs the perceptual network: a missing perceptual.net_file is an error (the reference's dd.io.load
         raises), never a silent fall-back to random weights."""
+        cfg = self._config
+        comp = list(getattr(getattr(cfg, 'perceptual', None), 'comp', []) or [])
+        if getattr(cfg, 'reconstruction_loss', 'perceptual') != 'perceptual' or all(n == 'input' for n in comp):
+            return       # no VGG layer is tapped: the reference only opens net_file inside the perceptual branch (imm_model.py:376-387)
         if hasattr(self, '_vgg_missing'):
             missing = self._vgg_missing
             raise FileNotFoundError("perceptual.net_file %r does not exist (set it to the vgg16.caffemodel.h5 / .npz file, or to "
@@ -80,6 +84,8 @@ class IMMModel(BaseModel):
         dst.load_parameters(src.named_parameters(), src.named_state())
         dst.adam_m.copy_(src.adam_m); dst.adam_v.copy_(src.adam_v)
         dst.step_count.copy_(src.step_count); dst.adam_t.copy_(src.adam_t)
+        if dst.loss_scale_state is not None and src.loss_scale_state is not None:
+            dst.loss_scale_state.copy_(src.loss_scale_state)
 
     def _get_engine(self, batch, size):
         """One engine (buffers + launch programs) per (batch, size); the variables are shared between instantiations

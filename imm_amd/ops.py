@@ -357,9 +357,9 @@ def masked_sse_f32(a, lda, b, ldb, batch, s, c, mask, partial, l1=False):
 LOSS_PERCEPTUAL, LOSS_L2 = 0, 1
 
 
-def perceptual_finalize(partial, nfeat, nel, agg, training, wd_loss, out, l1=False, mode=LOSS_PERCEPTUAL):
+def perceptual_finalize(partial, nfeat, nel, agg, training, wd_loss, out, l1=False, mode=LOSS_PERCEPTUAL, loss_scale=None):
     call('imm_perceptual_finalize', _p(partial), nfeat, _p(nel), _p(agg), int(training), _p(wd_loss), int(l1), int(mode),
-         _p(out), _s())
+         _p(loss_scale), _p(out), _s())
 
 
 def tap_grad(da, has_in, a_pred, a_gt, batch, s, c, mask, S, coef, idx, relu, l1=False):
@@ -373,10 +373,10 @@ def weight_decay_loss(params, tab, blk_partial, out):
          _p(blk_partial), _p(out), _s())
 
 
-def clip_adam_step(params, grads, m, v, tab, blk_partial, seg_norm2, step_count, adam_t, lr_state, hp):
+def clip_adam_step(params, grads, m, v, tab, blk_partial, seg_norm2, step_count, adam_t, lr_state, hp, loss_scale_state=None):
     call('imm_clip_adam_step', _p(params), _p(grads), _p(m), _p(v), _p(tab.blk_seg), _p(tab.blk_begin), _p(tab.blk_end),
          tab.nblk, tab.nseg, _p(tab.seg_first_blk), _p(tab.seg_wd), _p(blk_partial), _p(seg_norm2), _p(step_count),
-         _p(adam_t), _p(lr_state), C.byref(hp), _s())
+         _p(adam_t), _p(lr_state), C.byref(hp), _p(loss_scale_state), _s())
 
 
 class SegmentTable:

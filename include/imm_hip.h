@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define IMM_ABI_VERSION 13   /* 2: imm_vgg_conv1_1_fwd gained `halves` */
+#define IMM_ABI_VERSION 14   /* 14: loss scaling (imm_perceptual_finalize, imm_clip_adam_step, imm_opt_hparams) */
 
 enum imm_dtype { IMM_BF16 = 0, IMM_F16 = 1 };
 
@@ -279,8 +279,12 @@ int imm_masked_sse_f32(const float* a, int lda, const float* b, int ldb, int bat
  * out[3] = 1000*mean(mask*(pred-gt)^2), total = out[3]/255 + wd_loss, c_0 = (1000/255)*2/nel. */
 #define IMM_LOSS_PERCEPTUAL 0
 #define IMM_LOSS_L2 1
+/* loss_scale (device f32 scalar, or NULL = 1): the gradient coefficients c_k are written multiplied by it — the seeds of the
+ * whole backward chain (imm_tap_grad, imm_unpool_tap_grad, imm_vgg_conv1_1_bwd, imm_image_loss_grad read c_k), so that 16-bit
+ * gradient tensors stored as f16 stay inside f16's range; the loss values themselves are NOT scaled.  The reference computes
+ * in fp32 (imm_model.py:97) and needs none; imm_clip_adam_step divides the scale out again. */
 int imm_perceptual_finalize(const float* partial, int nfeat, const float* nel, float* agg, int training,
-                            const float* wd_loss, int l1, int mode, float* out, void* stream);
+                            const float* wd_loss, int l1, int mode, const float* loss_scale, float* out, void* stream);
 /* imm_maxpool2_bwd (no ReLU mask) followed by imm_tap_grad (has_in, relu) in one pass, for tapped layers that are pooled
  * next (conv1_2, conv2_2); dpool [batch, s/2, s/2, c] is the gradient of the pooled tensor.  Bitwise equal to the sequence. */
 int imm_unpool_tap_grad(void* da, const void* dpool, const void* a_pred, const void* a_gt, int dtype, int batch, int s, int c,
@@ -309,6 +313,8 @@ typedef struct imm_opt_hparams {
   float beta1, beta2, eps, clip;                                   /* clip <= 0 disables clipping  */
   float grad_scale;                                                /* 1 / number of towers         */
   int32_t optim;                                                   /* IMM_OPT_*                    */
+  int32_t scale_growth_interval;  /* loss scaling: double S after this many clean steps in a row (0 = static S)      */
+  float scale_max;                /* ... up to this value (<= 0: unbounded)                                          */
 } imm_opt_hparams;
 /* wd_loss = sum_seg wd/2 * sum w^2  -> *out  (base_model.py:33-37) */
 int imm_weight_decay_loss(const float* params, const int32_t* blk_seg, const int32_t* blk_begin,
@@ -319,11 +325,17 @@ int imm_weight_decay_loss(const float* params, const int32_t* blk_seg, const int
  * adam_t: device int32 = number of Adam updates applied to these m/v slots, i.e. TF's beta{1,2}_power accumulators
  * (tf.train.AdamOptimizer keeps them apart from global_step: a restore without the optimizer slots restarts the bias
  * correction at t = 1 while global_step carries on; cnn_train_multi.py:404-433); incremented by this call;
- * lr_state: device f32[2] = {lr_t, lr} written for inspection. */
+ * lr_state: device f32[2] = {lr_t, lr} written for inspection.
+ * loss_scale_state: NULL, or device f32[4] = {S, clean steps in a row, steps skipped so far, this step overflowed} for gradients
+ * that were computed with their seeds multiplied by S (imm_perceptual_finalize): g is divided by S first; if any tensor's
+ * norm is then not finite (an f16 gradient overflowed) the whole update is SKIPPED — weights, slots, step_count and adam_t
+ * stay as they are — and S is halved (not below 1); after hp.scale_growth_interval clean steps in a row S doubles (up to
+ * hp.scale_max).  The reference asserts on a NaN loss instead (cnn_train_multi.py:463); it has no reduced-precision mode. */
 int imm_clip_adam_step(float* params, float* grads, float* m, float* v, const int32_t* blk_seg,
                        const int32_t* blk_begin, const int32_t* blk_end, int nblk, int nseg,
                        const int32_t* seg_first_blk, const float* seg_wd, float* blk_partial, float* seg_norm2,
-                       int32_t* step_count, int32_t* adam_t, float* lr_state, const imm_opt_hparams* hp_host, void* stream);
+                       int32_t* step_count, int32_t* adam_t, float* lr_state, const imm_opt_hparams* hp_host,
+                       float* loss_scale_state, void* stream);
 
 /* ---- data-parallel gradient exchange (cnn_train_multi.py:66-106 average_gradients) ------------------------------------ */
 /* One process per GPU; ONE sum all-reduce of (a bucket of) the flat f32 gradient buffer over RCCL / xGMI on the caller's

@@ -61,7 +61,7 @@ def main():
         eng.forward(True); eng.backward()
         torch.cuda.synchronize()
         eng.loss_agg.copy_(agg0)
-        g_eng = eng.grads.clone()
+        g_eng = eng.grads.clone() / eng.loss_scale
         names = [n for n, _s, _w in eng.spec]
         for gname, pred in GROUPS.items():
             d = torch.zeros_like(g_eng)

@@ -28,7 +28,7 @@ def compare(tag, eng, g_ref):
             continue
         if float(v.norm()) < 1e-7:
             continue
-        a, b = eng.gview[k].detach().cpu().double().flatten(), v.detach().double().flatten()
+        a, b = (eng.gview[k].detach() / eng.loss_scale).cpu().double().flatten(), v.detach().double().flatten()
         rel = float((a - b).norm() / b.norm())
         cos = float((a * b).sum() / (a.norm() * b.norm() + 1e-300))
         worst = max(worst, rel)

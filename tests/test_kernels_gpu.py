@@ -118,8 +118,6 @@ def run_conv(ops, x16, w, bias, k, stride, co, ci_pad, out_f32, extra_flags=0, m
 @pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16], ids=['bf16', 'f16'])
 def test_conv_forward(ops, case, dt):
     B, H, ci_real, ci_pad, co, k, stride, out_f32, tag = case
-    if dt == torch.float16 and tag not in ('enc3x3', 'stride2', 'pose1x1'):
-        pytest.skip('f16 covered on a subset')
     x = rnd((B, H, H, ci_real), 1, 1.0, dt)
     w = rnd((k, k, ci_real, co), 2, 0.05, dt)
     b = rnd((co,), 3, 0.5, torch.float32)
@@ -175,13 +173,13 @@ DGRAD_CASES = [(2, 16, 32, 32, 32, 32, 3, 1, 'k3s1'), (2, 16, 32, 32, 64, 64, 3,
 
 
 @pytest.mark.parametrize('case', DGRAD_CASES, ids=[c[-1] for c in DGRAD_CASES])
-def test_conv_dgrad(ops, case):
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16], ids=['bf16', 'f16'])
+def test_conv_dgrad(ops, case, dt):
     B, H, ci_real, ci_pad, co, co_pad, k, stride, tag = case
-    dt = torch.bfloat16
-    w = rnd((k, k, ci_real, co), 11, 0.05)
+    w = rnd((k, k, ci_real, co), 11, 0.05, dt)
     xr = torch.zeros(B, H, H, ci_real, requires_grad=True)
     yref = O.conv2d_same(xr, w.float(), None, stride)
-    dy = rnd(tuple(yref.shape), 12)
+    dy = rnd(tuple(yref.shape), 12, 1.0, dt)
     (gx,) = torch.autograd.grad(yref, xr, dy.float())
     desc = ops.dgrad_desc(B, H, H, ci_real, ci_pad, co_pad, co_pad, k, stride, 0)
     rows = ops.round_up(ci_real, 128)
@@ -190,17 +188,18 @@ def test_conv_dgrad(ops, case):
     dx = torch.zeros(B, H, H, ci_pad, dtype=dt, device=DEV)
     ops.conv2d(desc, padded(dy, co_pad), wt, None, dx)
     torch.cuda.synchronize()
-    close(dx[..., :ci_real], gx, 1e-2, 2e-3, 'dgrad/' + tag)
+    close(dx[..., :ci_real], gx, 1e-2 if dt == torch.bfloat16 else 2e-3, 2e-3, 'dgrad/' + tag)
 
 
 @pytest.mark.parametrize('H,ci,co', [(16, 32, 64), (32, 64, 128), (64, 128, 256), (64, 32, 64)])
-def test_conv_dgrad_stride2_parity_classes(ops, H, ci, co):
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16], ids=['bf16', 'f16'])
+def test_conv_dgrad_stride2_parity_classes(ops, H, ci, co, dt):
     """Stride-2 data gradient as four dense sub-convolutions (one per input-pixel parity class) scattered into dx."""
-    B, k, dt = 2, 3, torch.bfloat16
-    w = rnd((k, k, ci, co), 13, 0.05)
+    B, k = 2, 3
+    w = rnd((k, k, ci, co), 13, 0.05, dt)
     xr = torch.zeros(B, H, H, ci, requires_grad=True)
     yref = O.conv2d_same(xr, w.float(), None, 2)
-    dy = rnd(tuple(yref.shape), 14)
+    dy = rnd(tuple(yref.shape), 14, 1.0, dt)
     (gx,) = torch.autograd.grad(yref, xr, dy.float())
     descs = ops.dgrad_s2_class_descs(B, H, H, ci, ci, co, co, k)
     assert descs is not None and len(descs) == 4 and sorted(d.kh * d.kw for d, _ in descs) == [1, 2, 2, 4]
@@ -225,13 +224,13 @@ WGRAD_CASES = [(2, 16, 32, 32, 32, 32, 3, 1, 1, 'k3s1_split1'), (2, 16, 32, 32, 
 
 
 @pytest.mark.parametrize('case', WGRAD_CASES, ids=[c[-1] for c in WGRAD_CASES])
-def test_conv_wgrad(ops, case):
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16], ids=['bf16', 'f16'])
+def test_conv_wgrad(ops, case, dt):
     B, H, ci_real, ci_pad, co, lddy, k, stride, nsplit, tag = case
-    dt = torch.bfloat16
-    x = rnd((B, H, H, ci_real), 21)
+    x = rnd((B, H, H, ci_real), 21, 1.0, dt)
     wr = torch.zeros(k, k, ci_real, co, requires_grad=True)
     yref = O.conv2d_same(x.float(), wr, None, stride)
-    dy = rnd(tuple(yref.shape), 22)
+    dy = rnd(tuple(yref.shape), 22, 1.0, dt)
     (gw,) = torch.autograd.grad(yref, wr, dy.float())
     desc = ops.fwd_desc(B, H, H, ci_pad, ci_pad, co, lddy, k, stride, 0)
     slab = torch.full((nsplit, desc.kpad, co), float('nan'), dtype=torch.float32, device=DEV)
@@ -249,14 +248,14 @@ WGRAD_HALO_CASES = [(1, 128, 32, 32, 32, 'h32_32'), (2, 64, 64, 64, 64, 'h64_64'
 
 
 @pytest.mark.parametrize('case', WGRAD_HALO_CASES, ids=[c[-1] for c in WGRAD_HALO_CASES])
-def test_conv_wgrad_halo(ops, case):
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16], ids=['bf16', 'f16'])
+def test_conv_wgrad_halo(ops, case, dt):
     """3x3 s1 filter gradient through the LDS-resident / transpose-read kernel (conv_wgrad_halo.hip)."""
     B, H, ci, co, lddy, tag = case
-    dt = torch.bfloat16
-    x = rnd((B, H, H, ci), 121)
+    x = rnd((B, H, H, ci), 121, 1.0, dt)
     wr = torch.zeros(3, 3, ci, co, requires_grad=True)
     yref = O.conv2d_same(x.float(), wr, None, 1)
-    dy = rnd(tuple(yref.shape), 122)
+    dy = rnd(tuple(yref.shape), 122, 1.0, dt)
     (gw,) = torch.autograd.grad(yref, wr, dy.float())
     desc = ops.fwd_desc(B, H, H, ci, ci, co, lddy, 3, 1, 0)
     nsplit = ops.conv2d_wgrad_splits(desc, lddy)
@@ -923,6 +922,83 @@ def test_clip_adam_and_weight_decay(ops):
     assert int(step) == 250001 and int(adam_t) == 1
     big = grads.abs() > 1e-4          # first bias-corrected step: |dw| = lr * |g| / (|g| + eps') ~ lr
     np.testing.assert_allclose((params - p0).abs()[big].max().item(), lr, rtol=1e-3)
+
+
+def test_clip_adam_loss_scaling(ops):
+    """Loss scaling inside imm_clip_adam_step (f16 gradient storage; the reference is fp32, imm_model.py:97): gradients that
+    carry the factor S give the SAME update as unscaled ones (S is a power of two: bitwise), S doubles after
+    scale_growth_interval clean steps, and a non-finite gradient anywhere skips the whole update — weights, slots, both
+    counters untouched — and halves S."""
+    sizes = [9 * 32 * 32, 32, 7, 20000, 1]
+    wds = [1e-5, 0.0, 0.0, 1e-5, 0.0]
+    tab = ops.SegmentTable(sizes, wds, DEV)
+    g = torch.Generator().manual_seed(9)
+    params0 = (torch.randn(tab.total, generator=g) * 0.3).to(DEV)
+    G = (torch.randn(tab.total, generator=g) * 0.7).to(DEV)
+    kw = dict(lr_start=1e-3, lr_decay=0.95, lr_step=100000, lr_multiple=1.0, beta1=0.9, beta2=0.999, eps=1e-8, clip=1.0,
+              grad_scale=0.5, scale_growth_interval=2, scale_max=4096.0)
+    hp = ops.OptHParams(**kw)
+
+    def fresh():
+        return dict(params=params0.clone(), m=torch.zeros_like(params0), v=torch.zeros_like(params0),
+                    part=torch.empty(tab.nblk, device=DEV), norm2=torch.empty(tab.nseg, device=DEV),
+                    step=torch.zeros(1, dtype=torch.int32, device=DEV), adam_t=torch.zeros(1, dtype=torch.int32, device=DEV),
+                    lrs=torch.zeros(2, device=DEV))
+
+    def run(st, grads, ls):
+        ops.clip_adam_step(st['params'], grads, st['m'], st['v'], tab, st['part'], st['norm2'], st['step'], st['adam_t'], st['lrs'],
+                           hp, ls)
+        torch.cuda.synchronize()
+    a, b = fresh(), fresh()
+    ls = torch.tensor([1024.0, 0.0, 0.0, 0.0], device=DEV)
+    scales = []
+    for it in range(3):
+        S = float(ls[0]); scales.append(S)
+        run(a, G.clone(), None)
+        run(b, G * S, ls)
+        assert torch.equal(a['params'], b['params']) and torch.equal(a['m'], b['m']) and torch.equal(a['v'], b['v']), it
+    assert scales == [1024.0, 1024.0, 2048.0] and ls.tolist() == [2048.0, 1.0, 0.0, 0.0]      # doubled after 2 clean steps
+    assert int(b['step']) == 3 and int(b['adam_t']) == 3
+    # overflow: one inf in the smallest tensor -> no update at all, S halved, counters as before, `skipped` = 1
+    keep = {k: v.clone() for k, v in b.items()}
+    bad = G * float(ls[0]); bad[-1] = float('inf')
+    run(b, bad, ls)
+    for k in ('params', 'm', 'v', 'step', 'adam_t'):
+        assert torch.equal(b[k], keep[k]), k
+    assert ls.tolist() == [1024.0, 0.0, 1.0, 1.0]
+    bad = G * float(ls[0]); bad[5] = float('nan')
+    run(b, bad, ls)
+    assert torch.equal(b['params'], keep['params']) and ls.tolist() == [512.0, 0.0, 2.0, 1.0]
+    # and the next clean step applies again (a one step behind b's counters now)
+    run(a, G.clone(), None); run(b, G * float(ls[0]), ls)
+    assert torch.equal(a['params'], b['params']) and ls.tolist() == [512.0, 1.0, 2.0, 0.0] and int(b['step']) == 4
+    # S never grows past scale_max, never drops below 1
+    ls = torch.tensor([4096.0, 1.0, 0.0, 0.0], device=DEV)
+    run(b, G * 4096.0, ls)
+    assert float(ls[0]) == 4096.0
+    ls = torch.tensor([1.0, 0.0, 0.0, 0.0], device=DEV)
+    bad = G.clone(); bad[0] = float('inf')
+    run(b, bad, ls)
+    assert float(ls[0]) == 1.0 and float(ls[3]) == 1.0
+
+
+def test_perceptual_finalize_loss_scale(ops):
+    """imm_perceptual_finalize with a loss scale: loss values unchanged, gradient coefficients x S exactly."""
+    from imm_amd import _lib as L
+    nfeat = 3
+    part = torch.rand(nfeat, L.SSE_BLOCKS, device=DEV)
+    nel = torch.tensor([1000.0, 5000.0, 64.0], device=DEV)
+    wd = torch.tensor([0.25], device=DEV)
+    outs = []
+    for ls in (None, torch.tensor([256.0, 0, 0, 0], device=DEV)):
+        agg = torch.tensor([100.0, 1.6, 2.3], device=DEV)
+        out = torch.zeros(3 * nfeat + 3, device=DEV)
+        ops.perceptual_finalize(part, nfeat, nel, agg, True, wd, out, False, ops.LOSS_PERCEPTUAL, ls)
+        torch.cuda.synchronize()
+        outs.append(out.cpu())
+    a, b = outs
+    assert torch.equal(a[:2 * nfeat], b[:2 * nfeat]) and torch.equal(a[3 * nfeat:], b[3 * nfeat:])
+    assert torch.equal(a[2 * nfeat:3 * nfeat] * 256.0, b[2 * nfeat:3 * nfeat])
 
 
 @pytest.mark.parametrize('optim', ['adadelta', 'adagrad'])

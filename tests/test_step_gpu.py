@@ -162,12 +162,14 @@ def test_f16_storage_scales_the_error_down():
         model.engine.backward()
         torch.cuda.synchronize()
         eng = model.engine
+        assert (eng.loss_scale > 1.0) == (dt == torch.float16)       # f16 runs with loss scaling, bf16 without
+        gv = eng.named_gradients()                                    # loss scale divided out
         res[dt] = dict(pred=rel(t['future_im_pred'], out_f['future_im_pred']),
                        mu=float((t['gauss_yx'].cpu() - out_f['gauss_yx'].detach()).abs().max()),
-                       ren1=rel(eng.gview['model/renderer/conv_1/w'], g_f['model/renderer/conv_1/w']),
-                       ren5=rel(eng.gview['model/renderer/conv_5/w'], g_f['model/renderer/conv_5/w']),
-                       enc8=rel(eng.gview['model/image_encoder/encoder/conv_8/w'], g_f['model/image_encoder/encoder/conv_8/w']),
-                       enc1=rel(eng.gview['model/image_encoder/encoder/conv_1/w'], g_f['model/image_encoder/encoder/conv_1/w']))
+                       ren1=rel(gv['model/renderer/conv_1/w'], g_f['model/renderer/conv_1/w']),
+                       ren5=rel(gv['model/renderer/conv_5/w'], g_f['model/renderer/conv_5/w']),
+                       enc8=rel(gv['model/image_encoder/encoder/conv_8/w'], g_f['model/image_encoder/encoder/conv_8/w']),
+                       enc1=rel(gv['model/image_encoder/encoder/conv_1/w'], g_f['model/image_encoder/encoder/conv_1/w']))
     print('\nF16_VS_BF16 ' + json.dumps({str(k): v for k, v in res.items()}))
     f, b = res[torch.float16], res[torch.bfloat16]
     assert f['pred'] < 0.4 * b['pred'] and f['pred'] < 0.03, res
@@ -292,6 +294,43 @@ def test_full_size_step_properties():
     assert float(eng.gview['model/renderer/conv_8/b'][3:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize('K,dt', [(10, torch.bfloat16), (50, torch.float16)], ids=['configs1_k10_bf16', 'configs4_k50_f16'])
+def test_full_size_forward_matches_oracle(K, dt):
+    """The benchmark's own size against the oracle (not only properties): batch 32 per GPU at 128x128 — BASELINE.json
+    configs[1] (K=10, bf16) and the per-GPU shape of configs[4] (K=50, f16) — forward + perceptual loss vs oracle.forward on
+    identical inputs: landmarks <= 1e-3 (the BASELINE target), total loss <= 1e-3 relative, each of the six terms <= 1e-2.
+    At this batch every large-grid kernel variant the bench runs is selected (persistent conv_hdeep / conv_halo2 tiles, the
+    grouped stride-2 data gradients, the pre-reduced batch-norm rows), which the batch-2 tests do not reach."""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    from imm_amd.models.imm_model import IMMModel
+    from imm_amd.utils.box import Box
+    B = 32
+    cfg = O.default_model_config(K)
+    inputs = O.synthetic_inputs(B, 128, seed=0)
+    model = IMMModel(Box(dict(cfg)), dtype=dt, device=DEV)
+    _, loss, _, t = model.build(inputs, True, output_tensors=True)
+    torch.cuda.synchronize()
+    eng = model.engine
+    P, St = O.init_params(cfg, 128)
+    with torch.no_grad():
+        out = O.forward(P, St, inputs, cfg, training=True)
+    mu_err = float((t['gauss_yx'].cpu() - out['gauss_yx']).abs().max())
+    loss_rel = abs(float(loss) - float(out['loss'])) / abs(float(out['loss']))
+    terms = eng.loss_terms.cpu()
+    oterms = torch.stack([x.detach().float() for x in out['loss_terms']])
+    term_rel = float(((terms - oterms).abs() / oterms.abs()).max())
+    pred_rel = rel(t['future_im_pred'], out['future_im_pred'])
+    print('\nFULLSIZE K=%d %s: mu_maxabs %.3g loss_rel %.3g terms_rel %.3g pred_rel %.3g' % (K, dt, mu_err, loss_rel, term_rel, pred_rel))
+    assert t['gauss_yx'].shape == (B, K, 2)
+    assert mu_err < 1e-3 and loss_rel < 1e-3 and term_rel < 1e-2
+    assert pred_rel < (0.12 if dt == torch.bfloat16 else 0.03)
+    # and one full step at this size runs clean (f16: with the loss scale; no overflow at the initial scale)
+    eng.backward(); eng.optimizer_step()
+    torch.cuda.synchronize()
+    assert int(eng.step_count) == 1 and bool(torch.isfinite(eng.params).all())
+
+
 def test_config4_256px_k30_forward_and_step():
     """BASELINE.json configs[3]: K=30 at 256x256 — exercises the align-corners 32->16 embedding resize
     (imm_model.py:324-335), the 32x32 heat-map bottleneck and the 10-conv renderer."""
@@ -338,7 +377,10 @@ def test_config5_k50_f16_step():
     ts = TrainStep(model, 2, 128, world_size=1, use_graph=True)
     losses = [float(ts.step(inputs).clone()) for _ in range(4)]
     ts.synchronize()
+    ls = ts.engine.loss_scale_state.tolist()
+    print('CONFIG5 loss scale state after 4 steps (S, clean, skipped, overflow): %r' % (ls,))
     assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+    assert ls[2] <= 1.0 and int(ts.engine.step_count) == 4 - int(ls[2])     # at most one step lost to finding the scale
 
 
 def test_training_reduces_the_loss_on_a_fixed_batch():
@@ -406,7 +448,8 @@ def _smooth_batch(B, S, seed=3):
     return {'image': img.contiguous(), 'future_image': fut.contiguous(), 'mask': mask.contiguous()}
 
 
-def test_gradient_parity_on_a_trained_model():
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16], ids=['bf16', 'f16'])
+def test_gradient_parity_on_a_trained_model(dt):
     """Chain-level gradient parity where the problem is WELL CONDITIONED.  At the 0.01-std initialisation the gradient is
     ill conditioned (test_gradient_parity); after 60 Adam steps on a smooth batch the fp32 oracle agrees with an fp64 run of
     itself to 1.3e-4 on every tensor (tests/diag_grad_conditioning.py), so a mis-scaled or mis-wired gradient anywhere in
@@ -417,7 +460,12 @@ def test_gradient_parity_on_a_trained_model():
     equivalent builds (another summation order of the batch-norm partial rows is enough) end in different trained states.
     Measured over such builds: worst 0.095 .. 0.23, median 0.04 .. 0.07, worst cosine 0.98 .. 0.9955; tensor by tensor the
     engine sits at 0.9 .. 2.2 x the emulation where the emulation itself is small (0.03), within +-10 % where it is large:
-    what is left is bf16 storage, not wiring."""
+    what is left is bf16 storage, not wiring.
+    f16 (BASELINE configs[4]; the reference is fp32, imm_model.py:97): the same test with the SAME bounds (against the oracle's
+    bf16 emulation).  Without loss scaling the stored dy tensors of the trained pose encoder underflow f16 (relative error up to
+    3.6 on its first convolution, round 2); with the dynamic loss scale of imm_clip_adam_step the f16 engine has to be at
+    least as close to the fp32 oracle as the bf16 engine is allowed to be, and no step of the 60 may be lost to an overflow
+    after the first few (the scale search)."""
     if not torch.cuda.is_available():
         pytest.skip('no GPU')
     from imm_amd.models.imm_model import IMMModel
@@ -426,12 +474,18 @@ def test_gradient_parity_on_a_trained_model():
     B, S, steps = 4, 128, 60
     cfg = O.default_model_config(10)
     inputs = _smooth_batch(B, S)
-    model = IMMModel(Box(dict(cfg)), dtype=torch.bfloat16, device=DEV)
+    model = IMMModel(Box(dict(cfg)), dtype=dt, device=DEV)
     ts = TrainStep(model, B, S, world_size=1, use_graph=True)
     for i in range(steps):
         ts.step(inputs if i == 0 else None)
     ts.synchronize()
     eng = ts.engine
+    if dt == torch.float16:
+        ls = eng.loss_scale_state.tolist()
+        print('TRAINED_GRAD f16 loss scale state (S, clean, skipped, overflow): %r, steps applied %d' % (ls, int(eng.step_count)))
+        assert ls[0] >= 2.0 and ls[2] <= 4 and int(eng.step_count) == steps - int(ls[2])
+    else:
+        assert eng.loss_scale_state is None and int(eng.step_count) == steps
     P0, St0 = O.init_params(cfg, S)
     P1 = type(P0)((k, v.cpu()) for k, v in eng.named_parameters().items())
     St1 = type(St0)(St0)
@@ -445,13 +499,14 @@ def test_gradient_parity_on_a_trained_model():
     _oe, g_e = O.loss_and_grads(Pe, Se, inputs, cfg, act_round=bf)
     assert abs(float(eng.loss) - float(out_f['loss'])) / abs(float(out_f['loss'])) < 2e-3
     bad, rels, worst = [], [], (0.0, 1.0)
+    gv = eng.named_gradients()            # loss scale divided out (f16); == gview for bf16
     for k, v in g_f.items():
         if k.endswith('/b') and (k[:-2] + '/gamma') in g_f:
-            assert float(eng.gview[k].abs().max()) == 0.0       # analytically zero (BN removes the mean); oracle: noise
+            assert float(gv[k].abs().max()) == 0.0       # analytically zero (BN removes the mean); oracle: noise
             continue
         if float(v.norm()) < 1e-7:
             continue
-        a, b = eng.gview[k].detach().cpu().double().flatten(), v.detach().double().flatten()
+        a, b = gv[k].detach().cpu().double().flatten(), v.detach().double().flatten()
         e = float((a - b).norm() / b.norm())
         cos = float((a * b).sum() / (a.norm() * b.norm()))
         e_emul = rel(g_e[k], v)
@@ -490,7 +545,7 @@ def test_backward_is_the_derivative_of_the_forward():
     eng.forward(True); eng.backward()
     torch.cuda.synchronize()
     eng.loss_agg.copy_(agg0)
-    g = eng.grads.clone()
+    g = eng.grads.clone() / eng.loss_scale          # f16 engine: gradients carry the loss scale until the optimizer step
     p0 = eng.params.clone()
     names = [n for n, _s, _w in eng.spec]
 
