@@ -5,6 +5,7 @@ hipcc cross-compiles without a GPU, so this runs in the CPU-only build container
 The library carries the sha256 of its sources (imm_source_digest(), repo-relative paths + contents); a rebuild is
 skipped only when the existing binary carries the digest of the current checkout — there is no stamp file to go stale.
 """
+import fcntl
 import glob
 import hashlib
 import os
@@ -22,8 +23,16 @@ def _sources():
     return sorted(glob.glob(os.path.join(CSRC, '*.hip')))
 
 
+def _extra_flags():
+    # IMM_HIPCC_FLAGS: extra compile flags for diagnosis builds (e.g. -DIMM_HDEEP_PROFILE), never set in normal use
+    return os.environ.get('IMM_HIPCC_FLAGS', '').split()
+
+
 def source_digest():
+    """sha256 over the sources AND what they are compiled with (target arch, extra flags): a diagnosis build never passes for
+    the production library."""
     h = hashlib.sha256()
+    h.update(('arch=%s flags=%s\0' % (ARCH, ' '.join(_extra_flags()))).encode())
     for p in _sources() + sorted(glob.glob(os.path.join(CSRC, '*.h'))) + [os.path.join(ROOT, 'include', 'imm_hip.h')]:
         with open(p, 'rb') as f:
             h.update(os.path.relpath(p, ROOT).replace(os.sep, '/').encode() + b'\0' + f.read() + b'\0')
@@ -52,17 +61,30 @@ def build(force=False, verbose=True):
     dig = source_digest()
     if not force and library_digest() == dig:
         return LIB
-    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    objs = []
     objdir = os.path.join(HERE, 'build')
     os.makedirs(objdir, exist_ok=True)
+    # One builder at a time: N ranks started together on a stale library (torchrun, bench.py --gpus N) would otherwise all
+    # run hipcc over the same object files and could link each other's half-written objects.  The others wait on the lock
+    # and then find the library current.
+    with open(os.path.join(objdir, '.lock'), 'w') as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and library_digest() == dig:
+                return LIB
+            return _build_locked(dig, objdir, verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(dig, objdir, verbose):
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    objs = []
     procs = []
     for src in _sources():
         obj = os.path.join(objdir, os.path.basename(src) + '.o')
         objs.append(obj)
-        # IMM_HIPCC_FLAGS: extra compile flags for diagnosis builds (e.g. -DIMM_HDEEP_PROFILE), never set in normal use
         cmd = [hipcc, '--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function',
-               '-DIMM_SOURCE_DIGEST="%s"' % dig] + os.environ.get('IMM_HIPCC_FLAGS', '').split() + ['-c', src, '-o', obj]
+               '-DIMM_SOURCE_DIGEST="%s"' % dig] + _extra_flags() + ['-c', src, '-o', obj]
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     for cmd, p in procs:
         out, _ = p.communicate()

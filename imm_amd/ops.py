@@ -478,7 +478,9 @@ class RcclComm:
             uid = torch.tensor(list(buf), dtype=torch.uint8)
         if world > 1:
             obj = [uid]
-            dist.broadcast_object_list(obj, src=0, group=group)
+            # `rank` is the rank inside `group`; broadcast's src is a GLOBAL rank
+            src = dist.get_global_rank(group, 0) if group is not None else 0
+            dist.broadcast_object_list(obj, src=src, group=group)
             uid = obj[0]
         self._uid = (C.c_ubyte * 128)(*[int(x) for x in uid])
         self._comm = C.c_void_p()

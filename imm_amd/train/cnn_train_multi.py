@@ -70,16 +70,16 @@ class TrainStep:
         self.world_size = world_size
         # two graphs with the all-reduce in between (always for world_size > 1; selectable at 1 to test that path)
         self.split = split_graphs or world_size > 1
-        # Two buckets at N > 1: the renderer's gradients (the tail of the flat buffer, 43 % of the 16.6 MB) are all-reduced on
-        # RCCL's stream while the encoders' backward graph still runs; the encoder bucket follows it.  One bucket when the
-        # split path is only being exercised on a single rank (the extra graph launch costs 0.25 ms there and overlaps
-        # nothing).  IMM_DP_BUCKETS overrides.
+        # ONE bucket by default: [fwd + bwd graph] -> all-reduce of the flat gradient buffer -> [clip + Adam graph].
+        # IMM_DP_BUCKETS=2 (opt-in): the renderer's gradients (the tail of the flat buffer, 43 % of the 16.6 MB) are all-reduced
+        # on RCCL's stream while the encoders' backward graph still runs, the encoder bucket follows it.  The asynchronous
+        # two-bucket branch has only ever run with gloo on one device (where it degenerates to synchronous host bounces); it
+        # stays opt-in until a >= 2-GPU RCCL run has compared its update with the one-bucket update.
         self.group = group
         model.require_vgg()                       # training against a missing perceptual network is an error, not a fallback
         self.engine = model._get_engine(batch_per_rank, image_size)
         model._master = self.engine               # the engine whose variables are trained; others mirror it (eval batches)
-        default_buckets = 2 if (world_size > 1 and self.engine.n_bwd_bucket0 is not None) else 1
-        self.buckets = int(os.environ.get('IMM_DP_BUCKETS', str(default_buckets)))
+        self.buckets = int(os.environ.get('IMM_DP_BUCKETS', '1'))
         if self.buckets >= 2 and self.engine.n_bwd_bucket0 is None:
             raise ValueError('IMM_DP_BUCKETS=2 needs the renderer gradients reduced early: set IMM_WGRAD_DEFER_REN=0')
         if abs(self.engine.hp.grad_scale - 1.0 / world_size) > 1e-9:
@@ -88,8 +88,13 @@ class TrainStep:
         # IMM_RCCL_NATIVE=1: the collective goes through the C-ABI (imm_rccl_allreduce, include/imm_hip.h) on a stream of
         # this object instead of through torch.distributed's process group (which then only carries the 128-byte
         # unique id at start-up).  Same sums; default off until it has run on a multi-GPU box.
+        # IMM_RCCL_GRAPH=1 (implies IMM_RCCL_NATIVE): the collective is a node of the step's HIP graph — imm_rccl_allreduce is
+        # issued on the capturing stream between the backward and the optimizer launches, so a step at N > 1 is ONE graph
+        # launch, like at N = 1 (no second graph, no host-side collective call per step).  Validated with a one-rank
+        # communicator on the single-GPU test box; multi-GPU timing has to come from a node.
+        self.graph_resident = self.split and use_graph and os.environ.get('IMM_RCCL_GRAPH', '0') != '0'
         self.native_comm = None
-        if self.split and os.environ.get('IMM_RCCL_NATIVE', '0') != '0':
+        if self.split and (self.graph_resident or os.environ.get('IMM_RCCL_NATIVE', '0') != '0'):
             rank = dist.get_rank(group) if dist.is_initialized() else 0
             with torch.cuda.device(self.engine.dev):
                 self.native_comm = ops.RcclComm(rank, world_size, group)
@@ -110,7 +115,18 @@ class TrainStep:
             eng.restore(snap)
             self.stream.synchronize()
             eng._training = True
-            if not self.split:
+            if self.graph_resident:
+                # one graph: fwd, bwd, all-reduce of the flat gradient buffer (RCCL kernels captured on this stream), clip + Adam
+                self.native_comm.all_reduce_sum(eng.grads)          # once outside capture: RCCL's lazy channel set-up
+                self.stream.synchronize()
+                g = ops.Graph()
+                g.capture_begin()
+                eng.run(eng.prog_fwd); eng.run(eng.prog_bwd)
+                self.native_comm.all_reduce_sum(eng.grads)
+                eng.run(eng.prog_opt)
+                g.capture_end()
+                self._graphs = (g,)
+            elif not self.split:
                 g = ops.Graph()
                 g.capture_begin()
                 eng.run(eng.prog_fwd); eng.run(eng.prog_bwd); eng.run(eng.prog_opt)
@@ -158,7 +174,9 @@ class TrainStep:
                 if self._graphs is None:
                     self._capture()
                 self._graphs[0].launch()
-                if self.split and self.native_comm is not None:
+                if self.graph_resident:
+                    pass                              # the collective and the optimizer are nodes of that graph
+                elif self.split and self.native_comm is not None:
                     self._native_exchange(eng)
                 elif self.split and self.buckets < 2:
                     average_gradients(eng.grads, self.world_size, self.group, force=True)

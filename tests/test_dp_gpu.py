@@ -115,8 +115,9 @@ def test_two_engines_equal_the_two_tower_reference(emu):
     assert not worst, worst
 
 
-def _rank_main(rank, world, port, ret):
+def _rank_main(rank, world, port, ret, buckets):
     sys.path.insert(0, ROOT)
+    os.environ['IMM_DP_BUCKETS'] = str(buckets)
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0')
     import torch.distributed as dist
     torch.cuda.set_device(0)
@@ -126,7 +127,7 @@ def _rank_main(rank, world, port, ret):
     mine = split_inputs(full, world, rank)
     model = _model(world)
     ts = TrainStep(model, B_GLOBAL // world, S_IMG, world_size=world, use_graph=True)
-    assert ts.split and ts.buckets == 2, (ts.split, ts.buckets)     # the N > 1 default: two overlapped buckets
+    assert ts.split and ts.buckets == buckets, (ts.split, ts.buckets)     # default 1; 2 = overlapped buckets (opt-in)
     losses = []
     for it in range(N_STEPS):
         loss = ts.step(mine if it == 0 else None)
@@ -140,13 +141,14 @@ def _rank_main(rank, world, port, ret):
 
 
 @pytest.mark.timeout(900)
-def test_two_ranks_on_one_gpu_run_the_split_graph_path_bitwise(emu):
+@pytest.mark.parametrize('buckets', [1, 2], ids=['one_bucket_default', 'two_buckets_optin'])
+def test_two_ranks_on_one_gpu_run_the_split_graph_path_bitwise(emu, buckets):
     import torch.multiprocessing as mp
     A, Bn, losses, _gA0, _gB0 = emu
-    port = 29700 + (os.getpid() % 200)
+    port = 29700 + (os.getpid() % 200) + 300 * buckets
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_rank_main, args=(2, port, ret), nprocs=2, join=True)
+    mp.spawn(_rank_main, args=(2, port, ret, buckets), nprocs=2, join=True)
     r0, r1 = ret[0], ret[1]
     assert r0['step'] == N_STEPS and r0['adam_t'] == N_STEPS
     assert torch.equal(r0['params'], r1['params'])                      # replicas stay identical
@@ -176,5 +178,5 @@ def test_bench_self_spawns_two_ranks(tmp_path):
     assert len(lines) == 1, out.stdout.decode()[-2000:]
     d = json.loads(lines[0])
     assert d['n_gpus'] == 2 and d['config']['global_batch'] == 64 and d['config']['parallelism'] == 'dp2'
-    assert d['config']['collective']['world_size'] == 2 and d['config']['collective']['buckets'] == 2
+    assert d['config']['collective']['world_size'] == 2 and d['config']['collective']['buckets'] == 1
     assert d['value'] > 0 and d['scaling'] == 'weak' and np.isfinite(d['step']['loss'])

@@ -601,17 +601,20 @@ def test_native_rccl_exchange_single_rank(monkeypatch):
         pytest.skip('no GPU')
     from imm_amd.train.cnn_train_multi import TrainStep
     res = []
-    for native, buckets in ((False, 1), (True, 1), (True, 2)):
+    for native, buckets, in_graph in ((False, 1, False), (True, 1, False), (True, 2, False), (True, 1, True)):
         monkeypatch.setenv('IMM_RCCL_NATIVE', '1' if native else '0')
         monkeypatch.setenv('IMM_DP_BUCKETS', str(buckets))
+        monkeypatch.setenv('IMM_RCCL_GRAPH', '1' if in_graph else '0')     # the collective as a node of the step's ONE graph
         cfg, model, eng, inputs, P, St = make(4)
         ts = TrainStep(model, 4, 128, world_size=1, use_graph=True, split_graphs=native)
-        assert (ts.native_comm is not None) == native
+        assert (ts.native_comm is not None) == native and ts.graph_resident == in_graph
         for it in range(3):
             loss = ts.step(inputs)
         ts.synchronize()
         res.append((float(loss), eng.params.clone()))
         if native:
             ts.native_comm.destroy()
-    assert res[0][0] == res[1][0] == res[2][0]
-    assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][1], res[2][1])
+        if in_graph:
+            assert len(ts._graphs) == 1
+    assert res[0][0] == res[1][0] == res[2][0] == res[3][0]
+    assert all(torch.equal(res[0][1], r[1]) for r in res[1:])
