@@ -33,6 +33,11 @@ class ConvDesc(C.Structure):
         'updiv', 'kpad', 'flags', 'ldmask', 'out_scale', 'out_off_y', 'out_off_x')]
 
 
+class WgradJob(C.Structure):
+    _fields_ = [('desc', ConvDesc), ('x', C.c_void_p), ('dy', C.c_void_p), ('slab', C.c_void_p), ('lddy', C.c_int32),
+                ('nsplit', C.c_int32)]
+
+
 class OptHParams(C.Structure):
     _fields_ = [('lr_start', C.c_float), ('lr_decay', C.c_float), ('lr_step', C.c_int32), ('lr_multiple', C.c_float),
                 ('beta1', C.c_float), ('beta2', C.c_float), ('eps', C.c_float), ('clip', C.c_float),
@@ -56,6 +61,9 @@ _SIGS = {
     'imm_conv_stats_blocks': [C.POINTER(ConvDesc)],
     'imm_conv2d_wgrad': [C.POINTER(ConvDesc), _I, _P, _P, _I, _P, _I, _P],
     'imm_conv2d_wgrad_splits': [C.POINTER(ConvDesc), _I],
+    'imm_conv2d_wgrad_variant': [C.POINTER(ConvDesc), _I, _I, C.POINTER(C.c_int), C.POINTER(C.c_int)],
+    'imm_conv2d_wgrad_multi_plan': [_P, _I, _I, _P],
+    'imm_conv2d_wgrad_multi': [_P, _P, _P],
     'imm_conv2d_wgrad_reduce': [_P, _I, _I, _I, _I, _I, _I, _I, _P, _P],
     'imm_colsum': [_P, _I, _L, _I, _I, _I, _P, _P, _P],
     'imm_colsum_blocks': [_L, _I],
@@ -65,7 +73,6 @@ _SIGS = {
     'imm_bn_bwd_apply_fused': [_P, _I, _I, _L, _P, _P, _I, _P, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _I, _P],
     'imm_rows_reduce': [_P, _I, _I, _I, _P, _P],
     'imm_bn_bwd_reduce': [_P, _I, _P, _I, _I, _L, _I, _P, _P, _P, _P, _I, _P, _P],
-    'imm_bn_bwd_reduce_finalize': [_P, _I, _P, _I, _I, _L, _I, _P, _P, _P, _P, _I, _L, _P, _P, _P, _P, _P, _P],
     'imm_bn_bwd_blocks': [_L, _I],
     'imm_bn_bwd_finalize': [_P, _I, _I, _I, _L, _P, _P, _P, _I, _P, _P, _P, _P],
     'imm_bn_bwd_apply': [_P, _I, _P, _I, _I, _L, _I, _P, _P, _P, _P, _I, _P, _P, _I, _P],
@@ -112,9 +119,9 @@ _SIGS64 = {
     'imm_conv2d_workspace_bytes': [C.POINTER(ConvDesc)],
     'imm_conv2d_group_workspace_bytes': [_P, _I],
     'imm_conv2d_wgrad_workspace_bytes': [C.POINTER(ConvDesc), _I, _I],
+    'imm_conv2d_wgrad_multi_table_bytes': [_I],
     'imm_colsum_workspace_bytes': [_L, _I],
     'imm_bn_bwd_workspace_bytes': [_L, _I],
-    'imm_bn_bwd_reduce_finalize_workspace_bytes': [_L, _I],
     'imm_upsample2x_bwd_bn_workspace_bytes': [_I, _I, _I, _I],
     'imm_masked_sse_workspace_bytes': [_I],
 }

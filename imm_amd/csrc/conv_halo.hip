@@ -268,7 +268,7 @@ static int halo_num_cu() {
 }
 
 bool imm_halo_applicable(const imm_conv_desc* d) {
-  static const bool off = getenv("IMM_NO_HALO") != nullptr;
+  static const bool off = imm_conv_disabled("halo");
   if (off) return false;
   if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->updiv != 1 || d->pad_t != 1 || d->pad_l != 1) return false;
   if (d->ci != 32 && d->ci != 64) return false;
@@ -276,8 +276,7 @@ bool imm_halo_applicable(const imm_conv_desc* d) {
   if (d->co > 64) return false;
   if (d->hi != d->ho || d->wi != d->wo || d->ho % HALO_PH || d->wo % HALO_PW) return false;
   if (d->ho * d->wo < 64 * 64) return false;      // deep layers: the im2col kernels have more parallelism
-  static const bool abl = getenv("IMM_HALO_ABL") != nullptr;
-  if ((d->flags & 0xf00) && !abl) return false;   // debug ablation bits normally select the im2col kernel
+  if (d->flags & 0xf00) return false;   // debug ablation bits select the im2col kernel
   const int64_t xb = (int64_t)d->batch * d->hi * d->wi * d->ldx * 2;
   return xb < (1LL << 31);
 }

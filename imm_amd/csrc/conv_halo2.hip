@@ -408,11 +408,7 @@ __global__ __launch_bounds__(256) void conv_halo2_kernel(const Halo2Args ha) {
 static int h2_ns(bool mask) {
   static int v[2] = {0, 0};
   if (v[mask] == 0) {
-    const char* e = getenv(mask ? "IMM_HALO2_NS_MASK" : "IMM_HALO2_NS");
-    int n = e ? atoi(e) : (mask ? 3 : 4);
-    if (n < 3) n = 3;
-    if (n > 4) n = 4;
-    v[mask] = n;
+    v[mask] = mask ? 3 : 4;
   }
   return v[mask];
 }
@@ -428,7 +424,7 @@ static int h2_num_cu() {
 }
 
 bool imm_halo2_applicable(const imm_conv_desc* d) {
-  static const bool off = getenv("IMM_NO_HALO2") != nullptr || getenv("IMM_NO_HALO") != nullptr;
+  static const bool off = imm_conv_disabled("halo2") || imm_conv_disabled("halo");
   if (off) return false;
   const bool k33 = d->kh == 3 && d->kw == 3 && d->pad_t == 1 && d->pad_l == 1;
   // the tap-unrolled first layer (imm_model.py:215 7x7 conv over the 7x3 horizontally unrolled image): 7x1 over 32 channels

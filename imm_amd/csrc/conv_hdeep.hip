@@ -554,16 +554,15 @@ static int hd_num_cu() {
 struct HdPlan { int ph, bn, n_patches, n_wg; bool map8, persist, row3; };
 
 static HdPlan hd_plan(const imm_conv_desc* d) {
-  static const bool no_small = getenv("IMM_HDEEP_NO_SMALL") != nullptr;
+  constexpr bool no_small = false;
   const int cus = hd_num_cu();
-  static const int small_below = getenv("IMM_HDEEP_SMALL_BELOW") ? atoi(getenv("IMM_HDEEP_SMALL_BELOW")) : 4;   // x CUs
-  static const bool no_big = getenv("IMM_HDEEP_NO_BIG") != nullptr;
+  constexpr int small_below = 4;   // x CUs
+  constexpr bool no_big = false;
   HdPlan p;
   p.map8 = false; p.persist = false; p.row3 = false;
   if (d->ho == 8 && d->wo == 8) {                      // two whole 8x8 images per (4-wave) workgroup
-    static const bool no_map8 = getenv("IMM_HDEEP_NO_MAP8") != nullptr;
     p.ph = 8; p.bn = 64; p.map8 = true;
-    p.n_patches = no_map8 ? 0 : (d->batch + 1) / 2;
+    p.n_patches = (d->batch + 1) / 2;
     p.n_wg = p.n_patches * (d->co / 64);
     return p;
   }
@@ -574,20 +573,20 @@ static HdPlan hd_plan(const imm_conv_desc* d) {
   else { p.ph = 16; p.bn = 64; p.n_patches = np16; }
   p.n_wg = p.n_patches * (d->co / p.bn);
   // 8x16 tiles that would be two rounds of 4-wave workgroups (e.g. 32x32 maps, 128 channels: 512) as ONE round of 8-wave
-  // 16x16x64 workgroups with the row-at-a-time schedule (IMM_HDEEP_ROW3_BIG=0: off)
-  static const bool row3_big = !(getenv("IMM_HDEEP_ROW3_BIG") && atoi(getenv("IMM_HDEEP_ROW3_BIG")) == 0);
+  // 16x16x64 workgroups with the row-at-a-time schedule
+  constexpr bool row3_big = true;
   if (row3_big && !no_small && p.ph == 8 && p.bn == 64 && p.n_wg > cus && np16 > 0 && np16 * (d->co / 64) <= cus &&
       np16 * (d->co / 64) >= cus / 2) {
     p.ph = 16; p.n_patches = np16; p.n_wg = np16 * (d->co / 64); p.row3 = true;
   }
-  // more tiles than CUs: one persistent workgroup per CU walks them (IMM_HDEEP_PERSIST=0: one workgroup per tile)
-  static const bool persist = !(getenv("IMM_HDEEP_PERSIST") && atoi(getenv("IMM_HDEEP_PERSIST")) == 0);
+  // more tiles than CUs: one persistent workgroup per CU walks them
+  constexpr bool persist = true;
   p.persist = persist && p.ph == 16 && p.n_wg > cus && (cus % 8) == 0 && !(d->flags & IMM_CONV_STATS);
   return p;
 }
 
 bool imm_hdeep_applicable(const imm_conv_desc* d) {
-  static const bool off = getenv("IMM_NO_HDEEP") != nullptr;
+  static const bool off = imm_conv_disabled("hdeep");
   if (off) return false;
   if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->updiv != 1 || d->pad_t != 1 || d->pad_l != 1) return false;
   if (d->ci % 64 || d->co % 64 || d->ci < 64) return false;
@@ -597,7 +596,7 @@ bool imm_hdeep_applicable(const imm_conv_desc* d) {
   const int64_t px = (int64_t)d->batch * d->hi * d->wi;
   if (px * d->ldx * 2 >= (1LL << 31) || (int64_t)d->co * d->kpad * 2 >= (1LL << 31)) return false;
   // small grids keep the im2col kernel (64x64 tiles give it 4x the workgroups)
-  static const int min_wg = getenv("IMM_HDEEP_MIN_WG") ? atoi(getenv("IMM_HDEEP_MIN_WG")) : 100;
+  constexpr int min_wg = 100;
   const HdPlan p = hd_plan(d);
   return p.n_patches > 0 && p.n_wg >= min_wg;
 }
@@ -619,7 +618,7 @@ static void hd_launch_cfg(const HdArgs& ha, hipStream_t s) {
 
 template <typename ET>
 static void hd_launch(const HdPlan& p, const HdArgs& ha, hipStream_t s) {
-  static const bool row3 = !(getenv("IMM_HDEEP_ROW3") && atoi(getenv("IMM_HDEEP_ROW3")) == 0);   // A/B: one barrier per filter row
+  constexpr bool row3 = true;   // one barrier per filter row (DESIGN item 27)
   // (119 KB of LDS: one workgroup per CU — only where the grid leaves it at one per CU anyway; with more tiles than CUs the
   // 78 KB tap-at-a-time form keeps two co-resident: 32x32 128->128, 512 tiles, 14.2 vs 17.1 us)
   const bool one_wave = p.n_wg <= hd_num_cu();

@@ -333,7 +333,7 @@ static int conv_launch(const imm_conv_desc* d, const void* x, const void* wt, co
   const bool fast = (d->ci % 32 == 0) && xb < (1LL << 31) && wb < (1LL << 31);
   a.x_bytes = (uint32_t)(fast ? xb : 0);
   a.wt_bytes = (uint32_t)(fast ? wb : 0);
-  const bool deep = fast && (d->ci % 64 == 0) && t.bn >= 64 && !(d->flags & 0xf00) && !getenv("IMM_NO_DEEPK");
+  const bool deep = fast && (d->ci % 64 == 0) && t.bn >= 64 && !(d->flags & 0xf00) && !imm_conv_disabled("deepk");
   if (deep) imm_conv64_launch(ET::kEnum, a, t.bm, t.bn, s);
   else if (t.bm == 128 && t.bn == 128) launch_cfg<ET, 128, 128, 2, 2>(a, fast, s);
   else if (t.bm == 128 && t.bn == 64) launch_cfg<ET, 128, 64, 2, 2>(a, fast, s);
@@ -364,8 +364,8 @@ extern "C" int imm_conv2d(const imm_conv_desc* d, int dtype, const void* x, cons
 struct GroupPlan { bool grouped, grouped32; int bm, bn; int rows[4]; int total_rows; };
 
 static int group_plan(const imm_conv_desc* descs, int n, GroupPlan* gp) {
-  static const bool off = getenv("IMM_NO_CONV_GROUP") != nullptr;
-  gp->grouped = !off; gp->grouped32 = !off && !getenv("IMM_NO_CONV_GROUP32"); gp->bm = gp->bn = 0; gp->total_rows = 0;
+  static const bool off = imm_conv_disabled("group");
+  gp->grouped = !off; gp->grouped32 = !off && !imm_conv_disabled("group32"); gp->bm = gp->bn = 0; gp->total_rows = 0;
   for (int i = 0; i < n; ++i) {
     const imm_conv_desc* d = descs + i;
     if (validate_desc(d)) return IMM_E_INVALID;
@@ -375,7 +375,7 @@ static int group_plan(const imm_conv_desc* descs, int n, GroupPlan* gp) {
     const TileCfg t = pick_tile(M, d->co);
     const int64_t xb = (int64_t)d->batch * d->hi * d->wi * d->ldx * 2, wb = (int64_t)d->co * d->kpad * 2;
     const bool deep = (d->ci % 64 == 0) && xb < (1LL << 31) && wb < (1LL << 31) && t.bn >= 64 && !(d->flags & 0xf00) &&
-                      !getenv("IMM_NO_DEEPK");
+                      !imm_conv_disabled("deepk");
     if (!deep || (i > 0 && (t.bm != gp->bm || t.bn != gp->bn))) gp->grouped = false;
     // the general kernel's 128x32 tile, one tap x 32 channels per K tile (ci % 32 == 0)
     const bool fast32 = (d->ci % 32 == 0) && xb < (1LL << 31) && wb < (1LL << 31) && t.bm == 128 && t.bn == 32 && !(d->flags & 0xf00);

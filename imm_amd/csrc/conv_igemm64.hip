@@ -194,15 +194,8 @@ static void launch64(ConvArgs& a, int bm, int bn, hipStream_t s) {
   a.KT = a.kpad / 64;
   // stage count: big tiles are throughput-bound and want 2-3 co-resident workgroups per CU (2 stages = 64 / 48 KB);
   // the 64x64 tile is used when the grid is small (deep layers), is latency-bound and wants a deeper ring instead
-  static const int ns64 = getenv("IMM_NS64") ? atoi(getenv("IMM_NS64")) : 4;
-  static const int nw8 = getenv("IMM_IGEMM_NW8") ? atoi(getenv("IMM_IGEMM_NW8")) : 0;   // experiment: 1 = 2 stages, 2 = 3 stages
-  if (bm == 128 && bn == 128 && nw8 == 1) launch64_cfg<ET, 128, 128, 2, 8>(a, s);
-  else if (bm == 128 && bn == 128 && nw8 == 2) launch64_cfg<ET, 128, 128, 3, 8>(a, s);
-  else if (bm == 128 && bn == 128) launch64_cfg<ET, 128, 128, 2>(a, s);
-  else if (bm == 128 && bn == 64 && nw8) launch64_cfg<ET, 128, 64, 2, 8>(a, s);
+  if (bm == 128 && bn == 128) launch64_cfg<ET, 128, 128, 2>(a, s);
   else if (bm == 128 && bn == 64) launch64_cfg<ET, 128, 64, 2>(a, s);
-  else if (ns64 == 3) launch64_cfg<ET, 64, 64, 3>(a, s);
-  else if (ns64 == 6) launch64_cfg<ET, 64, 64, 6>(a, s);
   else launch64_cfg<ET, 64, 64, 4>(a, s);
 }
 

@@ -12,6 +12,7 @@
 // slab[split][kpad][co]; imm_conv2d_wgrad_reduce sums slabs in a fixed order (deterministic).
 #include "common.h"
 #include <stdlib.h>
+#include <string.h>
 
 struct WgradArgs {
   const uint16_t* x;
@@ -278,7 +279,7 @@ static int wgrad_launch(const imm_conv_desc* d, const void* x, const void* dy, i
   const int hw = d->ho * d->wo;
   const int64_t xb = (int64_t)d->batch * d->hi * d->wi * d->ldx * 2, db = (int64_t)a.P * lddy * 2;
   const bool fast = (hw % 32 == 0) && (d->wo % 32 == 0 || 32 % d->wo == 0) && xb < (1LL << 31) && db < (1LL << 31);
-  static const int psub_env = getenv("IMM_WGRAD_PSUB") ? atoi(getenv("IMM_WGRAD_PSUB")) : 1;
+  constexpr int psub_env = 1;
   // 128 pixels per barrier when the pixel count allows it and each split still gets >= 4 steps
   int pps = (a.P + nsplit - 1) / nsplit;
   const int psub = (fast && psub_env == 4 && a.P % 128 == 0 && pps >= 512 && bn <= 64) ? 4 : 1;
@@ -328,6 +329,160 @@ extern "C" int imm_conv2d_wgrad(const imm_conv_desc* d, int dtype, const void* x
     return 0;
   }
   IMM_DISPATCH_DTYPE(dtype, return wgrad_launch<ET>(d, x, dy, lddy, slab, nsplit, (hipStream_t)stream));
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Multi-problem launch: the filter gradients of many layers in as few launches as there are kernel variants among them.
+// Nobody reads a filter gradient before the slab reduction at the end of the backward pass, so the engine collects the
+// layers' jobs and issues them together: the per-layer launches (15-48 us each, most of it ramp and tail on a 256-CU part)
+// leave the serial BN-backward -> data-gradient chain, a grouped launch has thousands of workgroups to balance, and — since
+// the chip no longer has to be filled by ONE layer — each layer needs far fewer pixel splits (slab traffic = nsplit x |dW|).
+// ---------------------------------------------------------------------------------------------------------------------
+int imm_wgrad_tr_variant(const imm_conv_desc* d);
+int imm_wgrad_tr_args_bytes();
+int imm_wgrad_tr_fill(const imm_conv_desc* d, const void* x, const void* dy, int lddy, float* slab, int nsplit, void* out, int* steps);
+void imm_wgrad_tr_launch_multi(int dtype, int bn, const void* tab_dev, const int* first_dev, int n, int blocks, hipStream_t s);
+int imm_wgrad_halo_variant(const imm_conv_desc* d, int lddy);
+int imm_wgrad_halo_blocks(const imm_conv_desc* d, int lddy, int* n_patches);
+int imm_wgrad_halo_args_bytes();
+int imm_wgrad_halo_fill(const imm_conv_desc* d, const void* x, const void* dy, int lddy, float* slab, int nsplit, void* out, int* steps);
+void imm_wgrad_halo_launch_multi(int dtype, int variant, const void* tab_dev, const int* first_dev, int n, int blocks, hipStream_t s);
+
+namespace {
+constexpr uint32_t WGM_MAGIC = 0x57474d31u;   // "WGM1"
+constexpr int WGM_MAX_LAUNCH = 16, WGM_MAX_JOBS = 64, WGM_ARG_STRIDE = 192, WGM_HEADER = 1024;
+enum { WGM_SINGLE = 0, WGM_TR = 1, WGM_HALO = 2 };
+struct WgmLaunch { int32_t kind, variant, n, arg_off, first_off, blocks, job0, pad; };
+struct WgmHeader { uint32_t magic; int32_t dtype, n_jobs, n_launch; WgmLaunch launch[WGM_MAX_LAUNCH]; };
+static_assert(sizeof(WgmHeader) <= WGM_HEADER, "header");
+
+// kernel family + variant a job runs with (the same choice imm_conv2d_wgrad makes, except that the halo kernel takes any
+// split count here)
+void wgm_classify(const imm_wgrad_job* j, int dtype, int* kind, int* variant) {
+  const bool fast_dt = dtype == IMM_BF16 || dtype == IMM_F16;
+  const int hv = fast_dt ? imm_wgrad_halo_variant(&j->desc, j->lddy) : 0;
+  if (hv) { *kind = WGM_HALO; *variant = hv; return; }
+  if (fast_dt && imm_wgrad_tr_applicable(&j->desc, j->lddy)) { *kind = WGM_TR; *variant = imm_wgrad_tr_variant(&j->desc); return; }
+  *kind = WGM_SINGLE; *variant = 0;
+}
+int wgm_check_job(const imm_wgrad_job* j) {
+  const imm_conv_desc* d = &j->desc;
+  IMM_REQUIRE(j->x && j->dy && j->slab, "wgrad_multi: null");
+  IMM_REQUIRE(d->ci > 0 && d->ci % 8 == 0 && d->ldx % 8 == 0 && d->ldx >= d->ci, "wgrad_multi: ci/ldx must be multiples of 8");
+  IMM_REQUIRE(j->lddy % 8 == 0 && j->lddy >= d->co, "wgrad_multi: lddy=%d must be a multiple of 8 and >= co", j->lddy);
+  IMM_REQUIRE(d->updiv == 1 && d->kpad % 32 == 0 && d->kpad >= d->kh * d->kw * d->ci && j->nsplit >= 1 && d->wo % 2 == 0,
+              "wgrad_multi: desc");
+  IMM_REQUIRE(((uintptr_t)j->x % 16 == 0) && ((uintptr_t)j->dy % 16 == 0) && ((uintptr_t)j->slab % 16 == 0), "wgrad_multi: alignment");
+  return 0;
+}
+}  // namespace
+
+extern "C" int64_t imm_conv2d_wgrad_multi_table_bytes(int n) {
+  if (n < 1 || n > WGM_MAX_JOBS) return IMM_E_INVALID;
+  // header, per job one argument block + one imm_wgrad_job (single launches), per launch a first[] array
+  return WGM_HEADER + (int64_t)n * (WGM_ARG_STRIDE + (int64_t)sizeof(imm_wgrad_job)) + WGM_MAX_LAUNCH * (WGM_MAX_JOBS + 1) * 4;
+}
+
+extern "C" int imm_conv2d_wgrad_variant(const imm_conv_desc* d, int lddy, int dtype, int* wg_per_split, int* units) {
+  IMM_REQUIRE(d && lddy >= d->co, "wgrad_variant: args");
+  imm_wgrad_job j; j.desc = *d; j.lddy = lddy; j.nsplit = 1; j.x = j.dy = nullptr; j.slab = nullptr;
+  int kind, variant;
+  wgm_classify(&j, dtype, &kind, &variant);
+  int wps = 1, un = 1;
+  if (kind == WGM_HALO) {
+    wps = imm_wgrad_halo_blocks(d, lddy, &un);                 // units: 8x16-pixel patches
+  } else {
+    const int bn = d->co > 64 ? 128 : d->co > 32 ? 64 : d->co > 16 ? 32 : 16;
+    wps = ((d->kpad + 127) / 128) * ((d->co + bn - 1) / bn);
+    un = (d->batch * d->ho * d->wo + 31) / 32;                 // units: 32-pixel steps
+  }
+  if (wg_per_split) *wg_per_split = wps;
+  if (units) *units = un;
+  return kind * 10000 + variant;
+}
+
+extern "C" int imm_conv2d_wgrad_multi_plan(const imm_wgrad_job* jobs, int n, int dtype, void* table_host) {
+  IMM_REQUIRE(jobs && table_host && n >= 1 && n <= WGM_MAX_JOBS, "wgrad_multi_plan: args");
+  IMM_REQUIRE(imm_wgrad_tr_args_bytes() <= WGM_ARG_STRIDE && imm_wgrad_halo_args_bytes() <= WGM_ARG_STRIDE, "wgrad_multi_plan: arg stride");
+  char* base = (char*)table_host;
+  memset(base, 0, (size_t)imm_conv2d_wgrad_multi_table_bytes(n));
+  WgmHeader* h = (WgmHeader*)base;
+  h->magic = WGM_MAGIC; h->dtype = dtype; h->n_jobs = n; h->n_launch = 0;
+  int kind[WGM_MAX_JOBS], variant[WGM_MAX_JOBS];
+  bool done[WGM_MAX_JOBS];
+  for (int i = 0; i < n; ++i) {
+    if (wgm_check_job(&jobs[i])) return IMM_E_INVALID;
+    wgm_classify(&jobs[i], dtype, &kind[i], &variant[i]);
+    done[i] = false;
+  }
+  int64_t off = WGM_HEADER;
+  int job_slot = 0;
+  for (int i = 0; i < n; ++i) {
+    if (done[i]) continue;
+    IMM_REQUIRE(h->n_launch < WGM_MAX_LAUNCH, "wgrad_multi_plan: more than %d kernel variants", WGM_MAX_LAUNCH);
+    WgmLaunch* L = &h->launch[h->n_launch++];
+    L->kind = kind[i]; L->variant = variant[i];
+    // members of this variant (a job without a multi kernel is a launch of its own)
+    int idx[WGM_MAX_JOBS], m = 0;
+    for (int k = i; k < n; ++k)
+      if (!done[k] && kind[k] == kind[i] && variant[k] == variant[i] && (kind[i] != WGM_SINGLE || k == i)) { idx[m++] = k; done[k] = true; }
+    L->n = m;
+    L->arg_off = (int32_t)off;
+    if (kind[i] == WGM_SINGLE) {
+      memcpy(base + off, &jobs[i], sizeof(imm_wgrad_job));
+      off += (int64_t)sizeof(imm_wgrad_job);
+      off = (off + 15) / 16 * 16;
+      L->first_off = 0; L->blocks = 0; L->job0 = job_slot++;
+      continue;
+    }
+    // argument blocks, longest workgroups first
+    int steps[WGM_MAX_JOBS], blocks[WGM_MAX_JOBS];
+    char tmp[WGM_MAX_JOBS][WGM_ARG_STRIDE];
+    for (int k = 0; k < m; ++k) {
+      const imm_wgrad_job* j = &jobs[idx[k]];
+      blocks[k] = (kind[i] == WGM_TR ? imm_wgrad_tr_fill : imm_wgrad_halo_fill)(&j->desc, j->x, j->dy, j->lddy, j->slab, j->nsplit, tmp[k], &steps[k]);
+    }
+    int order[WGM_MAX_JOBS];
+    for (int k = 0; k < m; ++k) order[k] = k;
+    for (int a = 1; a < m; ++a)                       // insertion sort, stable, descending work per workgroup
+      for (int b = a; b > 0 && steps[order[b]] > steps[order[b - 1]]; --b) { const int t = order[b]; order[b] = order[b - 1]; order[b - 1] = t; }
+    const int stride = kind[i] == WGM_TR ? imm_wgrad_tr_args_bytes() : imm_wgrad_halo_args_bytes();
+    for (int k = 0; k < m; ++k) memcpy(base + off + (int64_t)k * stride, tmp[order[k]], (size_t)stride);
+    off += (int64_t)m * stride;
+    off = (off + 15) / 16 * 16;
+    L->first_off = (int32_t)off;
+    int32_t* first = (int32_t*)(base + off);
+    first[0] = 0;
+    for (int k = 0; k < m; ++k) first[k + 1] = first[k] + blocks[order[k]];
+    L->blocks = first[m];
+    off += (int64_t)(m + 1) * 4;
+    off = (off + 15) / 16 * 16;
+    L->job0 = job_slot; job_slot += m;
+  }
+  IMM_REQUIRE(off <= imm_conv2d_wgrad_multi_table_bytes(n), "wgrad_multi_plan: table overflow");
+  return 0;
+}
+
+extern "C" int imm_conv2d_wgrad_multi(const void* table_host, const void* table_dev, void* stream) {
+  IMM_REQUIRE(table_host && table_dev, "wgrad_multi: null");
+  const char* hb = (const char*)table_host;
+  const char* db = (const char*)table_dev;
+  const WgmHeader* h = (const WgmHeader*)hb;
+  IMM_REQUIRE(h->magic == WGM_MAGIC && h->n_launch >= 1 && h->n_launch <= WGM_MAX_LAUNCH, "wgrad_multi: not a planned table");
+  for (int l = 0; l < h->n_launch; ++l) {
+    const WgmLaunch* L = &h->launch[l];
+    if (L->kind == WGM_SINGLE) {
+      const imm_wgrad_job* j = (const imm_wgrad_job*)(hb + L->arg_off);
+      const int rc = imm_conv2d_wgrad(&j->desc, h->dtype, j->x, j->dy, j->lddy, j->slab, j->nsplit, stream);
+      if (rc) return rc;
+    } else if (L->kind == WGM_TR) {
+      imm_wgrad_tr_launch_multi(h->dtype, L->variant, db + L->arg_off, (const int*)(db + L->first_off), L->n, L->blocks, (hipStream_t)stream);
+    } else {
+      imm_wgrad_halo_launch_multi(h->dtype, L->variant, db + L->arg_off, (const int*)(db + L->first_off), L->n, L->blocks, (hipStream_t)stream);
+    }
+  }
+  IMM_CHECK_LAUNCH("imm_conv2d_wgrad_multi");
   return 0;
 }
 

@@ -20,6 +20,7 @@
 // are written once as one f32 slab per workgroup (summed by imm_wgrad_reduce_multi, fixed order).
 #include "conv_common.h"
 #include <stdlib.h>
+#include <string.h>
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
@@ -50,6 +51,7 @@ struct WgradHaloArgs {
   const uint16_t* x; const uint16_t* dy; float* slab;
   int batch, h, w, ldx, lddy, co, kpad, ci_total;
   int n_patches, patches_x, patches_y;
+  int nsplit, nci, nco;          // grid of the member (multi-problem launches)
   uint32_t x_bytes, dy_bytes;
 };
 
@@ -58,8 +60,9 @@ struct WgradHaloArgs {
 // round 1 (wait vmcnt(0), then prefetch ONE patch ahead) every patch exposed most of its fetch latency (renderer conv_5:
 // 1.5 us per patch for 0.55 us of matrix work).  Now NS-1 patches are in flight and the wait is counted: every wave issues
 // exactly LPP DMA instructions per patch, so "at most (NS-2)*LPP outstanding" == "this patch has landed".
+// bx = pixel split of this workgroup, G = number of splits, by / bz = its ci / co slice
 template <typename ET, int CI, int CO, int NS>
-__global__ __launch_bounds__(256) void conv_wgrad_halo_kernel(const WgradHaloArgs a) {
+__device__ __forceinline__ void conv_wgrad_halo_body(const WgradHaloArgs& a, const int bx, const int G, const int by, const int bz) {
   constexpr int XC8 = CI / 8, YC8 = CO / 8;
   constexpr int NCT = CI / 16, NNT = CO / 16;          // 16-channel tiles
   constexpr int WC = NCT, WN = 4 / WC;                 // wave grid: wc = ci tile, wn = slice of the co tiles
@@ -74,7 +77,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_halo_kernel(const WgradHaloArg
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wc = wid % WC, wn = wid / WC;
-  const int ci0 = blockIdx.y * CI, co0 = blockIdx.z * CO;     // channel slice of this workgroup
+  const int ci0 = by * CI, co0 = bz * CO;     // channel slice of this workgroup
   constexpr uint32_t OOB = 0x80000000u;
   const uint64_t xa = (uint64_t)a.x, ya = (uint64_t)a.dy;
   const u32x4_t xr = {(uint32_t)xa, (uint32_t)(xa >> 32) & 0xffffu, a.x_bytes, 0x00020000u};
@@ -117,11 +120,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_halo_kernel(const WgradHaloArg
   const int k_row = g >> 1, k_x = (g & 1) * 8 + (i16 >> 2), ch4 = (i16 & 3) * 4;
   const char* lds_c = (const char*)smem;
 
-  const int G = gridDim.x;
-  const int n_mine = ((int)blockIdx.x < a.n_patches) ? (a.n_patches - (int)blockIdx.x + G - 1) / G : 0;
+  const int n_mine = (bx < a.n_patches) ? (a.n_patches - bx + G - 1) / G : 0;
 #pragma unroll
   for (int t = 0; t < NS - 1; ++t)
-    if (t < n_mine) issue(blockIdx.x + t * G, t);
+    if (t < n_mine) issue(bx + t * G, t);
   int stage = 0;
   for (int it = 0; it < n_mine; ++it) {
     // patches it .. min(it+NS-2, n_mine-1) are in flight; patch `it` must have landed (this wave's share, then everyone's)
@@ -130,7 +132,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_halo_kernel(const WgradHaloArg
     __builtin_amdgcn_s_barrier();
     if (it + NS - 1 < n_mine) {      // into the stage patch it-1 occupied: every wave is past its reads (the barrier above)
       int ns = stage + NS - 1; if (ns >= NS) ns -= NS;
-      issue(blockIdx.x + (it + NS - 1) * G, ns);
+      issue(bx + (it + NS - 1) * G, ns);
     }
     const char* Xl = lds_c + stage * STAGE;
     const char* Yl = Xl + X_BYTES;
@@ -166,7 +168,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_halo_kernel(const WgradHaloArg
   }
 
   // lane holds D[n = 4*(lane>>4)+r][c = lane&15] -> slab[split][kk = tap*ci + ci0 + wc*16 + c][co0 + n .. +3]
-  float* out = a.slab + (int64_t)blockIdx.x * a.kpad * a.co;
+  float* out = a.slab + (int64_t)bx * a.kpad * a.co;
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap) {
     const int kk = tap * a.ci_total + ci0 + wc * 16 + (lane & 15);
@@ -182,6 +184,26 @@ __global__ __launch_bounds__(256) void conv_wgrad_halo_kernel(const WgradHaloArg
       }
     }
   }
+}
+
+template <typename ET, int CI, int CO, int NS>
+__global__ __launch_bounds__(256) void conv_wgrad_halo_kernel(const WgradHaloArgs a) {
+  conv_wgrad_halo_body<ET, CI, CO, NS>(a, blockIdx.x, gridDim.x, blockIdx.y, blockIdx.z);
+}
+
+// Several filter gradients with the same slice shape in ONE launch (imm_conv2d_wgrad_multi): workgroup b belongs to member g
+// with first[g] <= b < first[g+1]; inside a member the workgroups are numbered split-fastest, (ci slice, co slice) slowest.
+template <typename ET, int CI, int CO, int NS>
+__global__ __launch_bounds__(256) void conv_wgrad_halo_multi_kernel(const WgradHaloArgs* __restrict__ tab,
+                                                                    const int* __restrict__ first, int n) {
+  const int b = blockIdx.x;
+  int g = 0;
+  while (g + 1 < n && b >= first[g + 1]) ++g;
+  const WgradHaloArgs a = tab[g];
+  int r = b - first[g];
+  const int bx = r % a.nsplit; r /= a.nsplit;
+  const int by = r % a.nci, bz = r / a.nci;
+  conv_wgrad_halo_body<ET, CI, CO, NS>(a, bx, a.nsplit, by, bz);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -242,13 +264,9 @@ static bool wh_plan(const imm_conv_desc* d, int lddy, WhPlan* pl) {
   const int blocks = pl->nci * pl->nco;
   // one workgroup per CU: two per CU (round 1) run the launches no faster and double the slab traffic of the whole-filter
   // layers (64->64 at 64x64: 75 MB of slabs each); measured 3.83 -> 3.80 ms per step (round 2, same box)
-  static const int per_cu = getenv("IMM_WGRAD_HALO_PER_CU") ? atoi(getenv("IMM_WGRAD_HALO_PER_CU")) : 1;
+  constexpr int per_cu = 1;
   int grid = per_cu * wh_num_cu();
-  static const int grid1 = getenv("IMM_WGRAD_HALO_GRID1") ? atoi(getenv("IMM_WGRAD_HALO_GRID1")) : 0;   // A/B: fewer, fatter workgroups
-  if (grid1 > 0) grid = grid1;
   if (blocks > 1) grid = wh_num_cu();                  // sliced layers: slab bytes = nsplit x |dW|, keep nsplit small
-  static const int grid64 = getenv("IMM_WGRAD_HALO_GRID64") ? atoi(getenv("IMM_WGRAD_HALO_GRID64")) : 0;
-  if (blocks > 1 && cs == 64 && grid64 > 0) grid = grid64;
   int nsplit = (grid + blocks - 1) / blocks;
   const int min_patches = blocks > 1 ? 2 : 4;          // patches per workgroup that amortise its slab write
   if (nsplit > n_patches / min_patches) nsplit = n_patches / min_patches;
@@ -258,7 +276,7 @@ static bool wh_plan(const imm_conv_desc* d, int lddy, WhPlan* pl) {
 }
 
 bool imm_wgrad_halo_applicable(const imm_conv_desc* d, int lddy) {
-  static const bool off = getenv("IMM_NO_WGRAD_HALO") != nullptr;
+  static const bool off = imm_conv_disabled("wgrad_halo");
   if (off) return false;
   WhPlan pl;
   return wh_plan(d, lddy, &pl);
@@ -275,11 +293,6 @@ static void wh_launch_cfg(const WgradHaloArgs& a, dim3 grid, hipStream_t s) {
   constexpr int stage = WH_HP * CI * 2 + 128 * CO * 2;
   constexpr int NS = stage > 36 * 1024 ? 3 : 4;         // 64x64 slices: 3 x 40 KB; the others 4 x 20..32 KB
   constexpr int lds = NS * stage;
-  static const bool two_stage = getenv("IMM_WGRAD_HALO_NS2") != nullptr;    // A/B: the round-1 schedule
-  if (two_stage) {
-    hipLaunchKernelGGL((conv_wgrad_halo_kernel<ET, CI, CO, 2>), grid, dim3(256), 2 * stage, s, a);
-    return;
-  }
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {
     (void)hipFuncSetAttribute((const void*)conv_wgrad_halo_kernel<ET, CI, CO, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -288,18 +301,25 @@ static void wh_launch_cfg(const WgradHaloArgs& a, dim3 grid, hipStream_t s) {
   hipLaunchKernelGGL((conv_wgrad_halo_kernel<ET, CI, CO, NS>), grid, dim3(256), lds, s, a);
 }
 
-void imm_wgrad_halo_launch(int dtype, const imm_conv_desc* d, const void* x, const void* dy, int lddy, float* slab,
-                           int nsplit, hipStream_t s) {
-  WhPlan pl;
-  (void)wh_plan(d, lddy, &pl);
+static WgradHaloArgs wh_fill(const imm_conv_desc* d, const void* x, const void* dy, int lddy, float* slab, int nsplit,
+                             const WhPlan& pl) {
   WgradHaloArgs a;
   a.x = (const uint16_t*)x; a.dy = (const uint16_t*)dy; a.slab = slab;
   a.batch = d->batch; a.h = d->ho; a.w = d->wo; a.ldx = d->ldx; a.lddy = lddy; a.co = d->co; a.kpad = d->kpad;
   a.ci_total = d->ci;
   a.patches_x = d->wo / WH_PW; a.patches_y = d->ho / WH_PH;
   a.n_patches = d->batch * a.patches_x * a.patches_y;
+  a.nsplit = nsplit; a.nci = pl.nci; a.nco = pl.nco;
   a.x_bytes = (uint32_t)((int64_t)d->batch * d->hi * d->wi * d->ldx * 2);
   a.dy_bytes = (uint32_t)((int64_t)d->batch * d->ho * d->wo * lddy * 2);
+  return a;
+}
+
+void imm_wgrad_halo_launch(int dtype, const imm_conv_desc* d, const void* x, const void* dy, int lddy, float* slab,
+                           int nsplit, hipStream_t s) {
+  WhPlan pl;
+  (void)wh_plan(d, lddy, &pl);
+  const WgradHaloArgs a = wh_fill(d, x, dy, lddy, slab, nsplit, pl);
   const dim3 grid(nsplit, pl.nci, pl.nco);
 #define WH_GO(ET_) \
   do { \
@@ -307,6 +327,57 @@ void imm_wgrad_halo_launch(int dtype, const imm_conv_desc* d, const void* x, con
     else if (pl.cs == 64) wh_launch_cfg<ET_, 64, 32>(a, grid, s); \
     else if (pl.ns == 64) wh_launch_cfg<ET_, 32, 64>(a, grid, s); \
     else wh_launch_cfg<ET_, 32, 32>(a, grid, s); \
+  } while (0)
+  if (dtype == IMM_BF16) WH_GO(BF16); else WH_GO(F16);
+#undef WH_GO
+}
+
+// ---- members of a multi-problem launch (imm_conv2d_wgrad_multi, conv_wgrad.hip) ---------------------------------------------
+// variant = slice shape: 64*100+64, 64*100+32, 32*100+64, 32*100+32; 0 = this kernel does not take the layer
+int imm_wgrad_halo_variant(const imm_conv_desc* d, int lddy) {
+  WhPlan pl;
+  return wh_plan(d, lddy, &pl) ? pl.cs * 100 + pl.ns : 0;
+}
+// workgroups per pixel split (channel-slice blocks) and the number of 8x16 patches of the layer
+int imm_wgrad_halo_blocks(const imm_conv_desc* d, int lddy, int* n_patches) {
+  WhPlan pl;
+  if (!wh_plan(d, lddy, &pl)) return 0;
+  if (n_patches) *n_patches = d->batch * (d->ho / WH_PH) * (d->wo / WH_PW);
+  return pl.nci * pl.nco;
+}
+int imm_wgrad_halo_args_bytes() { return (int)sizeof(WgradHaloArgs); }
+int imm_wgrad_halo_fill(const imm_conv_desc* d, const void* x, const void* dy, int lddy, float* slab, int nsplit, void* out,
+                        int* steps) {
+  WhPlan pl;
+  (void)wh_plan(d, lddy, &pl);
+  const WgradHaloArgs a = wh_fill(d, x, dy, lddy, slab, nsplit, pl);
+  memcpy(out, &a, sizeof(a));
+  if (steps) *steps = (a.n_patches + nsplit - 1) / nsplit * 4 * (pl.cs / 16);     // ~ matrix work per workgroup
+  return nsplit * pl.nci * pl.nco;
+}
+
+template <typename ET, int CI, int CO>
+static void wh_launch_multi_cfg(const WgradHaloArgs* tab, const int* first, int n, int blocks, hipStream_t s) {
+  constexpr int stage = WH_HP * CI * 2 + 128 * CO * 2;
+  constexpr int NS = stage > 36 * 1024 ? 3 : 4;
+  constexpr int lds = NS * stage;
+  static bool attr_set = false;
+  if (!attr_set && lds > 64 * 1024) {
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_halo_multi_kernel<ET, CI, CO, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_wgrad_halo_multi_kernel<ET, CI, CO, NS>), dim3(blocks), dim3(256), lds, s, tab, first, n);
+}
+
+void imm_wgrad_halo_launch_multi(int dtype, int variant, const void* tab_dev, const int* first_dev, int n, int blocks,
+                                 hipStream_t s) {
+  const WgradHaloArgs* t = (const WgradHaloArgs*)tab_dev;
+#define WH_GO(ET_) \
+  do { \
+    if (variant == 6464) wh_launch_multi_cfg<ET_, 64, 64>(t, first_dev, n, blocks, s); \
+    else if (variant == 6432) wh_launch_multi_cfg<ET_, 64, 32>(t, first_dev, n, blocks, s); \
+    else if (variant == 3264) wh_launch_multi_cfg<ET_, 32, 64>(t, first_dev, n, blocks, s); \
+    else wh_launch_multi_cfg<ET_, 32, 32>(t, first_dev, n, blocks, s); \
   } while (0)
   if (dtype == IMM_BF16) WH_GO(BF16); else WH_GO(F16);
 #undef WH_GO

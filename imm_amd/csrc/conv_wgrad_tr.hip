@@ -13,6 +13,7 @@
 // Requires the wave-uniform pixel walk (ho*wo % 32 == 0, wo | 32 or 32 | wo) and ci % 8 == 0.
 #include "common.h"
 #include <stdlib.h>
+#include <string.h>
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
@@ -51,7 +52,7 @@ __device__ __forceinline__ uint32_t wt_piece(int p, int ch) {   // byte offset o
 }
 
 template <typename ET, int BN, int WGK, int WGN, int NS>
-__global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(const WgradTrArgs a) {
+__device__ __forceinline__ void conv_wgrad_tr_body(const WgradTrArgs& a, int bid) {
   constexpr int BK = 128;
   constexpr int TK = BK / WGK, TN = BN / WGN, KT_ = TK / 16, NT = TN / 16;
   constexpr int CA = BK / 8, CB = BN / 8;                 // 16-byte chunks per pixel row
@@ -66,7 +67,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(const WgradTrArgs a)
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wk = wid / WGN, wn = wid % WGN;
-  int bid = blockIdx.x;
   const int nblk = bid % a.n_nblk; bid /= a.n_nblk;
   const int kblk = bid % a.n_kblk; bid /= a.n_kblk;
   const int split = bid;
@@ -221,6 +221,35 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(const WgradTrArgs a)
 }
 
 template <typename ET, int BN, int WGK, int WGN, int NS>
+__global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(const WgradTrArgs a) {
+  conv_wgrad_tr_body<ET, BN, WGK, WGN, NS>(a, blockIdx.x);
+}
+
+// Several filter gradients of the same tile shape in ONE launch (imm_conv2d_wgrad_multi): workgroup b belongs to member g
+// with first[g] <= b < first[g+1] and runs that member's argument block (read from the device table with scalar loads)
+// unchanged.  Members are ordered longest workgroups first.
+template <typename ET, int BN, int WGK, int WGN, int NS>
+__global__ __launch_bounds__(256) void conv_wgrad_tr_multi_kernel(const WgradTrArgs* __restrict__ tab,
+                                                                  const int* __restrict__ first, int n) {
+  const int b = blockIdx.x;
+  int g = 0;
+  while (g + 1 < n && b >= first[g + 1]) ++g;
+  const WgradTrArgs a = tab[g];
+  conv_wgrad_tr_body<ET, BN, WGK, WGN, NS>(a, b - first[g]);
+}
+
+template <typename ET, int BN, int WGK, int WGN, int NS>
+static void wt_launch_multi_cfg(const WgradTrArgs* tab, const int* first, int n, int blocks, hipStream_t s) {
+  constexpr int lds = NS * (32 * 128 * 2 + 32 * BN * 2) + 1024;
+  static bool attr_set = false;
+  if (!attr_set && lds > 64 * 1024) {
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_tr_multi_kernel<ET, BN, WGK, WGN, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_wgrad_tr_multi_kernel<ET, BN, WGK, WGN, NS>), dim3(blocks), dim3(256), lds, s, tab, first, n);
+}
+
+template <typename ET, int BN, int WGK, int WGN, int NS>
 static void wt_launch_cfg(const WgradTrArgs& a, hipStream_t s) {
   constexpr int lds = NS * (32 * 128 * 2 + 32 * BN * 2) + 1024;
   static bool attr_set = false;
@@ -240,7 +269,7 @@ static void wt_launch(const WgradTrArgs& a, int bn, hipStream_t s) {
 }
 
 bool imm_wgrad_tr_applicable(const imm_conv_desc* d, int lddy) {
-  static const bool off = getenv("IMM_NO_WGRAD_TR") != nullptr;
+  static const bool off = imm_conv_disabled("wgrad_tr");
   if (off) return false;
   const int hw = d->ho * d->wo;
   const int64_t P = (int64_t)d->batch * hw;
@@ -248,9 +277,9 @@ bool imm_wgrad_tr_applicable(const imm_conv_desc* d, int lddy) {
   return (hw % 32 == 0) && (d->wo % 32 == 0 || 32 % d->wo == 0) && xb < (1LL << 31) && db < (1LL << 31) && d->updiv == 1;
 }
 
-// called from conv_wgrad.hip
-void imm_wgrad_tr_launch(int dtype, const imm_conv_desc* d, const void* x, const void* dy, int lddy, float* slab, int nsplit,
-                         hipStream_t s) {
+static int wt_bn(int co) { return co > 64 ? 128 : co > 32 ? 64 : co > 16 ? 32 : 16; }
+
+static WgradTrArgs wt_fill(const imm_conv_desc* d, const void* x, const void* dy, int lddy, float* slab, int nsplit) {
   WgradTrArgs a;
   a.x = (const uint16_t*)x; a.dy = (const uint16_t*)dy; a.slab = slab;
   a.P = d->batch * d->ho * d->wo;
@@ -258,7 +287,7 @@ void imm_wgrad_tr_launch(int dtype, const imm_conv_desc* d, const void* x, const
   a.ho = d->ho; a.wo = d->wo; a.co = d->co; a.lddy = lddy;
   a.kh = d->kh; a.kw = d->kw; a.stride = d->stride; a.pad_t = d->pad_t; a.pad_l = d->pad_l;
   a.kpad = d->kpad; a.ntaps = d->kh * d->kw;
-  const int bn = d->co > 64 ? 128 : d->co > 32 ? 64 : d->co > 16 ? 32 : 16;
+  const int bn = wt_bn(d->co);
   a.n_kblk = (d->kpad + 127) / 128;
   a.n_nblk = (d->co + bn - 1) / bn;
   a.nsplit = nsplit;
@@ -267,6 +296,38 @@ void imm_wgrad_tr_launch(int dtype, const imm_conv_desc* d, const void* x, const
   a.p_per_split = pps;
   a.x_bytes = (uint32_t)((int64_t)d->batch * d->hi * d->wi * d->ldx * 2);
   a.dy_bytes = (uint32_t)((int64_t)a.P * lddy * 2);
+  return a;
+}
+
+// called from conv_wgrad.hip
+void imm_wgrad_tr_launch(int dtype, const imm_conv_desc* d, const void* x, const void* dy, int lddy, float* slab, int nsplit,
+                         hipStream_t s) {
+  const WgradTrArgs a = wt_fill(d, x, dy, lddy, slab, nsplit);
+  const int bn = wt_bn(d->co);
   if (dtype == IMM_BF16) wt_launch<BF16>(a, bn, s);
   else wt_launch<F16>(a, bn, s);
+}
+
+// ---- members of a multi-problem launch (imm_conv2d_wgrad_multi, conv_wgrad.hip) ---------------------------------------------
+int imm_wgrad_tr_variant(const imm_conv_desc* d) { return wt_bn(d->co); }       // tile width = the variant of the kernel
+int imm_wgrad_tr_args_bytes() { return (int)sizeof(WgradTrArgs); }
+// writes the member's argument block, returns its workgroup count; *steps = 32-pixel steps of one workgroup (its length)
+int imm_wgrad_tr_fill(const imm_conv_desc* d, const void* x, const void* dy, int lddy, float* slab, int nsplit, void* out,
+                      int* steps) {
+  const WgradTrArgs a = wt_fill(d, x, dy, lddy, slab, nsplit);
+  memcpy(out, &a, sizeof(a));
+  if (steps) *steps = a.p_per_split / 32;
+  return a.n_kblk * a.n_nblk * a.nsplit;
+}
+void imm_wgrad_tr_launch_multi(int dtype, int bn, const void* tab_dev, const int* first_dev, int n, int blocks, hipStream_t s) {
+  const WgradTrArgs* t = (const WgradTrArgs*)tab_dev;
+#define WT_GO(ET_) \
+  do { \
+    if (bn == 128) wt_launch_multi_cfg<ET_, 128, 2, 2, 4>(t, first_dev, n, blocks, s); \
+    else if (bn == 64) wt_launch_multi_cfg<ET_, 64, 2, 2, 4>(t, first_dev, n, blocks, s); \
+    else if (bn == 32) wt_launch_multi_cfg<ET_, 32, 4, 1, 4>(t, first_dev, n, blocks, s); \
+    else wt_launch_multi_cfg<ET_, 16, 4, 1, 4>(t, first_dev, n, blocks, s); \
+  } while (0)
+  if (dtype == IMM_BF16) WT_GO(BF16); else WT_GO(F16);
+#undef WT_GO
 }

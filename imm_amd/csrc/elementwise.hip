@@ -442,9 +442,9 @@ static int col_reduce_blocks(int64_t npix, int c) {
   int64_t b = (npix + (int64_t)rows * 4 - 1) / ((int64_t)rows * 4);
   if (b < 1) b = 1;
   // <= 256 rows for the small tensors (<= 4M elements): imm_bn_bwd_apply_fused re-reduces the rows in every workgroup.  The
-  // large ones keep up to 1024 workgroups (IMM_COL_REDUCE_CAP): MEASURED 256 (one per CU, 8 loads in flight per thread) 3.594 ->
+  // large ones keep up to 1024 workgroups: MEASURED 256 (one per CU, 8 loads in flight per thread) 3.594 ->
   // 3.631 ms per step, 512 3.587 — the pre-reduction of the rows (imm_rows_reduce) is cheaper than a thinner grid
-  static const int64_t cap_env = getenv("IMM_COL_REDUCE_CAP") ? atoi(getenv("IMM_COL_REDUCE_CAP")) : 1024;
+  constexpr int64_t cap_env = 1024;
   const int64_t cap = (npix * c <= (1LL << 22)) ? 256 : cap_env;
   if (b > cap) b = cap;
   return (int)b;
@@ -536,134 +536,6 @@ extern "C" int imm_bn_bwd_reduce(const void* dout, int lddo, const void* y, int 
                                                (hipStream_t)stream, (const uint16_t*)dout, lddo, (const uint16_t*)y,
                                                ldy, npix, c, scale, shift, mean, rstd, relu, partial));
   IMM_CHECK_LAUNCH("imm_bn_bwd_reduce");
-  return 0;
-}
-
-// ---- reduce + finalize in ONE launch ---------------------------------------------------------------------------------
-// The finalize pass is a 9 us latency chain behind a kernel boundary (11 launches per step on the layers whose partial rows
-// are too many for imm_bn_bwd_apply_fused).  Here the reduce kernel finishes the job itself with the classic "last block
-// done" hand-over, two levels deep so that no workgroup ever sums more than 32 rows: groups of BG = 32 consecutive
-// workgroups share a ticket; the one that draws the last ticket of its group sums the group's rows (f64, row order) into
-// a group row; the one that draws the last GROUP ticket sums the group rows (f64, group order) and writes dgamma / dbeta /
-// coef.  WHO does the sums depends on timing, WHAT is summed in which order does not: bitwise reproducible.  Tickets are
-// left at zero for the next launch.
-#define BG 32
-template <typename ET>
-__global__ __launch_bounds__(EW_THREADS) void bn_bwd_reduce_finalize_kernel(
-    const uint16_t* __restrict__ dout, int lddo, const uint16_t* __restrict__ y, int ldy, int64_t npix, int c,
-    const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
-    const float* __restrict__ rstd, int relu, float* partial, double* gpartial, int* tickets, double count,
-    const float* __restrict__ gamma, float* dgamma, float* dbeta, float* coef) {
-  const int tpp = c / 8, rows = EW_THREADS / tpp;
-  const int r = threadIdx.x / tpp, cg = threadIdx.x - r * tpp;
-  const int nblk = gridDim.x;
-  const int64_t per_blk = (npix + nblk - 1) / nblk;
-  const int64_t p0 = (int64_t)blockIdx.x * per_blk;
-  const int64_t p1 = p0 + per_blk < npix ? p0 + per_blk : npix;
-  float sc[8], sh[8], mu[8], rs[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    sc[i] = scale[cg * 8 + i]; sh[i] = shift[cg * 8 + i]; mu[i] = mean[cg * 8 + i]; rs[i] = rstd[cg * 8 + i];
-  }
-  float acc[2][8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
-  for (int64_t p = p0 + r; p < p1; p += rows) {
-    float d[8], v[8];
-    unpack8<ET>(*(const uint4*)(dout + p * lddo + cg * 8), d);
-    unpack8<ET>(*(const uint4*)(y + p * ldy + cg * 8), v);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      float dz = d[i];
-      if (relu && !(v[i] * sc[i] + sh[i] > 0.f)) dz = 0.f;
-      acc[0][i] += dz;
-      acc[1][i] += dz * ((v[i] - mu[i]) * rs[i]);
-    }
-  }
-  col_reduce_tail<2, true>(acc, c, tpp, rows, partial + (int64_t)blockIdx.x * 2 * c);
-
-  // Hand-over without fences: a device-scope release/acquire fence is buffer_wbl2 / buffer_inv of the whole L2 on this part
-  // (measured: 160 us per launch with 1024 workgroups, and the other lane's kernels lose their L2 contents).  Instead every
-  // datum that crosses workgroups is moved with agent-scope atomic stores / loads (sc1: performed at the device coherence
-  // point), and a workgroup draws its ticket only after its stores have been acknowledged (s_waitcnt vmcnt(0) + barrier).
-  __shared__ int s_last;
-  const int g = blockIdx.x / BG, ng = (nblk + BG - 1) / BG;
-  const int gsize = (g + 1) * BG <= nblk ? BG : nblk - g * BG;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0)
-    s_last = __hip_atomic_fetch_add(&tickets[1 + g], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gsize - 1;
-  __syncthreads();
-  if (!s_last) return;
-  const int two_c = 2 * c;
-  for (int t = threadIdx.x; t < two_c; t += EW_THREADS) {
-    const float* col = partial + (int64_t)g * BG * two_c + t;
-    float v[BG];
-#pragma unroll
-    for (int k = 0; k < BG; ++k)
-      v[k] = k < gsize ? __hip_atomic_load(col + (int64_t)k * two_c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
-    double a = 0.0;
-#pragma unroll
-    for (int k = 0; k < BG; ++k) a += (double)v[k];
-    __hip_atomic_store(gpartial + (int64_t)g * two_c + t, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  if (threadIdx.x == 0) __hip_atomic_store(&tickets[1 + g], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0)
-    s_last = __hip_atomic_fetch_add(&tickets[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ng - 1;
-  __syncthreads();
-  if (!s_last) return;
-  __shared__ double tot[512];                         // 2c values, c <= 256 (checked by the host)
-  for (int t = threadIdx.x; t < two_c; t += EW_THREADS) {
-    double a = 0.0;
-    for (int k = 0; k < ng; ++k) a += __hip_atomic_load(gpartial + (int64_t)k * two_c + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    tot[t] = a;
-  }
-  __syncthreads();
-  for (int ch = threadIdx.x; ch < c; ch += EW_THREADS) {
-    const double s0 = tot[ch], s1 = tot[c + ch];
-    dbeta[ch] = (float)s0;
-    dgamma[ch] = (float)s1;
-    coef[ch] = gamma[ch] * rstd[ch];
-    coef[c + ch] = (float)(s0 / count);
-    coef[2 * c + ch] = (float)(s1 / count);
-  }
-  if (threadIdx.x == 0) __hip_atomic_store(&tickets[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-extern "C" int64_t imm_bn_bwd_reduce_finalize_workspace_bytes(int64_t npix, int c) {
-  const int nblk = imm_bn_bwd_blocks(npix, c);
-  if (nblk < 0) return nblk;
-  const int64_t ng = (nblk + BG - 1) / BG;
-  // [partial rows: nblk x 2c f32][group rows: ng x 2c f64][tickets: 1 + ng i32], each part 16-byte aligned
-  const int64_t a = ((int64_t)nblk * 2 * c * 4 + 15) / 16 * 16, b = (ng * 2 * c * 8 + 15) / 16 * 16, t = ((1 + ng) * 4 + 15) / 16 * 16;
-  return a + b + t;
-}
-
-extern "C" int imm_bn_bwd_reduce_finalize(const void* dout, int lddo, const void* y, int ldy, int dtype, int64_t npix, int c,
-                                          const float* scale, const float* shift, const float* mean, const float* rstd,
-                                          int relu, int64_t count, const float* gamma, float* dgamma, float* dbeta, float* coef,
-                                          void* workspace, void* stream) {
-  IMM_REQUIRE(dout && y && scale && shift && mean && rstd && gamma && dgamma && dbeta && coef && workspace && npix > 0 && count > 0,
-              "bn_bwd_reduce_finalize: null");
-  EW_REQUIRE_VEC(c, lddo, "bn_bwd_reduce_finalize(dout)");
-  EW_REQUIRE_VEC(c, ldy, "bn_bwd_reduce_finalize(y)");
-  IMM_REQUIRE((uintptr_t)workspace % 16 == 0, "bn_bwd_reduce_finalize: workspace alignment");
-  const int nblk = imm_bn_bwd_blocks(npix, c);
-  if (nblk < 0 || c > 256) return imm_fail(IMM_E_UNSUPPORTED, "bn_bwd_reduce_finalize: C=%d unsupported (C/8 must divide 256, C <= 256)", c);
-  const int64_t ng = (nblk + BG - 1) / BG;
-  char* w = (char*)workspace;
-  float* partial = (float*)w;
-  w += ((int64_t)nblk * 2 * c * 4 + 15) / 16 * 16;
-  double* gpartial = (double*)w;
-  w += (ng * 2 * c * 8 + 15) / 16 * 16;
-  int* tickets = (int*)w;                             // zero before the first launch; every launch leaves them zero
-  IMM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_bwd_reduce_finalize_kernel<ET>), dim3(nblk), dim3(EW_THREADS), 0,
-                                               (hipStream_t)stream, (const uint16_t*)dout, lddo, (const uint16_t*)y, ldy, npix, c,
-                                               scale, shift, mean, rstd, relu, partial, gpartial, tickets, (double)count, gamma,
-                                               dgamma, dbeta, coef));
-  IMM_CHECK_LAUNCH("imm_bn_bwd_reduce_finalize");
   return 0;
 }
 

@@ -16,6 +16,19 @@ int imm_fail(int code, const char* fmt, ...) {
 }
 
 extern "C" int imm_abi_version(void) { return IMM_ABI_VERSION; }
+
+bool imm_conv_disabled(const char* name) {
+  const char* e = getenv("IMM_CONV_DISABLE");
+  if (!e || !*e) return false;
+  const size_t n = strlen(name);
+  for (const char* p = e; *p;) {
+    const char* q = strchr(p, ',');
+    const size_t len = q ? (size_t)(q - p) : strlen(p);
+    if (len == n && strncmp(p, name, n) == 0) return true;
+    p += len + (q ? 1 : 0);
+  }
+  return false;
+}
 extern "C" const char* imm_last_error(void) { return imm_err_buf; }
 #ifndef IMM_SOURCE_DIGEST
 #define IMM_SOURCE_DIGEST "unknown"

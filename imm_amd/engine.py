@@ -215,33 +215,18 @@ class IMMEngine:
         self.vgg_w = OrderedDict((k, v.to(self.dev).contiguous()) for k, v in (vgg_weights or synthetic_vgg_weights()).items())
 
         self.prog_pack, self.prog_fwd, self.prog_bwd, self.prog_opt = [], [], [], []
+        # IMM_TWO_STREAMS=0: everything on one stream (A/B of the two-lane schedule; the results are identical)
         self.two_streams = os.environ.get('IMM_TWO_STREAMS', '1') != '0'
-        # timing experiment only (results become wrong): drop every launch whose tag is listed, to measure how much of the
-        # step's critical path a kernel class occupies under graph replay / stream concurrency
-        self.vgg_split = int(os.environ.get('IMM_VGG_SPLIT', '0')) if self.two_streams else 0
-        if self.loss_kind != 'perceptual' or all(n == 'input' for n in self.comp):
-            self.vgg_split = 0                   # no VGG feature is tapped: nothing to split
-        self.reduce_per_layer = os.environ.get('IMM_REDUCE_PER_LAYER', '0') != '0'
+        # IMM_DEBUG_SKIP_TAGS=tag,tag: timing experiment only (results become wrong): drop every launch whose tag is listed, to
+        # measure how much of the step's critical path a kernel class occupies under graph replay / stream concurrency
         self._skip_tags = set(t for t in os.environ.get('IMM_DEBUG_SKIP_TAGS', '').split(',') if t)
         # IMM_DEBUG_STAMPS=marks|all: device wall-clock probes between the launches (lane boundaries / every launch) -> a
         # profiler-free timeline of a graph replay, read with stamp_report()
-        # IMM_BN_PREREDUCE (default 1): layers with > 256 partial rows: parallel 32-row pre-reduction + fused apply instead of a
-        # finalize launch (see imm_rows_reduce)
-        self.bn_prereduce = os.environ.get('IMM_BN_PREREDUCE', '1') != '0'
         self._stamp_mode = os.environ.get('IMM_DEBUG_STAMPS', '')
         self._stamp_buf = torch.zeros(8192, dtype=torch.int64, device=self.dev) if self._stamp_mode else None
         self._stamp_names = []
-        self.wgrad_lane = int(os.environ.get('IMM_WGRAD_LANE', '0')) if self.two_streams else 0
-        # IMM_BN_FUSE_BWD=1: batch-norm backward sums (sum dz, sum dz*out) taken in the epilogue of whatever produces dz (data
-        # gradient of the next layer, up-sampling adjoint) instead of a separate pass over dz and the conv output.  MEASURED
-        # (round 2, same box): 23 reduce launches (0.25 ms of kernel time) disappear, but the mask loads + sum reductions make
-        # the data-gradient epilogues 0.14 ms and the up-sampling adjoints 0.03 ms slower; step 3.841 -> 3.828 ms, and
-        # recovering xhat from the 16-bit `out` costs gradient precision (trained-model parity 0.095 -> 0.13 worst) => OFF.
-        self.bn_fuse_bwd = os.environ.get('IMM_BN_FUSE_BWD', '0') != '0'
-        # finalize + apply of a batch norm in one launch where the partial rows are few (IMM_BN_FUSE_FINALIZE=0: A/B)
-        self.bn_fuse_finalize = os.environ.get('IMM_BN_FUSE_FINALIZE', '1') != '0'
         self._side = None
-        self._pack_jobs, self._reduce_jobs = [], []
+        self._pack_jobs, self._reduce_jobs, self._wgrad_pending = [], [], []
         self._training = True
         self._build_network()
         self.init_parameters(seed)
@@ -378,16 +363,16 @@ class IMMEngine:
             cbytes = 2.0 * (B * H * W * ci_pad + npix * co + fd.kpad * co)
             self._add(self.prog_fwd, f_conv, 'conv_fwd', flops, cbytes)
             lay.up = None
-            if self.bn_fuse_finalize and nblk <= 256 and co % 32 == 0:
+            if nblk <= 256 and co % 32 == 0:
                 # few partial rows: the finalize is redone by every workgroup of the apply pass (one launch, one kernel
                 # boundary and a 6-9 us latency chain less per layer); the renderer's x2 up-sampling rides along
-                if up2x and os.environ.get('IMM_BN_FUSE_UPSAMPLE', '1') != '0':
+                if up2x:
                     lay.up = self._act(B, 2 * fd.ho, 2 * fd.wo, co)
                 self._add(self.prog_fwd, lambda: ops.bn_apply_fused(lay.stats, nblk, co, npix, gamma, beta, BN_EPS, BN_MOMENTUM,
                                                                     self._training, mm, mv, lay.scale, lay.shift, lay.mean, lay.rstd,
                                                                     lay.y, ldy, relu, out, ldo, lay.up, co, fd.ho, fd.wo),
                           'bn_apply', 0.0, npix * co * (4.0 + (8.0 if lay.up is not None else 0.0)))
-            elif self.bn_fuse_finalize and self.bn_prereduce and co % 32 == 0:
+            elif co % 32 == 0:
                 # many partial rows: 32-row groups are summed by rows/32 workgroups in parallel, the fused apply pass finishes
                 # the <= 32 group rows (instead of a finalize launch whose few workgroups walk every row)
                 g = max(32, -(-nblk // 32))
@@ -439,40 +424,18 @@ class IMMEngine:
                                         rows_d * kpad_d))
         else:
             lay.lddy = ldy if not out_f32 else ops.round_up(co, 32)
-        # wgrad split: enough workgroups to fill the chip, at least 512 pixels per split
-        bn_w = 128 if co > 64 else 64 if co > 32 else 32 if co > 16 else 16
-        tiles = -(-fd.kpad // 128) * -(-co // bn_w)
-        # 2 workgroups per CU for small filters; 1 per CU once a slab copy exceeds 512 KB (slab traffic = nsplit x filter)
-        big = fd.kpad * co * 4 > (1 << 19)
-        target = float(os.environ.get('IMM_WGRAD_TARGET_BIG', '1')) if big else 2
-        nsplit = max(1, min(int(-(-target * self.n_cu // tiles)), max(1, npix // 512)))
-        forced = ops.conv2d_wgrad_splits(fd, lay.lddy)     # LDS-resident-tile wgrad kernel: one slab per workgroup
-        if forced > 0:
-            nsplit = forced
-        lay.nsplit = nsplit
-        lay.slab = self._zeros(nsplit, fd.kpad, co)
+        # the filter gradient's pixel splits and slabs are decided when the layer's job joins a multi-problem launch
+        # (_flush_wgrads): the split count depends on what else shares that launch
         if bn:
-            lay.bwd_fused = False          # set by the producer of this block's output gradient (_fuse_bn_sums)
-            lay.bwd_nblk, lay.bwd_partial, lay.bwd_ldp = 0, None, co
             lay.coef = self._zeros(3, co)
             lay.dy = self._act(B, fd.ho, fd.wo, ldy)
         else:
             lay.cs_partial = self._zeros(ops.colsum_blocks(npix, lay.lddy), lay.lddy)
         return lay
 
-    def _fuse_bn_sums(self, bn_lay, rows, ldp):
-        """The producer of bn_lay's output gradient writes `rows` rows of (sum dz, sum dz*out)[ldp] and stores dz already
-        masked by [out > 0]: bn_lay's backward then needs no reduction pass (and no ReLU mask in its apply pass)."""
-        bn_lay.bwd_fused, bn_lay.bwd_nblk, bn_lay.bwd_ldp = True, rows, ldp
-        bn_lay.bwd_partial = self._zeros(rows, 2, ldp)
-        return bn_lay.bwd_partial
-
-    def _conv_backward(self, lay, d_out, ldd, dx, lddx, dx_bn=None):
+    def _conv_backward(self, lay, d_out, ldd, dx, lddx):
         """d_out: gradient w.r.t. the block output (post BN/ReLU for BN blocks; w.r.t. the conv output,
-        16-bit with stride lay.lddy, otherwise).  dx: buffer receiving the input gradient (or None).
-        dx_bn: the conv+BN+ReLU block whose OUTPUT gradient dx is (the layer in front of this one), when dx feeds its
-        batch-norm backward directly: the data gradient's epilogue then applies that block's ReLU mask and takes its
-        batch-norm sums."""
+        16-bit with stride lay.lddy, otherwise).  dx: buffer receiving the input gradient (or None)."""
         B, co, k = self.B, lay.co, lay.k
         npix = lay.npix
         scope = lay.scope
@@ -481,50 +444,32 @@ class IMMEngine:
         if lay.bn:
             gg, gbeta = self.gview[scope + '/gamma'], self.gview[scope + '/beta']
             gamma, beta = self.pview[scope + '/gamma'], self.pview[scope + '/beta']
-            fused = lay.bwd_fused and lay.relu
-            lay.bwd_nblk = lay.bwd_nblk if fused else ops.bn_bwd_blocks(npix, co)
-            small = self.bn_fuse_finalize and lay.bwd_nblk <= 256 and co % 32 == 0
-            # IMM_BN_BWD_TICKET=1: layers with too many partial rows for the fused apply pass finish their sums in the reduce
-            # kernel itself (last workgroup done, imm_bn_bwd_reduce_finalize) instead of a finalize launch.  MEASURED (round 2,
-            # 11 layers, same box): with device-scope fences 3.64 -> 5.44 ms (every fence writes back / invalidates a whole
-            # L2); with fence-free sc1 atomics 3.70 -> 3.80 ms — two cross-XCD hand-overs through memory cost more than the
-            # 9 us finalize launch they replace.  A kernel boundary is the cheapest device-wide barrier here => off.
-            ticket = not fused and not small and co <= 256 and os.environ.get('IMM_BN_BWD_TICKET', '0') != '0'
-            if ticket:
-                lay.bwd_ws = ops.bn_bwd_reduce_finalize_workspace(npix, co, self.dev)
-                self._add(self.prog_bwd, lambda: ops.bn_bwd_reduce_finalize(d_out, ldd, lay.y, lay.ldy, npix, co, lay.scale, lay.shift,
-                                                                            lay.mean, lay.rstd, lay.relu, npix, gamma, gg, gbeta,
-                                                                            lay.coef, lay.bwd_ws),
-                          'bn_bwd_reduce', 0.0, npix * co * 4.0)
-            elif not fused:
-                lay.bwd_ldp = co
-                lay.bwd_partial = self._zeros(lay.bwd_nblk, 2, co)
-                self._add(self.prog_bwd, lambda: ops.bn_bwd_reduce(d_out, ldd, lay.y, lay.ldy, npix, co, lay.scale, lay.shift,
-                                                                   lay.mean, lay.rstd, lay.relu, lay.bwd_partial),
-                          'bn_bwd_reduce', 0.0, npix * co * 4.0)
-            prered = (not fused and not small and not ticket and self.bn_fuse_finalize and self.bn_prereduce and co % 32 == 0)
-            if prered:
-                g = max(32, -(-lay.bwd_nblk // 32))
-                nred = -(-lay.bwd_nblk // g)
-                lay.bwd_red = self._zeros(nred, 2, co)
-                self._add(self.prog_bwd, lambda: ops.rows_reduce(lay.bwd_partial, lay.bwd_nblk, 2 * co, g, lay.bwd_red), 'bn_bwd_finalize')
-                self._add(self.prog_bwd, lambda: ops.bn_bwd_apply_fused(lay.bwd_red, nred, co, npix, gamma, d_out, ldd,
-                                                                        lay.y, lay.ldy, lay.scale, lay.shift, lay.mean, lay.rstd,
-                                                                        lay.relu, gg, gbeta, lay.dy, lay.ldy),
-                          'bn_bwd_apply', 0.0, npix * co * 6.0)
-            elif small and not fused:
-                self._add(self.prog_bwd, lambda: ops.bn_bwd_apply_fused(lay.bwd_partial, lay.bwd_nblk, co, npix, gamma, d_out, ldd,
+            # sums (reduce) -> [parallel pre-reduction of > 256 partial rows] -> finalize + apply in one launch.  (Taking the sums
+            # in the epilogue of the producer of d_out — built in round 2 behind IMM_BN_FUSE_BWD — removed the 23 reduce launches but
+            # made the data-gradient epilogues slower by about as much and cost gradient precision: DESIGN.md item 18; finishing
+            # the sums inside the reduce kernel with a last-workgroup ticket was slower too: item 22.  Both paths are gone.)
+            nblk = ops.bn_bwd_blocks(npix, co)
+            lay.bwd_partial = self._zeros(nblk, 2, co)
+            self._add(self.prog_bwd, lambda: ops.bn_bwd_reduce(d_out, ldd, lay.y, lay.ldy, npix, co, lay.scale, lay.shift,
+                                                               lay.mean, lay.rstd, lay.relu, lay.bwd_partial),
+                      'bn_bwd_reduce', 0.0, npix * co * 4.0)
+            if co % 32 == 0:
+                rows, nrows = lay.bwd_partial, nblk
+                if nblk > 256:
+                    g = max(32, -(-nblk // 32))
+                    nrows = -(-nblk // g)
+                    lay.bwd_red = rows_red = self._zeros(nrows, 2, co)
+                    self._add(self.prog_bwd, lambda: ops.rows_reduce(lay.bwd_partial, nblk, 2 * co, g, rows_red), 'bn_bwd_finalize')
+                    rows = rows_red
+                self._add(self.prog_bwd, lambda: ops.bn_bwd_apply_fused(rows, nrows, co, npix, gamma, d_out, ldd,
                                                                         lay.y, lay.ldy, lay.scale, lay.shift, lay.mean, lay.rstd,
                                                                         lay.relu, gg, gbeta, lay.dy, lay.ldy),
                           'bn_bwd_apply', 0.0, npix * co * 6.0)
             else:
-                if not ticket:
-                    self._add(self.prog_bwd, lambda: ops.bn_bwd_finalize(lay.bwd_partial, lay.bwd_nblk, co, npix, gamma, beta, lay.rstd,
-                                                                         gg, gbeta, lay.coef, from_out=fused, ldp=lay.bwd_ldp),
-                              'bn_bwd_finalize')
-                # fused: d_out already is dz (ReLU mask applied by its producer)
+                self._add(self.prog_bwd, lambda: ops.bn_bwd_finalize(lay.bwd_partial, nblk, co, npix, gamma, beta, lay.rstd,
+                                                                     gg, gbeta, lay.coef), 'bn_bwd_finalize')
                 self._add(self.prog_bwd, lambda: ops.bn_bwd_apply(d_out, ldd, lay.y, lay.ldy, npix, co, lay.scale, lay.shift,
-                                                                  lay.mean, lay.rstd, lay.relu and not fused, lay.coef, lay.dy, lay.ldy),
+                                                                  lay.mean, lay.rstd, lay.relu, lay.coef, lay.dy, lay.ldy),
                           'bn_bwd_apply', 0.0, npix * co * 6.0)
             dy, lddy = lay.dy, lay.ldy
             # conv bias feeds a batch norm: its gradient is analytically zero (sum of dy == 0); the
@@ -534,63 +479,71 @@ class IMMEngine:
             self._add(self.prog_bwd, lambda: ops.colsum(dy, npix, lddy, co, lddy, lay.cs_partial, gb), 'colsum')
         fd = lay.fd
         flops = 2.0 * npix * k * lay.kw * lay.ci_real * co
-        # Filter gradients are off the critical path (nobody reads them before the final slab reduction).  Moving them
-        # to a third stream was MEASURED SLOWER (4.49 -> 5.02 ms/step: the MFMA/LDS-heavy wgrad workgroups take CU
-        # resources from the critical BN-backward/dgrad chain), so it stays an experiment switch.
-        if self.wgrad_lane:
-            self._signal(self.prog_bwd, 'dy:' + scope)
-            self._wait(self.prog_bwd, 'dy:' + scope, lane=self.wgrad_lane)
-        lane_save = getattr(self, '_cur_lane', 0)
-        if self.wgrad_lane:
-            self._cur_lane = self.wgrad_lane
-        if getattr(self, '_defer_wgrad', None) is not None:
-            # renderer: collected and issued as ONE side-stream branch next to the encoders' backward (one fork/join;
-            # per-layer cross-stream edges were measured slower, see above)
-            self._add(self._defer_wgrad, lambda: ops.conv2d_wgrad(fd, lay.x, dy, lddy, lay.slab, lay.nsplit), 'conv_wgrad', flops)
-        else:
-            self._add(self.prog_bwd, lambda: ops.conv2d_wgrad(fd, lay.x, dy, lddy, lay.slab, lay.nsplit), 'conv_wgrad', flops)
-        self._cur_lane = lane_save
-        job = (lay.slab.data_ptr(), gw.data_ptr(), lay.nsplit, k * lay.kw, lay.ci_pad, lay.ci_real, co, fd.kpad)
-        if self.reduce_per_layer and getattr(self, '_defer_wgrad', None) is None and not self.wgrad_lane:
-            # sum this layer's slabs right away, while they still sit in the 256 MB memory-side cache (one table-driven
-            # launch for all layers at the end reads 467 MB back from HBM)
-            tab1 = ops.JobTable([job], [k * lay.kw * lay.ci_real * co], 64, self.dev)
-            self._add(self.prog_bwd, (lambda tab1=tab1: ops.wgrad_reduce_multi(tab1)), 'wgrad_reduce')
-        else:
-            self._reduce_jobs.append((job, k * lay.kw * lay.ci_real * co))
-        fuse = self.bn_fuse_bwd and dx_bn is not None and dx_bn.bn and dx_bn.relu
-        mflags = (L.CONV_MASK | L.CONV_STATS) if fuse else 0
-        mask, ldmask = (dx_bn.out, dx_bn.ldo) if fuse else (None, 0)
+        # Filter gradient: nobody reads it before the slab reduction at the end of the backward pass, so the job is only
+        # COLLECTED here and issued with the other layers' in one multi-problem launch per kernel variant (_flush_wgrads):
+        # the per-layer launches (15-48 us each) leave the serial BN-backward -> data-gradient chain.
+        self._wgrad_pending.append((lay, dy, lddy, flops))
         if lay.needs_dgrad and dx is not None and getattr(lay, 's2', None) is not None:
-            grouped = os.environ.get('IMM_S2_GROUP', '1') != '0'
-            if not grouped:
-                mflags, mask, ldmask, fuse = 0, None, 0, False
-            classes = ops.dgrad_s2_class_descs(B, lay.H, lay.W, lay.ci_real, lddx, lddy, lddy, k, flags=mflags, ldmask=ldmask)
-            if grouped:
-                # the four parity classes as one grouped launch (falls back to four launches inside the library when the
-                # members do not take the deep-K 64x64 tile)
-                grp = ops.ConvGroup([dd0 for dd0, _m in classes], list(lay.wt_s2))
-                ntaps = sum(dd0.kh * dd0.kw for dd0, _m in classes)
-                stats = self._fuse_bn_sums(dx_bn, ops.conv2d_group_stats_blocks(grp), lay.ci_real) if fuse else None
-                self._add(self.prog_bwd, (lambda grp=grp, stats=stats, mask=mask: ops.conv2d_group(grp, dy, dx, stats, mask)), 'conv_dgrad',
-                          2.0 * npix * ntaps * lay.ci_real * co,
-                          2.0 * (4 * npix * lddy + 4 * npix * lay.ci_real + sum(dd0.kpad for dd0, _m in classes) * lay.ci_real))
-            else:
-                for (dd0, _mode), wt_c in zip(classes, lay.wt_s2):
-                    ntap = dd0.kh * dd0.kw
-                    self._add(self.prog_bwd, (lambda dd0=dd0, wt_c=wt_c: ops.conv2d(dd0, dy, wt_c, None, dx)), 'conv_dgrad',
-                              2.0 * npix * ntap * lay.ci_real * co,
-                              2.0 * (npix * lddy + npix * lay.ci_real + dd0.kpad * lay.ci_real))
+            # stride 2: the four input-pixel parity classes as one grouped launch (falls back to four launches inside the
+            # library when the members do not take a grouped tile)
+            classes = ops.dgrad_s2_class_descs(B, lay.H, lay.W, lay.ci_real, lddx, lddy, lddy, k)
+            grp = ops.ConvGroup([dd0 for dd0, _m in classes], list(lay.wt_s2))
+            ntaps = sum(dd0.kh * dd0.kw for dd0, _m in classes)
+            self._add(self.prog_bwd, (lambda grp=grp: ops.conv2d_group(grp, dy, dx, None, None)), 'conv_dgrad',
+                      2.0 * npix * ntaps * lay.ci_real * co,
+                      2.0 * (4 * npix * lddy + 4 * npix * lay.ci_real + sum(dd0.kpad for dd0, _m in classes) * lay.ci_real))
         elif lay.needs_dgrad and dx is not None:
             # output channels: the padded count when that makes whole 64-channel blocks (the concat layer: 266 -> 320, its
             # packed filter rows beyond ci_real are zeros) — the deep-K kernels need co % 64 == 0
             co_dx = lay.ci_pad if (lay.ci_pad != lay.ci_real and lay.ci_pad % 64 == 0 and lddx >= lay.ci_pad
                                    and lay.wt_d.shape[0] >= lay.ci_pad) else lay.ci_real
-            dd = ops.dgrad_desc(B, lay.H, lay.W, co_dx, lddx, lddy, lddy, k, lay.stride, mflags, ldmask=ldmask)
+            dd = ops.dgrad_desc(B, lay.H, lay.W, co_dx, lddx, lddy, lddy, k, lay.stride, 0)
             assert dd.kpad == lay.wt_d.shape[1], (dd.kpad, lay.wt_d.shape)
-            stats = self._fuse_bn_sums(dx_bn, ops.conv_stats_blocks(dd), co_dx) if fuse else None
-            self._add(self.prog_bwd, lambda: ops.conv2d(dd, dy, lay.wt_d, None, dx, stats, mask), 'conv_dgrad', flops,
+            self._add(self.prog_bwd, lambda: ops.conv2d(dd, dy, lay.wt_d, None, dx), 'conv_dgrad', flops,
                       2.0 * (npix * lddy + B * lay.H * lay.W * lay.ci_real + dd.kpad * lay.ci_real))
+
+    def _flush_wgrads(self, name):
+        """Issue the collected filter-gradient jobs as ONE multi-problem launch per kernel variant (imm_conv2d_wgrad_multi) and
+        register their slab reductions.  Jobs that share a launch share the chip, so a layer no longer needs enough pixel
+        splits to fill 256 CUs on its own: the splits of a group are sized to a common length per workgroup with about
+        IMM_WGRAD_MULTI_WGS (default "2,1": transpose-read kernel, LDS-halo kernel) workgroups per CU in total — slab traffic
+        (nsplit x |dW| x 4 B, written and read back by the reduction) falls with the split count."""
+        jobs, self._wgrad_pending = self._wgrad_pending, []
+        if not jobs:
+            return
+        per_cu = [float(v) for v in os.environ.get('IMM_WGRAD_MULTI_WGS', '2,1').split(',')]
+        groups = OrderedDict()
+        for lay, dy, lddy, flops in jobs:
+            key, wps, units = ops.conv2d_wgrad_variant(lay.fd, lddy, self.dt)
+            groups.setdefault(key, []).append((lay, dy, lddy, wps, units))
+        multi_jobs = []
+        for key, members in groups.items():
+            kind = key // 10000                     # 0 generic kernel (one launch per job), 1 transpose-read, 2 LDS-halo
+            target = max(1, int(per_cu[min(kind, len(per_cu)) - 1] * self.n_cu)) if kind else 2 * self.n_cu
+            # shortest useful workgroup: 16 steps of 32 pixels / 2 (sliced) or 4 (whole-filter) patches of 128 pixels
+            floor_units = [16 if kind != 2 else (2 if wps > 1 else 4) for _l, _d, _ld, wps, _u in members]
+
+            def splits(u):
+                return [max(1, min(-(-units // u), max(1, units // fl))) for (_l, _d, _ld, _w, units), fl in zip(members, floor_units)]
+            if kind == 0:
+                ns = [max(1, min(-(-target // wps), max(1, units // 16))) for _l, _d, _ld, wps, units in members]
+            else:
+                u = max(units for _l, _d, _ld, _w, units in members)
+                ns = splits(u)
+                while u > 1 and sum(n * m[3] for n, m in zip(ns, members)) < target:
+                    u = max(1, int(u / 1.1)) if u > 64 else u - 1
+                    ns = splits(u)
+            for (lay, dy, lddy, wps, units), nsplit in zip(members, ns):
+                lay.nsplit = nsplit
+                lay.slab = self._zeros(nsplit, lay.fd.kpad, lay.co)
+                multi_jobs.append((lay.fd, lay.x, dy, lddy, lay.slab, nsplit))
+                gw = self.gview[lay.scope + '/w']
+                job = (lay.slab.data_ptr(), gw.data_ptr(), nsplit, lay.k * lay.kw, lay.ci_pad, lay.ci_real, lay.co, lay.fd.kpad)
+                self._reduce_jobs.append((job, lay.k * lay.kw * lay.ci_real * lay.co))
+        multi = ops.WgradMulti(multi_jobs, self.dt)
+        self._wgrad_multis = getattr(self, '_wgrad_multis', []) + [multi]
+        self._cur_scope = name
+        self._add(self.prog_bwd, lambda: ops.conv2d_wgrad_multi(multi), 'conv_wgrad', sum(j[3] for j in jobs), name=name)
 
     def _build_network(self):
         cfg, B, S, K, dt = self.cfg, self.B, self.S, self.K, self.dt
@@ -657,13 +610,7 @@ class IMMEngine:
         self._add(self.prog_fwd, lambda: ops.softargmax_gauss_fwd(self.heat, self.ldh, B, He, He, K, self.inv_std, 16,
                                                                   self.mu, self.py, self.px, gview, Cj, dt, cfg.gauss_mode), 'bottleneck')
 
-        if self.vgg_split == 2:
-            # the image-encoder stream carries on with the VGG gt half while the main stream renders
-            self._signal(self.prog_fwd, 'enc_im_done', lane=1)
-            self._wait(self.prog_fwd, 'enc_im_done', lane=0)
-            self._gt_splice = len(self.prog_fwd)
-        else:
-            self._mark(self.prog_fwd, 'join')
+        self._mark(self.prog_fwd, 'join')
         # ---- renderer ---------------------------------------------------------------------------------
         self.ren, self.ren_up = [], []
         x, H, ci_real, ci_pad, ldx = self.joint, 16, 8 * nf + K, Cj, Cj
@@ -689,13 +636,12 @@ class IMMEngine:
         self.n_fwd_model = len(self.prog_fwd)   # launches up to here produce future_im_pred / gauss_yx
 
         # ---- frozen VGG16 on concat([gt, pred]) --------------------------------------------------------
-        # The activations keep the reference's concat layout [gt images; pred images] (imm_model.py:126).  With
-        # vgg_split the gt half -- which does not depend on the network -- is issued on a third stream at the very start
-        # of the step and fills the CUs the low-resolution encoder/renderer layers leave idle; the main stream then
-        # only runs the pred half before the loss.  Same kernels, same per-image arithmetic: results are bitwise equal.
+        # The activations keep the reference's concat layout [gt images; pred images] (imm_model.py:126): every VGG launch
+        # covers 2B images.  (Running the gt half — which does not depend on the network — ahead on another lane was measured
+        # twice without gain: the VGG kernels fill the chip on their own)
         # Only the layers up to the deepest tapped one are built; no tapped layer (perceptual.comp == ['input'] or
         # reconstruction_loss 'l2') => no VGG at all.
-        self.vgg_act, self.vgg_wt, self.vgg_wtd, self.vgg_desc, self.vgg_dd = OrderedDict(), {}, {}, {}, {}
+        self.vgg_act, self.vgg_wt, self.vgg_wtd, self.vgg_desc = OrderedDict(), {}, {}, {}
         self.vgg_pool = {}
         self.tap_idx = {n: k for k, n in enumerate(self.comp)}          # feature name -> position in the loss
         vnames = [n for n, _ci, _co in VGG_LAYERS]
@@ -703,46 +649,15 @@ class IMMEngine:
         self.vgg_layers = VGG_LAYERS[:max(vnames.index(n) for n in taps) + 1] if taps else []
         nfeat = self.nfeat
         self.sse_partial = self._zeros(nfeat, L.SSE_BLOCKS)
-        split = self.vgg_split if self.vgg_layers else 0
-        nimg = B if split else 2 * B
-        gt_prog, pred_prog = [], self.prog_fwd
+        nimg = 2 * B
         fuse_ok = not self.l1                    # the fused SSE+pool / unpool+tap passes exist for the squared error only
-        # IMM_SSE_SIDE=1: the error sums that nothing in the VGG chain waits for ('input', conv3_2, conv4_2) on the side lane.
-        # MEASURED (round 2, same box, A/B twice): 3.717 -> 3.757 ms — the three fork edges + one join of the HIP graph cost
-        # more than the 30 us of reductions taken off the chain => off.
-        sse_side = self.two_streams and not split and os.environ.get('IMM_SSE_SIDE', '0') != '0' and bool(self.vgg_layers)
-        side_sse = set()
-        if sse_side and 'input' in self.tap_idx:
-            idx0 = self.tap_idx['input']
-            self._signal(self.prog_fwd, 'pred_done', lane=0)
-            self._wait(self.prog_fwd, 'pred_done', lane=1)
-            self._cur_lane = 1
-            self._add(self.prog_fwd, lambda: ops.masked_sse_f32(self.in_future, 3, self.pred, self.ldp, B, S, 3, self.in_mask,
-                                                                self.sse_partial[idx0], self.l1), 'sse')
-            self._cur_lane = 0
-            side_sse.add('input')
-
-        def vadd(fn_for, tag, flops, nbytes, name=''):
-            # fn_for(lo) -> launch closure over images [lo, lo + nimg)
-            if split:
-                self._cur_lane = 1 if split == 2 else 2
-                self._add(gt_prog, fn_for(0), tag, flops, nbytes, name + '[gt]')
-                self._cur_lane = 0
-                self._add(pred_prog, fn_for(B), tag, flops, nbytes, name + '[pred]')
-            else:
-                self._add(pred_prog, fn_for(0), tag, flops, nbytes, name)
-
+        fused_sse = set()
         if self.vgg_layers:
             self.w11 = self._zeros(9, 64); self.b11 = self._zeros(64)
             a = self._act(2 * B, S, S, 64)
             self.vgg_act['conv1_1'] = (a, S)
-            if split:
-                vadd(lambda lo: (lambda: ops.vgg_conv1_1_fwd(self.in_future, self.pred, self.ldp, B, S, self.w11, self.b11, a,
-                                                             1 if lo == 0 else 2)),
-                     'vgg_conv1_1', 2.0 * B * S * S * 9 * 64, B * S * S * 128.0, 'vgg16/conv1_1')
-            else:
-                self._add(self.prog_fwd, lambda: ops.vgg_conv1_1_fwd(self.in_future, self.pred, self.ldp, B, S, self.w11, self.b11, a),
-                          'vgg_conv1_1', 2.0 * 2 * B * S * S * 9 * 64, 2 * B * S * S * 128.0)
+            self._add(self.prog_fwd, lambda: ops.vgg_conv1_1_fwd(self.in_future, self.pred, self.ldp, B, S, self.w11, self.b11, a),
+                      'vgg_conv1_1', 2.0 * 2 * B * S * S * 9 * 64, 2 * B * S * S * 128.0, name='vgg16/conv1_1')
             x, H = a, S
         for li, (name, cin, cout) in enumerate(self.vgg_layers[1:], start=1):
             fd = ops.fwd_desc(nimg, H, H, cin, cin, cout, cout, 3, 1, L.CONV_BIAS | L.CONV_RELU)
@@ -751,65 +666,26 @@ class IMMEngine:
             y = self._act(2 * B, H, H, cout)
             self.vgg_wt[name], self.vgg_wtd[name], self.vgg_desc[name] = wt, wtd, fd
             bias = self.vgg_w['vgg16/%s/biases' % name]
-            if cin == 64 and cout == 128 and H >= 64 and H % 16 == 0 and os.environ.get('IMM_VGG_NSPLIT', '0') != '0':
-                # conv2_1: K = 576 is too short for the deep-K kernel (9 taps, prologue + epilogue dominate: 59 us);
-                # two 64 -> 64 launches of the register-filter kernel over the two halves of the output channels
-                fh = ops.fwd_desc(nimg, H, H, cin, cin, 64, cout, 3, 1, L.CONV_BIAS | L.CONV_RELU)
-                for h in range(2):
-                    vadd(lambda lo, fh=fh, x=x, wt=wt, bias=bias, y=y, h=h: (
-                        lambda: ops.conv2d(fh, x[lo:lo + nimg], wt[64 * h:], bias[64 * h:], y[lo:lo + nimg, :, :, 64 * h:])),
-                         'vgg_fwd', 1.0 * nimg * H * H * 9 * cin * cout, 1.0 * (nimg * H * H * (cin + cout) + 9 * cin * cout),
-                         'vgg16/%s[%d]' % (name, h))
-            else:
-                vadd(lambda lo, fd=fd, x=x, wt=wt, bias=bias, y=y: (lambda: ops.conv2d(fd, x[lo:lo + nimg], wt, bias, y[lo:lo + nimg])),
-                     'vgg_fwd', 2.0 * nimg * H * H * 9 * cin * cout, 2.0 * (nimg * H * H * (cin + cout) + 9 * cin * cout),
-                     'vgg16/' + name)
+            self._add(self.prog_fwd, (lambda fd=fd, x=x, wt=wt, bias=bias, y=y: ops.conv2d(fd, x, wt, bias, y)),
+                      'vgg_fwd', 2.0 * nimg * H * H * 9 * cin * cout, 2.0 * (nimg * H * H * (cin + cout) + 9 * cin * cout),
+                      name='vgg16/' + name)
             self.vgg_act[name] = (y, H)
             x = y
-            pooled_next = name in VGG_POOL_AFTER and li < len(self.vgg_layers) - 1
-            if (sse_side and name in taps and li < len(self.vgg_layers) - 1 and
-                    not (pooled_next and fuse_ok and os.environ.get('IMM_SSE_POOL_FUSE', '1') != '0')):
-                # a tapped layer in the middle of the network: its masked error sum is off the critical chain (the next
-                # convolution does not need it) -> side lane, next to the matrix-bound convolutions that follow
-                idx = self.tap_idx[name]
-                self._signal(self.prog_fwd, 'tap:' + name, lane=0)
-                self._wait(self.prog_fwd, 'tap:' + name, lane=1)
-                self._cur_lane = 1
-                self._add(self.prog_fwd, (lambda y=y, H=H, cout=cout, idx=idx: ops.masked_sse(
-                    y[:B], y[B:], B, H, cout, self.in_mask, S, self.sse_partial[idx], self.l1)), 'sse', 0.0, 2 * B * H * H * cout * 2.0)
-                self._cur_lane = 0
-                side_sse.add(name)
             if name in VGG_POOL_AFTER and li < len(self.vgg_layers) - 1:      # the deepest layer is not pooled: nobody reads it
                 p = self._act(2 * B, H // 2, H // 2, cout)
-                if name in taps and not split and fuse_ok and os.environ.get('IMM_SSE_POOL_FUSE', '1') != '0':
+                if name in taps and fuse_ok:
                     # the loss taps this layer AND it is pooled next: one pass computes the masked SSE of the two halves
                     # and both pooled halves (the feature map is read once instead of twice)
                     idx = self.tap_idx[name]
-                    self._fused_sse = getattr(self, '_fused_sse', set()) | {name}
+                    fused_sse.add(name)
                     self._add(self.prog_fwd, (lambda x=x, p=p, H=H, cout=cout, idx=idx: ops.masked_sse_pool(
                         x[:B], x[B:], B, H, cout, self.in_mask, S, self.sse_partial[idx], p[:B], p[B:])), 'sse',
                               0.0, 2 * B * H * H * cout * 2.5, name='vgg16/%s+pool' % name)
                 else:
-                    vadd(lambda lo, x=x, p=p, H=H, cout=cout: (lambda: ops.maxpool2_fwd(x[lo:lo + nimg], p[lo:lo + nimg], nimg, H, H, cout)),
-                         'maxpool', 0.0, nimg * H * H * cout * 2.5)
+                    self._add(self.prog_fwd, (lambda x=x, p=p, H=H, cout=cout: ops.maxpool2_fwd(x, p, nimg, H, H, cout)),
+                              'maxpool', 0.0, nimg * H * H * cout * 2.5, name='vgg16/pool_' + name)
                 self.vgg_pool[name] = p
                 x, H = p, H // 2
-        if split:
-            # splice: [start event, gt-half launches on lane 2, done event] at the head of the step; wait before the loss
-            head = []
-            if split == 2:
-                head.extend(gt_prog)
-                self._signal(head, 'vgg_gt', lane=1)
-                at = self._gt_splice
-            else:
-                self._signal(head, 'step_start', lane=0)
-                self._wait(head, 'step_start', lane=2)
-                head.extend(gt_prog)
-                self._signal(head, 'vgg_gt', lane=2)
-                at = 0
-            self.prog_fwd[at:at] = head
-            self.n_fwd_model += len(head)
-            self._wait(self.prog_fwd, 'vgg_gt', lane=0)
         if self.vgg_layers:
             self._pack_vgg()
 
@@ -825,12 +701,13 @@ class IMMEngine:
         self.loss_out = self._zeros(3 * nfeat + 3)
         mask = self.in_mask
         l1 = self.l1
-        if 'input' in self.tap_idx and 'input' not in side_sse:
+        self._cur_scope = 'loss'
+        if 'input' in self.tap_idx:
             idx0 = self.tap_idx['input']
             self._add(self.prog_fwd, lambda: ops.masked_sse_f32(self.in_future, 3, self.pred, self.ldp, B, S, 3, mask,
                                                                 self.sse_partial[idx0], l1), 'sse')
-        tail = [name for name in taps if name not in getattr(self, '_fused_sse', ()) and name not in side_sse]
-        if len(tail) > 1 and os.environ.get('IMM_SSE_MULTI', '1') != '0':
+        tail = [name for name in taps if name not in fused_sse]
+        if len(tail) > 1:
             # the deep tapped layers' error sums in one launch (they sit back to back in front of the loss)
             feats = []
             for name in tail:
@@ -847,9 +724,6 @@ class IMMEngine:
             self._add(self.prog_fwd, (lambda y=y, H=H, c=c, idx=idx: ops.masked_sse(y[:B], y[B:], B, H, c, mask, S,
                                                                                   self.sse_partial[idx], l1)), 'sse',
                       0.0, 2 * B * H * H * c * 2.0)
-        if side_sse:
-            self._signal(self.prog_fwd, 'sse_side_done', lane=1)
-            self._wait(self.prog_fwd, 'sse_side_done', lane=0)
         mode = ops.LOSS_L2 if self.loss_kind == 'l2' else ops.LOSS_PERCEPTUAL
         self._add(self.prog_fwd, lambda: ops.perceptual_finalize(self.sse_partial, nfeat, self.nel, self.loss_agg,
                                                                  self._training, self.wd_loss, self.loss_out, l1, mode,
@@ -921,7 +795,7 @@ class IMMEngine:
 
         def unpool_tap(name, dy):
             """unpool(name, dy, 0) + tap(name, True) in one pass (the tapped layer is the pooled one)."""
-            if l1 or os.environ.get('IMM_UNPOOL_TAP_FUSE', '1') == '0':
+            if l1:
                 unpool(name, dy, 0); tap(name, True)
                 return
             y, H = acts[name]
@@ -962,63 +836,43 @@ class IMMEngine:
         # ---- renderer backward -----------------------------------------------------------------------------
         ups = {idx: (ub, H, co) for idx, ub, H, co in self.ren_up}
         d_out, ldd = self.d_pred, last.lddy
-        defer = self.two_streams and not self.wgrad_lane and os.environ.get('IMM_WGRAD_DEFER_REN', '0') != '0'
-        self._defer_wgrad = [] if defer else None
         for i in range(len(self.ren) - 1, -1, -1):
             lay = self.ren[i]
-            dx_bn = None
             if i == 0:
                 dx, lddx = self.d_joint, Cj
-                if self.He == 16:      # channels 0..8nf-1 of d_joint ARE the output gradient of the image encoder's conv_8
-                    dx_bn = self.enc_im[-1]   # (whose `out` is the joint buffer: the Gaussian / pad channels behind it are >= 0)
             else:
                 prev = self.ren[i - 1]
                 if (i - 1) in ups:     # this conv's input is the upsampled output of conv i-1
                     _ub, Hp, cp = ups[i - 1]
-                    d_up = self._act(B, 2 * Hp, 2 * Hp, cp)
-                    dx, lddx = d_up, cp
+                    dx, lddx = self._act(B, 2 * Hp, 2 * Hp, cp), cp
                 else:
                     dx, lddx = self._act(B, prev.Ho, prev.Wo, prev.co), prev.co
-                    dx_bn = prev
-            self._conv_backward(lay, d_out, ldd, dx, lddx, dx_bn=dx_bn)
+            self._conv_backward(lay, d_out, ldd, dx, lddx)
             if i > 0:
                 if (i - 1) in ups:
                     _ub, Hp, cp = ups[i - 1]
                     d_prev = self._act(B, Hp, Hp, cp)
-                    if self.bn_fuse_bwd and prev.bn and prev.relu:
-                        # adjoint of the up-sampling + ReLU mask + batch-norm sums of conv i-1 in one pass
-                        part = self._fuse_bn_sums(prev, ops.upsample2x_bwd_bn_blocks(B, Hp, Hp, cp), cp)
-                        self._add(self.prog_bwd, (lambda dx=dx, d_prev=d_prev, Hp=Hp, cp=cp, prev=prev, part=part:
-                                                  ops.upsample2x_bwd_bn(dx, d_prev, B, Hp, Hp, cp, cp, cp, prev.out, prev.ldo, part)),
-                                  'upsample_bwd', 0.0, B * Hp * Hp * cp * 12.0)
-                    else:
-                        self._add(self.prog_bwd, (lambda dx=dx, d_prev=d_prev, Hp=Hp, cp=cp:
-                                                  ops.upsample2x_bwd(dx, d_prev, B, Hp, Hp, cp, cp, cp)), 'upsample_bwd',
-                                  0.0, B * Hp * Hp * cp * 10.0)
+                    self._add(self.prog_bwd, (lambda dx=dx, d_prev=d_prev, Hp=Hp, cp=cp:
+                                              ops.upsample2x_bwd(dx, d_prev, B, Hp, Hp, cp, cp, cp)), 'upsample_bwd',
+                              0.0, B * Hp * Hp * cp * 10.0)
                     d_out, ldd = d_prev, cp
                 else:
                     d_out, ldd = dx, lddx
 
-        deferred, self._defer_wgrad = self._defer_wgrad, None
-        if deferred is None:
-            # renderer gradients are complete: reduce their slabs now so that a data-parallel run can all-reduce this
-            # bucket (the tail of the flat gradient buffer) while the encoders' backward is still running
-            if self._reduce_jobs:
-                self.reduce_tab_ren = ops.JobTable([j for j, _n in self._reduce_jobs], [n for _j, n in self._reduce_jobs], 64, self.dev)
-                self._add(self.prog_bwd, lambda: ops.wgrad_reduce_multi(self.reduce_tab_ren), 'wgrad_reduce', name='renderer')
+        # By default every layer's filter gradient waits for ONE set of grouped launches at the end of the backward pass (more
+        # members per launch, fewer splits).  IMM_DP_BUCKETS=2 (two overlapped all-reduce buckets, imm_amd/train/cnn_train_multi.py):
+        # the renderer's are issued and reduced here, so that this bucket (the tail of the flat gradient buffer) can travel while
+        # the encoders' backward is still running.
+        self.n_bwd_bucket0 = None
+        if int(os.environ.get('IMM_DP_BUCKETS', '1')) >= 2:
+            self._flush_wgrads('renderer')
+            self.reduce_tab_ren = ops.JobTable([j for j, _n in self._reduce_jobs], [n for _j, n in self._reduce_jobs], 64, self.dev)
+            self._add(self.prog_bwd, lambda: ops.wgrad_reduce_multi(self.reduce_tab_ren), 'wgrad_reduce', name='renderer')
             self._reduce_jobs = []
-        self.n_bwd_bucket0 = len(self.prog_bwd) if deferred is None else None
+            self.n_bwd_bucket0 = len(self.prog_bwd)
         self.bucket0_offset = self.tab.offsets[[n for n, _s, _w in self.spec].index('model/renderer/conv_1/w')]
         # ---- bottleneck + pose encoder backward (main stream) || image encoder backward (side stream) --------------
         self._mark(self.prog_bwd, 'fork')       # d_joint is complete here
-        if deferred:
-            # third branch: the renderer's filter gradients (their dY buffers are all live), beside the two encoder branches
-            self._signal(self.prog_bwd, 'ren_bwd_done', lane=0)
-            self._wait(self.prog_bwd, 'ren_bwd_done', lane=2)
-            for l in deferred:
-                l.lane = 2
-                self.prog_bwd.append(l)
-            self._signal(self.prog_bwd, 'ren_wgrad_done', lane=2)
         nf8 = 8 * self.cfg.n_filters
         He = self.He
         ph = self.pose_head
@@ -1027,7 +881,7 @@ class IMMEngine:
         self._add(self.prog_bwd, lambda: ops.softargmax_gauss_bwd(dg, Cj, B, He, He, K, self.inv_std, 16, self.mu, self.py,
                                                                   self.px, self.d_heat, ph.lddy, self.cfg.gauss_mode), 'bottleneck_bwd')
         d_feat = self._act(B, He, He, nf8)
-        self._conv_backward(ph, self.d_heat, ph.lddy, d_feat, nf8, dx_bn=self.enc_pose[-1])
+        self._conv_backward(ph, self.d_heat, ph.lddy, d_feat, nf8)
         self._encoder_backward(self.enc_pose, d_feat, nf8)
 
         # ---- image encoder backward ----------------------------------------------------------------------------
@@ -1041,15 +895,12 @@ class IMMEngine:
             self._encoder_backward(self.enc_im, d_e, nf8)
         self._cur_lane = 0
         self._mark(self.prog_bwd, 'join')
-        if deferred:
-            self._wait(self.prog_bwd, 'ren_wgrad_done', lane=0)
-        if self.wgrad_lane:
-            self._signal(self.prog_bwd, 'wgrad_done', lane=self.wgrad_lane)
-            self._wait(self.prog_bwd, 'wgrad_done', lane=0)
+        self._flush_wgrads('encoders' if self.n_bwd_bucket0 is not None else 'all layers')
         # one table-driven launch sums every layer's split-K slabs into the flat gradient buffer
         if self._reduce_jobs:
             self.reduce_tab = ops.JobTable([j for j, _n in self._reduce_jobs], [n for _j, n in self._reduce_jobs], 64, self.dev)
-            self._add(self.prog_bwd, lambda: ops.wgrad_reduce_multi(self.reduce_tab), 'wgrad_reduce', name='encoders')
+            self._add(self.prog_bwd, lambda: ops.wgrad_reduce_multi(self.reduce_tab), 'wgrad_reduce',
+                      name='encoders' if self.n_bwd_bucket0 is not None else 'all layers')
 
     def _encoder_backward(self, layers, d_out, ldd):
         B = self.B
@@ -1059,8 +910,8 @@ class IMMEngine:
                 prev = layers[i - 1]
                 dx, lddx = self._act(B, prev.Ho, prev.Wo, prev.co), prev.co
             else:
-                prev, dx, lddx = None, None, 0
-            self._conv_backward(lay, d_out, ldd, dx, lddx, dx_bn=prev)
+                dx, lddx = None, 0
+            self._conv_backward(lay, d_out, ldd, dx, lddx)
             d_out, ldd = dx, lddx
 
     # ------------------------------------------------------------------------------------------
@@ -1095,14 +946,8 @@ class IMMEngine:
                 ops.debug_stamp(self._stamp_buf, len(self._stamp_names))
             self._stamp_names.append((lane, '%s:%s' % (pname, label)))
         stamp(0, 'start')
-        skip_lane = int(os.environ.get('IMM_DEBUG_SKIP_LANE', '-1'))      # timing experiment (wrong results): drop a whole lane
-        only = os.environ.get('IMM_DEBUG_SKIP_LANE_PROG', '')             # ... in the forward / backward program only,
-        if (only == 'fwd' and prog is not self.prog_fwd) or (only == 'bwd' and prog is not self.prog_bwd):
-            skip_lane = -1
-        skip_scopes = tuple(x for x in os.environ.get('IMM_DEBUG_SKIP_SCOPES', '').split(',') if x)   # ... or launches by scope
         for l in prog:
-            if l.fn is not None and (l.tag in self._skip_tags or l.lane == skip_lane or
-                                     (skip_scopes and any(x in l.name for x in skip_scopes))):
+            if l.fn is not None and l.tag in self._skip_tags:
                 continue
             if l.fn is not None:
                 if l.lane == 0:
@@ -1140,10 +985,7 @@ class IMMEngine:
         if self._side is None:
             self._side = {}
         if i not in self._side:
-            # IMM_LANE<i>_PRIO: stream priority of a side lane (-1 = high, 0 = normal); with the training stream raised to
-            # -1 (IMM_MAIN_PRIO) a lane left at 0 only gets the CUs the critical chain leaves idle
-            prio = int(os.environ.get('IMM_LANE%d_PRIO' % i, os.environ.get('IMM_MAIN_PRIO', '0')))
-            self._side[i] = torch.cuda.Stream(device=self.dev, priority=prio)
+            self._side[i] = torch.cuda.Stream(device=self.dev)
         return self._side[i]
 
     def run_timed(self, prog):

@@ -161,6 +161,41 @@ def conv2d_wgrad(desc, x, dy, lddy, slab, nsplit):
     call('imm_conv2d_wgrad', C.byref(desc), dtype_enum(x.dtype), _p(x), _p(dy), lddy, _p(slab), nsplit, _s())
 
 
+def conv2d_wgrad_variant(desc, lddy, dtype):
+    """(variant key, workgroups per pixel split, length in units) of a layer's filter-gradient kernel: jobs with the same key
+    share a launch of imm_conv2d_wgrad_multi."""
+    wps, units = C.c_int(0), C.c_int(0)
+    key = L.load().imm_conv2d_wgrad_variant(C.byref(desc), lddy, dtype_enum(dtype), C.byref(wps), C.byref(units))
+    if key < 0:
+        raise L.ImmHipError('imm_conv2d_wgrad_variant: ' + L.load().imm_last_error().decode())
+    return key, wps.value, units.value
+
+
+class WgradMulti(object):
+    """Planned multi-problem filter-gradient launch: jobs = [(desc, x, dy, lddy, slab, nsplit)].  Keeps the host table, its
+    device copy and the operand tensors alive."""
+
+    def __init__(self, jobs, dtype):
+        n = len(jobs)
+        self.keep = [t for j in jobs for t in (j[1], j[2], j[4])]
+        arr = (L.WgradJob * n)()
+        for i, (desc, x, dy, lddy, slab, nsplit) in enumerate(jobs):
+            arr[i].desc = desc
+            arr[i].x, arr[i].dy, arr[i].slab = x.data_ptr(), dy.data_ptr(), slab.data_ptr()
+            arr[i].lddy, arr[i].nsplit = int(lddy), int(nsplit)
+        nbytes = L.load().imm_conv2d_wgrad_multi_table_bytes(n)
+        if nbytes <= 0:
+            raise L.ImmHipError('imm_conv2d_wgrad_multi_table_bytes(%d)' % n)
+        self.host = (C.c_ubyte * nbytes)()
+        call('imm_conv2d_wgrad_multi_plan', C.cast(arr, C.c_void_p), n, dtype_enum(dtype), C.cast(self.host, C.c_void_p))
+        self.dev = torch.frombuffer(self.host, dtype=torch.uint8).clone().to(jobs[0][1].device)
+        self.n = n
+
+
+def conv2d_wgrad_multi(multi):
+    call('imm_conv2d_wgrad_multi', C.cast(multi.host, C.c_void_p), _p(multi.dev), _s())
+
+
 def conv2d_wgrad_splits(desc, lddy):
     n = L.load().imm_conv2d_wgrad_splits(C.byref(desc), lddy)
     if n < 0:
@@ -226,19 +261,6 @@ def bn_bwd_reduce(dout, lddo, y, ldy, npix, c, scale, shift, mean, rstd, relu, p
 def bn_bwd_finalize(partial, nblk, c, count, gamma, beta, rstd, dgamma, dbeta, coef, from_out=False, ldp=None):
     call('imm_bn_bwd_finalize', _p(partial), nblk, c, c if ldp is None else ldp, count, _p(gamma), _p(beta), _p(rstd),
          int(from_out), _p(dgamma), _p(dbeta), _p(coef), _s())
-
-
-def bn_bwd_reduce_finalize_workspace(npix, c, device):
-    """Zeroed workspace of bn_bwd_reduce_finalize (partial rows | group rows | ticket counters)."""
-    n = L.load().imm_bn_bwd_reduce_finalize_workspace_bytes(int(npix), int(c))
-    if n < 0:
-        raise L.ImmHipError('imm_bn_bwd_reduce_finalize_workspace_bytes(%d, %d) failed' % (npix, c))
-    return torch.zeros((n + 15) // 16 * 2, dtype=torch.float64, device=device)      # 16-byte aligned
-
-
-def bn_bwd_reduce_finalize(dout, lddo, y, ldy, npix, c, scale, shift, mean, rstd, relu, count, gamma, dgamma, dbeta, coef, workspace):
-    call('imm_bn_bwd_reduce_finalize', _p(dout), lddo, _p(y), ldy, dtype_enum(y.dtype), npix, c, _p(scale), _p(shift), _p(mean),
-         _p(rstd), int(relu), int(count), _p(gamma), _p(dgamma), _p(dbeta), _p(coef), _p(workspace), _s())
 
 
 def bn_bwd_apply(dout, lddo, y, ldy, npix, c, scale, shift, mean, rstd, relu, coef, dy_out, lddy):

@@ -81,7 +81,7 @@ class TrainStep:
         model._master = self.engine               # the engine whose variables are trained; others mirror it (eval batches)
         self.buckets = int(os.environ.get('IMM_DP_BUCKETS', '1'))
         if self.buckets >= 2 and self.engine.n_bwd_bucket0 is None:
-            raise ValueError('IMM_DP_BUCKETS=2 needs the renderer gradients reduced early: set IMM_WGRAD_DEFER_REN=0')
+            raise ValueError('IMM_DP_BUCKETS=2 must be set before the engine is built (it places the renderer gradients\' early reduction)')
         if abs(self.engine.hp.grad_scale - 1.0 / world_size) > 1e-9:
             raise ValueError('engine was built for world_size %g' % (1.0 / self.engine.hp.grad_scale))
         self.use_graph = use_graph
@@ -99,7 +99,7 @@ class TrainStep:
             with torch.cuda.device(self.engine.dev):
                 self.native_comm = ops.RcclComm(rank, world_size, group)
             self.comm_stream = torch.cuda.Stream(device=self.engine.dev)
-        self.stream = torch.cuda.Stream(device=self.engine.dev, priority=int(os.environ.get('IMM_MAIN_PRIO', '0')))
+        self.stream = torch.cuda.Stream(device=self.engine.dev)
         self._graphs = None
         torch.cuda.synchronize(self.engine.dev)   # engine construction ran on the default stream
 

@@ -132,6 +132,25 @@ int imm_conv2d_wgrad(const imm_conv_desc* desc_host, int dtype, const void* x, c
 int imm_conv2d_wgrad_splits(const imm_conv_desc* desc_host, int lddy);
 int imm_conv2d_wgrad_reduce(const float* slab, int nsplit, int kh, int kw, int ci_pad, int ci_real, int co,
                             int kpad, float* dw, void* stream);
+/* The filter gradients of MANY layers in as few launches as there are kernel variants among them (tf.gradients w.r.t. every
+ * `w` of the towers' graph, cnn_train_multi.py:157,231: TF schedules them freely too — nobody reads a filter gradient before
+ * apply_gradients).  A job = the arguments of one imm_conv2d_wgrad call.  imm_conv2d_wgrad_multi_plan writes a table of
+ * imm_conv2d_wgrad_multi_table_bytes(n) bytes into HOST memory (launch list + the members' argument blocks, longest
+ * workgroups first); the caller copies it once to device memory (16-byte aligned) and passes both copies to every launch:
+ * the host copy carries the launch geometry, the device copy is what the kernels read.  Results are identical to n single
+ * calls with the same split counts.  n <= 64.
+ * imm_conv2d_wgrad_variant: the kernel (family * 10000 + tile variant) a layer's filter gradient runs with, its workgroups
+ * per pixel split and its length in units (32-pixel steps or 8x16-pixel patches) — what a caller needs to choose split counts
+ * for jobs that share a launch (jobs with equal return values do). */
+typedef struct imm_wgrad_job {
+  imm_conv_desc desc;          /* the FORWARD convolution */
+  const void* x; const void* dy; float* slab;
+  int32_t lddy, nsplit;
+} imm_wgrad_job;
+int64_t imm_conv2d_wgrad_multi_table_bytes(int n);
+int imm_conv2d_wgrad_variant(const imm_conv_desc* desc_host, int lddy, int dtype, int* wg_per_split_host, int* units_host);
+int imm_conv2d_wgrad_multi_plan(const imm_wgrad_job* jobs_host, int n, int dtype, void* table_host);
+int imm_conv2d_wgrad_multi(const void* table_host, const void* table_dev, void* stream);
 /* db[n] = sum_m dy[m][n], n < c_out, for convolutions not followed by batch norm (bias_add gradient,
  * nn_utils.py:108); c = padded channel count summed per row (multiple of 8);
  * partial: [nblk][c] scratch with nblk = imm_colsum_blocks(npix, c). */
@@ -169,14 +188,6 @@ int imm_bn_bwd_blocks(int64_t npix, int c);
  * (IMM_CONV_STATS | IMM_CONV_MASK) or imm_upsample2x_bwd_bn: sum dz*xhat = (sum dz*out - beta * sum dz) / gamma. */
 int imm_bn_bwd_finalize(const float* partial, int nblk, int c, int ldp, int64_t count, const float* gamma, const float* beta,
                         const float* rstd, int from_out, float* dgamma, float* dbeta, float* coef, void* stream);
-/* imm_bn_bwd_reduce + imm_bn_bwd_finalize (from_out = 0) in ONE launch: the workgroup that finishes last does the finalize
- * ("last block done", two levels of 32: fixed summation order, bitwise reproducible).  `workspace`:
- * imm_bn_bwd_reduce_finalize_workspace_bytes(npix, c) bytes, 16-byte aligned, ZEROED ONCE by the caller before the first launch
- * (it ends with ticket counters that every launch leaves at zero).  c <= 256. */
-int imm_bn_bwd_reduce_finalize(const void* dout, int lddo, const void* y, int ldy, int dtype, int64_t npix, int c,
-                               const float* scale, const float* shift, const float* mean, const float* rstd, int relu,
-                               int64_t count, const float* gamma, float* dgamma, float* dbeta, float* coef, void* workspace,
-                               void* stream);
 int imm_bn_bwd_apply(const void* dout, int lddo, const void* y, int ldy, int dtype, int64_t npix, int c,
                      const float* scale, const float* shift, const float* mean, const float* rstd, int relu,
                      const float* coef, void* dy_out, int lddy, void* stream);
@@ -354,7 +365,6 @@ int64_t imm_conv2d_wgrad_workspace_bytes(const imm_conv_desc* desc_host, int ldd
                                                                                       forced / minimal split count)        */
 int64_t imm_colsum_workspace_bytes(int64_t npix, int c);                          /* partial of imm_colsum                  */
 int64_t imm_bn_bwd_workspace_bytes(int64_t npix, int c);                          /* partial of imm_bn_bwd_reduce           */
-int64_t imm_bn_bwd_reduce_finalize_workspace_bytes(int64_t npix, int c);          /* workspace of imm_bn_bwd_reduce_finalize */
 int64_t imm_upsample2x_bwd_bn_workspace_bytes(int batch, int h, int w, int c);    /* partial of imm_upsample2x_bwd_bn       */
 int64_t imm_masked_sse_workspace_bytes(int nfeat);                                /* partial of imm_masked_sse* (per loss)  */
 

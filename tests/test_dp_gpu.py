@@ -146,10 +146,10 @@ def test_two_ranks_on_one_gpu_run_the_split_graph_path_bitwise(emu, buckets):
     import torch.multiprocessing as mp
     A, Bn, losses, _gA0, _gB0 = emu
     port = 29700 + (os.getpid() % 200) + 300 * buckets
-    mgr = mp.Manager()
-    ret = mgr.dict()
-    mp.spawn(_rank_main, args=(2, port, ret, buckets), nprocs=2, join=True)
-    r0, r1 = ret[0], ret[1]
+    with mp.Manager() as mgr:          # shut the manager process down even when an assertion below fails
+        ret = mgr.dict()
+        mp.spawn(_rank_main, args=(2, port, ret, buckets), nprocs=2, join=True)
+        r0, r1 = dict(ret[0]), dict(ret[1])
     assert r0['step'] == N_STEPS and r0['adam_t'] == N_STEPS
     assert torch.equal(r0['params'], r1['params'])                      # replicas stay identical
     assert torch.equal(r0['params'], A.params.cpu())                    # == the single-process two-tower emulation, bitwise

@@ -275,6 +275,46 @@ def test_conv_wgrad_halo(ops, case, dt):
     close(dw, dw2, 1e-3, 2e-4, 'wgrad_halo_vs_general/' + tag)
 
 
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16], ids=['bf16', 'f16'])
+def test_conv_wgrad_multi_equals_single_launches(ops, dt):
+    """imm_conv2d_wgrad_multi: many layers' filter gradients in one launch per kernel variant (transpose-read tiles of four widths,
+    LDS-halo slices of three shapes, one job of the generic kernel) == the same jobs through imm_conv2d_wgrad one by one with the
+    same split counts, bit for bit; and == autograd of the oracle convolution for the reduced gradients."""
+    # B, H, ci, co, lddy, k, stride, nsplit
+    jobs_def = [(2, 16, 256, 256, 256, 3, 1, 2), (2, 16, 256, 256, 256, 3, 1, 3), (4, 32, 128, 128, 128, 3, 1, 4),
+                (2, 32, 64, 128, 128, 3, 2, 2), (2, 64, 32, 64, 64, 3, 2, 5), (1, 128, 32, 32, 32, 3, 1, 7),
+                (2, 64, 64, 64, 64, 3, 1, 6), (2, 64, 64, 32, 32, 3, 1, 3), (2, 16, 256, 10, 16, 1, 1, 2),
+                (5, 64, 128, 64, 64, 3, 1, 9), (1, 10, 64, 64, 64, 3, 1, 2)]
+    made, multi_jobs, keys = [], [], []
+    for i, (B, H, ci, co, lddy, k, stride, nsplit) in enumerate(jobs_def):
+        x = rnd((B, H, H, ci), 500 + i, 1.0, dt)
+        wr = torch.zeros(k, k, ci, co, requires_grad=True)
+        yref = O.conv2d_same(x.float(), wr, None, stride)
+        dy = rnd(tuple(yref.shape), 600 + i, 1.0, dt)
+        (gw,) = torch.autograd.grad(yref, wr, dy.float())
+        desc = ops.fwd_desc(B, H, H, ci, ci, co, lddy, k, stride, 0)
+        xd, dyd = x.to(DEV).contiguous(), padded(dy, lddy)
+        slab_m = torch.full((nsplit, desc.kpad, co), float('nan'), dtype=torch.float32, device=DEV)
+        made.append((desc, xd, dyd, lddy, nsplit, k, ci, co, gw, slab_m))
+        multi_jobs.append((desc, xd, dyd, lddy, slab_m, nsplit))
+        keys.append(ops.conv2d_wgrad_variant(desc, lddy, dt)[0])
+    assert len(set(keys)) >= 6 and 0 in [k // 10000 for k in keys], keys      # several variants of both families + the generic kernel
+    multi = ops.WgradMulti(multi_jobs, dt)
+    ops.conv2d_wgrad_multi(multi)
+    torch.cuda.synchronize()
+    for i, (desc, xd, dyd, lddy, nsplit, k, ci, co, gw, slab_m) in enumerate(made):
+        dw = torch.full((k, k, ci, co), float('nan'), dtype=torch.float32, device=DEV)
+        ops.conv2d_wgrad_reduce(slab_m, nsplit, k, k, ci, ci, co, desc.kpad, dw)
+        torch.cuda.synchronize()
+        close(dw, gw, 2e-3, 5e-4, 'wgrad_multi/job%d' % i)
+        if keys[i] // 10000 == 2 and nsplit != ops.conv2d_wgrad_splits(desc, lddy):
+            continue     # the single entry point only takes the halo kernel at its own split count: nothing to compare bitwise
+        slab_s = torch.full_like(slab_m, float('nan'))
+        ops.conv2d_wgrad(desc, xd, dyd, lddy, slab_s, nsplit)
+        torch.cuda.synchronize()
+        assert torch.equal(slab_s, slab_m), 'job %d (variant %d)' % (i, keys[i])
+
+
 def test_table_driven_pack_and_reduce(ops):
     """imm_pack_weights_multi (bit for bit) / imm_wgrad_reduce_multi (to f32 rounding) vs their single-tensor counterparts."""
     dt = torch.bfloat16
@@ -411,43 +451,6 @@ def test_rows_reduce(ops, rows, width, group):
     pad[:rows] = src.cpu().double()
     ref = pad.reshape(n, group, width).sum(1)
     assert torch.allclose(outs[0].cpu().double(), ref, rtol=2e-7, atol=1e-4)
-
-
-@pytest.mark.parametrize('c,npix', [(32, 32 * 128 * 128), (64, 32 * 64 * 64), (32, 5000), (256, 700), (128, 33 * 1024 + 5)],
-                         ids=['1024_rows', '64x64', 'few_rows', 'one_group', 'ragged_group'])
-def test_batch_norm_bwd_reduce_finalize_in_one_launch(ops, c, npix):
-    """imm_bn_bwd_reduce_finalize (last workgroup done, two levels) against reduce + finalize: same rows, f64 sums in another
-    grouping -> equal to ~1 ulp of f32; launch after launch bitwise identical (the ticket counters reset themselves)."""
-    dt = torch.bfloat16
-    g = torch.Generator().manual_seed(c + npix)
-    y = (torch.randn(npix, c, generator=g) * 2 + 0.5).to(dt).to(DEV)
-    dout = torch.randn(npix, c, generator=g).to(dt).to(DEV)
-    gamma = (torch.rand(c, generator=g) + 0.5).to(DEV)
-    beta = (torch.rand(c, generator=g) - 0.5).to(DEV)
-    yf = y.float()
-    mean = yf.mean(0); var = yf.var(0, unbiased=False)
-    rstd = torch.rsqrt(var + 1e-3); scale = gamma * rstd; shift = beta - mean * scale
-    nblk = ops.bn_bwd_blocks(npix, c)
-    part = torch.empty(nblk, 2, c, dtype=torch.float32, device=DEV)
-    ops.bn_bwd_reduce(dout, c, y, c, npix, c, scale, shift, mean, rstd, True, part)
-    dg0, db0, coef0 = torch.empty(c, device=DEV), torch.empty(c, device=DEV), torch.empty(3, c, device=DEV)
-    ops.bn_bwd_finalize(part, nblk, c, npix, gamma, beta, rstd, dg0, db0, coef0)
-    ws = ops.bn_bwd_reduce_finalize_workspace(npix, c, DEV)
-    outs = []
-    for _ in range(4):
-        dg, db, coef = (torch.full((c,), float('nan'), device=DEV), torch.full((c,), float('nan'), device=DEV),
-                        torch.full((3, c), float('nan'), device=DEV))
-        ops.bn_bwd_reduce_finalize(dout, c, y, c, npix, c, scale, shift, mean, rstd, True, npix, gamma, dg, db, coef, ws)
-        torch.cuda.synchronize()
-        outs.append((dg, db, coef))
-    for dg, db, coef in outs[1:]:
-        assert torch.equal(dg, outs[0][0]) and torch.equal(db, outs[0][1]) and torch.equal(coef, outs[0][2])
-    dg, db, coef = outs[0]
-    tol = dict(rtol=2e-6, atol=1e-6 * float(part.abs().sum(0).max()))
-    assert torch.allclose(dg, dg0, **tol) and torch.allclose(db, db0, **tol), (float((dg - dg0).abs().max()), float((db - db0).abs().max()))
-    assert torch.allclose(coef, coef0, rtol=2e-6, atol=tol['atol'] / npix)
-    # the partial rows the fused launch leaves behind are the reduce kernel's rows
-    assert torch.equal(ws.view(torch.float32)[:nblk * 2 * c].reshape(nblk, 2, c), part)
 
 
 @pytest.mark.parametrize('c,npix,nrows', [(32, 4096, 7), (256, 8192, 64), (64, 1000, 256), (128, 32768, 33)])
