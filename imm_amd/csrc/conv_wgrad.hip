@@ -346,6 +346,7 @@ void imm_wgrad_tr_launch_multi(int dtype, int bn, const void* tab_dev, const int
 int imm_wgrad_halo_variant(const imm_conv_desc* d, int lddy);
 int imm_wgrad_halo_blocks(const imm_conv_desc* d, int lddy, int* n_patches);
 int imm_wgrad_halo_args_bytes();
+int imm_wgrad_halo_per_cu(int variant);
 int imm_wgrad_halo_fill(const imm_conv_desc* d, const void* x, const void* dy, int lddy, float* slab, int nsplit, void* out, int* steps);
 void imm_wgrad_halo_launch_multi(int dtype, int variant, const void* tab_dev, const int* first_dev, int n, int blocks, hipStream_t s);
 
@@ -384,14 +385,15 @@ extern "C" int64_t imm_conv2d_wgrad_multi_table_bytes(int n) {
   return WGM_HEADER + (int64_t)n * (WGM_ARG_STRIDE + (int64_t)sizeof(imm_wgrad_job)) + WGM_MAX_LAUNCH * (WGM_MAX_JOBS + 1) * 4;
 }
 
-extern "C" int imm_conv2d_wgrad_variant(const imm_conv_desc* d, int lddy, int dtype, int* wg_per_split, int* units) {
+extern "C" int imm_conv2d_wgrad_variant(const imm_conv_desc* d, int lddy, int dtype, int* wg_per_split, int* units, int* wg_per_cu) {
   IMM_REQUIRE(d && lddy >= d->co, "wgrad_variant: args");
   imm_wgrad_job j; j.desc = *d; j.lddy = lddy; j.nsplit = 1; j.x = j.dy = nullptr; j.slab = nullptr;
   int kind, variant;
   wgm_classify(&j, dtype, &kind, &variant);
-  int wps = 1, un = 1;
+  int wps = 1, un = 1, pcu = 2;                                // transpose-read / generic kernels: 65 KB of LDS, two per CU
   if (kind == WGM_HALO) {
     wps = imm_wgrad_halo_blocks(d, lddy, &un);                 // units: 8x16-pixel patches
+    pcu = imm_wgrad_halo_per_cu(variant);
   } else {
     const int bn = d->co > 64 ? 128 : d->co > 32 ? 64 : d->co > 16 ? 32 : 16;
     wps = ((d->kpad + 127) / 128) * ((d->co + bn - 1) / bn);
@@ -399,7 +401,8 @@ extern "C" int imm_conv2d_wgrad_variant(const imm_conv_desc* d, int lddy, int dt
   }
   if (wg_per_split) *wg_per_split = wps;
   if (units) *units = un;
-  return kind * 10000 + variant;
+  if (wg_per_cu) *wg_per_cu = pcu;
+  return kind * 100000 + variant;
 }
 
 extern "C" int imm_conv2d_wgrad_multi_plan(const imm_wgrad_job* jobs, int n, int dtype, void* table_host) {

@@ -29,8 +29,12 @@ typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
 
 #define WH_PH 8
 #define WH_PW 16
-#define WH_HW (WH_PW + 2)
-#define WH_HP 192               // 10*18 = 180 halo pixels, padded to whole DMA instructions
+// halo of an 8x16-pixel patch under a KH x KW stride-1 SAME filter: (8+KH-1) x (16+KW-1) pixels, padded to whole rounds of DMA
+// instructions (64 pixels at 32 channels / 32 pixels at 64 channels per instruction, 4 waves): 3x3 -> 10x18 = 180 -> 192;
+// 7x1 (the tap-unrolled first encoder convolution) -> 14x16 = 224 -> 256
+#define WH_HROWS(KH) (WH_PH + (KH) - 1)
+#define WH_HCOLS(KW) (WH_PW + (KW) - 1)
+#define WH_HP(KH, KW) ((WH_HROWS(KH) * WH_HCOLS(KW) + 63) / 64 * 64)
 
 __device__ __forceinline__ void wh_dma16(u32x4_t rsrc, uint32_t lds_addr, uint32_t voff, uint32_t soff) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
@@ -61,16 +65,18 @@ struct WgradHaloArgs {
 // 1.5 us per patch for 0.55 us of matrix work).  Now NS-1 patches are in flight and the wait is counted: every wave issues
 // exactly LPP DMA instructions per patch, so "at most (NS-2)*LPP outstanding" == "this patch has landed".
 // bx = pixel split of this workgroup, G = number of splits, by / bz = its ci / co slice
-template <typename ET, int CI, int CO, int NS>
+template <typename ET, int CI, int CO, int NS, int KH = 3, int KW = 3>
 __device__ __forceinline__ void conv_wgrad_halo_body(const WgradHaloArgs& a, const int bx, const int G, const int by, const int bz) {
+  constexpr int NTAP = KH * KW, PT = (KH - 1) / 2, PL = (KW - 1) / 2;
+  constexpr int WH_HW = WH_HCOLS(KW), HPIX = WH_HROWS(KH) * WH_HCOLS(KW), WH_HP_ = WH_HP(KH, KW);
   constexpr int XC8 = CI / 8, YC8 = CO / 8;
   constexpr int NCT = CI / 16, NNT = CO / 16;          // 16-channel tiles
   constexpr int WC = NCT, WN = 4 / WC;                 // wave grid: wc = ci tile, wn = slice of the co tiles
   constexpr int TNT = NNT / WN;                        // co tiles per wave
   static_assert(WC * WN == 4 && TNT >= 1, "tile split");
   constexpr int X_PIX_PER_DMA = 64 / XC8, Y_PIX_PER_DMA = 64 / YC8;
-  constexpr int X_DMA = WH_HP / X_PIX_PER_DMA, Y_DMA = 128 / Y_PIX_PER_DMA;
-  constexpr int X_BYTES = WH_HP * CI * 2, Y_BYTES = 128 * CO * 2, STAGE = X_BYTES + Y_BYTES;
+  constexpr int X_DMA = WH_HP_ / X_PIX_PER_DMA, Y_DMA = 128 / Y_PIX_PER_DMA;
+  constexpr int X_BYTES = WH_HP_ * CI * 2, Y_BYTES = 128 * CO * 2, STAGE = X_BYTES + Y_BYTES;
   constexpr int LPP = X_DMA / 4 + Y_DMA / 4;           // DMA instructions per wave and patch
   static_assert(X_DMA % 4 == 0 && Y_DMA % 4 == 0 && NS >= 2 && (NS - 2) * LPP < 64, "uniform per-wave DMA count");
   extern __shared__ __attribute__((aligned(16))) uint4 smem[];   // NS stages of [X halo | dY patch]
@@ -93,8 +99,8 @@ __device__ __forceinline__ void conv_wgrad_halo_body(const WgradHaloArgs& a, con
     for (int i = wid; i < X_DMA; i += 4) {
       const int hp = i * X_PIX_PER_DMA + lane / XC8;
       const int hy = hp / WH_HW, hx = hp - hy * WH_HW;
-      const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
-      const bool ok = (hp < (WH_PH + 2) * WH_HW) && ((unsigned)iy < (unsigned)a.h) && ((unsigned)ix < (unsigned)a.w);
+      const int iy = y0 - PT + hy, ix = x0 - PL + hx;
+      const bool ok = (hp < HPIX) && ((unsigned)iy < (unsigned)a.h) && ((unsigned)ix < (unsigned)a.w);
       const int sc = (lane % XC8) ^ wh_swz<XC8>(hp);
       const uint32_t vo = ok ? (uint32_t)(((iy * a.w + ix) * a.ldx + ci0) * 2 + sc * 16) : OOB;
       wh_dma16(xr, __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)(stage * STAGE + i * 1024)), vo, xs);
@@ -108,9 +114,9 @@ __device__ __forceinline__ void conv_wgrad_halo_body(const WgradHaloArgs& a, con
     }
   };
 
-  f32x4_t acc[9][TNT];
+  f32x4_t acc[NTAP][TNT];
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+  for (int t = 0; t < NTAP; ++t)
 #pragma unroll
     for (int j = 0; j < TNT; ++j) acc[t][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
@@ -151,8 +157,8 @@ __device__ __forceinline__ void conv_wgrad_halo_body(const WgradHaloArgs& a, con
         bfr[ks][j] = make_uint4(l2.x, l2.y, h2.x, h2.y);
       }
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int ky = tap / 3, kx = tap % 3;
+    for (int tap = 0; tap < NTAP; ++tap) {
+      const int ky = tap / KW, kx = tap % KW;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         const int hp = (ks * 2 + k_row + ky) * WH_HW + k_x + kx;
@@ -170,7 +176,7 @@ __device__ __forceinline__ void conv_wgrad_halo_body(const WgradHaloArgs& a, con
   // lane holds D[n = 4*(lane>>4)+r][c = lane&15] -> slab[split][kk = tap*ci + ci0 + wc*16 + c][co0 + n .. +3]
   float* out = a.slab + (int64_t)bx * a.kpad * a.co;
 #pragma unroll
-  for (int tap = 0; tap < 9; ++tap) {
+  for (int tap = 0; tap < NTAP; ++tap) {
     const int kk = tap * a.ci_total + ci0 + wc * 16 + (lane & 15);
 #pragma unroll
     for (int j = 0; j < TNT; ++j) {
@@ -186,14 +192,14 @@ __device__ __forceinline__ void conv_wgrad_halo_body(const WgradHaloArgs& a, con
   }
 }
 
-template <typename ET, int CI, int CO, int NS>
+template <typename ET, int CI, int CO, int NS, int KH = 3, int KW = 3>
 __global__ __launch_bounds__(256) void conv_wgrad_halo_kernel(const WgradHaloArgs a) {
-  conv_wgrad_halo_body<ET, CI, CO, NS>(a, blockIdx.x, gridDim.x, blockIdx.y, blockIdx.z);
+  conv_wgrad_halo_body<ET, CI, CO, NS, KH, KW>(a, blockIdx.x, gridDim.x, blockIdx.y, blockIdx.z);
 }
 
 // Several filter gradients with the same slice shape in ONE launch (imm_conv2d_wgrad_multi): workgroup b belongs to member g
 // with first[g] <= b < first[g+1]; inside a member the workgroups are numbered split-fastest, (ci slice, co slice) slowest.
-template <typename ET, int CI, int CO, int NS>
+template <typename ET, int CI, int CO, int NS, int KH = 3, int KW = 3>
 __global__ __launch_bounds__(256) void conv_wgrad_halo_multi_kernel(const WgradHaloArgs* __restrict__ tab,
                                                                     const int* __restrict__ first, int n) {
   const int b = blockIdx.x;
@@ -203,7 +209,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_halo_multi_kernel(const WgradH
   int r = b - first[g];
   const int bx = r % a.nsplit; r /= a.nsplit;
   const int by = r % a.nci, bz = r / a.nci;
-  conv_wgrad_halo_body<ET, CI, CO, NS>(a, bx, a.nsplit, by, bz);
+  conv_wgrad_halo_body<ET, CI, CO, NS, KH, KW>(a, bx, a.nsplit, by, bz);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -220,12 +226,16 @@ static int wh_num_cu() {
 }
 
 // Slice plan of a layer: channel slice widths, number of slices and pixel splits.
-struct WhPlan { int cs, ns, nci, nco, nsplit; };
+struct WhPlan { int cs, ns, nci, nco, nsplit; bool k71; };
 
 static bool wh_plan(const imm_conv_desc* d, int lddy, WhPlan* pl) {
-  if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->updiv != 1 || d->pad_t != 1 || d->pad_l != 1) return false;
+  const bool k33 = d->kh == 3 && d->kw == 3 && d->pad_t == 1 && d->pad_l == 1;
+  // the tap-unrolled first encoder convolution (7x1 over the 32-channel unrolled image -> 32 channels, imm_model.py:190)
+  const bool k71 = d->kh == 7 && d->kw == 1 && d->pad_t == 3 && d->pad_l == 0 && d->ci == 32 && lddy == 32 && d->co <= 32;
+  pl->k71 = k71;
+  if ((!k33 && !k71) || d->stride != 1 || d->updiv != 1) return false;
   if (d->hi != d->ho || d->wi != d->wo || d->ho % WH_PH || d->wo % WH_PW) return false;
-  if (d->kpad != 9 * d->ci || d->ci % 32) return false;
+  if (d->kpad != d->kh * d->kw * d->ci || d->ci % 32) return false;
   const int64_t xb = (int64_t)d->batch * d->hi * d->wi * d->ldx * 2, yb = (int64_t)d->batch * d->ho * d->wo * lddy * 2;
   if (xb >= (1LL << 31) || yb >= (1LL << 31)) return false;
   const int n_patches = d->batch * (d->ho / WH_PH) * (d->wo / WH_PW);
@@ -236,26 +246,17 @@ static bool wh_plan(const imm_conv_desc* d, int lddy, WhPlan* pl) {
     cs = d->ci; ns = lddy;
     pl->nci = 1; pl->nco = 1;
   } else {
-    // Channel slices of deeper filters: X is fetched co/ns times and dY ci/cs times.  32-slices (default) pay off at
-    // >= 64x64 maps only (renderer conv_5: 65 -> 45 us; below, a workgroup sees too few patches and the transpose-read
-    // kernel with its larger tiles is faster).  64x64 slices (IMM_WGRAD_HALO_SLICE=64) are faster per launch wherever both
-    // channel counts allow (tools/wgrad_sweep.sh: conv_5 45 -> 31 us, 32^2 128->128 29.7 -> 20.3, 32^2 256->128 36.4 -> 30.6,
-    // 16^2 256->256 23.2 -> 20.4) but SLOWER per training step (3.747 -> 3.785 ms, same box, either split count): the filter
-    // gradients run on the second stream under the data-gradient chain, which is the critical path, and the 4x larger slab
-    // traffic of 2-block layers (nsplit 128 vs 32; wgrad_reduce 0.144 -> 0.180 ms) costs more there than the shorter
-    // launches give back => off by default.  Restricting 64-slices to the small maps (=6400) is neutral (3.734 vs 3.731 ms):
-    // their split counts grow too (16^2: 15 -> 64), the reduction eats the gain.
+    // Channel slices of deeper filters: X is fetched co/ns times and dY ci/cs times.  64 x 64 slices wherever both channel
+    // counts allow (per launch they were always the faster ones: renderer conv_5 45 -> 31 us, 32^2 128->128 29.7 -> 20.3, 16^2
+    // 256->256 23.2 -> 20.4; round 2 kept 32-slices because a layer alone needed 4x the pixel splits to fill the chip with
+    // 64-slices and the slab traffic ate the gain — in a multi-problem launch the layers share the chip and the splits are few:
+    // 3.474 -> 3.436 ms per step, round 3), 32 x 32 slices otherwise, and then only at >= 64x64 maps (below, the
+    // transpose-read kernel with its larger tiles is faster).
     if (d->co % 32 || lddy < d->co) return false;
-    static const int slice = getenv("IMM_WGRAD_HALO_SLICE") ? atoi(getenv("IMM_WGRAD_HALO_SLICE")) : 32;
-    static const int min64 = getenv("IMM_WGRAD_HALO_SLICE64_MIN") ? atoi(getenv("IMM_WGRAD_HALO_SLICE64_MIN")) : 16;
-    static const int min_side = getenv("IMM_WGRAD_HALO_SLICE_MIN") ? atoi(getenv("IMM_WGRAD_HALO_SLICE_MIN")) : 64;
-    // IMM_WGRAD_HALO_SLICE=6400: 64-slices only BELOW the 32-slice threshold (the layers the transpose-read kernel
-    // takes otherwise; their split count, hence slab traffic, stays about the same)
-    const bool small_map = d->ho * d->wo < min_side * min_side;
-    if ((slice == 64 || (slice == 6400 && small_map)) && d->ci % 64 == 0 && d->co % 64 == 0 && d->ho * d->wo >= min64 * min64) {
+    if (d->ci % 64 == 0 && d->co % 64 == 0 && d->ho * d->wo >= 16 * 16) {
       cs = 64; ns = 64;
     } else {
-      if (d->ho * d->wo < min_side * min_side) return false;
+      if (d->ho * d->wo < 64 * 64) return false;
       cs = 32; ns = 32;
     }
     pl->nci = d->ci / cs; pl->nco = d->co / ns;
@@ -288,17 +289,29 @@ int imm_wgrad_halo_splits(const imm_conv_desc* d, int lddy) {
   return wh_plan(d, lddy, &pl) ? pl.nsplit : 0;
 }
 
-template <typename ET, int CI, int CO>
+// Ring depth.  32 x 32 slices (20-25 KB per stage): 3 stages = 61-74 KB, so that TWO workgroups share a CU — their patches are
+// short chains of 8-byte transpose reads and 4 MFMAs per fragment with one wave per SIMD, and a second resident workgroup fills
+// the issue gaps (measured in the multi-problem launch: 74 -> 52 us for encoder conv_2 x 2 + renderer conv_8; 40 -> 36 us for the
+// 7x1 layers).  The wider slices keep one workgroup per CU and the deepest ring that fits: 64x64 3 x 40 KB (two-per-CU with 2
+// stages: 188 vs 187 us), 64x32 4 x 32 KB (two-per-CU with 2 stages: 46 vs 42 us).
+template <int CI, int CO, int KH, int KW>
+struct WhRing {
+  static constexpr int stage = WH_HP(KH, KW) * CI * 2 + 128 * CO * 2;
+  static constexpr int NS = (CI == 32 && CO == 32) ? 3 : (stage > 36 * 1024 ? 3 : 4);
+  static constexpr int per_cu = (CI == 32 && CO == 32) ? 2 : 1;
+};
+
+template <typename ET, int CI, int CO, int KH = 3, int KW = 3>
 static void wh_launch_cfg(const WgradHaloArgs& a, dim3 grid, hipStream_t s) {
-  constexpr int stage = WH_HP * CI * 2 + 128 * CO * 2;
-  constexpr int NS = stage > 36 * 1024 ? 3 : 4;         // 64x64 slices: 3 x 40 KB; the others 4 x 20..32 KB
+  constexpr int stage = WhRing<CI, CO, KH, KW>::stage;
+  constexpr int NS = WhRing<CI, CO, KH, KW>::NS;
   constexpr int lds = NS * stage;
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {
-    (void)hipFuncSetAttribute((const void*)conv_wgrad_halo_kernel<ET, CI, CO, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_halo_kernel<ET, CI, CO, NS, KH, KW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_wgrad_halo_kernel<ET, CI, CO, NS>), grid, dim3(256), lds, s, a);
+  hipLaunchKernelGGL((conv_wgrad_halo_kernel<ET, CI, CO, NS, KH, KW>), grid, dim3(256), lds, s, a);
 }
 
 static WgradHaloArgs wh_fill(const imm_conv_desc* d, const void* x, const void* dy, int lddy, float* slab, int nsplit,
@@ -323,7 +336,8 @@ void imm_wgrad_halo_launch(int dtype, const imm_conv_desc* d, const void* x, con
   const dim3 grid(nsplit, pl.nci, pl.nco);
 #define WH_GO(ET_) \
   do { \
-    if (pl.cs == 64 && pl.ns == 64) wh_launch_cfg<ET_, 64, 64>(a, grid, s); \
+    if (pl.k71) wh_launch_cfg<ET_, 32, 32, 7, 1>(a, grid, s); \
+    else if (pl.cs == 64 && pl.ns == 64) wh_launch_cfg<ET_, 64, 64>(a, grid, s); \
     else if (pl.cs == 64) wh_launch_cfg<ET_, 64, 32>(a, grid, s); \
     else if (pl.ns == 64) wh_launch_cfg<ET_, 32, 64>(a, grid, s); \
     else wh_launch_cfg<ET_, 32, 32>(a, grid, s); \
@@ -336,7 +350,7 @@ void imm_wgrad_halo_launch(int dtype, const imm_conv_desc* d, const void* x, con
 // variant = slice shape: 64*100+64, 64*100+32, 32*100+64, 32*100+32; 0 = this kernel does not take the layer
 int imm_wgrad_halo_variant(const imm_conv_desc* d, int lddy) {
   WhPlan pl;
-  return wh_plan(d, lddy, &pl) ? pl.cs * 100 + pl.ns : 0;
+  return wh_plan(d, lddy, &pl) ? (pl.k71 ? 7100 : 0) + pl.cs * 100 + pl.ns : 0;   // 7x1: 7100 + 3232
 }
 // workgroups per pixel split (channel-slice blocks) and the number of 8x16 patches of the layer
 int imm_wgrad_halo_blocks(const imm_conv_desc* d, int lddy, int* n_patches) {
@@ -356,17 +370,20 @@ int imm_wgrad_halo_fill(const imm_conv_desc* d, const void* x, const void* dy, i
   return nsplit * pl.nci * pl.nco;
 }
 
-template <typename ET, int CI, int CO>
+// resident workgroups per CU of a variant's kernel (the engine sizes a launch to one round of them)
+int imm_wgrad_halo_per_cu(int variant) { return (variant == 3232 || variant == 7100 + 3232) ? 2 : 1; }
+
+template <typename ET, int CI, int CO, int KH = 3, int KW = 3>
 static void wh_launch_multi_cfg(const WgradHaloArgs* tab, const int* first, int n, int blocks, hipStream_t s) {
-  constexpr int stage = WH_HP * CI * 2 + 128 * CO * 2;
-  constexpr int NS = stage > 36 * 1024 ? 3 : 4;
+  constexpr int stage = WhRing<CI, CO, KH, KW>::stage;
+  constexpr int NS = WhRing<CI, CO, KH, KW>::NS;
   constexpr int lds = NS * stage;
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {
-    (void)hipFuncSetAttribute((const void*)conv_wgrad_halo_multi_kernel<ET, CI, CO, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_halo_multi_kernel<ET, CI, CO, NS, KH, KW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_wgrad_halo_multi_kernel<ET, CI, CO, NS>), dim3(blocks), dim3(256), lds, s, tab, first, n);
+  hipLaunchKernelGGL((conv_wgrad_halo_multi_kernel<ET, CI, CO, NS, KH, KW>), dim3(blocks), dim3(256), lds, s, tab, first, n);
 }
 
 void imm_wgrad_halo_launch_multi(int dtype, int variant, const void* tab_dev, const int* first_dev, int n, int blocks,
@@ -374,7 +391,8 @@ void imm_wgrad_halo_launch_multi(int dtype, int variant, const void* tab_dev, co
   const WgradHaloArgs* t = (const WgradHaloArgs*)tab_dev;
 #define WH_GO(ET_) \
   do { \
-    if (variant == 6464) wh_launch_multi_cfg<ET_, 64, 64>(t, first_dev, n, blocks, s); \
+    if (variant == 7100 + 3232) wh_launch_multi_cfg<ET_, 32, 32, 7, 1>(t, first_dev, n, blocks, s); \
+    else if (variant == 6464) wh_launch_multi_cfg<ET_, 64, 64>(t, first_dev, n, blocks, s); \
     else if (variant == 6432) wh_launch_multi_cfg<ET_, 64, 32>(t, first_dev, n, blocks, s); \
     else if (variant == 3264) wh_launch_multi_cfg<ET_, 32, 64>(t, first_dev, n, blocks, s); \
     else wh_launch_multi_cfg<ET_, 32, 32>(t, first_dev, n, blocks, s); \

@@ -162,13 +162,13 @@ def conv2d_wgrad(desc, x, dy, lddy, slab, nsplit):
 
 
 def conv2d_wgrad_variant(desc, lddy, dtype):
-    """(variant key, workgroups per pixel split, length in units) of a layer's filter-gradient kernel: jobs with the same key
-    share a launch of imm_conv2d_wgrad_multi."""
-    wps, units = C.c_int(0), C.c_int(0)
-    key = L.load().imm_conv2d_wgrad_variant(C.byref(desc), lddy, dtype_enum(dtype), C.byref(wps), C.byref(units))
+    """(variant key, workgroups per pixel split, length in units, resident workgroups per CU) of a layer's filter-gradient
+    kernel: jobs with the same key share a launch of imm_conv2d_wgrad_multi."""
+    wps, units, pcu = C.c_int(0), C.c_int(0), C.c_int(0)
+    key = L.load().imm_conv2d_wgrad_variant(C.byref(desc), lddy, dtype_enum(dtype), C.byref(wps), C.byref(units), C.byref(pcu))
     if key < 0:
         raise L.ImmHipError('imm_conv2d_wgrad_variant: ' + L.load().imm_last_error().decode())
-    return key, wps.value, units.value
+    return key, wps.value, units.value, pcu.value
 
 
 class WgradMulti(object):

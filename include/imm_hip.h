@@ -139,16 +139,18 @@ int imm_conv2d_wgrad_reduce(const float* slab, int nsplit, int kh, int kw, int c
  * workgroups first); the caller copies it once to device memory (16-byte aligned) and passes both copies to every launch:
  * the host copy carries the launch geometry, the device copy is what the kernels read.  Results are identical to n single
  * calls with the same split counts.  n <= 64.
- * imm_conv2d_wgrad_variant: the kernel (family * 10000 + tile variant) a layer's filter gradient runs with, its workgroups
- * per pixel split and its length in units (32-pixel steps or 8x16-pixel patches) — what a caller needs to choose split counts
- * for jobs that share a launch (jobs with equal return values do). */
+ * imm_conv2d_wgrad_variant: the kernel (family * 100000 + tile variant) a layer's filter gradient runs with, its workgroups
+ * per pixel split, its length in units (32-pixel steps or 8x16-pixel patches) and how many workgroups of that kernel are
+ * resident per CU — what a caller needs to choose split counts for jobs that share a launch (jobs with equal return values
+ * do; one round of resident, equally long workgroups is the target). */
 typedef struct imm_wgrad_job {
   imm_conv_desc desc;          /* the FORWARD convolution */
   const void* x; const void* dy; float* slab;
   int32_t lddy, nsplit;
 } imm_wgrad_job;
 int64_t imm_conv2d_wgrad_multi_table_bytes(int n);
-int imm_conv2d_wgrad_variant(const imm_conv_desc* desc_host, int lddy, int dtype, int* wg_per_split_host, int* units_host);
+int imm_conv2d_wgrad_variant(const imm_conv_desc* desc_host, int lddy, int dtype, int* wg_per_split_host, int* units_host,
+                             int* wg_per_cu_host);
 int imm_conv2d_wgrad_multi_plan(const imm_wgrad_job* jobs_host, int n, int dtype, void* table_host);
 int imm_conv2d_wgrad_multi(const void* table_host, const void* table_dev, void* stream);
 /* db[n] = sum_m dy[m][n], n < c_out, for convolutions not followed by batch norm (bias_add gradient,

@@ -39,13 +39,23 @@ def _towers():
     return full, [{k: v[i * per:(i + 1) * per] for k, v in full.items()} for i in range(2)]
 
 
-def emulate_two_towers(n_steps):
+def emulate_two_towers(n_steps, buckets=1):
     """Single process: engines A and B are the two towers; A carries the variables (B is refreshed from A every step, like
-    TF's reuse_variables), the flat gradient buffers are added on the device, A applies the update."""
+    TF's reuse_variables), the flat gradient buffers are added on the device, A applies the update.
+    `buckets`: the engines are built the way a rank with IMM_DP_BUCKETS=<buckets> builds them (with two buckets the renderer's
+    filter gradients are issued and reduced early, with other split counts: the same sums in another order)."""
     _full, towers = _towers()
     per = B_GLOBAL // 2
-    mA, mB = _model(2), _model(2)
-    A, Bn = mA._get_engine(per, S_IMG), mB._get_engine(per, S_IMG)
+    old = os.environ.get('IMM_DP_BUCKETS')
+    os.environ['IMM_DP_BUCKETS'] = str(buckets)
+    try:
+        mA, mB = _model(2), _model(2)
+        A, Bn = mA._get_engine(per, S_IMG), mB._get_engine(per, S_IMG)
+    finally:
+        if old is None:
+            del os.environ['IMM_DP_BUCKETS']
+        else:
+            os.environ['IMM_DP_BUCKETS'] = old
     losses = []
     for it in range(n_steps):
         if it > 0:       # tower B reads tower A's variables; its BN moving statistics / loss normalisers stay its own (:155)
@@ -144,7 +154,7 @@ def _rank_main(rank, world, port, ret, buckets):
 @pytest.mark.parametrize('buckets', [1, 2], ids=['one_bucket_default', 'two_buckets_optin'])
 def test_two_ranks_on_one_gpu_run_the_split_graph_path_bitwise(emu, buckets):
     import torch.multiprocessing as mp
-    A, Bn, losses, _gA0, _gB0 = emu
+    A, Bn, losses, _gA0, _gB0 = emu if buckets == 1 else emulate_two_towers(N_STEPS, buckets)
     port = 29700 + (os.getpid() % 200) + 300 * buckets
     with mp.Manager() as mgr:          # shut the manager process down even when an assertion below fails
         ret = mgr.dict()

@@ -298,7 +298,7 @@ def test_conv_wgrad_multi_equals_single_launches(ops, dt):
         made.append((desc, xd, dyd, lddy, nsplit, k, ci, co, gw, slab_m))
         multi_jobs.append((desc, xd, dyd, lddy, slab_m, nsplit))
         keys.append(ops.conv2d_wgrad_variant(desc, lddy, dt)[0])
-    assert len(set(keys)) >= 6 and 0 in [k // 10000 for k in keys], keys      # several variants of both families + the generic kernel
+    assert len(set(keys)) >= 6 and 0 in [k // 100000 for k in keys], keys      # several variants of both families + the generic kernel
     multi = ops.WgradMulti(multi_jobs, dt)
     ops.conv2d_wgrad_multi(multi)
     torch.cuda.synchronize()
@@ -307,12 +307,46 @@ def test_conv_wgrad_multi_equals_single_launches(ops, dt):
         ops.conv2d_wgrad_reduce(slab_m, nsplit, k, k, ci, ci, co, desc.kpad, dw)
         torch.cuda.synchronize()
         close(dw, gw, 2e-3, 5e-4, 'wgrad_multi/job%d' % i)
-        if keys[i] // 10000 == 2 and nsplit != ops.conv2d_wgrad_splits(desc, lddy):
+        if keys[i] // 100000 == 2 and nsplit != ops.conv2d_wgrad_splits(desc, lddy):
             continue     # the single entry point only takes the halo kernel at its own split count: nothing to compare bitwise
         slab_s = torch.full_like(slab_m, float('nan'))
         ops.conv2d_wgrad(desc, xd, dyd, lddy, slab_s, nsplit)
         torch.cuda.synchronize()
         assert torch.equal(slab_s, slab_m), 'job %d (variant %d)' % (i, keys[i])
+
+
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16], ids=['bf16', 'f16'])
+@pytest.mark.parametrize('B,S', [(2, 64), (5, 128)])
+def test_conv_wgrad_halo_7x1_first_layer(ops, B, S, dt):
+    """Filter gradient of the tap-unrolled first encoder convolution (7x1 over 32 channels, imm_model.py:190) through the
+    LDS-halo kernel (14x16-pixel halo, seven vertical taps): against autograd of the oracle convolution, alone and as a member
+    of a multi-problem launch at another split count, and against the transpose-read kernel."""
+    ci, co = 32, 32
+    x = rnd((B, S, S, ci), 131, 1.0, dt)
+    x[..., 21:] = 0          # channels 21..31 of the unrolled image are padding
+    wr = torch.zeros(7, 1, ci, co, requires_grad=True)
+    yref = O.conv2d_same(x.float(), wr, None, 1)
+    dy = rnd(tuple(yref.shape), 132, 1.0, dt)
+    (gw,) = torch.autograd.grad(yref, wr, dy.float())
+    desc = ops.fwd_desc(B, S, S, ci, ci, co, co, 7, 1, 0, kw=1)
+    key, wps, units, pcu = ops.conv2d_wgrad_variant(desc, co, dt)
+    assert key // 100000 == 2 and wps == 1 and pcu == 2, key                 # LDS-halo family, whole filter = one slice
+    xd, dyd = x.to(DEV).contiguous(), dy.to(DEV).contiguous()
+    nsplit = ops.conv2d_wgrad_splits(desc, co)
+    assert nsplit > 0
+    res = []
+    for ns, multi in ((nsplit, False), (7, True), (3, False)):       # (3, False): any other split count = transpose-read kernel
+        slab = torch.full((ns, desc.kpad, co), float('nan'), dtype=torch.float32, device=DEV)
+        if multi:
+            ops.conv2d_wgrad_multi(ops.WgradMulti([(desc, xd, dyd, co, slab, ns)], dt))
+        else:
+            ops.conv2d_wgrad(desc, xd, dyd, co, slab, ns)
+        dw = torch.full((7, 1, ci, co), float('nan'), dtype=torch.float32, device=DEV)
+        ops.conv2d_wgrad_reduce(slab, ns, 7, 1, ci, ci, co, desc.kpad, dw)
+        torch.cuda.synchronize()
+        close(dw, gw, 2e-3, 5e-4, 'wgrad_halo_7x1/%d%s' % (ns, 'm' if multi else ''))
+        res.append(dw)
+    close(res[0], res[2], 1e-3, 2e-4, 'wgrad_halo_7x1 vs transpose-read')
 
 
 def test_table_driven_pack_and_reduce(ops):
