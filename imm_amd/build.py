@@ -99,5 +99,28 @@ def _build_locked(dig, objdir, verbose):
     return LIB
 
 
+def build_variant(out, flags):
+    """A/B builds: the same sources with extra compile flags into another file (objects under build/<name>/); load it with
+    IMM_HIP_LIB=<out>."""
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    objdir = os.path.join(HERE, 'build', os.path.basename(out))
+    os.makedirs(objdir, exist_ok=True)
+    procs, objs = [], []
+    for src in _sources():
+        obj = os.path.join(objdir, os.path.basename(src) + '.o')
+        objs.append(obj)
+        procs.append(subprocess.Popen([hipcc, '--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-DIMM_SOURCE_DIGEST="variant"'] +
+                                      flags + ['-c', src, '-o', obj]))
+    for p in procs:
+        if p.wait() != 0:
+            raise RuntimeError('hipcc failed')
+    subprocess.check_call([hipcc, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', out] + objs)
+    return out
+
+
 if __name__ == '__main__':
-    print(build(force='--force' in sys.argv))
+    if '--out' in sys.argv:
+        i = sys.argv.index('--out')
+        print(build_variant(sys.argv[i + 1], sys.argv[i + 2:]))
+    else:
+        print(build(force='--force' in sys.argv))
