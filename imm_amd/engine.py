@@ -869,6 +869,8 @@ class IMMEngine:
         # the renderer's are issued and reduced here, so that this bucket (the tail of the flat gradient buffer) can travel while
         # the encoders' backward is still running.
         self.n_bwd_bucket0 = None
+        # (The renderer's grouped launches as a third lane beside the encoders' backward chains: 3.37 -> 3.48 ms — the matrix-heavy
+        # workgroups take the CUs the latency-bound BN / data-gradient chains need; round 3, same box.)
         if int(os.environ.get('IMM_DP_BUCKETS', '1')) >= 2:
             self._flush_wgrads('renderer')
             self.reduce_tab_ren = ops.JobTable([j for j, _n in self._reduce_jobs], [n for _j, n in self._reduce_jobs], 64, self.dev)

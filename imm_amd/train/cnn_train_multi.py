@@ -42,12 +42,28 @@ def average_gradients(flat_grads, world_size, group=None, force=False, async_op=
     through the host — same sum, same flat layout, no claim about speed."""
     if world_size > 1 or (force and dist.is_initialized()):
         if flat_grads.is_cuda and dist.get_backend(group) == 'gloo':
-            host = flat_grads.detach().cpu()          # synchronises with the producing stream
+            # pinned staging buffer + explicit stream synchronisation on both legs: a pageable bounce buffer that is freed
+            # right after an asynchronous 16 MB host-to-device copy was the one non-deterministic piece of the two-rank test
+            host = _pinned_like(flat_grads)
+            stream = torch.cuda.current_stream(flat_grads.device)
+            host.copy_(flat_grads.detach(), non_blocking=True)
+            stream.synchronize()                      # the producing graph and the copy have finished
             dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
-            flat_grads.copy_(host)
+            flat_grads.copy_(host, non_blocking=True)
+            stream.synchronize()                      # the staging buffer may be reused
             return None
         return dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
     return None
+
+
+_PINNED = {}
+
+
+def _pinned_like(t):
+    key = (t.numel(), t.dtype)
+    if key not in _PINNED:
+        _PINNED[key] = torch.empty(t.numel(), dtype=t.dtype).pin_memory()
+    return _PINNED[key].view(t.shape)
 
 
 def mean_tower_loss(loss, world_size, group=None):

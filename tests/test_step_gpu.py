@@ -600,8 +600,10 @@ def test_native_rccl_exchange_single_rank(monkeypatch):
     if not torch.cuda.is_available():
         pytest.skip('no GPU')
     from imm_amd.train.cnn_train_multi import TrainStep
-    res = []
-    for native, buckets, in_graph in ((False, 1, False), (True, 1, False), (True, 2, False), (True, 1, True)):
+    res = {}
+    # the engine is built per bucket mode (IMM_DP_BUCKETS=2 issues and reduces the renderer's filter gradients early: the same
+    # sums in another order), so every mode is compared with the plain single-graph step of an engine built the same way
+    for native, buckets, in_graph in ((False, 1, False), (True, 1, False), (True, 1, True), (False, 2, False), (True, 2, False)):
         monkeypatch.setenv('IMM_RCCL_NATIVE', '1' if native else '0')
         monkeypatch.setenv('IMM_DP_BUCKETS', str(buckets))
         monkeypatch.setenv('IMM_RCCL_GRAPH', '1' if in_graph else '0')     # the collective as a node of the step's ONE graph
@@ -611,10 +613,13 @@ def test_native_rccl_exchange_single_rank(monkeypatch):
         for it in range(3):
             loss = ts.step(inputs)
         ts.synchronize()
-        res.append((float(loss), eng.params.clone()))
+        res[(native, buckets, in_graph)] = (float(loss), eng.params.clone())
         if native:
             ts.native_comm.destroy()
         if in_graph:
             assert len(ts._graphs) == 1
-    assert res[0][0] == res[1][0] == res[2][0] == res[3][0]
-    assert all(torch.equal(res[0][1], r[1]) for r in res[1:])
+    for key, (loss, params) in res.items():
+        ref = res[(False, key[1], False)]
+        assert loss == ref[0] and torch.equal(params, ref[1]), key
+    # and the two engine builds agree to rounding
+    assert abs(res[(False, 1, False)][0] - res[(False, 2, False)][0]) <= 1e-5 * abs(res[(False, 1, False)][0])
