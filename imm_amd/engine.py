@@ -226,7 +226,7 @@ class IMMEngine:
         self._stamp_buf = torch.zeros(8192, dtype=torch.int64, device=self.dev) if self._stamp_mode else None
         self._stamp_names = []
         self._side = None
-        self._pack_jobs, self._reduce_jobs, self._wgrad_pending = [], [], []
+        self._pack_jobs, self._reduce_jobs, self._wgrad_pending, self._colsum_pending = [], [], [], []
         self._training = True
         self._build_network()
         self.init_parameters(seed)
@@ -476,7 +476,10 @@ class IMMEngine:
             # reference computes rounding noise there.  The flat gradient slice stays 0.
         else:
             dy, lddy = d_out, ldd
-            self._add(self.prog_bwd, lambda: ops.colsum(dy, npix, lddy, co, lddy, lay.cs_partial, gb), 'colsum')
+            # bias gradient of a convolution without batch norm (renderer head, pose head): nothing in the chain reads it, so the
+            # launch is deferred to the image-encoder lane of the backward fork (90 us shorter than the pose lane): -25 us of
+            # critical path (15 in front of the renderer's backward, 10.6 on the pose lane)
+            self._colsum_pending.append((scope, lambda: ops.colsum(dy, npix, lddy, co, lddy, lay.cs_partial, gb)))
         fd = lay.fd
         flops = 2.0 * npix * k * lay.kw * lay.ci_real * co
         # Filter gradient: nobody reads it before the slab reduction at the end of the backward pass, so the job is only
@@ -872,6 +875,9 @@ class IMMEngine:
         # (The renderer's grouped launches as a third lane beside the encoders' backward chains: 3.37 -> 3.48 ms — the matrix-heavy
         # workgroups take the CUs the latency-bound BN / data-gradient chains need; round 3, same box.)
         if int(os.environ.get('IMM_DP_BUCKETS', '1')) >= 2:
+            for scope, fn in self._colsum_pending:       # the renderer head's bias gradient belongs to this bucket
+                self._add(self.prog_bwd, fn, 'colsum', name=scope)
+            self._colsum_pending = []
             self._flush_wgrads('renderer')
             self.reduce_tab_ren = ops.JobTable([j for j, _n in self._reduce_jobs], [n for _j, n in self._reduce_jobs], 64, self.dev)
             self._add(self.prog_bwd, lambda: ops.wgrad_reduce_multi(self.reduce_tab_ren), 'wgrad_reduce', name='renderer')
@@ -888,6 +894,8 @@ class IMMEngine:
         self._add(self.prog_bwd, lambda: ops.softargmax_gauss_bwd(dg, Cj, B, He, He, K, self.inv_std, 16, self.mu, self.py,
                                                                   self.px, self.d_heat, ph.lddy, self.cfg.gauss_mode), 'bottleneck_bwd')
         d_feat = self._act(B, He, He, nf8)
+        if self.two_streams:
+            self._signal(self.prog_bwd, 'd_heat', lane=0)          # for the pose head's deferred bias gradient on lane 1
         self._conv_backward(ph, self.d_heat, ph.lddy, d_feat, nf8)
         self._encoder_backward(self.enc_pose, d_feat, nf8)
 
@@ -900,6 +908,12 @@ class IMMEngine:
             d_e = self._act(B, He, He, nf8)
             self._add(self.prog_bwd, lambda: ops.resize_ac_bwd(self.d_joint, d_e, B, He, He, 16, 16, nf8, Cj, nf8), 'resize_ac_bwd')
             self._encoder_backward(self.enc_im, d_e, nf8)
+        # deferred bias gradients, at the tail of the (shorter) image-encoder lane
+        if self.two_streams and self._colsum_pending:
+            self._wait(self.prog_bwd, 'd_heat', lane=1)
+        for scope, fn in self._colsum_pending:
+            self._add(self.prog_bwd, fn, 'colsum', name=scope)
+        self._colsum_pending = []
         self._cur_lane = 0
         self._mark(self.prog_bwd, 'join')
         self._flush_wgrads('encoders' if self.n_bwd_bucket0 is not None else 'all layers')
