@@ -87,6 +87,8 @@ _SIGS = {
     'imm_softargmax_gauss_fwd': [_P, _I, _I, _I, _I, _I, _F, _I, _P, _P, _P, _P, _I, _I, _I, _P],
     'imm_softargmax_gauss_bwd': [_P, _I, _I, _I, _I, _I, _I, _F, _I, _P, _P, _P, _P, _I, _I, _P],
     'imm_gauss_render_f32': [_P, _I, _I, _F, _I, _P, _I, _P],
+    'imm_pose_head_fwd': [_P, _I, _I, _P, _I, _P, _I, _I, _I, _I, _I, _F, _I, _P, _I, _P, _P, _P, _P, _I, _I, _P],
+    'imm_pose_head_bwd': [_P, _I, _I, _I, _I, _I, _I, _F, _I, _P, _P, _P, _P, _I, _I, _P, _I, _I, _P, _I, _P, _P],
     'imm_vgg_conv1_1_fwd': [_P, _P, _I, _I, _I, _P, _P, _P, _I, _I, _P],
     'imm_vgg_conv1_1_bwd': [_P, _I, _I, _I, _P, _P, _P, _I, _P, _P, _I, _I, _P, _I, _P],
     'imm_image_loss_grad': [_P, _P, _I, _I, _I, _P, _P, _I, _I, _P, _I, _I, _P],

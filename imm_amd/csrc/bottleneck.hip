@@ -45,24 +45,18 @@ __device__ __forceinline__ void gauss_grad(int mode, float dy, float dx, float i
   }
 }
 
-template <typename ET>
-__global__ __launch_bounds__(BT_THREADS) void softargmax_gauss_fwd_kernel(
-    const float* __restrict__ heat, int ldh, int h, int w, int K, float inv_std, int s, float* __restrict__ mu,
-    float* __restrict__ py, float* __restrict__ px, uint16_t* __restrict__ gauss, int ldg, int mode) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];
+// means over the other axis, softmax + expectation, render — from the heat-map of sample b staged in LDS (sm: [h*w][K] heat |
+// [h][K] | [w][K] | [K][2])
+template <typename ET, int NTHR>
+__device__ __forceinline__ void bt_softargmax_tail(float* sm, int b, int tid, int h, int w, int K, float inv_std, int s,
+                                                   float* __restrict__ mu, float* __restrict__ py, float* __restrict__ px,
+                                                   uint16_t* __restrict__ gauss, int ldg, int mode) {
   float* sheat = sm;                      // [h*w][K]
   float* rmean = sheat + h * w * K;       // [h][K] row means -> probabilities
   float* cmean = rmean + h * K;           // [w][K]
   float* smu = cmean + w * K;             // [K][2]
-  const int b = blockIdx.x, tid = threadIdx.x;
-  const float* hb = heat + (int64_t)b * h * w * ldh;
-  for (int i = tid; i < h * w * K; i += BT_THREADS) {
-    const int p = i / K, k = i - p * K;
-    sheat[i] = hb[(int64_t)p * ldh + k];
-  }
-  __syncthreads();
   // means over the other axis (imm_model.py:254)
-  for (int i = tid; i < (h + w) * K; i += BT_THREADS) {
+  for (int i = tid; i < (h + w) * K; i += NTHR) {
     if (i < h * K) {
       const int r = i / K, k = i - r * K;
       float acc = 0.f;
@@ -78,7 +72,7 @@ __global__ __launch_bounds__(BT_THREADS) void softargmax_gauss_fwd_kernel(
   }
   __syncthreads();
   // softmax + expectation, one thread per (axis, k)  (imm_model.py:255-258)
-  for (int i = tid; i < 2 * K; i += BT_THREADS) {
+  for (int i = tid; i < 2 * K; i += NTHR) {
     const int axis = i / K, k = i - axis * K;
     float* v = axis == 0 ? rmean : cmean;
     const int n = axis == 0 ? h : w;
@@ -99,7 +93,7 @@ __global__ __launch_bounds__(BT_THREADS) void softargmax_gauss_fwd_kernel(
   __syncthreads();
   // render (imm_model.py:48-59, transposed to NHWC at :77)
   if (gauss != nullptr) {
-    for (int i = tid; i < s * s * K; i += BT_THREADS) {
+    for (int i = tid; i < s * s * K; i += NTHR) {
       const int p = i / K, k = i - p * K;
       const int yy = p / s, xx = p - yy * s;
       const float dy = lin_pm1(yy, s) - smu[k * 2], dx = lin_pm1(xx, s) - smu[k * 2 + 1];
@@ -108,18 +102,97 @@ __global__ __launch_bounds__(BT_THREADS) void softargmax_gauss_fwd_kernel(
   }
 }
 
-// backward: dG -> dmu (through the Gaussian) -> d row/col means (through softmax-expectation) -> dheat
 template <typename ET>
-__global__ __launch_bounds__(BT_THREADS) void softargmax_gauss_bwd_kernel(
+__global__ __launch_bounds__(BT_THREADS) void softargmax_gauss_fwd_kernel(
+    const float* __restrict__ heat, int ldh, int h, int w, int K, float inv_std, int s, float* __restrict__ mu,
+    float* __restrict__ py, float* __restrict__ px, uint16_t* __restrict__ gauss, int ldg, int mode) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* hb = heat + (int64_t)b * h * w * ldh;
+  for (int i = tid; i < h * w * K; i += BT_THREADS) {
+    const int p = i / K, k = i - p * K;
+    sm[i] = hb[(int64_t)p * ldh + k];
+  }
+  __syncthreads();
+  bt_softargmax_tail<ET, BT_THREADS>(sm, b, tid, h, w, K, inv_std, s, mu, py, px, gauss, ldg, mode);
+}
+
+// The pose head in ONE launch (imm_model.py:247-264): 1x1 convolution C -> K (+ bias; no batch norm, no activation) by MFMA
+// straight from global memory — both operands are K-contiguous as they lie (a pixel's channels; a packed filter row), so a lane
+// loads its 8-value MFMA operand with one 16-byte load and no LDS staging is needed — into the LDS heat-map, then the soft-argmax
+// and the render as above.  One workgroup of 16 waves per sample (a 16x16 heat-map = one 16-pixel tile per wave: every load of
+// the convolution is in flight at once; with 4 waves the four tiles of a wave were a chain of L2 latencies, 29 us per launch);
+// wave v takes the tiles v, v+16, ...
+#define PH_THREADS 1024           // forward: 16 waves
+#define PH_BWD_THREADS 512        // backward: 8 waves (the filter rows of the data gradient take 64-128 registers per lane)
+template <typename ET>
+__global__ __launch_bounds__(PH_THREADS) void pose_head_fwd_kernel(
+    const uint16_t* __restrict__ feat, int ldf, int C, const uint16_t* __restrict__ wt, int kpad, const float* __restrict__ bias,
+    float* __restrict__ heat, int ldh, int h, int w, int K, float inv_std, int s, float* __restrict__ mu,
+    float* __restrict__ py, float* __restrict__ px, uint16_t* __restrict__ gauss, int ldg, int mode) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int hw = h * w, NT = (K + 15) >> 4, KK = C >> 5;
+  const int lm = lane & 15, lk = (lane >> 4) * 8;
+  for (int m0 = wv * 16; m0 < hw; m0 += PH_THREADS / 4) {
+    f32x4_t acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const uint16_t* ap = feat + ((int64_t)b * hw + m0 + lm) * ldf + lk;
+    const uint16_t* bp = wt + (int64_t)lm * kpad + lk;
+    for (int k0 = 0; k0 < KK; k0 += 8) {                 // chunks of 8 k-steps (256 channels): all loads of a chunk in flight
+      uint4 af[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        if (k0 + q < KK) af[q] = *(const uint4*)(ap + (k0 + q) * 32);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (j < NT) {
+          uint4 bf[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q)
+            if (k0 + q < KK) bf[q] = *(const uint4*)(bp + (int64_t)j * 16 * kpad + (k0 + q) * 32);
+#pragma unroll
+          for (int q = 0; q < 8; ++q)
+            if (k0 + q < KK) acc[j] = ET::mfma(bf[q], af[q], acc[j]);           // D[n = 4 (lane >> 4) + r][m = lane & 15]
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (j < NT) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int n = j * 16 + 4 * (lane >> 4) + r;
+          if (n < K) {
+            const float v = acc[j][r] + bias[n];
+            sm[(m0 + lm) * K + n] = v;
+            heat[((int64_t)b * hw + m0 + lm) * ldh + n] = v;
+          }
+        }
+      }
+  }
+  __syncthreads();
+  bt_softargmax_tail<ET, PH_THREADS>(sm, b, tid, h, w, K, inv_std, s, mu, py, px, gauss, ldg, mode);
+}
+
+// backward: dG -> dmu (through the Gaussian) -> d row/col means (through softmax-expectation) -> dheat
+// HEAD: the same pass continued through the pose head's 1x1 convolution (imm_model.py:247-248) — the 16-bit heat-map gradient
+// stays in LDS as the MFMA operand of the data gradient d_feat[p][c] = sum_k dheat[p][k] W[c][k] (packed filter rows straight
+// from global memory), and its per-sample column sums (the bias gradient's partial row) are written for the final table-driven
+// reduction: one launch instead of bottleneck backward + column sum + 1x1 data gradient.
+template <typename ET, bool HEAD>
+__global__ __launch_bounds__(HEAD ? PH_BWD_THREADS : BT_THREADS) void softargmax_gauss_bwd_kernel(
     const uint16_t* __restrict__ dgauss, int ldg, int h, int w, int K, float inv_std, int s,
     const float* __restrict__ mu, const float* __restrict__ py, const float* __restrict__ px,
-    uint16_t* __restrict__ dheat, int lddh, int mode) {
+    uint16_t* __restrict__ dheat, int lddh, int mode, const uint16_t* __restrict__ wtd, int kpad_d, int C,
+    uint16_t* __restrict__ dfeat, int lddf, float* __restrict__ bias_partial) {
+  constexpr int NTHR = HEAD ? PH_BWD_THREADS : BT_THREADS;
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* dmu = sm;              // [K][2]
   float* drow = dmu + 2 * K;    // [h][K]  d loss / d row-mean
   float* dcol = drow + h * K;   // [w][K]
   constexpr int KC = 10;                       // landmarks per pass: 2*KC partial sums per thread, reduced together
-  __shared__ float red[BT_THREADS / 64][2 * KC];
+  __shared__ float red[NTHR / 64][2 * KC];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   // dmu[k][axis] = sum_p dG * dG/dmu  ('rot': G*2*inv_std^2*(coord - mu)).  A thread walks its pixels once per pass and
   // keeps the sums of KC landmarks (their dG values are adjacent in memory); the 2*KC sums then go through ONE reduction
@@ -133,7 +206,7 @@ __global__ __launch_bounds__(BT_THREADS) void softargmax_gauss_bwd_kernel(
       const int k = k0 + c < K ? k0 + c : K - 1;
       my[c] = mu[((int64_t)b * K + k) * 2]; mx[c] = mu[((int64_t)b * K + k) * 2 + 1];
     }
-    for (int p = tid; p < s * s; p += BT_THREADS) {
+    for (int p = tid; p < s * s; p += NTHR) {
       const int yy = p / s, xx = p - yy * s;
       const float ly = lin_pm1(yy, s), lx = lin_pm1(xx, s);
       const uint16_t* dgp = dgauss + ((int64_t)b * s * s + p) * ldg + k0;
@@ -161,13 +234,13 @@ __global__ __launch_bounds__(BT_THREADS) void softargmax_gauss_bwd_kernel(
     if (tid < 2 * KC && k0 + tid / 2 < K) {
       float t = 0.f;
 #pragma unroll
-      for (int wq = 0; wq < BT_THREADS / 64; ++wq) t += red[wq][tid];
+      for (int wq = 0; wq < NTHR / 64; ++wq) t += red[wq][tid];
       dmu[(k0 + tid / 2) * 2 + (tid & 1)] = t;
     }
     __syncthreads();
   }
   // mu = sum_j p_j lin_j, p = softmax(r):  dr_j = p_j (lin_j - mu) dmu
-  for (int i = tid; i < (h + w) * K; i += BT_THREADS) {
+  for (int i = tid; i < (h + w) * K; i += NTHR) {
     if (i < h * K) {
       const int j = i / K, k = i - j * K;
       const float p = py[(int64_t)b * h * K + i];
@@ -181,14 +254,63 @@ __global__ __launch_bounds__(BT_THREADS) void softargmax_gauss_bwd_kernel(
   }
   __syncthreads();
   // row mean = sum_x heat/w, col mean = sum_y heat/h
-  for (int i = tid; i < h * w * lddh; i += BT_THREADS) {
+  // HEAD: after the floats (rounded to 16 bytes): [NTHR] column-sum scratch, then the [h*w][lddh] 16-bit copy of dheat
+  float* cs = sm + (((2 + h + w) * K + 3) & ~3);
+  uint16_t* sdh = (uint16_t*)(cs + NTHR);
+  for (int i = tid; i < h * w * lddh; i += NTHR) {
     const int p = i / lddh, k = i - p * lddh;
     float v = 0.f;
     if (k < K) {
       const int yy = p / w, xx = p - yy * w;
       v = drow[yy * K + k] / (float)w + dcol[xx * K + k] / (float)h;
     }
-    dheat[(int64_t)b * h * w * lddh + i] = ET::from_f32(v);
+    const uint16_t q = ET::from_f32(v);
+    dheat[(int64_t)b * h * w * lddh + i] = q;
+    if constexpr (HEAD) sdh[i] = q;
+  }
+  if constexpr (HEAD) {
+    __syncthreads();
+    const int hw = h * w;
+    // bias gradient partial of this sample: column sums of the STORED (16-bit) gradient, like imm_colsum; thread = (part, k)
+    {
+      const int parts = NTHR / lddh;                // lddh in {32, 64}
+      const int k = tid % lddh, part = tid / lddh;
+      float acc = 0.f;
+      for (int p = part; p < hw; p += parts) acc += ET::to_f32(sdh[p * lddh + k]);
+      cs[part * lddh + k] = acc;
+      __syncthreads();
+      if (tid < K) {
+        float t = 0.f;
+        for (int q = 0; q < parts; ++q) t += cs[q * lddh + tid];
+        bias_partial[(int64_t)b * K + tid] = t;
+      }
+    }
+    // data gradient: 16-pixel tiles x 16-channel tiles, contraction over the lddh landmark channels (zeros beyond K)
+    const int lm = lane & 15, lk = (lane >> 4) * 8, KS = lddh >> 5, NTc = C >> 4;
+    for (int n0 = 0; n0 < NTc; n0 += 16) {                // 256 output channels at a time: their filter rows live in registers
+      uint4 bfr[2][16];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+          if (ks < KS && n0 + q < NTc) bfr[ks][q] = *(const uint4*)(wtd + ((int64_t)(n0 + q) * 16 + lm) * kpad_d + ks * 32 + lk);
+      for (int m0 = wv * 16; m0 < hw; m0 += NTHR / 4) {
+        uint4 af[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+          if (ks < KS) af[ks] = *(const uint4*)(sdh + (m0 + lm) * lddh + ks * 32 + lk);
+        uint16_t* op = dfeat + ((int64_t)b * hw + m0 + lm) * lddf + n0 * 16 + 4 * (lane >> 4);
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+          if (n0 + q < NTc) {
+            f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+              if (ks < KS) acc = ET::mfma(bfr[ks][q], af[ks], acc);               // D[c = 4 (lane >> 4) + r][m = lane & 15]
+            *(uint2*)(op + q * 16) = make_uint2(ET::pack2(acc[0], acc[1]), ET::pack2(acc[2], acc[3]));
+          }
+      }
+    }
   }
 }
 
@@ -242,10 +364,59 @@ extern "C" int imm_softargmax_gauss_bwd(const void* dgauss, int ldg, int dtype, 
   IMM_REQUIRE(gauss_mode >= IMM_GAUSS_ROT && gauss_mode <= IMM_GAUSS_ANKUSH, "softargmax_bwd: gauss_mode %d", gauss_mode);
   IMM_REQUIRE(batch > 0 && h > 0 && w > 0 && k > 0 && ldg >= k && lddh >= k && s > 0, "softargmax_bwd: dims");
   const size_t lds = sizeof(float) * (2 * (size_t)k + (size_t)(h + w) * k);
-  IMM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((softargmax_gauss_bwd_kernel<ET>), dim3(batch), dim3(BT_THREADS), lds,
+  IMM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((softargmax_gauss_bwd_kernel<ET, false>), dim3(batch), dim3(BT_THREADS), lds,
                                                (hipStream_t)stream, (const uint16_t*)dgauss, ldg, h, w, k, inv_std, s, mu,
-                                               py, px, (uint16_t*)dheat, lddh, gauss_mode));
+                                               py, px, (uint16_t*)dheat, lddh, gauss_mode, (const uint16_t*)nullptr, 0, 0,
+                                               (uint16_t*)nullptr, 0, (float*)nullptr));
   IMM_CHECK_LAUNCH("imm_softargmax_gauss_bwd");
+  return 0;
+}
+
+// ---- the pose head as one launch each way ---------------------------------------------------------------------------------
+extern "C" int imm_pose_head_fwd(const void* feat, int ldf, int c, const void* wt, int kpad, const float* bias, int dtype,
+                                 int batch, int h, int w, int k, float inv_std, int s, float* heat, int ldh, float* mu, float* py,
+                                 float* px, void* gauss_out, int ldg, int gauss_mode, void* stream) {
+  IMM_REQUIRE(feat && wt && bias && heat && mu && py && px, "pose_head_fwd: null");
+  IMM_REQUIRE(gauss_mode >= IMM_GAUSS_ROT && gauss_mode <= IMM_GAUSS_ANKUSH, "pose_head_fwd: gauss_mode %d", gauss_mode);
+  IMM_REQUIRE(batch > 0 && h > 0 && w > 0 && k > 0 && ldh >= k && s > 0, "pose_head_fwd: dims");
+  IMM_REQUIRE(gauss_out == nullptr || ldg >= k, "pose_head_fwd: ldg");
+  IMM_REQUIRE(((uintptr_t)feat % 16 == 0) && ((uintptr_t)wt % 16 == 0) && ldf % 8 == 0 && kpad % 8 == 0, "pose_head_fwd: alignment");
+  if (c <= 0 || c % 32 || ldf < c || kpad < c || k > 64 || (h * w) % 16)
+    return imm_fail(IMM_E_UNSUPPORTED, "pose_head_fwd: needs c %% 32 == 0, k <= 64, h*w %% 16 == 0 (c=%d k=%d h*w=%d)", c, k, h * w);
+  const size_t lds = sizeof(float) * ((size_t)h * w * k + (size_t)(h + w) * k + 2 * (size_t)k);
+  if (lds > kMaxDynLds) return imm_fail(IMM_E_UNSUPPORTED, "pose_head_fwd: heat-map %dx%dx%d needs %zu B LDS", h, w, k, lds);
+  IMM_DISPATCH_DTYPE(dtype, {
+    if (set_dyn_lds(pose_head_fwd_kernel<ET>, lds)) return IMM_E_HIP;
+    hipLaunchKernelGGL((pose_head_fwd_kernel<ET>), dim3(batch), dim3(PH_THREADS), lds, (hipStream_t)stream, (const uint16_t*)feat,
+                       ldf, c, (const uint16_t*)wt, kpad, bias, heat, ldh, h, w, k, inv_std, s, mu, py, px, (uint16_t*)gauss_out, ldg,
+                       gauss_mode);
+  });
+  IMM_CHECK_LAUNCH("imm_pose_head_fwd");
+  return 0;
+}
+
+extern "C" int imm_pose_head_bwd(const void* dgauss, int ldg, int dtype, int batch, int h, int w, int k, float inv_std, int s,
+                                 const float* mu, const float* py, const float* px, void* dheat, int lddh, int gauss_mode,
+                                 const void* wt_dgrad, int kpad_d, int c, void* dfeat, int lddf, float* bias_partial, void* stream) {
+  IMM_REQUIRE(dgauss && mu && py && px && dheat && wt_dgrad && dfeat && bias_partial, "pose_head_bwd: null");
+  IMM_REQUIRE(gauss_mode >= IMM_GAUSS_ROT && gauss_mode <= IMM_GAUSS_ANKUSH, "pose_head_bwd: gauss_mode %d", gauss_mode);
+  IMM_REQUIRE(batch > 0 && h > 0 && w > 0 && k > 0 && ldg >= k && lddh >= k && s > 0, "pose_head_bwd: dims");
+  IMM_REQUIRE(((uintptr_t)wt_dgrad % 16 == 0) && ((uintptr_t)dfeat % 8 == 0) && lddf % 4 == 0 && kpad_d % 8 == 0, "pose_head_bwd: alignment");
+  if ((lddh != 32 && lddh != 64) || kpad_d < lddh || c <= 0 || c % 16 || lddf < c || (h * w) % 16)
+    return imm_fail(IMM_E_UNSUPPORTED, "pose_head_bwd: needs lddh in {32, 64}, c %% 16 == 0, h*w %% 16 == 0 (lddh=%d c=%d h*w=%d)",
+                    lddh, c, h * w);
+  // dmu | drow | dcol (floats), padded to 16 bytes, then the 16-bit heat-map gradient
+  size_t fl = 2 * (size_t)k + (size_t)(h + w) * k;
+  fl = (fl + 3) / 4 * 4 + PH_BWD_THREADS;                              // + the column-sum scratch
+  const size_t lds = sizeof(float) * fl + (size_t)h * w * lddh * 2;
+  if (lds > kMaxDynLds) return imm_fail(IMM_E_UNSUPPORTED, "pose_head_bwd: %dx%dx%d needs %zu B LDS", h, w, lddh, lds);
+  IMM_DISPATCH_DTYPE(dtype, {
+    if (set_dyn_lds(softargmax_gauss_bwd_kernel<ET, true>, lds)) return IMM_E_HIP;
+    hipLaunchKernelGGL((softargmax_gauss_bwd_kernel<ET, true>), dim3(batch), dim3(PH_BWD_THREADS), lds, (hipStream_t)stream,
+                       (const uint16_t*)dgauss, ldg, h, w, k, inv_std, s, mu, py, px, (uint16_t*)dheat, lddh, gauss_mode,
+                       (const uint16_t*)wt_dgrad, kpad_d, c, (uint16_t*)dfeat, lddf, bias_partial);
+  });
+  IMM_CHECK_LAUNCH("imm_pose_head_bwd");
   return 0;
 }
 

@@ -319,7 +319,7 @@ class IMMEngine:
         prog.append(_Launch(None, what))
 
     def _conv_block(self, scope, x, H, W, ci_real, ci_pad, ldx, co, k, stride, bn, relu, needs_dgrad,
-                    out=None, ldo=None, out_f32=False, kw=None, up2x=False):
+                    out=None, ldo=None, out_f32=False, kw=None, up2x=False, fwd_launch=True):
         """Registers forward launches now and returns a layer record whose .backward(d_out, dx) registers the
         backward launches later (in reverse order)."""
         B, dt, dev = self.B, self.dt, self.dev
@@ -393,8 +393,10 @@ class IMMEngine:
                           'bn_apply', 0.0, npix * co * 4.0)
         else:
             lay.out, lay.ldo = lay.y, ldy
-            self._add(self.prog_fwd, lambda: ops.conv2d(fd_eval, x, lay.wt, b, lay.y), 'conv_fwd', flops,
-                      2.0 * (B * H * W * ci_pad + fd.kpad * co) + npix * co * (4.0 if out_f32 else 2.0))
+            lay.fwd_flops = flops
+            if fwd_launch:      # (the pose head's convolution is part of the fused imm_pose_head_fwd launch instead)
+                self._add(self.prog_fwd, lambda: ops.conv2d(fd_eval, x, lay.wt, b, lay.y), 'conv_fwd', flops,
+                          2.0 * (B * H * W * ci_pad + fd.kpad * co) + npix * co * (4.0 if out_f32 else 2.0))
 
         # ---- backward resources -------------------------------------------------------------------
         lay.needs_dgrad = needs_dgrad
@@ -606,17 +608,30 @@ class IMMEngine:
         self._cur_lane = 0
         self.enc_pose = build_encoder('model/pose_encoder', self.in_future)
         pe = self.enc_pose[-1]
+        # the pose head (1x1 convolution -> soft-argmax -> Gaussian maps, imm_model.py:247-264) as ONE launch each way where the
+        # shapes allow (every shipped configuration): -1 launch forward, -2 backward on the pose lane, the longer one
+        lddy_h = ops.round_up(K, 32)
+        self.fused_head = ((8 * nf) % 32 == 0 and K <= 64 and (He * He) % 16 == 0 and lddy_h in (32, 64) and
+                           4 * (He * He * K + 2 * He * K + 2 * K) <= 158 * 1024 and
+                           4 * ((2 + 2 * He) * K + 516) + He * He * lddy_h * 2 <= 158 * 1024)
         self.pose_head = self._conv_block('model/pose_encoder/conv_1', pe.out, He, He, 8 * nf, 8 * nf, pe.ldo, K, 1, 1,
-                                          False, False, needs_dgrad=True, out_f32=True)
+                                          False, False, needs_dgrad=True, out_f32=True, fwd_launch=not self.fused_head)
         ph = self.pose_head
+        assert ph.lddy == lddy_h
         self.heat, self.ldh = ph.y, ph.ldy
         self.mu = self._zeros(B, K, 2)
         self.py = self._zeros(B, He, K)
         self.px = self._zeros(B, He, K)
         self.inv_std = 1.0 / float(cfg.gauss_std)
         gview = self.joint[..., 8 * nf:]
-        self._add(self.prog_fwd, lambda: ops.softargmax_gauss_fwd(self.heat, self.ldh, B, He, He, K, self.inv_std, 16,
-                                                                  self.mu, self.py, self.px, gview, Cj, dt, cfg.gauss_mode), 'bottleneck')
+        if self.fused_head:
+            bias_h = self.pview['model/pose_encoder/conv_1/b']
+            self._add(self.prog_fwd, lambda: ops.pose_head_fwd(pe.out, pe.ldo, 8 * nf, ph.wt, bias_h, B, He, He, K, self.inv_std, 16,
+                                                               self.heat, self.ldh, self.mu, self.py, self.px, gview, Cj, dt,
+                                                               cfg.gauss_mode), 'bottleneck', ph.fwd_flops)
+        else:
+            self._add(self.prog_fwd, lambda: ops.softargmax_gauss_fwd(self.heat, self.ldh, B, He, He, K, self.inv_std, 16,
+                                                                      self.mu, self.py, self.px, gview, Cj, dt, cfg.gauss_mode), 'bottleneck')
 
         self._mark(self.prog_fwd, 'join')
         # ---- renderer ---------------------------------------------------------------------------------
@@ -891,12 +906,26 @@ class IMMEngine:
         ph = self.pose_head
         self.d_heat = self._act(B, He, He, ph.lddy)
         dg = self.d_joint[..., nf8:]
-        self._add(self.prog_bwd, lambda: ops.softargmax_gauss_bwd(dg, Cj, B, He, He, K, self.inv_std, 16, self.mu, self.py,
-                                                                  self.px, self.d_heat, ph.lddy, self.cfg.gauss_mode), 'bottleneck_bwd')
         d_feat = self._act(B, He, He, nf8)
-        if self.two_streams:
-            self._signal(self.prog_bwd, 'd_heat', lane=0)          # for the pose head's deferred bias gradient on lane 1
-        self._conv_backward(ph, self.d_heat, ph.lddy, d_feat, nf8)
+        self._colsum_needs_dheat = False
+        if self.fused_head:
+            # bottleneck backward + the head's data gradient + its bias-gradient partial rows in one launch; the head's filter
+            # gradient joins the multi-problem launch like every other layer's, the bias rows the final slab reduction
+            self.head_bias_partial = self._zeros(B, K)
+            flops_h = 2.0 * B * He * He * nf8 * K
+            self._add(self.prog_bwd, lambda: ops.pose_head_bwd(dg, Cj, B, He, He, K, self.inv_std, 16, self.mu, self.py, self.px,
+                                                               self.d_heat, ph.lddy, ph.wt_d, nf8, d_feat, nf8,
+                                                               self.head_bias_partial, self.cfg.gauss_mode), 'bottleneck_bwd', flops_h)
+            self._wgrad_pending.append((ph, self.d_heat, ph.lddy, flops_h))
+            gb_h = self.gview['model/pose_encoder/conv_1/b']
+            self._reduce_jobs.append(((self.head_bias_partial.data_ptr(), gb_h.data_ptr(), B, 1, 1, 1, K, 1), K))
+        else:
+            self._add(self.prog_bwd, lambda: ops.softargmax_gauss_bwd(dg, Cj, B, He, He, K, self.inv_std, 16, self.mu, self.py,
+                                                                      self.px, self.d_heat, ph.lddy, self.cfg.gauss_mode), 'bottleneck_bwd')
+            if self.two_streams:
+                self._signal(self.prog_bwd, 'd_heat', lane=0)          # for the pose head's deferred bias gradient on lane 1
+                self._colsum_needs_dheat = True
+            self._conv_backward(ph, self.d_heat, ph.lddy, d_feat, nf8)
         self._encoder_backward(self.enc_pose, d_feat, nf8)
 
         # ---- image encoder backward ----------------------------------------------------------------------------
@@ -909,7 +938,7 @@ class IMMEngine:
             self._add(self.prog_bwd, lambda: ops.resize_ac_bwd(self.d_joint, d_e, B, He, He, 16, 16, nf8, Cj, nf8), 'resize_ac_bwd')
             self._encoder_backward(self.enc_im, d_e, nf8)
         # deferred bias gradients, at the tail of the (shorter) image-encoder lane
-        if self.two_streams and self._colsum_pending:
+        if self._colsum_needs_dheat:
             self._wait(self.prog_bwd, 'd_heat', lane=1)
         for scope, fn in self._colsum_pending:
             self._add(self.prog_bwd, fn, 'colsum', name=scope)

@@ -329,6 +329,16 @@ def softargmax_gauss_bwd(dgauss, ldg, batch, h, w, k, inv_std, s, mu, py, px, dh
          _p(py), _p(px), _p(dheat), lddh, gauss_mode_enum(mode), _s())
 
 
+def pose_head_fwd(feat, ldf, c, wt, bias, batch, h, w, k, inv_std, s, heat, ldh, mu, py, px, gauss_out, ldg, dtype, mode='rot'):
+    call('imm_pose_head_fwd', _p(feat), ldf, c, _p(wt), wt.shape[1], _p(bias), dtype_enum(dtype), batch, h, w, k, float(inv_std), s,
+         _p(heat), ldh, _p(mu), _p(py), _p(px), _p(gauss_out), ldg, gauss_mode_enum(mode), _s())
+
+
+def pose_head_bwd(dgauss, ldg, batch, h, w, k, inv_std, s, mu, py, px, dheat, lddh, wt_dgrad, c, dfeat, lddf, bias_partial, mode='rot'):
+    call('imm_pose_head_bwd', _p(dgauss), ldg, dtype_enum(dheat.dtype), batch, h, w, k, float(inv_std), s, _p(mu), _p(py), _p(px),
+         _p(dheat), lddh, gauss_mode_enum(mode), _p(wt_dgrad), wt_dgrad.shape[1], c, _p(dfeat), lddf, _p(bias_partial), _s())
+
+
 def gauss_render_f32(mu, batch, k, inv_std, s, out, mode='rot'):
     call('imm_gauss_render_f32', _p(mu), batch, k, float(inv_std), s, _p(out), gauss_mode_enum(mode), _s())
 

@@ -246,6 +246,22 @@ int imm_softargmax_gauss_fwd(const float* heat, int ldh, int batch, int h, int w
 int imm_softargmax_gauss_bwd(const void* dgauss, int ldg, int dtype, int batch, int h, int w, int k, float inv_std,
                              int s, const float* mu, const float* py, const float* px, void* dheat, int lddh,
                              int gauss_mode, void* stream);
+/* The pose head as ONE launch each way (imm_model.py:247-264: 1x1 convolution 8f -> K with bias, no batch norm / activation,
+ * then the soft-argmax and the Gaussian render above).
+ * fwd: feat 16-bit [B,h,w,ldf] (c channels, c % 32 == 0), wt = the forward-packed filter (imm_pack_weights mode 0: rows >=
+ *      round_up(K,16), row length kpad >= c), bias f32[K] -> heat f32 [B,h,w,ldh] (channels < K written) and everything
+ *      imm_softargmax_gauss_fwd writes.  K <= 64, h*w % 16 == 0.
+ * bwd: everything imm_softargmax_gauss_bwd does (dheat 16-bit [B,h,w,lddh], lddh in {32, 64}: the filter gradient of the head
+ *      still reads it) plus the head's data gradient dfeat 16-bit [B,h,w,lddf] = dheat x W^T (wt_dgrad = imm_pack_weights mode 1
+ *      image, row length kpad_d >= lddh) and bias_partial f32 [B][K] = per-sample column sums of the stored dheat, to be summed
+ *      over B by imm_wgrad_reduce_multi (job {bias_partial, db, B, 1, 1, 1, K, 1}).  Replaces imm_softargmax_gauss_bwd +
+ *      imm_colsum + imm_conv2d(data gradient) of the head. */
+int imm_pose_head_fwd(const void* feat, int ldf, int c, const void* wt, int kpad, const float* bias, int dtype, int batch, int h,
+                      int w, int k, float inv_std, int s, float* heat, int ldh, float* mu, float* py, float* px, void* gauss_out,
+                      int ldg, int gauss_mode, void* stream);
+int imm_pose_head_bwd(const void* dgauss, int ldg, int dtype, int batch, int h, int w, int k, float inv_std, int s, const float* mu,
+                      const float* py, const float* px, void* dheat, int lddh, int gauss_mode, const void* wt_dgrad, int kpad_d,
+                      int c, void* dfeat, int lddf, float* bias_partial, void* stream);
 /* render only (pose_embedding summary maps at other sizes; f32 output [B,s,s,K]) */
 int imm_gauss_render_f32(const float* mu, int batch, int k, float inv_std, int s, float* out, int gauss_mode, void* stream);
 

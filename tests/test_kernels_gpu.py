@@ -15,6 +15,7 @@ from oracle import imm_oracle as O
 pytestmark = pytest.mark.gpu
 
 DEV = 'cuda:0'
+L_CONV_BIAS_F32 = 1 | 16       # IMM_CONV_BIAS | IMM_CONV_OUT_F32
 
 
 @pytest.fixture(scope='module')
@@ -825,6 +826,73 @@ def test_softargmax_gauss(ops, h, K, s, mode):
     ops.gauss_render_f32(mu, B, K, 10.0, 128, out, mode)
     torch.cuda.synchronize()
     close(out, O.gaussian_maps(mu_r.detach(), [128, 128], 10.0, mode), 1e-4, 1e-5, 'render128')
+
+
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16], ids=['bf16', 'f16'])
+@pytest.mark.parametrize('h,K,mode', [(16, 10, 'rot'), (16, 50, 'rot'), (32, 30, 'rot'), (16, 10, 'ankush')])
+def test_pose_head_fused(ops, h, K, mode, dt):
+    """imm_pose_head_fwd / _bwd — the pose head as one launch each way (imm_model.py:247-264) — against the oracle (1x1
+    convolution + soft-argmax + Gaussian maps, autograd for the backward) and against the launches they replace
+    (imm_conv2d, imm_softargmax_gauss_fwd/bwd, imm_colsum, the 1x1 data gradient)."""
+    B, C, s = 3, 256, 16
+    ldh, ldg, lddh = ops.round_up(K, 4), ops.round_up(C + K, 64), ops.round_up(K, 32)
+    feat = rnd((B, h, h, C), 161, 1.0, dt)
+    w = rnd((1, 1, C, K), 162, 0.05, dt)
+    bias = rnd((K,), 163, 0.3, torch.float32)
+    fr = feat.float().clone().requires_grad_(True)
+    wr = w.float().clone().requires_grad_(True)
+    br = bias.clone().requires_grad_(True)
+    heat_r = O.conv2d_same(fr, wr, br, 1)
+    mu_r, py_r, px_r = O.soft_argmax(heat_r)
+    g_r = O.gaussian_maps(mu_r, [s, s], 10.0, mode)
+    # ---- forward
+    fd = ops.fwd_desc(B, h, h, C, C, K, ldh, 1, 1, 0)
+    wt = torch.zeros(128, fd.kpad, dtype=dt, device=DEV)
+    ops.pack_weights(w.float().to(DEV).contiguous(), wt, 0, 1, 1, C, K, C, 128, fd.kpad)
+    featd = feat.to(DEV).contiguous()
+    heat = torch.zeros(B, h, h, ldh, device=DEV)
+    mu = torch.empty(B, K, 2, device=DEV); py = torch.empty(B, h, K, device=DEV); px = torch.empty(B, h, K, device=DEV)
+    joint = torch.zeros(B, s, s, ldg, dtype=dt, device=DEV)
+    ops.pose_head_fwd(featd, C, C, wt, bias.to(DEV), B, h, h, K, 10.0, s, heat, ldh, mu, py, px, joint[..., C:], ldg, dt, mode)
+    torch.cuda.synchronize()
+    close(heat[..., :K], heat_r, 2e-3, 2e-4, 'heat')                 # f32 accumulation of exact 16-bit products
+    assert float((mu.cpu() - mu_r.detach()).abs().max()) < 2e-5
+    close(py, py_r, 1e-3, 1e-5, 'py'); close(px, px_r, 1e-3, 1e-5, 'px')
+    close(joint[..., C:C + K], g_r, 8e-3 if dt == torch.bfloat16 else 2e-3, 1e-3, 'gauss')
+    assert float(joint[..., :C].float().abs().max()) == 0.0 and float(joint[..., C + K:].float().abs().max()) == 0.0
+    # the two-launch path it replaces: same heat-map to accumulation order, same landmarks
+    fd2 = ops.fwd_desc(B, h, h, C, C, K, ldh, 1, 1, L_CONV_BIAS_F32)
+    heat2 = torch.zeros(B, h, h, ldh, device=DEV)
+    ops.conv2d(fd2, featd, wt, bias.to(DEV), heat2)
+    mu2 = torch.empty_like(mu); py2 = torch.empty_like(py); px2 = torch.empty_like(px)
+    ops.softargmax_gauss_fwd(heat2, ldh, B, h, h, K, 10.0, s, mu2, py2, px2, None, ldg, dt, mode)
+    torch.cuda.synchronize()
+    close(heat[..., :K], heat2[..., :K], 1e-4, 1e-5, 'heat vs conv2d')
+    assert float((mu - mu2).abs().max()) < 1e-5
+    # ---- backward
+    dg = rnd((B, s, s, K), 164, 1.0, dt)
+    gf, gw, gb = torch.autograd.grad(g_r, (fr, wr, br), dg.float())
+    dj = torch.zeros(B, s, s, ldg, dtype=dt, device=DEV)
+    dj[..., C:C + K] = dg.to(DEV)
+    wtd = torch.zeros(ops.round_up(C, 128), lddh, dtype=dt, device=DEV)
+    ops.pack_weights(w.float().to(DEV).contiguous(), wtd, 1, 1, 1, C, K, lddh, wtd.shape[0], lddh)
+    dheat = torch.full((B, h, h, lddh), float('nan'), dtype=dt, device=DEV)
+    dfeat = torch.full((B, h, h, C), float('nan'), dtype=dt, device=DEV)
+    bpart = torch.full((B, K), float('nan'), device=DEV)
+    ops.pose_head_bwd(dj[..., C:], ldg, B, h, h, K, 10.0, s, mu, py, px, dheat, lddh, wtd, C, dfeat, C, bpart, mode)
+    torch.cuda.synchronize()
+    dheat2 = torch.full_like(dheat, float('nan'))
+    ops.softargmax_gauss_bwd(dj[..., C:], ldg, B, h, h, K, 10.0, s, mu, py, px, dheat2, lddh, mode)
+    torch.cuda.synchronize()
+    assert torch.equal(dheat, dheat2)                                 # the shared part of the pass: bit for bit
+    tol = 1e-2 if dt == torch.bfloat16 else 2e-3
+    close(dfeat, gf, tol, 2e-3, 'dfeat')
+    # the bias gradient is analytically ZERO (a constant added to a landmark's heat-map changes neither softmax): autograd
+    # returns cancellation noise (|gb| ~ 1e-6), the kernel the sum of the 16-bit-rounded dheat — noise of the storage rounding
+    assert float(gb.abs().max()) < 1e-4 and float(bpart.sum(0).abs().max()) <= 4e-3 * float(dheat[..., :K].float().abs().sum() / K) + 1e-6
+    np.testing.assert_allclose(bpart.sum(0).cpu().numpy(), dheat[..., :K].float().sum((0, 1, 2)).cpu().numpy(), rtol=1e-5, atol=1e-6)
+    # the head's filter gradient still comes from the stored dheat (a member of the multi-problem launch): consistent with gw
+    close(torch.einsum('bhwc,bhwk->ck', feat.float(), dheat[..., :K].float().cpu()).reshape(1, 1, C, K), gw, tol, 5e-3, 'dW from dheat')
 
 
 # ----------------------------------------------------------------------------------------------
