@@ -2,6 +2,7 @@
 calls without a GPU), config/attr-dict behaviour, network specs against the oracle, launch-table helpers."""
 import os
 import re
+import sys
 
 import pytest
 import torch
@@ -128,3 +129,24 @@ def test_split_inputs_is_an_even_batch_split():
     assert torch.equal(torch.cat([p['future_image'] for p in parts]), inp['future_image'])
     with pytest.raises(AssertionError):
         split_inputs(O.synthetic_inputs(3, 64), 2, 0)
+
+
+def test_ab_build_switches(tmp_path, monkeypatch):
+    """IMM_HIPCC_FLAGS (diagnosis builds) changes the source digest, so such a build is never mistaken for the production
+    library; IMM_HIP_LIB points the binding at another build of the same ABI (A/B timing on one box)."""
+    import shutil
+    import subprocess
+    from imm_amd import build as B
+    d0 = B.source_digest()
+    monkeypatch.setenv('IMM_HIPCC_FLAGS', '-DIMM_HDEEP_PROFILE')
+    assert B.source_digest() != d0
+    monkeypatch.delenv('IMM_HIPCC_FLAGS')
+    assert B.source_digest() == d0
+    other = str(tmp_path / 'libimm_other.so')
+    shutil.copy(B.LIB, other)
+    code = "from imm_amd import _lib as L; h = L.load(); print(L.LIB_PATH); print(h.imm_abi_version())"
+    env = dict(os.environ, IMM_HIP_LIB=other)
+    out = subprocess.run([sys.executable, '-c', code], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert out.returncode == 0, out.stderr.decode()[-1500:]
+    lines = out.stdout.decode().split()
+    assert lines[0] == other and int(lines[1]) == 14

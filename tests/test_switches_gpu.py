@@ -1,0 +1,67 @@
+"""Every IMM_* environment switch the product path still reads, exercised in both positions: the
+kernel-dispatch ablation list IMM_CONV_DISABLE (each specialised kernel family off -> the layer falls back to the next more
+general kernel, same numbers to accumulation order), IMM_TWO_STREAMS, IMM_DEBUG_STAMPS, IMM_DEBUG_SKIP_TAGS.  The switches are
+read once per process (static dispatch tables / engine construction), hence the child processes (tests/_switch_probe.py).
+IMM_DP_BUCKETS, IMM_RCCL_NATIVE and IMM_RCCL_GRAPH have their tests in test_dp_gpu.py / test_step_gpu.py; IMM_HIP_LIB and
+IMM_HIPCC_FLAGS (A/B builds) in test_host_cpu.py."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def probe(**env):
+    e = {k: v for k, v in os.environ.items() if not k.startswith('IMM_')}
+    e.update({k: str(v) for k, v in env.items()})
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', '_switch_probe.py')], env=e, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, timeout=280)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    line = [l for l in out.stdout.decode().splitlines() if l.startswith('PROBE ')][-1]
+    return json.loads(line[6:])
+
+
+@pytest.fixture(scope='module')
+def base():
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    return probe()
+
+
+def same(a, b, rel):
+    return all(abs(a[k] - b[k]) <= rel * abs(a[k]) for k in ('loss0', 'loss1', 'mu_abs_sum', 'params_abs_sum'))
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize('names', ['halo,halo2,hdeep,deepk', 'group,group32', 'wgrad_tr,wgrad_halo'])
+def test_conv_disable_falls_back_to_the_general_kernels(base, names):
+    """IMM_CONV_DISABLE: with the specialised kernels out of the dispatch every layer runs on the im2col / generic kernels —
+    the same step to accumulation order (loss 1e-4, parameters after two updates 1e-4 of their abs-sum)."""
+    got = probe(IMM_CONV_DISABLE=names)
+    assert same(base, got, 2e-4), (names, base, got)
+
+
+@pytest.mark.timeout(300)
+def test_single_stream_and_eager_equal_the_two_lane_graph(base):
+    """IMM_TWO_STREAMS=0 (one stream, no fork/join) and eager execution: the same launches in another schedule — bitwise."""
+    one = probe(IMM_TWO_STREAMS=0)
+    eager = probe(PROBE_GRAPH=0)
+    for got in (one, eager):
+        assert all(got[k] == base[k] for k in ('loss0', 'loss1', 'mu_abs_sum', 'params_abs_sum')), (base, got)
+
+
+@pytest.mark.timeout(300)
+def test_debug_stamps_and_skip_tags(base):
+    """IMM_DEBUG_STAMPS=all: a probe after every launch, monotone on the main lane, results untouched.
+    IMM_DEBUG_SKIP_TAGS (timing experiment; results become wrong by design): the tagged launches are gone from the step."""
+    st = probe(IMM_DEBUG_STAMPS='all', PROBE_GRAPH=0)
+    assert st['stamps'] > base['n_launches'] and st['stamps_monotone_lane0']
+    assert all(st[k] == base[k] for k in ('loss0', 'loss1', 'params_abs_sum'))
+    sk = probe(IMM_DEBUG_SKIP_TAGS='clip_adam,pack')
+    assert sk['step_count'] == 0 and base['step_count'] == 2                # no optimizer launch: the counters never moved
+    assert sk['loss0'] == base['loss0'] and sk['params_abs_sum'] != base['params_abs_sum']
