@@ -211,6 +211,9 @@ class TrainStep:
                 eng.backward()
                 average_gradients(eng.grads, self.world_size, self.group)
                 eng.optimizer_step()
+        # the returned loss (a view of the engine's result buffer) is consumed on the CALLER's stream: order that stream after
+        # this step (an event wait on the device, no host synchronisation)
+        torch.cuda.current_stream(eng.dev).wait_stream(self.stream)
         return eng.loss
 
     def _native_exchange(self, eng):

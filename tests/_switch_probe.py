@@ -19,6 +19,7 @@ inputs = O.synthetic_inputs(B, 128, seed=0)
 model = IMMModel(Box(dict(cfg)), dtype=torch.bfloat16, device='cuda:0')
 ts = TrainStep(model, B, 128, world_size=1, use_graph=os.environ.get('PROBE_GRAPH', '1') != '0')
 l0 = float(ts.step(inputs).clone())
+ts.synchronize()
 l1 = float(ts.step(None).clone())
 ts.synchronize()
 eng = ts.engine
