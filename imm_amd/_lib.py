@@ -59,6 +59,8 @@ _SIGS = {
     'imm_wgrad_reduce_multi': [_P, _P, _I, _I, _P],
     'imm_conv2d': [C.POINTER(ConvDesc), _I, _P, _P, _P, _P, _P, _P, _P],
     'imm_conv_stats_blocks': [C.POINTER(ConvDesc)],
+    'imm_conv2d_tap_supported': [C.POINTER(ConvDesc)],
+    'imm_conv2d_tap': [C.POINTER(ConvDesc), _I, _P, _P, _P, _P, _P, _I, _P, _I, _P, _I, _I, _P],
     'imm_conv2d_wgrad': [C.POINTER(ConvDesc), _I, _P, _P, _I, _P, _I, _P],
     'imm_conv2d_wgrad_splits': [C.POINTER(ConvDesc), _I],
     'imm_conv2d_wgrad_variant': [C.POINTER(ConvDesc), _I, _I, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)],

@@ -17,7 +17,13 @@ struct ConvArgs {
   int n_nblk, n_blocks;
   int oscale, ooff_y, ooff_x;   // output scatter (oscale 1 = dense)
   uint32_t x_bytes, wt_bytes;   // buffer-descriptor extents (fast path: out-of-range lanes read zeros)
+  // perceptual tap folded into a data gradient's epilogue (IMM_CONV_TAP_, conv_hdeep.hip only; imm_conv2d_tap)
+  const uint16_t* tap_gt;       // gt half of the tapped activation (geometry of y / mask)
+  const float* tap_lmask;       // loss mask f32 [batch, tap_S, tap_S] or NULL
+  const float* tap_coef;        // device table of gradient coefficients
+  int tap_idx, tap_S, tap_l1;
 };
+#define IMM_CONV_TAP_ 0x20      // internal flag bit (set by imm_conv2d_tap only)
 
 
 // Several convolutions of the same tile shape in ONE launch (conv_igemm64.hip / conv_igemm.hip group kernels): workgroup b

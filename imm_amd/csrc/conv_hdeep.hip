@@ -418,7 +418,42 @@ __global__ __launch_bounds__(NW * 64) void conv_hdeep_kernel(const HdArgs ha) {
   typedef short s16x2_t __attribute__((ext_vector_type(2)));
   typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
   const s16x2_t zero2 = {0, 0}, one2 = {1, 1};
-  if (!f_stats && rows_exist) {
+  if ((a.flags & IMM_CONV_TAP_) && rows_exist) {
+    // ---- perceptual tap (imm_conv2d_tap): v = acc + c_k * lossmask[pixel] * (a_pred - a_gt), zero where a_pred <= 0 -----
+    const float ck = a.tap_coef[a.tap_idx];
+    const int hw = a.ho * a.wo, rr = a.tap_lmask ? a.tap_S / a.ho : 1;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int64_t m = m_first + i * m_step;
+      float cm = ck;
+      if (a.tap_lmask) {
+        const int im = (int)(m / hw), rem = (int)(m - (int64_t)im * hw);
+        const int yy = rem / a.wo, xx = rem - yy * a.wo;
+        cm *= a.tap_lmask[((int64_t)im * a.tap_S + (int64_t)yy * rr) * a.tap_S + (int64_t)xx * rr];
+      }
+#pragma unroll
+      for (int h = 0; h < NT / 2; ++h) {
+        float v[8], fp[8], fg[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int j = 2 * h + (e >> 1), r = (e & 1) * 2;
+          v[2 * e] = acc[i][j][r]; v[2 * e + 1] = acc[i][j][r + 1];
+        }
+        unpack8<ET>(*(const uint4*)(a.mask + m * a.ldmask + nb + 8 * h), fp);
+        unpack8<ET>(*(const uint4*)(a.tap_gt + m * a.ldmask + nb + 8 * h), fg);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float d = fp[e] - fg[e];
+          if (a.tap_l1) d = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+          // the separate pass rounds the incoming gradient to 16 bits before adding the tap term: same here (bitwise equal)
+          float t = ET::to_f32(ET::from_f32(v[e])) + cm * d;
+          if (!(fp[e] > 0.f)) t = 0.f;
+          v[e] = t;
+        }
+        *(uint4*)((uint16_t*)a.y + m * a.ldy + nb + 8 * h) = pack8<ET>(v);
+      }
+    }
+  } else if (!f_stats && rows_exist) {
     // ---- plain / masked store: ~12 (+12 with the mask) VALU per 8 outputs --------------------------------------------
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
@@ -590,7 +625,7 @@ bool imm_hdeep_applicable(const imm_conv_desc* d) {
   if (off) return false;
   if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->updiv != 1 || d->pad_t != 1 || d->pad_l != 1) return false;
   if (d->ci % 64 || d->co % 64 || d->ci < 64) return false;
-  if (d->out_scale > 1 || (d->flags & (IMM_CONV_OUT_F32 | 0xf00))) return false;
+  if (d->out_scale > 1 || (d->flags & (IMM_CONV_OUT_F32 | 0xf00))) return false;   // (bit 0x20 = IMM_CONV_TAP_ is this kernel's own)
   if (d->hi != d->ho || d->wi != d->wo || d->ho % 8 || (d->wo % HD_PW && !(d->ho == 8 && d->wo == 8))) return false;
   if (d->ldy % 8 || ((d->flags & IMM_CONV_MASK) && d->ldmask % 8)) return false;
   const int64_t px = (int64_t)d->batch * d->hi * d->wi;

@@ -305,6 +305,7 @@ static void fill_args(ConvArgs& a, const imm_conv_desc* d, const void* x, const 
   a.kpad = d->kpad; a.KT = d->kpad / 32; a.ntaps = d->kh * d->kw;
   a.flags = d->flags; a.ldmask = d->ldmask;
   a.oscale = d->out_scale > 1 ? d->out_scale : 1; a.ooff_y = d->out_off_y; a.ooff_x = d->out_off_x;
+  a.tap_gt = nullptr; a.tap_lmask = nullptr; a.tap_coef = nullptr; a.tap_idx = 0; a.tap_S = 0; a.tap_l1 = 0;
 }
 
 template <typename ET>
@@ -353,6 +354,37 @@ extern "C" int imm_conv2d(const imm_conv_desc* d, int dtype, const void* x, cons
   IMM_REQUIRE(!(d->flags & IMM_CONV_MASK) || (mask_ref && d->ldmask >= d->co), "conv: mask flag without mask/ldmask");
   IMM_REQUIRE(((uintptr_t)x % 16 == 0) && ((uintptr_t)wt % 16 == 0) && ((uintptr_t)y % 16 == 0), "conv: 16-byte alignment");
   IMM_DISPATCH_DTYPE(dtype, return conv_launch<ET>(d, x, wt, bias, y, stats_partial, mask_ref, (hipStream_t)stream));
+  return 0;
+}
+
+// Data gradient entering a TAPPED activation of the frozen VGG16 (imm_model.py:142-147: conv3_2, conv4_2 sit in the middle of the
+// network): the feature-loss term and the tapped layer's ReLU backward in the epilogue of the data gradient that produces the
+// incoming gradient, instead of a separate pass over it (imm_tap_grad: read da, a_pred, a_gt, write da).  LDS-halo deep-K kernel only.
+extern "C" int imm_conv2d_tap_supported(const imm_conv_desc* d) {
+  if (!d || validate_desc(d)) return 0;
+  if (d->flags & (IMM_CONV_BIAS | IMM_CONV_RELU | IMM_CONV_STATS | IMM_CONV_MASK | IMM_CONV_OUT_F32 | 0xfe0)) return 0;
+  if (imm_halo2_applicable(d) || imm_halo_applicable(d)) return 0;
+  return imm_hdeep_applicable(d) && d->co % 8 == 0 ? 1 : 0;
+}
+
+extern "C" int imm_conv2d_tap(const imm_conv_desc* d, int dtype, const void* x, const void* wt, void* y, const void* a_pred,
+                              const void* a_gt, int lda, const float* loss_mask, int S, const float* coef, int idx, int l1,
+                              void* stream) {
+  IMM_REQUIRE(d && x && wt && y && a_pred && a_gt && coef && idx >= 0, "conv_tap: null");
+  if (!imm_conv2d_tap_supported(d)) return imm_fail(IMM_E_UNSUPPORTED, "conv_tap: shape not served by the LDS-halo deep-K kernel");
+  IMM_REQUIRE(lda >= d->co && lda % 8 == 0, "conv_tap: lda=%d (co=%d) must be a multiple of 8", lda, d->co);
+  IMM_REQUIRE(loss_mask == nullptr || (S >= d->ho && S % d->ho == 0 && d->ho == d->wo), "conv_tap: mask side");
+  IMM_REQUIRE(((uintptr_t)x % 16 == 0) && ((uintptr_t)wt % 16 == 0) && ((uintptr_t)y % 16 == 0) && ((uintptr_t)a_pred % 16 == 0) &&
+                  ((uintptr_t)a_gt % 16 == 0), "conv_tap: 16-byte alignment");
+  IMM_REQUIRE(dtype == IMM_BF16 || dtype == IMM_F16, "unknown dtype %d", dtype);
+  imm_conv_desc dd = *d;
+  dd.ldmask = lda;
+  ConvArgs a;
+  fill_args(a, &dd, x, wt, nullptr, y, nullptr, a_pred);
+  a.flags |= IMM_CONV_TAP_;
+  a.tap_gt = (const uint16_t*)a_gt; a.tap_lmask = loss_mask; a.tap_coef = coef; a.tap_idx = idx; a.tap_S = S; a.tap_l1 = l1;
+  imm_conv_hdeep_launch(dtype, &dd, a, (hipStream_t)stream);
+  IMM_CHECK_LAUNCH("imm_conv2d_tap");
   return 0;
 }
 

@@ -798,16 +798,29 @@ class IMMEngine:
             self._add(self.prog_bwd, lambda: ops.tap_grad(dbuf[name], has_in, y[B:], y[:B], B, H, c, mask, S, self.coef,
                                                           taps[name], True, l1), 'tap_grad', 0.0, B * H * H * c * 8.0)
 
-        def dgrad(name, dst, mask_ref):
-            """conv `name`: dz(name) -> gradient w.r.t. its input written to dst (masked by mask_ref>0 if given)."""
+        fused_taps = set()
+
+        def dgrad(name, dst, mask_ref, tap_of=None):
+            """conv `name`: dz(name) -> gradient w.r.t. its input written to dst (masked by mask_ref>0 if given).  tap_of: the
+            input IS a tapped activation: its feature-loss term and ReLU backward go into this launch's epilogue
+            (imm_conv2d_tap) when the kernel that takes the shape has that epilogue, instead of a pass of their own."""
             cin, cout = [(ci, co) for n, ci, co in VGG_LAYERS if n == name][0]
             H = acts[name][1]
-            flags = L.CONV_MASK if mask_ref is not None else 0
-            dd = ops.dgrad_desc(B, H, H, cin, cin, cout, cout, 3, 1, flags, ldmask=cin)
             wtd = self.vgg_wtd[name]
             src = dbuf[name]
-            self._add(self.prog_bwd, lambda: ops.conv2d(dd, src, wtd, None, dst, None, mask_ref), 'vgg_dgrad',
-                      2.0 * B * H * H * 9 * cin * cout,
+            flops = 2.0 * B * H * H * 9 * cin * cout
+            if tap_of is not None:
+                dt0 = ops.dgrad_desc(B, H, H, cin, cin, cout, cout, 3, 1, 0)
+                if ops.conv2d_tap_supported(dt0):
+                    ya = acts[tap_of][0]
+                    self._add(self.prog_bwd, lambda: ops.conv2d_tap(dt0, src, wtd, dst, ya[B:], ya[:B], cin, mask, S, self.coef,
+                                                                    taps[tap_of], l1), 'vgg_dgrad', flops,
+                              2.0 * (B * H * H * (3 * cin + cout) + 9 * cin * cout), name='vgg16/%s+tap(%s)' % (name, tap_of))
+                    fused_taps.add(tap_of)
+                    return
+            flags = L.CONV_MASK if mask_ref is not None else 0
+            dd = ops.dgrad_desc(B, H, H, cin, cin, cout, cout, 3, 1, flags, ldmask=cin)
+            self._add(self.prog_bwd, lambda: ops.conv2d(dd, src, wtd, None, dst, None, mask_ref), 'vgg_dgrad', flops,
                       2.0 * (B * H * H * (cin + cout + (cin if mask_ref is not None else 0)) + 9 * cin * cout), name='vgg16/' + name)
 
         def unpool(src_name, dy, relu_mask):
@@ -838,12 +851,14 @@ class IMMEngine:
                     unpool_tap(name, dpool[name])
                 else:
                     unpool(name, dpool[name], 1)
-            elif name in taps:
+            elif name in taps and name not in fused_taps:
                 tap(name, not deepest)
             if prev in self.vgg_pool:
                 dgrad(name, dpool[prev], None)
+            elif prev in taps:
+                dgrad(name, dbuf[prev], None, tap_of=prev)
             else:
-                dgrad(name, dbuf[prev], None if prev in taps else pred_half(acts[prev][0]))
+                dgrad(name, dbuf[prev], pred_half(acts[prev][0]))
         # first layer + 'input' feature -> gradient of the renderer's last convolution
         last = self.ren[-1]
         self.d_pred = self._act(B, S, S, last.lddy)

@@ -150,6 +150,15 @@ def conv2d(desc, x, wt, bias, y, stats=None, mask=None):
     call('imm_conv2d', C.byref(desc), dtype_enum(x.dtype), _p(x), _p(wt), _p(bias), _p(y), _p(stats), _p(mask), _s())
 
 
+def conv2d_tap_supported(desc):
+    return bool(L.load().imm_conv2d_tap_supported(C.byref(desc)))
+
+
+def conv2d_tap(desc, x, wt, y, a_pred, a_gt, lda, loss_mask, S, coef, idx, l1=False):
+    call('imm_conv2d_tap', C.byref(desc), dtype_enum(x.dtype), _p(x), _p(wt), _p(y), _p(a_pred), _p(a_gt), lda, _p(loss_mask), S,
+         _p(coef), idx, int(l1), _s())
+
+
 def conv_stats_blocks(desc):
     n = L.load().imm_conv_stats_blocks(C.byref(desc))
     if n <= 0:

@@ -122,6 +122,15 @@ int imm_conv2d_group_stats_blocks(const imm_conv_desc* descs, int n);
 int imm_conv2d(const imm_conv_desc* desc_host, int dtype, const void* x, const void* wt, const float* bias,
                void* y, float* stats_partial, const void* mask_ref, void* stream);
 int imm_conv_stats_blocks(const imm_conv_desc* desc_host);
+/* imm_conv2d of a data gradient (no bias / ReLU / statistics) that ENTERS a tapped activation of the frozen VGG16 (conv3_2, conv4_2 of
+ * imm_model.py:124-147), with the perceptual tap folded into its epilogue:
+ *     y = [a_pred > 0] * ( round16(conv) + coef[idx] * loss_mask[pixel] * (a_pred - a_gt) )        (sign(a_pred - a_gt) with l1)
+ * = imm_conv2d followed by imm_tap_grad(has_in = 1, relu = 1), bit for bit, without the extra pass over y.  a_pred / a_gt: the two
+ * halves of the tapped activation, geometry of y, pixel stride lda; loss_mask f32 [batch,S,S] or NULL.  Served by the LDS-halo
+ * deep-K kernel only: imm_conv2d_tap_supported(desc) != 0, else IMM_E_UNSUPPORTED (issue the two calls instead). */
+int imm_conv2d_tap_supported(const imm_conv_desc* desc_host);
+int imm_conv2d_tap(const imm_conv_desc* desc_host, int dtype, const void* x, const void* wt, void* y, const void* a_pred,
+                   const void* a_gt, int lda, const float* loss_mask, int S, const float* coef, int idx, int l1, void* stream);
 /* Filter gradient: slab[split][kpad][co] f32 partials over `nsplit` pixel ranges, then
  * imm_conv2d_wgrad_reduce sums the slabs into the HWIO f32 gradient [kh,kw,ci_real,co]
  * (tf.gradients of nn_utils.py:100 w.r.t. `w`).  desc describes the FORWARD convolution. */

@@ -215,6 +215,36 @@ def test_conv_dgrad_stride2_parity_classes(ops, H, ci, co, dt):
     close(dx, gx, 1e-2, 2e-3, 'dgrad_s2_classes')       # every pixel written exactly once (no NaN left)
 
 
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16], ids=['bf16', 'f16'])
+@pytest.mark.parametrize('B,H,cin,cout,l1', [(32, 16, 512, 512, False), (8, 32, 256, 256, False), (4, 32, 256, 256, True),
+                                              (33, 8, 512, 512, False)],
+                         ids=['vgg4_3_into_4_2', 'vgg3_3_into_3_2', 'l1', 'map8_odd_batch'])
+def test_conv_dgrad_with_tap_epilogue(ops, B, H, cin, cout, l1, dt):
+    """imm_conv2d_tap == imm_conv2d (data gradient) followed by imm_tap_grad(has_in, relu), bit for bit: the perceptual tap of
+    conv3_2 / conv4_2 (imm_model.py:142-147) in the epilogue of the data gradient that enters the tapped layer."""
+    S = 128
+    w = rnd((3, 3, cin, cout), 171, 0.02, dt)
+    dz = rnd((B, H, H, cout), 172, 1e-3, dt).to(DEV).contiguous()
+    act = rnd((2 * B, H, H, cin), 173, 1.0, dt).to(DEV).contiguous()          # [gt ; pred] halves of the tapped activation
+    mask = torch.rand(B, S, S, device=DEV)
+    coef = torch.tensor([0.0, 3.7e-4, 0.0], device=DEV)
+    desc = ops.dgrad_desc(B, H, H, cin, cin, cout, cout, 3, 1, 0)
+    assert ops.conv2d_tap_supported(desc)
+    wt = torch.zeros(ops.round_up(cin, 128), desc.kpad, dtype=dt, device=DEV)
+    ops.pack_weights(w.float().to(DEV).contiguous(), wt, 1, 3, 3, cin, cout, cout, wt.shape[0], desc.kpad)
+    for mk in (mask, None):
+        ref = torch.full((B, H, H, cin), float('nan'), dtype=dt, device=DEV)
+        ops.conv2d(desc, dz, wt, None, ref)
+        ops.tap_grad(ref, True, act[B:], act[:B], B, H, cin, mk, S, coef, 1, True, l1)
+        got = torch.full_like(ref, float('nan'))
+        ops.conv2d_tap(desc, dz, wt, got, act[B:], act[:B], cin, mk, S, coef, 1, l1)
+        torch.cuda.synchronize()
+        assert torch.equal(got, ref), float((got.float() - ref.float()).abs().max())
+        assert float(got.float().abs().max()) > 0
+    # shapes the LDS-halo deep-K kernel does not take are refused (the caller issues the two launches)
+    assert not ops.conv2d_tap_supported(ops.dgrad_desc(2, 16, 16, 32, 32, 32, 32, 3, 1, 0))
+
+
 # ----------------------------------------------------------------------------------------------
 # filter gradient
 # ----------------------------------------------------------------------------------------------
