@@ -100,23 +100,26 @@ extern "C" int imm_pack_weights_multi(const int64_t* jobs, const int32_t* blk_fi
   return 0;
 }
 
-// job: {slab, dw, nsplit, ntaps, ci_pad, ci_real, co, kpad, 0...}; 64 outputs per workgroup: 16 lanes of 4 consecutive
-// outputs x 16 split lanes (each sums every 16th slab, 16-byte loads), then a fixed-order LDS reduction over the
-// split lanes -> the per-lane dependent chain is nsplit/16 loads instead of nsplit (the kernel is latency-, not
-// bandwidth-bound: up to 512 slabs per tensor).
+// job: {slab, dw, nsplit, ntaps, ci_pad, ci_real, co, kpad, lanes, 0...}.  A workgroup = 256/lanes quads of 4 consecutive
+// outputs x `lanes` split lanes (lane sl sums the slabs sl, sl + lanes, ...; 16-byte loads), then a fixed-order LDS reduction
+// over the split lanes: the per-lane dependent chain is nsplit/lanes loads (the kernel is latency-, not bandwidth-bound).
+// lanes in {1, 2, 4, 8, 16} (0 = 16) is the caller's choice per job, about the split count: since the multi-problem filter-
+// gradient launches most layers have 1-8 slabs, and 16 split lanes left 15/16 of every workgroup idle (64 k workgroups of 16
+// live threads each for a step's gradients: 74 us).  Workgroups per job = ceil(outputs / (1024 / lanes)).
 __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const int64_t* __restrict__ jobs,
                                                                 const int32_t* __restrict__ blk_first, int n_jobs) {
-  __shared__ float4 red[16][17];
+  __shared__ float4 red[256 + 16];
   const int j = find_job(blk_first, n_jobs, blockIdx.x);
   const int64_t* jb = jobs + (int64_t)j * MULTI_FIELDS;
   const float* __restrict__ slab = (const float*)jb[0];
   float* __restrict__ dw = (float*)jb[1];
   const int nsplit = (int)jb[2], ntaps = (int)jb[3], ci_pad = (int)jb[4], ci_real = (int)jb[5], co = (int)jb[6];
   const int kpad = (int)jb[7];
+  const int SL = (int)jb[8] > 0 ? (int)jb[8] : 16, QL = 256 / SL;
   const int64_t total = (int64_t)ntaps * ci_real * co;
   const int64_t sstride = (int64_t)kpad * co;
-  const int ql = threadIdx.x & 15, sl = threadIdx.x >> 4;
-  const int64_t idx = ((int64_t)(blockIdx.x - blk_first[j]) * 16 + ql) * 4;
+  const int ql = threadIdx.x % QL, sl = threadIdx.x / QL;
+  const int64_t idx = ((int64_t)(blockIdx.x - blk_first[j]) * QL + ql) * 4;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   const bool vec = (co & 3) == 0;
   if (idx < total) {
@@ -127,8 +130,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const int64_t* 
       const float* sp = slab + ((int64_t)tap * ci_pad + c) * co + n;
       float4 a1 = make_float4(0.f, 0.f, 0.f, 0.f);
       int s = sl;
-      for (; s + 16 < nsplit; s += 32) {
-        const float4 v0 = *(const float4*)(sp + (int64_t)s * sstride), v1 = *(const float4*)(sp + (int64_t)(s + 16) * sstride);
+      for (; s + SL < nsplit; s += 2 * SL) {
+        const float4 v0 = *(const float4*)(sp + (int64_t)s * sstride), v1 = *(const float4*)(sp + (int64_t)(s + SL) * sstride);
         acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
         a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
       }
@@ -147,21 +150,26 @@ __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const int64_t* 
         const int c = (int)(tc % ci_real), tap = (int)(tc / ci_real);
         const float* sp = slab + ((int64_t)tap * ci_pad + c) * co + n;
         float t = 0.f;
-        for (int s = sl; s < nsplit; s += 16) t += sp[s * sstride];
+        for (int s = sl; s < nsplit; s += SL) t += sp[s * sstride];
         ap[e] = t;
       }
     }
   }
-  red[sl][ql] = acc;
-  __syncthreads();
+  if (SL > 1) {
+    red[sl * (QL + 1) + ql] = acc;
+    __syncthreads();
+    if (sl == 0 && idx < total) {
+      for (int s = 1; s < SL; ++s) { const float4 v = red[s * (QL + 1) + ql]; acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+    }
+  }
   if (sl == 0 && idx < total) {
-    float4 t = red[0][ql];
-#pragma unroll
-    for (int s = 1; s < 16; ++s) { const float4 v = red[s][ql]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
-    dw[idx] = t.x;
-    if (idx + 1 < total) dw[idx + 1] = t.y;
-    if (idx + 2 < total) dw[idx + 2] = t.z;
-    if (idx + 3 < total) dw[idx + 3] = t.w;
+    if (idx + 3 < total && ((uintptr_t)(dw + idx) & 15) == 0) *(float4*)(dw + idx) = acc;
+    else {
+      dw[idx] = acc.x;
+      if (idx + 1 < total) dw[idx + 1] = acc.y;
+      if (idx + 2 < total) dw[idx + 2] = acc.z;
+      if (idx + 3 < total) dw[idx + 3] = acc.w;
+    }
   }
 }
 

@@ -909,7 +909,7 @@ class IMMEngine:
                 self._add(self.prog_bwd, fn, 'colsum', name=scope)
             self._colsum_pending = []
             self._flush_wgrads('renderer')
-            self.reduce_tab_ren = ops.JobTable([j for j, _n in self._reduce_jobs], [n for _j, n in self._reduce_jobs], 64, self.dev)
+            self.reduce_tab_ren = ops.reduce_table([j for j, _n in self._reduce_jobs], [n for _j, n in self._reduce_jobs], self.dev)
             self._add(self.prog_bwd, lambda: ops.wgrad_reduce_multi(self.reduce_tab_ren), 'wgrad_reduce', name='renderer')
             self._reduce_jobs = []
             self.n_bwd_bucket0 = len(self.prog_bwd)
@@ -963,7 +963,7 @@ class IMMEngine:
         self._flush_wgrads('encoders' if self.n_bwd_bucket0 is not None else 'all layers')
         # one table-driven launch sums every layer's split-K slabs into the flat gradient buffer
         if self._reduce_jobs:
-            self.reduce_tab = ops.JobTable([j for j, _n in self._reduce_jobs], [n for _j, n in self._reduce_jobs], 64, self.dev)
+            self.reduce_tab = ops.reduce_table([j for j, _n in self._reduce_jobs], [n for _j, n in self._reduce_jobs], self.dev)
             self._add(self.prog_bwd, lambda: ops.wgrad_reduce_multi(self.reduce_tab), 'wgrad_reduce',
                       name='encoders' if self.n_bwd_bucket0 is not None else 'all layers')
 

@@ -142,6 +142,19 @@ def pack_weights_multi(tab, dtype):
     call('imm_pack_weights_multi', _p(tab.jobs), _p(tab.blk_first), tab.n_jobs, tab.n_blocks, dtype_enum(dtype), _s())
 
 
+def reduce_table(jobs, outputs_per_job, device):
+    """Job table of imm_wgrad_reduce_multi: jobs = (slab, dw, nsplit, taps, ci_pad, ci_real, co, kpad) tuples; the split-lane
+    count of a job (field 8) is the power of two next to its slab count, capped at 16."""
+    rows, blocks = [], []
+    for j, n in zip(jobs, outputs_per_job):
+        lanes = 1
+        while lanes < min(16, int(j[2])):
+            lanes *= 2
+        rows.append(tuple(j[:8]) + (lanes,))
+        blocks.append(max(1, -(-int(n) // (1024 // lanes))))
+    return JobTable(rows, None, None, device, blocks_per_job=blocks)
+
+
 def wgrad_reduce_multi(tab):
     call('imm_wgrad_reduce_multi', _p(tab.jobs), _p(tab.blk_first), tab.n_jobs, tab.n_blocks, _s())
 

@@ -94,7 +94,8 @@ int imm_pack_weights(const float* w, void* wt, int dtype, int mode, int kh, int 
 /* Table-driven variants: ONE launch re-packs / reduces every tensor of a step.  jobs: device int64[n_jobs][12];
  * pack job  = {w, wt, mode, kh, kw, ci_real, co_real, c_pad, rows, kpad, 0, 0}  (imm_pack_weights_multi_blocks workgroups:
  *             mode 0 = 32 x 64 tiles transposed through LDS, the other modes 256*8 consecutive elements per workgroup)
- * reduce job = {slab, dw, nsplit, kh*kw, ci_pad, ci_real, co, kpad, 0, 0, 0, 0}   (64 outputs per workgroup)
+ * reduce job = {slab, dw, nsplit, kh*kw, ci_pad, ci_real, co, kpad, lanes, 0, 0, 0}   (1024/lanes outputs per workgroup; lanes =
+ *             split lanes that share the slabs of an output, a power of two <= 16, 0 = 16: choose it about nsplit)
  * blk_first: device int32[n_jobs+1] prefix sums of workgroups per job; n_blocks = blk_first[n_jobs]. */
 int imm_pack_weights_multi_blocks(int mode, int rows, int kpad);
 int imm_pack_weights_multi(const int64_t* jobs, const int32_t* blk_first, int n_jobs, int n_blocks, int dtype,

@@ -403,18 +403,22 @@ def test_table_driven_pack_and_reduce(ops):
     for _w, wt, wt_ref in refs:
         assert torch.equal(wt.view(torch.int16), wt_ref.view(torch.int16))
     jobs, items, refs = [], [], []
-    for k, ci_real, ci_pad, co, nsplit in [(3, 32, 32, 32, 5), (7, 3, 8, 32, 3), (3, 266, 288, 256, 2), (1, 256, 256, 10, 1)]:
+    for k, ci_real, ci_pad, co, nsplit in [(3, 32, 32, 32, 5), (7, 3, 8, 32, 3), (3, 266, 288, 256, 2), (1, 256, 256, 10, 1),
+                                           (3, 64, 64, 64, 1), (3, 32, 32, 9, 54), (3, 128, 128, 128, 16), (1, 1, 1, 10, 32)]:
         kpad = ops.round_up(k * k * ci_pad, 32)
         slab = rnd((nsplit, kpad, co), 200 + co, 1.0, torch.float32).to(DEV).contiguous()
         dw_ref = torch.empty(k, k, ci_real, co, device=DEV); dw = torch.full((k, k, ci_real, co), float('nan'), device=DEV)
         ops.conv2d_wgrad_reduce(slab, nsplit, k, k, ci_pad, ci_real, co, kpad, dw_ref)
         jobs.append((slab.data_ptr(), dw.data_ptr(), nsplit, k * k, ci_pad, ci_real, co, kpad)); items.append(k * k * ci_real * co)
         refs.append((slab, dw, dw_ref))
-    tab = ops.JobTable(jobs, items, 64, DEV)
-    ops.wgrad_reduce_multi(tab)
-    torch.cuda.synchronize()
-    for _s, dw, dw_ref in refs:
-        close(dw, dw_ref, 1e-6, 1e-6, 'wgrad_reduce_multi')      # 4 interleaved partial sums vs a serial sum
+    # split lanes per job chosen about its slab count (1 .. 16), and the all-16 form of rounds 1-2
+    for tab in (ops.reduce_table(jobs, items, DEV), ops.JobTable(jobs, items, 64, DEV)):
+        for _s, dw, _r in refs:
+            dw.fill_(float('nan'))
+        ops.wgrad_reduce_multi(tab)
+        torch.cuda.synchronize()
+        for _s, dw, dw_ref in refs:
+            close(dw, dw_ref, 1e-6, 1e-6, 'wgrad_reduce_multi')      # interleaved partial sums vs a serial sum
 
 
 def test_colsum(ops):
