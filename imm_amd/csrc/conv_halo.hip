@@ -44,18 +44,29 @@ struct HaloArgs {
   int n_patches, patches_x, patches_y;    // per image: patches_x * patches_y
 };
 
-template <typename ET, int CI, int BN>
+// S2: 3x3 STRIDE-2 forward (encoder conv_3: 32 -> 64 channels at 128^2 -> 64^2, imm_model.py:197; TF SAME on an even side pads
+// bottom / right only).  An 8x16 output patch reads a 17x33 input halo; it is stored PARITY-DE-INTERLEAVED — four
+// planes (row parity, column parity) of 9 x 17 pixels, padded to 160 — so that tap (ky,kx) of output pixel (y,x), source pixel
+// (2y+ky, 2x+kx), is pixel (y + ky/2, x + kx/2) of plane (ky&1, kx&1): the 16 lanes of an MFMA operand row read 16 CONSECUTIVE
+// LDS pixels exactly as in the stride-1 form (a stride of two 64-byte pixels would put all of them on the same banks).  The
+// im2col kernel it replaces gathered every input pixel 2.25x through L2 and spent its 9 short K-steps in load latency
+// (30 us per encoder for 4.8 GFLOP); here the halo arrives once by DMA, two patches ahead.
+#define HALO_S2_PW 17            // plane width  (33 columns -> 17 even + 16 odd)
+#define HALO_S2_PP 160           // plane pitch in pixels (9 x 17 = 153, padded)
+#define HALO_S2_HP 640           // 4 planes
+template <typename ET, int CI, int BN, bool S2 = false>
 __global__ __launch_bounds__(256) void conv_halo_kernel(const HaloArgs ha) {
   const ConvArgs& a = ha.c;
+  constexpr int HP = S2 ? HALO_S2_HP : HALO_HP;    // halo pixels per stage
   constexpr int C8 = CI / 8;                       // 16-byte chunks per pixel / filter row
   constexpr int KS = CI / 32;                      // MFMA k-steps per tap
   constexpr int WGM = (BN == 64) ? 2 : 4, WGN = 4 / WGM;
   constexpr int TM = 128 / WGM, TN = BN / WGN, MT = TM / 16, NT = TN / 16;
   constexpr int PIX_PER_DMA = 64 / C8;             // pixels (or filter rows) per 1-KB DMA instruction
-  constexpr int HALO_DMA = HALO_HP / PIX_PER_DMA;  // instructions per halo tile (24 / 12)
+  constexpr int HALO_DMA = HP / PIX_PER_DMA;       // instructions per halo tile (24 / 12; stride 2: 40)
   constexpr int W_DMA = 9 * BN / PIX_PER_DMA;      // instructions for the whole filter
   constexpr int W_U4 = 9 * BN * C8;                // uint4 of the filter image
-  constexpr int H_U4 = HALO_HP * C8;               // uint4 per halo stage
+  constexpr int H_U4 = HP * C8;                    // uint4 per halo stage
   extern __shared__ __attribute__((aligned(16))) uint4 smem[];   // [W_U4] filter | [2][H_U4] halo tiles
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -83,10 +94,19 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const HaloArgs ha) {
     const int y0 = (pr / ha.patches_x) * HALO_PH, x0 = (pr % ha.patches_x) * HALO_PW;
     const uint32_t soff = (uint32_t)(img * a.hi * a.wi) * (uint32_t)(a.ldx * 2);
     for (int i = wid; i < HALO_DMA; i += 4) {
-      const int hp = i * PIX_PER_DMA + lane / C8;        // halo pixel index 0..191
-      const int hy = hp / HALO_HW, hx = hp - hy * HALO_HW;
-      const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
-      const bool ok = (hp < (HALO_PH + 2) * HALO_HW) && ((unsigned)iy < (unsigned)a.hi) && ((unsigned)ix < (unsigned)a.wi);
+      const int hp = i * PIX_PER_DMA + lane / C8;        // halo pixel index 0..191 (stride 2: 0..639)
+      int iy, ix;
+      bool ok;
+      if constexpr (S2) {
+        const int plane = hp / HALO_S2_PP, rem = hp - plane * HALO_S2_PP;
+        const int pi = rem / HALO_S2_PW, pj = rem - pi * HALO_S2_PW;
+        iy = 2 * (y0 + pi) + (plane >> 1); ix = 2 * (x0 + pj) + (plane & 1);
+        ok = rem < 9 * HALO_S2_PW && iy < a.hi && ix < a.wi;
+      } else {
+        const int hy = hp / HALO_HW, hx = hp - hy * HALO_HW;
+        iy = y0 - 1 + hy; ix = x0 - 1 + hx;
+        ok = (hp < (HALO_PH + 2) * HALO_HW) && ((unsigned)iy < (unsigned)a.hi) && ((unsigned)ix < (unsigned)a.wi);
+      }
       const int sc = (lane % C8) ^ halo_swz<C8>(hp);
       const uint32_t vo = ok ? (uint32_t)((iy * a.wi + ix) * a.ldx * 2 + sc * 16) : OOB;
       halo_dma16(xr, __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)((W_U4 + stage * H_U4) * 16 + i * 1024)), vo, soff);
@@ -139,7 +159,8 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const HaloArgs ha) {
         uint4 af[MT], bf[NT];
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
-          const int hp = (wm * MT + i + ky) * HALO_HW + frow + kx;
+          const int hp = S2 ? ((ky & 1) * 2 + (kx & 1)) * HALO_S2_PP + (wm * MT + i + (ky >> 1)) * HALO_S2_PW + frow + (kx >> 1)
+                            : (wm * MT + i + ky) * HALO_HW + frow + kx;
           af[i] = Hl[hp * C8 + ((ks * 4 + fchunk) ^ halo_swz<C8>(hp))];
         }
 #pragma unroll
@@ -267,9 +288,16 @@ static int halo_num_cu() {
   return g_halo_cu;
 }
 
+static bool halo_is_s2(const imm_conv_desc* d) {
+  return d->kh == 3 && d->kw == 3 && d->stride == 2 && d->updiv == 1 && d->pad_t == 0 && d->pad_l == 0 && d->ci == 32 &&
+         d->co > 32 && d->co <= 64 && d->hi == 2 * d->ho && d->wi == 2 * d->wo && d->ho % HALO_PH == 0 && d->wo % HALO_PW == 0 &&
+         d->ho * d->wo >= 32 * 32 && d->out_scale <= 1 && !(d->flags & (0xf00 | IMM_CONV_MASK)) && d->kpad == 9 * d->ci;
+}
+
 bool imm_halo_applicable(const imm_conv_desc* d) {
   static const bool off = imm_conv_disabled("halo");
   if (off) return false;
+  if (halo_is_s2(d)) return (int64_t)d->batch * d->hi * d->wi * d->ldx * 2 < (1LL << 31);
   if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->updiv != 1 || d->pad_t != 1 || d->pad_l != 1) return false;
   if (d->ci != 32 && d->ci != 64) return false;
   if (d->out_scale > 1) return false;
@@ -282,11 +310,11 @@ bool imm_halo_applicable(const imm_conv_desc* d) {
 }
 
 static int halo_bn(int co) { return co > 32 ? 64 : co > 16 ? 32 : 16; }
-static size_t halo_lds(int ci, int bn) { return (size_t)(9 * bn * (ci / 8) + 2 * HALO_HP * (ci / 8)) * 16; }
+static size_t halo_lds(int ci, int bn, bool s2 = false) { return (size_t)(9 * bn * (ci / 8) + 2 * (s2 ? HALO_S2_HP : HALO_HP) * (ci / 8)) * 16; }
 
 int imm_halo_grid(const imm_conv_desc* d) {
   const int n_patches = d->batch * (d->ho / HALO_PH) * (d->wo / HALO_PW);
-  const size_t lds = halo_lds(d->ci, halo_bn(d->co));
+  const size_t lds = halo_lds(d->ci, halo_bn(d->co), halo_is_s2(d));
   int per_cu = (int)((160 * 1024) / lds);
   if (per_cu > 4) per_cu = 4;
   if (per_cu < 1) per_cu = 1;
@@ -294,15 +322,15 @@ int imm_halo_grid(const imm_conv_desc* d) {
   return n_patches < grid ? n_patches : grid;
 }
 
-template <typename ET, int CI, int BN>
+template <typename ET, int CI, int BN, bool S2 = false>
 static void halo_launch_cfg(const HaloArgs& ha, int grid, hipStream_t s) {
-  const size_t lds = halo_lds(CI, BN);
+  const size_t lds = halo_lds(CI, BN, S2);
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {
-    (void)hipFuncSetAttribute((const void*)conv_halo_kernel<ET, CI, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)conv_halo_kernel<ET, CI, BN, S2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_halo_kernel<ET, CI, BN>), dim3(grid), dim3(256), lds, s, ha);
+  hipLaunchKernelGGL((conv_halo_kernel<ET, CI, BN, S2>), dim3(grid), dim3(256), lds, s, ha);
 }
 
 template <typename ET>
@@ -314,6 +342,7 @@ static void halo_launch(const imm_conv_desc* d, const ConvArgs& a, hipStream_t s
   ha.c.x_bytes = (uint32_t)((int64_t)d->batch * d->hi * d->wi * d->ldx * 2);
   ha.c.wt_bytes = (uint32_t)((int64_t)d->co * d->kpad * 2);
   const int grid = imm_halo_grid(d), bn = halo_bn(d->co);
+  if (halo_is_s2(d)) { halo_launch_cfg<ET, 32, 64, true>(ha, grid, s); return; }
   if (d->ci == 64) {
     if (bn == 64) halo_launch_cfg<ET, 64, 64>(ha, grid, s);
     else if (bn == 32) halo_launch_cfg<ET, 64, 32>(ha, grid, s);

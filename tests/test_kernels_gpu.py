@@ -74,6 +74,10 @@ CONV_CASES = [
     (3, 64, 32, 32, 9, 3, 1, True, 'halo_32_9_f32'),
     (2, 64, 64, 64, 32, 3, 1, False, 'halo_64_32'),
     (70, 64, 32, 32, 64, 3, 1, False, 'halo_32_64_many_patches'),
+    # 3x3 STRIDE 2, 32 -> 64 channels, >= 32x32 outputs: parity-de-interleaved LDS-halo kernel (conv_halo.hip, encoder conv_3)
+    (2, 128, 32, 32, 64, 3, 2, False, 'halo_s2_128px'),
+    (33, 64, 32, 32, 64, 3, 2, False, 'halo_s2_64px_many_patches'),
+    (1, 64, 32, 32, 48, 3, 2, False, 'halo_s2_co48'),
     # 3x3 s1, ci % 64 == 0, co % 64 == 0, maps % 16 == 0, >= 192 workgroups: LDS-halo deep-K kernel (conv_hdeep.hip)
     (16, 64, 64, 64, 128, 3, 1, False, 'hdeep_bn128_one_slice'),
     (13, 32, 128, 128, 256, 3, 1, False, 'hdeep_bn64_two_slices'),
@@ -162,6 +166,25 @@ def test_conv_relu_stats_mask(ops, B, H, ci, co, dt):
     mref = rnd((B, H, H, co), 7, 1.0, dt).to(DEV).contiguous()
     y3, _, _ = run_conv(ops, x, w, b, 3, 1, co, ci, False, extra_flags=L.CONV_MASK, mask=mref)
     close(y3, ref * (mref.float().cpu() > 0), 1e-2, 2e-3, 'conv+mask')
+
+
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16], ids=['bf16', 'f16'])
+def test_conv_stride2_halo_bias_and_bn_sums(ops, dt):
+    """The stride-2 LDS-halo forward as the encoder uses it (conv_3: bias + batch-norm partial sums, one row per persistent
+    workgroup) against the oracle, and against the im2col kernel it replaces (IMM_CONV_DISABLE is per process: the im2col
+    result comes from a shape just below the halo kernel's threshold instead — same arithmetic, other tiling)."""
+    from imm_amd import _lib as L
+    B, H, ci, co = 3, 128, 32, 64
+    x = rnd((B, H, H, ci), 181, 1.0, dt)
+    w = rnd((3, 3, ci, co), 182, 0.05, dt)
+    b = rnd((co,), 183, 0.5, torch.float32)
+    y, stats, desc = run_conv(ops, x, w, b, 3, 2, co, ci, False, extra_flags=L.CONV_STATS)
+    assert (desc.ho, desc.pad_t, desc.pad_l) == (64, 0, 0) and stats.shape[0] <= 256
+    ref = O.conv2d_same(x.float(), w.float(), b, 2)
+    close(y, ref, 1e-2 if dt == torch.bfloat16 else 2e-3, 2e-3, 'halo_s2+bias')
+    st = stats.sum(dim=0).cpu()
+    close(st[0], ref.sum(dim=(0, 1, 2)), 1e-3, 1e-3, 'halo_s2/sum')
+    close(st[1], (ref ** 2).sum(dim=(0, 1, 2)), 1e-3, 1e-3, 'halo_s2/sumsq')
 
 
 # ----------------------------------------------------------------------------------------------
