@@ -76,6 +76,7 @@ _SIGS = {
     'imm_rows_reduce': [_P, _I, _I, _I, _P, _P],
     'imm_bn_bwd_reduce': [_P, _I, _P, _I, _I, _L, _I, _P, _P, _P, _P, _I, _P, _P],
     'imm_bn_bwd_blocks': [_L, _I],
+    'imm_bn_bwd_reduce_up': [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P],
     'imm_bn_bwd_finalize': [_P, _I, _I, _I, _L, _P, _P, _P, _I, _P, _P, _P, _P],
     'imm_bn_bwd_apply': [_P, _I, _P, _I, _I, _L, _I, _P, _P, _P, _P, _I, _P, _P, _I, _P],
     'imm_upsample2x_fwd': [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P],

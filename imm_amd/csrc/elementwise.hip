@@ -519,11 +519,15 @@ __device__ __forceinline__ void col_reduce_tail(float (&acc)[NS][8], int c, int 
   }
 }
 
-template <typename ET>
+// UP: `dout` is the gradient of the x2 up-sampled tensor ([batch, 2h, 2w], imm_model.py:175); the adjoint of the up-sampling is
+// gathered here (the arithmetic of upsample2x_bwd_kernel, same order: bitwise equal), stored 16-bit to dprev (the apply pass
+// reads it) and taken as this pass's d_out — the standalone adjoint launch and the re-read of its result are gone.
+template <typename ET, bool UP = false>
 __global__ __launch_bounds__(EW_THREADS) void bn_bwd_reduce_kernel(
     const uint16_t* __restrict__ dout, int lddo, const uint16_t* __restrict__ y, int ldy, int64_t npix, int c,
     const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
-    const float* __restrict__ rstd, int relu, float* __restrict__ partial) {
+    const float* __restrict__ rstd, int relu, float* __restrict__ partial, uint16_t* __restrict__ dprev = nullptr,
+    int lddp = 0, int h = 0, int w = 0) {
   const int tpp = c / 8, rows = EW_THREADS / tpp;
   const int r = threadIdx.x / tpp, cg = threadIdx.x - r * tpp;
   const int64_t per_blk = (npix + gridDim.x - 1) / gridDim.x;
@@ -549,6 +553,51 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_reduce_kernel(
       acc[1][i] += dz * ((v[i] - mu[i]) * rs[i]);
     }
   };
+  if constexpr (UP) {
+    const int H = 2 * h, W = 2 * w;
+    for (int64_t p = p0 + r; p < p1; p += rows) {
+      const int j = (int)(p % w);
+      const int64_t t = p / w;
+      const int i = (int)(t % h);
+      const int64_t b = t / h;
+      int Ys[3], Xs[3]; float wy[3], wx[3];
+      Ys[0] = 2 * i - 1; wy[0] = (i >= 1) ? 0.5f : 0.f;
+      Ys[1] = 2 * i;     wy[1] = 1.f;
+      Ys[2] = 2 * i + 1; wy[2] = (i == h - 1) ? 1.f : 0.5f;
+      Xs[0] = 2 * j - 1; wx[0] = (j >= 1) ? 0.5f : 0.f;
+      Xs[1] = 2 * j;     wx[1] = 1.f;
+      Xs[2] = 2 * j + 1; wx[2] = (j == w - 1) ? 1.f : 0.5f;
+      const uint4 yq = *(const uint4*)(y + p * ldy + cg * 8);
+      uint4 q[9];
+      const uint16_t* base = dout + b * H * W * lddo + cg * 8;
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int bb = 0; bb < 3; ++bb)
+          q[a * 3 + bb] = (wy[a] != 0.f && wx[bb] != 0.f) ? *(const uint4*)(base + ((int64_t)Ys[a] * W + Xs[bb]) * lddo) : make_uint4(0, 0, 0, 0);
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = 0.f;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        if (wy[a] == 0.f) continue;
+#pragma unroll
+        for (int bb = 0; bb < 3; ++bb) {
+          if (wx[bb] == 0.f) continue;
+          float d[8];
+          unpack8<ET>(q[a * 3 + bb], d);
+          const float wgt = wy[a] * wx[bb];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] += wgt * d[e];
+        }
+      }
+      const uint4 dq = pack8<ET>(o);
+      *(uint4*)(dprev + p * lddp + cg * 8) = dq;
+      take(dq, yq);
+    }
+    col_reduce_tail<2>(acc, c, tpp, rows, partial + (int64_t)blockIdx.x * 2 * c);
+    return;
+  }
   // 4 pixels (8 x 16-byte loads) in flight per thread
   int64_t p = p0 + r;
   for (; p + 3 * (int64_t)rows < p1; p += 4 * (int64_t)rows) {
@@ -577,6 +626,23 @@ extern "C" int imm_bn_bwd_reduce(const void* dout, int lddo, const void* y, int 
                                                (hipStream_t)stream, (const uint16_t*)dout, lddo, (const uint16_t*)y,
                                                ldy, npix, c, scale, shift, mean, rstd, relu, partial));
   IMM_CHECK_LAUNCH("imm_bn_bwd_reduce");
+  return 0;
+}
+
+extern "C" int imm_bn_bwd_reduce_up(const void* dy_up, int lddy, void* dprev, int lddp, const void* y, int ldy, int dtype, int batch,
+                                    int h, int w, int c, const float* scale, const float* shift, const float* mean,
+                                    const float* rstd, int relu, float* partial, void* stream) {
+  IMM_REQUIRE(dy_up && dprev && y && scale && shift && mean && rstd && partial && batch > 0 && h > 0 && w > 0, "bn_bwd_reduce_up: null");
+  EW_REQUIRE_VEC(c, lddy, "bn_bwd_reduce_up(dy)");
+  EW_REQUIRE_VEC(c, lddp, "bn_bwd_reduce_up(dprev)");
+  EW_REQUIRE_VEC(c, ldy, "bn_bwd_reduce_up(y)");
+  const int64_t npix = (int64_t)batch * h * w;
+  const int nblk = imm_bn_bwd_blocks(npix, c);
+  if (nblk < 0) return imm_fail(IMM_E_UNSUPPORTED, "bn_bwd_reduce_up: C=%d unsupported (C/8 must divide 256)", c);
+  IMM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_bwd_reduce_kernel<ET, true>), dim3(nblk), dim3(EW_THREADS), 0,
+                                               (hipStream_t)stream, (const uint16_t*)dy_up, lddy, (const uint16_t*)y,
+                                               ldy, npix, c, scale, shift, mean, rstd, relu, partial, (uint16_t*)dprev, lddp, h, w));
+  IMM_CHECK_LAUNCH("imm_bn_bwd_reduce_up");
   return 0;
 }
 

@@ -435,9 +435,11 @@ class IMMEngine:
             lay.cs_partial = self._zeros(ops.colsum_blocks(npix, lay.lddy), lay.lddy)
         return lay
 
-    def _conv_backward(self, lay, d_out, ldd, dx, lddx):
+    def _conv_backward(self, lay, d_out, ldd, dx, lddx, up_src=None):
         """d_out: gradient w.r.t. the block output (post BN/ReLU for BN blocks; w.r.t. the conv output,
-        16-bit with stride lay.lddy, otherwise).  dx: buffer receiving the input gradient (or None)."""
+        16-bit with stride lay.lddy, otherwise).  dx: buffer receiving the input gradient (or None).
+        up_src = (dy_up, lddy): the block's output was up-sampled x2 and dy_up is the gradient of the up-sampled tensor: the
+        adjoint into d_out is taken inside the batch-norm backward reduction (imm_bn_bwd_reduce_up) instead of a launch of its own."""
         B, co, k = self.B, lay.co, lay.k
         npix = lay.npix
         scope = lay.scope
@@ -452,9 +454,14 @@ class IMMEngine:
             # the sums inside the reduce kernel with a last-workgroup ticket was slower too: item 22.  Both paths are gone.)
             nblk = ops.bn_bwd_blocks(npix, co)
             lay.bwd_partial = self._zeros(nblk, 2, co)
-            self._add(self.prog_bwd, lambda: ops.bn_bwd_reduce(d_out, ldd, lay.y, lay.ldy, npix, co, lay.scale, lay.shift,
-                                                               lay.mean, lay.rstd, lay.relu, lay.bwd_partial),
-                      'bn_bwd_reduce', 0.0, npix * co * 4.0)
+            if up_src is not None:
+                self._add(self.prog_bwd, lambda: ops.bn_bwd_reduce_up(up_src[0], up_src[1], d_out, ldd, lay.y, lay.ldy, B, lay.Ho, lay.Wo,
+                                                                      co, lay.scale, lay.shift, lay.mean, lay.rstd, lay.relu,
+                                                                      lay.bwd_partial), 'bn_bwd_reduce', 0.0, npix * co * 12.0)
+            else:
+                self._add(self.prog_bwd, lambda: ops.bn_bwd_reduce(d_out, ldd, lay.y, lay.ldy, npix, co, lay.scale, lay.shift,
+                                                                   lay.mean, lay.rstd, lay.relu, lay.bwd_partial),
+                          'bn_bwd_reduce', 0.0, npix * co * 4.0)
             if co % 32 == 0:
                 rows, nrows = lay.bwd_partial, nblk
                 if nblk > 256:
@@ -874,6 +881,7 @@ class IMMEngine:
         # ---- renderer backward -----------------------------------------------------------------------------
         ups = {idx: (ub, H, co) for idx, ub, H, co in self.ren_up}
         d_out, ldd = self.d_pred, last.lddy
+        up_src = None
         for i in range(len(self.ren) - 1, -1, -1):
             lay = self.ren[i]
             if i == 0:
@@ -885,14 +893,19 @@ class IMMEngine:
                     dx, lddx = self._act(B, 2 * Hp, 2 * Hp, cp), cp
                 else:
                     dx, lddx = self._act(B, prev.Ho, prev.Wo, prev.co), prev.co
-            self._conv_backward(lay, d_out, ldd, dx, lddx)
+            self._conv_backward(lay, d_out, ldd, dx, lddx, up_src=up_src)
+            up_src = None
             if i > 0:
                 if (i - 1) in ups:
                     _ub, Hp, cp = ups[i - 1]
                     d_prev = self._act(B, Hp, Hp, cp)
-                    self._add(self.prog_bwd, (lambda dx=dx, d_prev=d_prev, Hp=Hp, cp=cp:
-                                              ops.upsample2x_bwd(dx, d_prev, B, Hp, Hp, cp, cp, cp)), 'upsample_bwd',
-                              0.0, B * Hp * Hp * cp * 10.0)
+                    if prev.bn:
+                        # the adjoint of the up-sampling rides in conv i-1's batch-norm backward reduction (next iteration)
+                        up_src = (dx, lddx)
+                    else:
+                        self._add(self.prog_bwd, (lambda dx=dx, d_prev=d_prev, Hp=Hp, cp=cp:
+                                                  ops.upsample2x_bwd(dx, d_prev, B, Hp, Hp, cp, cp, cp)), 'upsample_bwd',
+                                  0.0, B * Hp * Hp * cp * 10.0)
                     d_out, ldd = d_prev, cp
                 else:
                     d_out, ldd = dx, lddx

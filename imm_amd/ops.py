@@ -280,6 +280,11 @@ def bn_bwd_reduce(dout, lddo, y, ldy, npix, c, scale, shift, mean, rstd, relu, p
          _p(rstd), int(relu), _p(partial), _s())
 
 
+def bn_bwd_reduce_up(dy_up, lddy, dprev, lddp, y, ldy, batch, h, w, c, scale, shift, mean, rstd, relu, partial):
+    call('imm_bn_bwd_reduce_up', _p(dy_up), lddy, _p(dprev), lddp, _p(y), ldy, dtype_enum(y.dtype), batch, h, w, c, _p(scale),
+         _p(shift), _p(mean), _p(rstd), int(relu), _p(partial), _s())
+
+
 def bn_bwd_finalize(partial, nblk, c, count, gamma, beta, rstd, dgamma, dbeta, coef, from_out=False, ldp=None):
     call('imm_bn_bwd_finalize', _p(partial), nblk, c, c if ldp is None else ldp, count, _p(gamma), _p(beta), _p(rstd),
          int(from_out), _p(dgamma), _p(dbeta), _p(coef), _s())

@@ -195,6 +195,13 @@ int imm_bn_bwd_reduce(const void* dout, int lddo, const void* y, int ldy, int dt
                       const float* scale, const float* shift, const float* mean, const float* rstd, int relu,
                       float* partial, void* stream);
 int imm_bn_bwd_blocks(int64_t npix, int c);
+/* imm_upsample2x_bwd followed by imm_bn_bwd_reduce in ONE pass, for the renderer blocks whose output is up-sampled (conv_2/4/6,
+ * imm_model.py:166-175): dy_up 16-bit [batch,2h,2w] (stride lddy) = gradient of the up-sampled tensor; its adjoint is written
+ * 16-bit to dprev [batch,h,w] (stride lddp; bitwise = imm_upsample2x_bwd) for the apply pass and summed into `partial`
+ * (imm_bn_bwd_blocks(batch*h*w, c) rows) as imm_bn_bwd_reduce(dprev, ...) would. */
+int imm_bn_bwd_reduce_up(const void* dy_up, int lddy, void* dprev, int lddp, const void* y, int ldy, int dtype, int batch, int h,
+                         int w, int c, const float* scale, const float* shift, const float* mean, const float* rstd, int relu,
+                         float* partial, void* stream);
 /* partial rows [2][ldp] (ldp >= c: rows written by a producer with more channels than this layer).  from_out = 0: rows of
  * (sum dz, sum dz*xhat) from imm_bn_bwd_reduce; from_out = 1: rows of (sum dz, sum dz*out) from a data-gradient epilogue
  * (IMM_CONV_STATS | IMM_CONV_MASK) or imm_upsample2x_bwd_bn: sum dz*xhat = (sum dz*out - beta * sum dz) / gamma. */

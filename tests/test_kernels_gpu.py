@@ -526,6 +526,28 @@ def test_masked_sse_multi_equals_single_launches(ops):
             assert torch.equal(part, ref)
 
 
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16], ids=['bf16', 'f16'])
+@pytest.mark.parametrize('B,h,c', [(32, 16, 256), (3, 32, 128), (5, 64, 64), (2, 8, 16)])
+def test_bn_bwd_reduce_with_upsampling_adjoint(ops, B, h, c, dt):
+    """imm_bn_bwd_reduce_up == imm_upsample2x_bwd followed by imm_bn_bwd_reduce (renderer conv_2/4/6: the block's output is
+    up-sampled x2, imm_model.py:175): the adjoint written for the apply pass and the partial rows, bit for bit."""
+    dy_up = rnd((B, 2 * h, 2 * h, c), 191, 1.0, dt).to(DEV).contiguous()
+    y = (rnd((B, h, h, c), 192) * 2 + 0.3).to(dt).to(DEV).contiguous()
+    scale = (rnd((c,), 193, 0.3, torch.float32) + 1.0).to(DEV); shift = rnd((c,), 194, 0.5, torch.float32).to(DEV)
+    mean = rnd((c,), 195, 0.5, torch.float32).to(DEV); rstd = (rnd((c,), 196, 0.1, torch.float32).abs() + 0.5).to(DEV)
+    npix = B * h * h
+    nblk = ops.bn_bwd_blocks(npix, c)
+    d_ref = torch.full((B, h, h, c), float('nan'), dtype=dt, device=DEV)
+    p_ref = torch.full((nblk, 2, c), float('nan'), device=DEV)
+    ops.upsample2x_bwd(dy_up, d_ref, B, h, h, c, c, c)
+    ops.bn_bwd_reduce(d_ref, c, y, c, npix, c, scale, shift, mean, rstd, True, p_ref)
+    d_got = torch.full_like(d_ref, float('nan')); p_got = torch.full_like(p_ref, float('nan'))
+    ops.bn_bwd_reduce_up(dy_up, c, d_got, c, y, c, B, h, h, c, scale, shift, mean, rstd, True, p_got)
+    torch.cuda.synchronize()
+    assert torch.equal(d_got, d_ref)
+    assert torch.equal(p_got, p_ref), float((p_got - p_ref).abs().max())
+
+
 @pytest.mark.parametrize('rows,width,group', [(1024, 64, 32), (512, 128, 32), (700, 64, 32), (33, 512, 32), (2048, 64, 64)])
 def test_rows_reduce(ops, rows, width, group):
     """imm_rows_reduce: group sums of partial rows (f64 accumulation); bitwise repeatable."""
