@@ -35,6 +35,13 @@ typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
 #define WH_HROWS(KH) (WH_PH + (KH) - 1)
 #define WH_HCOLS(KW) (WH_PW + (KW) - 1)
 #define WH_HP(KH, KW) ((WH_HROWS(KH) * WH_HCOLS(KW) + 63) / 64 * 64)
+// 3x3 STRIDE 2 (encoder conv_3; TF SAME on an even side pads bottom / right only): the 17 x 33 input halo of an 8x16 output patch is
+// stored parity-de-interleaved exactly as in conv_halo.hip's stride-2 forward — four planes (row parity, column parity) of 9 x 17
+// pixels padded to 160 — so tap (ky,kx) of output pixel (y,x) is pixel (y + ky/2, x + kx/2) of plane (ky&1, kx&1) and the four
+// consecutive pixels a transpose read delivers are consecutive in LDS
+#define WH_S2_PW 17
+#define WH_S2_PP 160
+#define WH_S2_HP 640
 
 __device__ __forceinline__ void wh_dma16(u32x4_t rsrc, uint32_t lds_addr, uint32_t voff, uint32_t soff) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
@@ -65,10 +72,11 @@ struct WgradHaloArgs {
 // 1.5 us per patch for 0.55 us of matrix work).  Now NS-1 patches are in flight and the wait is counted: every wave issues
 // exactly LPP DMA instructions per patch, so "at most (NS-2)*LPP outstanding" == "this patch has landed".
 // bx = pixel split of this workgroup, G = number of splits, by / bz = its ci / co slice
-template <typename ET, int CI, int CO, int NS, int KH = 3, int KW = 3>
+template <typename ET, int CI, int CO, int NS, int KH = 3, int KW = 3, int ST = 1>
 __device__ __forceinline__ void conv_wgrad_halo_body(const WgradHaloArgs& a, const int bx, const int G, const int by, const int bz) {
+  static_assert(ST == 1 || (ST == 2 && KH == 3 && KW == 3), "stride 2: 3x3 only");
   constexpr int NTAP = KH * KW, PT = (KH - 1) / 2, PL = (KW - 1) / 2;
-  constexpr int WH_HW = WH_HCOLS(KW), HPIX = WH_HROWS(KH) * WH_HCOLS(KW), WH_HP_ = WH_HP(KH, KW);
+  constexpr int WH_HW = WH_HCOLS(KW), HPIX = WH_HROWS(KH) * WH_HCOLS(KW), WH_HP_ = ST == 2 ? WH_S2_HP : WH_HP(KH, KW);
   constexpr int XC8 = CI / 8, YC8 = CO / 8;
   constexpr int NCT = CI / 16, NNT = CO / 16;          // 16-channel tiles
   constexpr int WC = NCT, WN = 4 / WC;                 // wave grid: wc = ci tile, wn = slice of the co tiles
@@ -94,15 +102,24 @@ __device__ __forceinline__ void conv_wgrad_halo_body(const WgradHaloArgs& a, con
   auto issue = [&](int patch, int stage) {
     const int img = patch / per_img, pr = patch - img * per_img;
     const int y0 = (pr / a.patches_x) * WH_PH, x0 = (pr % a.patches_x) * WH_PW;
-    const uint32_t xs = (uint32_t)(img * a.h * a.w) * (uint32_t)(a.ldx * 2);
+    const uint32_t xs = (uint32_t)(img * (ST * a.h) * (ST * a.w)) * (uint32_t)(a.ldx * 2);   // a.h, a.w = OUTPUT map (input = ST x)
     const uint32_t ys = (uint32_t)(img * a.h * a.w) * (uint32_t)(a.lddy * 2);
     for (int i = wid; i < X_DMA; i += 4) {
       const int hp = i * X_PIX_PER_DMA + lane / XC8;
-      const int hy = hp / WH_HW, hx = hp - hy * WH_HW;
-      const int iy = y0 - PT + hy, ix = x0 - PL + hx;
-      const bool ok = (hp < HPIX) && ((unsigned)iy < (unsigned)a.h) && ((unsigned)ix < (unsigned)a.w);
+      int iy, ix;
+      bool ok;
+      if constexpr (ST == 2) {
+        const int plane = hp / WH_S2_PP, rem = hp - plane * WH_S2_PP;
+        const int pi = rem / WH_S2_PW, pj = rem - pi * WH_S2_PW;
+        iy = 2 * (y0 + pi) + (plane >> 1); ix = 2 * (x0 + pj) + (plane & 1);
+        ok = rem < 9 * WH_S2_PW && iy < ST * a.h && ix < ST * a.w;
+      } else {
+        const int hy = hp / WH_HW, hx = hp - hy * WH_HW;
+        iy = y0 - PT + hy; ix = x0 - PL + hx;
+        ok = (hp < HPIX) && ((unsigned)iy < (unsigned)a.h) && ((unsigned)ix < (unsigned)a.w);
+      }
       const int sc = (lane % XC8) ^ wh_swz<XC8>(hp);
-      const uint32_t vo = ok ? (uint32_t)(((iy * a.w + ix) * a.ldx + ci0) * 2 + sc * 16) : OOB;
+      const uint32_t vo = ok ? (uint32_t)(((iy * (ST * a.w) + ix) * a.ldx + ci0) * 2 + sc * 16) : OOB;
       wh_dma16(xr, __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)(stage * STAGE + i * 1024)), vo, xs);
     }
     for (int i = wid; i < Y_DMA; i += 4) {
@@ -161,7 +178,8 @@ __device__ __forceinline__ void conv_wgrad_halo_body(const WgradHaloArgs& a, con
       const int ky = tap / KW, kx = tap % KW;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        const int hp = (ks * 2 + k_row + ky) * WH_HW + k_x + kx;
+        const int hp = ST == 2 ? ((ky & 1) * 2 + (kx & 1)) * WH_S2_PP + (ks * 2 + k_row + (ky >> 1)) * WH_S2_PW + k_x + (kx >> 1)
+                               : (ks * 2 + k_row + ky) * WH_HW + k_x + kx;
         const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(Xl + wh_piece<XC8>(hp, wc * 16 + ch4)));
         const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(Xl + wh_piece<XC8>(hp + 4, wc * 16 + ch4)));
         const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
@@ -192,14 +210,14 @@ __device__ __forceinline__ void conv_wgrad_halo_body(const WgradHaloArgs& a, con
   }
 }
 
-template <typename ET, int CI, int CO, int NS, int KH = 3, int KW = 3>
+template <typename ET, int CI, int CO, int NS, int KH = 3, int KW = 3, int ST = 1>
 __global__ __launch_bounds__(256) void conv_wgrad_halo_kernel(const WgradHaloArgs a) {
-  conv_wgrad_halo_body<ET, CI, CO, NS, KH, KW>(a, blockIdx.x, gridDim.x, blockIdx.y, blockIdx.z);
+  conv_wgrad_halo_body<ET, CI, CO, NS, KH, KW, ST>(a, blockIdx.x, gridDim.x, blockIdx.y, blockIdx.z);
 }
 
 // Several filter gradients with the same slice shape in ONE launch (imm_conv2d_wgrad_multi): workgroup b belongs to member g
 // with first[g] <= b < first[g+1]; inside a member the workgroups are numbered split-fastest, (ci slice, co slice) slowest.
-template <typename ET, int CI, int CO, int NS, int KH = 3, int KW = 3>
+template <typename ET, int CI, int CO, int NS, int KH = 3, int KW = 3, int ST = 1>
 __global__ __launch_bounds__(256) void conv_wgrad_halo_multi_kernel(const WgradHaloArgs* __restrict__ tab,
                                                                     const int* __restrict__ first, int n) {
   const int b = blockIdx.x;
@@ -209,7 +227,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_halo_multi_kernel(const WgradH
   int r = b - first[g];
   const int bx = r % a.nsplit; r /= a.nsplit;
   const int by = r % a.nci, bz = r / a.nci;
-  conv_wgrad_halo_body<ET, CI, CO, NS, KH, KW>(a, bx, a.nsplit, by, bz);
+  conv_wgrad_halo_body<ET, CI, CO, NS, KH, KW, ST>(a, bx, a.nsplit, by, bz);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -226,13 +244,28 @@ static int wh_num_cu() {
 }
 
 // Slice plan of a layer: channel slice widths, number of slices and pixel splits.
-struct WhPlan { int cs, ns, nci, nco, nsplit; bool k71; };
+struct WhPlan { int cs, ns, nci, nco, nsplit; bool k71, s2; };
 
 static bool wh_plan(const imm_conv_desc* d, int lddy, WhPlan* pl) {
   const bool k33 = d->kh == 3 && d->kw == 3 && d->pad_t == 1 && d->pad_l == 1;
   // the tap-unrolled first encoder convolution (7x1 over the 32-channel unrolled image -> 32 channels, imm_model.py:190)
   const bool k71 = d->kh == 7 && d->kw == 1 && d->pad_t == 3 && d->pad_l == 0 && d->ci == 32 && lddy == 32 && d->co <= 32;
   pl->k71 = k71;
+  // encoder conv_3: 3x3 stride 2, 32 -> 64 channels (whole filter = one slice; its halo + dY stage is 57 KB: two stages)
+  const bool s2 = d->kh == 3 && d->kw == 3 && d->stride == 2 && d->pad_t == 0 && d->pad_l == 0 && d->updiv == 1 && d->ci == 32 &&
+                  lddy == 64 && d->co > 32 && d->co <= 64 && d->hi == 2 * d->ho && d->wi == 2 * d->wo && d->ho % WH_PH == 0 &&
+                  d->wo % WH_PW == 0 && d->ho * d->wo >= 32 * 32 && d->kpad == 9 * d->ci;
+  pl->s2 = s2;
+  if (s2) {
+    const int64_t xb2 = (int64_t)d->batch * d->hi * d->wi * d->ldx * 2, yb2 = (int64_t)d->batch * d->ho * d->wo * lddy * 2;
+    if (xb2 >= (1LL << 31) || yb2 >= (1LL << 31)) return false;
+    pl->cs = 32; pl->ns = 64; pl->nci = 1; pl->nco = 1;
+    const int n_patches2 = d->batch * (d->ho / WH_PH) * (d->wo / WH_PW);
+    int ns2 = wh_num_cu();
+    if (ns2 > n_patches2 / 4) ns2 = n_patches2 / 4;
+    pl->nsplit = ns2 < 1 ? 1 : ns2;
+    return true;
+  }
   if ((!k33 && !k71) || d->stride != 1 || d->updiv != 1) return false;
   if (d->hi != d->ho || d->wi != d->wo || d->ho % WH_PH || d->wo % WH_PW) return false;
   if (d->kpad != d->kh * d->kw * d->ci || d->ci % 32) return false;
@@ -294,24 +327,24 @@ int imm_wgrad_halo_splits(const imm_conv_desc* d, int lddy) {
 // the issue gaps (measured in the multi-problem launch: 74 -> 52 us for encoder conv_2 x 2 + renderer conv_8; 40 -> 36 us for the
 // 7x1 layers).  The wider slices keep one workgroup per CU and the deepest ring that fits: 64x64 3 x 40 KB (two-per-CU with 2
 // stages: 188 vs 187 us), 64x32 4 x 32 KB (two-per-CU with 2 stages: 46 vs 42 us).
-template <int CI, int CO, int KH, int KW>
+template <int CI, int CO, int KH, int KW, int ST = 1>
 struct WhRing {
-  static constexpr int stage = WH_HP(KH, KW) * CI * 2 + 128 * CO * 2;
-  static constexpr int NS = (CI == 32 && CO == 32) ? 3 : (stage > 36 * 1024 ? 3 : 4);
+  static constexpr int stage = (ST == 2 ? WH_S2_HP : WH_HP(KH, KW)) * CI * 2 + 128 * CO * 2;
+  static constexpr int NS = ST == 2 ? 2 : (CI == 32 && CO == 32) ? 3 : (stage > 36 * 1024 ? 3 : 4);
   static constexpr int per_cu = (CI == 32 && CO == 32) ? 2 : 1;
 };
 
-template <typename ET, int CI, int CO, int KH = 3, int KW = 3>
+template <typename ET, int CI, int CO, int KH = 3, int KW = 3, int ST = 1>
 static void wh_launch_cfg(const WgradHaloArgs& a, dim3 grid, hipStream_t s) {
-  constexpr int stage = WhRing<CI, CO, KH, KW>::stage;
-  constexpr int NS = WhRing<CI, CO, KH, KW>::NS;
+  constexpr int stage = WhRing<CI, CO, KH, KW, ST>::stage;
+  constexpr int NS = WhRing<CI, CO, KH, KW, ST>::NS;
   constexpr int lds = NS * stage;
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {
-    (void)hipFuncSetAttribute((const void*)conv_wgrad_halo_kernel<ET, CI, CO, NS, KH, KW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_halo_kernel<ET, CI, CO, NS, KH, KW, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_wgrad_halo_kernel<ET, CI, CO, NS, KH, KW>), grid, dim3(256), lds, s, a);
+  hipLaunchKernelGGL((conv_wgrad_halo_kernel<ET, CI, CO, NS, KH, KW, ST>), grid, dim3(256), lds, s, a);
 }
 
 static WgradHaloArgs wh_fill(const imm_conv_desc* d, const void* x, const void* dy, int lddy, float* slab, int nsplit,
@@ -336,7 +369,8 @@ void imm_wgrad_halo_launch(int dtype, const imm_conv_desc* d, const void* x, con
   const dim3 grid(nsplit, pl.nci, pl.nco);
 #define WH_GO(ET_) \
   do { \
-    if (pl.k71) wh_launch_cfg<ET_, 32, 32, 7, 1>(a, grid, s); \
+    if (pl.s2) wh_launch_cfg<ET_, 32, 64, 3, 3, 2>(a, grid, s); \
+    else if (pl.k71) wh_launch_cfg<ET_, 32, 32, 7, 1>(a, grid, s); \
     else if (pl.cs == 64 && pl.ns == 64) wh_launch_cfg<ET_, 64, 64>(a, grid, s); \
     else if (pl.cs == 64) wh_launch_cfg<ET_, 64, 32>(a, grid, s); \
     else if (pl.ns == 64) wh_launch_cfg<ET_, 32, 64>(a, grid, s); \
@@ -350,7 +384,7 @@ void imm_wgrad_halo_launch(int dtype, const imm_conv_desc* d, const void* x, con
 // variant = slice shape: 64*100+64, 64*100+32, 32*100+64, 32*100+32; 0 = this kernel does not take the layer
 int imm_wgrad_halo_variant(const imm_conv_desc* d, int lddy) {
   WhPlan pl;
-  return wh_plan(d, lddy, &pl) ? (pl.k71 ? 7100 : 0) + pl.cs * 100 + pl.ns : 0;   // 7x1: 7100 + 3232
+  return wh_plan(d, lddy, &pl) ? (pl.s2 ? 20000 : pl.k71 ? 7100 : 0) + pl.cs * 100 + pl.ns : 0;   // 7x1: 7100 + 3232; stride 2: 20000 + 3264
 }
 // workgroups per pixel split (channel-slice blocks) and the number of 8x16 patches of the layer
 int imm_wgrad_halo_blocks(const imm_conv_desc* d, int lddy, int* n_patches) {
@@ -373,17 +407,17 @@ int imm_wgrad_halo_fill(const imm_conv_desc* d, const void* x, const void* dy, i
 // resident workgroups per CU of a variant's kernel (the engine sizes a launch to one round of them)
 int imm_wgrad_halo_per_cu(int variant) { return (variant == 3232 || variant == 7100 + 3232) ? 2 : 1; }
 
-template <typename ET, int CI, int CO, int KH = 3, int KW = 3>
+template <typename ET, int CI, int CO, int KH = 3, int KW = 3, int ST = 1>
 static void wh_launch_multi_cfg(const WgradHaloArgs* tab, const int* first, int n, int blocks, hipStream_t s) {
-  constexpr int stage = WhRing<CI, CO, KH, KW>::stage;
-  constexpr int NS = WhRing<CI, CO, KH, KW>::NS;
+  constexpr int stage = WhRing<CI, CO, KH, KW, ST>::stage;
+  constexpr int NS = WhRing<CI, CO, KH, KW, ST>::NS;
   constexpr int lds = NS * stage;
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {
-    (void)hipFuncSetAttribute((const void*)conv_wgrad_halo_multi_kernel<ET, CI, CO, NS, KH, KW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_halo_multi_kernel<ET, CI, CO, NS, KH, KW, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_wgrad_halo_multi_kernel<ET, CI, CO, NS, KH, KW>), dim3(blocks), dim3(256), lds, s, tab, first, n);
+  hipLaunchKernelGGL((conv_wgrad_halo_multi_kernel<ET, CI, CO, NS, KH, KW, ST>), dim3(blocks), dim3(256), lds, s, tab, first, n);
 }
 
 void imm_wgrad_halo_launch_multi(int dtype, int variant, const void* tab_dev, const int* first_dev, int n, int blocks,
@@ -391,7 +425,8 @@ void imm_wgrad_halo_launch_multi(int dtype, int variant, const void* tab_dev, co
   const WgradHaloArgs* t = (const WgradHaloArgs*)tab_dev;
 #define WH_GO(ET_) \
   do { \
-    if (variant == 7100 + 3232) wh_launch_multi_cfg<ET_, 32, 32, 7, 1>(t, first_dev, n, blocks, s); \
+    if (variant == 20000 + 3264) wh_launch_multi_cfg<ET_, 32, 64, 3, 3, 2>(t, first_dev, n, blocks, s); \
+    else if (variant == 7100 + 3232) wh_launch_multi_cfg<ET_, 32, 32, 7, 1>(t, first_dev, n, blocks, s); \
     else if (variant == 6464) wh_launch_multi_cfg<ET_, 64, 64>(t, first_dev, n, blocks, s); \
     else if (variant == 6432) wh_launch_multi_cfg<ET_, 64, 32>(t, first_dev, n, blocks, s); \
     else if (variant == 3264) wh_launch_multi_cfg<ET_, 32, 64>(t, first_dev, n, blocks, s); \

@@ -403,6 +403,40 @@ def test_conv_wgrad_halo_7x1_first_layer(ops, B, S, dt):
     close(res[0], res[2], 1e-3, 2e-4, 'wgrad_halo_7x1 vs transpose-read')
 
 
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16], ids=['bf16', 'f16'])
+@pytest.mark.parametrize('B,S,co', [(2, 128, 64), (9, 64, 64), (1, 64, 48)])
+def test_conv_wgrad_halo_stride2(ops, B, S, co, dt):
+    """Filter gradient of the encoder's first stride-2 convolution (3x3, 32 -> 64 channels, imm_model.py:195) through the LDS-halo
+    kernel with the parity-de-interleaved input halo: against autograd of the oracle convolution, alone and as a member of a
+    multi-problem launch at another split count, and against the transpose-read kernel."""
+    ci = 32
+    x = rnd((B, S, S, ci), 141, 1.0, dt)
+    wr = torch.zeros(3, 3, ci, co, requires_grad=True)
+    yref = O.conv2d_same(x.float(), wr, None, 2)
+    dy = rnd(tuple(yref.shape[:3]) + (64,), 142, 1.0, dt)
+    dy[..., co:] = 0
+    (gw,) = torch.autograd.grad(yref, wr, dy[..., :co].float())
+    desc = ops.fwd_desc(B, S, S, ci, ci, co, 64, 3, 2, 0)
+    key, wps, units, pcu = ops.conv2d_wgrad_variant(desc, 64, dt)
+    assert key == 200000 + 20000 + 3264 and wps == 1 and pcu == 1, key
+    xd, dyd = x.to(DEV).contiguous(), dy.to(DEV).contiguous()
+    nsplit = ops.conv2d_wgrad_splits(desc, 64)
+    assert nsplit > 0
+    res = []
+    for ns, multi in ((nsplit, False), (5, True), (3, False)):       # (3, False): any other split count = transpose-read kernel
+        slab = torch.full((ns, desc.kpad, co), float('nan'), dtype=torch.float32, device=DEV)
+        if multi:
+            ops.conv2d_wgrad_multi(ops.WgradMulti([(desc, xd, dyd, 64, slab, ns)], dt))
+        else:
+            ops.conv2d_wgrad(desc, xd, dyd, 64, slab, ns)
+        dw = torch.full((3, 3, ci, co), float('nan'), dtype=torch.float32, device=DEV)
+        ops.conv2d_wgrad_reduce(slab, ns, 3, 3, ci, ci, co, desc.kpad, dw)
+        torch.cuda.synchronize()
+        close(dw, gw, 2e-3, 5e-4, 'wgrad_halo_s2/%d%s' % (ns, 'm' if multi else ''))
+        res.append(dw)
+    close(res[0], res[2], 1e-3, 2e-4, 'wgrad_halo_s2 vs transpose-read')
+
+
 def test_table_driven_pack_and_reduce(ops):
     """imm_pack_weights_multi (bit for bit) / imm_wgrad_reduce_multi (to f32 rounding) vs their single-tensor counterparts."""
     dt = torch.bfloat16
