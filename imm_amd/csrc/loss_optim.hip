@@ -11,6 +11,7 @@
 #include "common.h"
 
 #define LO_THREADS 256
+#define IMM_NORM2_SANE 1e30f   // a chunk's sum of squared gradients beyond this counts as an overflow (grad_prepare_kernel)
 
 // ---------------------------------------------------------------------------------------------
 // masked sum of squared differences (per feature; IMM_SSE_BLOCKS deterministic partials)
@@ -476,15 +477,38 @@ extern "C" int imm_weight_decay_loss(const float* params, const int32_t* blk_seg
   return 0;
 }
 
+// The optimizer step is TWO launches (round 3; three before, with a one-workgroup "tick" between them whose threads walked their
+// tensor's chunk sums serially: 12 us of latency chain on the strictly serial tail of the step):
+//   grad_prepare: g <- g * grad_scale / S + wd * w and the chunk sums of g^2; one extra workgroup computes the step's learning
+//                 rate (three f64 pow: microseconds on one thread — once, not per workgroup of the update: measured +45 us);
+//   clip_adam:    EVERY workgroup rebuilds what it needs from the chunk sums (a few KB from L2): its tensor's squared norm (f64,
+//                 fixed order) and the skip decision (any chunk sum NaN / inf / absurd), then updates its chunk; one extra
+//                 workgroup advances the state nobody in this launch reads (counters, loss scale).
+// No atomics: a ticket per workgroup (tried first) serialises on its one address, ~30 ns each — 2000 workgroups, +60 us; agent-scope
+// loads of a shared flag bypass the L2 and queue up at one memory channel the same way.
+// learning rate of this step: staircase decay on TF's global_step, Adam's bias correction on its own update count
+__device__ __forceinline__ void opt_learning_rate(const imm_opt_hparams& hp, int gs, int tt, float* lr_t, float* lr) {
+  const double l = (double)hp.lr_multiple * (double)hp.lr_start * pow((double)hp.lr_decay, (double)(gs / hp.lr_step));
+  *lr_t = (float)(l * sqrt(1.0 - pow((double)hp.beta2, (double)tt)) / (1.0 - pow((double)hp.beta1, (double)tt)));
+  *lr = (float)l;
+}
+
 __global__ __launch_bounds__(LO_THREADS) void grad_prepare_kernel(const float* __restrict__ params, float* __restrict__ grads,
                                                                   const int32_t* __restrict__ blk_seg,
                                                                   const int32_t* __restrict__ blk_begin,
                                                                   const int32_t* __restrict__ blk_end,
                                                                   const float* __restrict__ seg_wd, float grad_scale,
                                                                   const float* __restrict__ loss_scale,
-                                                                  float* __restrict__ blk_partial) {
+                                                                  float* __restrict__ blk_partial, int nblk,
+                                                                  const int32_t* __restrict__ step_count,
+                                                                  const int32_t* __restrict__ adam_t, float* __restrict__ lr_state,
+                                                                  imm_opt_hparams hp) {
   __shared__ float red[4];
   const int blk = blockIdx.x;
+  if (blk == nblk) {           // the extra workgroup: this step's learning rate (the counters move in the update launch)
+    if (threadIdx.x == 0) opt_learning_rate(hp, step_count[0], adam_t[0] + 1, lr_state, lr_state + 1);
+    return;
+  }
   if (loss_scale) grad_scale *= 1.f / loss_scale[0];     // S is a power of two: exact
   const float wd = seg_wd[blk_seg[blk]];
   float acc = 0.f;
@@ -511,59 +535,68 @@ __global__ __launch_bounds__(LO_THREADS) void grad_prepare_kernel(const float* _
   if (threadIdx.x == 0) blk_partial[blk] = acc;
 }
 
-// One workgroup: per-tensor squared norms from the block partials, the step counters, the learning rate — and, with loss
-// scaling (ls != NULL: {S, clean steps in a row, steps skipped so far, this step overflowed}), the decision to skip the update
-// when any tensor's norm is not finite (an f16 gradient overflowed somewhere in the backward chain) and the dynamic scale:
-// halved on overflow, doubled after hp.scale_growth_interval clean steps (0: static), kept within [1, hp.scale_max].
-__global__ __launch_bounds__(LO_THREADS) void opt_tick_kernel(const float* __restrict__ blk_partial,
-                                                              const int32_t* __restrict__ seg_first_blk, int nseg,
-                                                              float* __restrict__ seg_norm2, int32_t* step_count, int32_t* adam_t,
-                                                              float* lr_state, float* ls, imm_opt_hparams hp) {
-  __shared__ int bad;
-  if (threadIdx.x == 0) bad = 0;
-  __syncthreads();
-  for (int t = threadIdx.x; t < nseg; t += LO_THREADS) {
-    double s = 0.0;
-    for (int b = seg_first_blk[t]; b < seg_first_blk[t + 1]; ++b) s += (double)blk_partial[b];
-    seg_norm2[t] = (float)s;
-    if (!isfinite((float)s)) atomicOr(&bad, 1);
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const bool skip = ls != nullptr && bad != 0;
-    if (ls) {
-      float S = ls[0], clean = ls[1];
-      if (skip) { S = fmaxf(S * 0.5f, 1.f); clean = 0.f; ls[2] += 1.f; }
-      else if (hp.scale_growth_interval > 0 && clean + 1.f >= (float)hp.scale_growth_interval) {
-        S = fminf(S * 2.f, hp.scale_max > 0.f ? hp.scale_max : S * 2.f); clean = 0.f;
-      } else clean += 1.f;
-      ls[0] = S; ls[1] = clean; ls[3] = skip ? 1.f : 0.f;
-    }
-    const int gs = step_count[0];           // TF global_step before this apply: learning-rate schedule only
-    const int tt = adam_t[0] + 1;           // Adam's t (TF: beta1_power / beta2_power, independent of global_step)
-    const double lr = (double)hp.lr_multiple * (double)hp.lr_start * pow((double)hp.lr_decay, (double)(gs / hp.lr_step));
-    const double lr_t = lr * sqrt(1.0 - pow((double)hp.beta2, (double)tt)) / (1.0 - pow((double)hp.beta1, (double)tt));
-    lr_state[0] = (float)lr_t;
-    lr_state[1] = (float)lr;
-    if (!skip) {                            // a skipped step leaves the weights, the slots and both counters untouched
-      step_count[0] = gs + 1;
-      adam_t[0] = tt;
-    }
-  }
-}
-
 __global__ __launch_bounds__(LO_THREADS) void clip_adam_kernel(float* __restrict__ params, const float* __restrict__ grads,
                                                                float* __restrict__ m, float* __restrict__ v,
                                                                const int32_t* __restrict__ blk_seg,
                                                                const int32_t* __restrict__ blk_begin,
                                                                const int32_t* __restrict__ blk_end,
-                                                               const float* __restrict__ seg_norm2,
-                                                               const float* __restrict__ lr_state,
-                                                               const float* __restrict__ ls, imm_opt_hparams hp) {
-  const int blk = blockIdx.x;
-  if (ls && ls[3] != 0.f) return;      // overflow in this step's gradients: no update (opt_tick_kernel)
+                                                               const int32_t* __restrict__ seg_first_blk,
+                                                               const float* __restrict__ blk_partial, int nblk,
+                                                               float* __restrict__ seg_norm2, int32_t* __restrict__ step_count,
+                                                               int32_t* __restrict__ adam_t, const float* __restrict__ lr_state,
+                                                               float* __restrict__ ls, imm_opt_hparams hp) {
+  __shared__ double dred[LO_THREADS / 64];
+  const int blk = blockIdx.x, tid = threadIdx.x;
+  const bool extra = blk == nblk;                         // the workgroup that advances the state
+  const int seg = extra ? 0 : blk_seg[blk];
+  const int b0 = extra ? 0 : blk_begin[blk], b1 = extra ? 0 : blk_end[blk];
+  const int a0 = min((b0 + 3) & ~3, b1), a1 = max(a0, b1 & ~3);
+  // the first 16-byte pass of this chunk is requested before the prologue below (its latency hides the prologue's)
+  const int i0 = a0 + 4 * tid;
+  const bool first = i0 < a1;
+  float4 g0 = {0.f, 0.f, 0.f, 0.f}, m0 = g0, v0 = g0, w0 = g0;
+  if (first) { g0 = *(const float4*)(grads + i0); m0 = *(const float4*)(m + i0); v0 = *(const float4*)(v + i0); w0 = *(const float4*)(params + i0); }
+
+  // ---- prologue: one pass over ALL chunk sums: not-a-sane-number anywhere => skip; this tensor's chunks => its squared norm ----
+  const int f0 = seg_first_blk[seg], f1 = seg_first_blk[seg + 1];
+  double ps = 0.0;
+  int bad = 0;
+  for (int b = tid; b < nblk; b += LO_THREADS) {
+    const float p = blk_partial[b];
+    // NaN, inf, or so large that a tensor's sum of chunk sums could leave the f32 range: an f16 gradient overflowed upstream
+    bad |= !(p <= IMM_NORM2_SANE);
+    if (b >= f0 && b < f1) ps += (double)p;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) ps += __shfl_xor(ps, o, 64);
+  if ((tid & 63) == 0) dred[tid >> 6] = ps;
+  bad = __syncthreads_or(bad);
+  const bool skip = ls != nullptr && bad != 0;
+  double t = 0.0;
+#pragma unroll
+  for (int w = 0; w < LO_THREADS / 64; ++w) t += dred[w];
+  const float norm2 = (float)t;
+  if (tid == 0 && !extra && blk == f0) seg_norm2[seg] = norm2;
+  if (extra) {
+    if (tid == 0) {
+      if (ls) {
+        float S = ls[0], clean = ls[1];
+        if (skip) { S = fmaxf(S * 0.5f, 1.f); clean = 0.f; ls[2] += 1.f; }
+        else if (hp.scale_growth_interval > 0 && clean + 1.f >= (float)hp.scale_growth_interval) {
+          S = fminf(S * 2.f, hp.scale_max > 0.f ? hp.scale_max : S * 2.f); clean = 0.f;
+        } else clean += 1.f;
+        ls[0] = S; ls[1] = clean; ls[3] = skip ? 1.f : 0.f;
+      }
+      if (!skip) {                          // a skipped step leaves the weights, the slots and both counters untouched
+        step_count[0] += 1;                 // TF global_step: learning-rate schedule only
+        adam_t[0] += 1;                     // Adam's t (TF: beta1_power / beta2_power, independent of global_step)
+      }
+    }
+    return;
+  }
+  if (skip) return;                         // overflow in this step's gradients: no update
   float factor = 1.f;
-  if (hp.clip > 0.f) factor = hp.clip / fmaxf(sqrtf(seg_norm2[blk_seg[blk]]), hp.clip);
+  if (hp.clip > 0.f) factor = hp.clip / fmaxf(sqrtf(norm2), hp.clip);
   const float lr_t = lr_state[0], lr = lr_state[1];
   auto one = [&](float g, float& mi, float& vi, float& w) {
     g *= factor;
@@ -581,16 +614,18 @@ __global__ __launch_bounds__(LO_THREADS) void clip_adam_kernel(float* __restrict
       w -= lr * g / sqrtf(vi);
     }
   };
-  const int b0 = blk_begin[blk], b1 = blk_end[blk];
-  const int a0 = min((b0 + 3) & ~3, b1), a1 = max(a0, b1 & ~3);
-  for (int i = b0 + threadIdx.x; i < a0; i += LO_THREADS) one(grads[i], m[i], v[i], params[i]);
-  for (int i = a0 + 4 * threadIdx.x; i < a1; i += 4 * LO_THREADS) {
+  for (int i = b0 + tid; i < a0; i += LO_THREADS) one(grads[i], m[i], v[i], params[i]);
+  if (first) {
+    one(g0.x, m0.x, v0.x, w0.x); one(g0.y, m0.y, v0.y, w0.y); one(g0.z, m0.z, v0.z, w0.z); one(g0.w, m0.w, v0.w, w0.w);
+    *(float4*)(m + i0) = m0; *(float4*)(v + i0) = v0; *(float4*)(params + i0) = w0;
+  }
+  for (int i = i0 + 4 * LO_THREADS; i < a1; i += 4 * LO_THREADS) {
     const float4 g = *(const float4*)(grads + i);
     float4 mi = *(const float4*)(m + i), vi = *(const float4*)(v + i), w = *(const float4*)(params + i);
     one(g.x, mi.x, vi.x, w.x); one(g.y, mi.y, vi.y, w.y); one(g.z, mi.z, vi.z, w.z); one(g.w, mi.w, vi.w, w.w);
     *(float4*)(m + i) = mi; *(float4*)(v + i) = vi; *(float4*)(params + i) = w;
   }
-  for (int i = a1 + threadIdx.x; i < b1; i += LO_THREADS) one(grads[i], m[i], v[i], params[i]);
+  for (int i = a1 + tid; i < b1; i += LO_THREADS) one(grads[i], m[i], v[i], params[i]);
 }
 
 extern "C" int imm_clip_adam_step(float* params, float* grads, float* m, float* v, const int32_t* blk_seg,
@@ -603,12 +638,10 @@ extern "C" int imm_clip_adam_step(float* params, float* grads, float* m, float* 
   IMM_REQUIRE(nblk > 0 && nseg > 0 && hp->lr_step > 0, "clip_adam_step: dims");
   IMM_REQUIRE(hp->optim >= IMM_OPT_ADAM && hp->optim <= IMM_OPT_ADAGRAD, "clip_adam_step: optim %d", hp->optim);
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(grad_prepare_kernel, dim3(nblk), dim3(LO_THREADS), 0, s, params, grads, blk_seg, blk_begin, blk_end,
-                     seg_wd, hp->grad_scale, loss_scale_state, blk_partial);
-  hipLaunchKernelGGL(opt_tick_kernel, dim3(1), dim3(LO_THREADS), 0, s, blk_partial, seg_first_blk, nseg, seg_norm2,
-                     step_count, adam_t, lr_state, loss_scale_state, *hp);
-  hipLaunchKernelGGL(clip_adam_kernel, dim3(nblk), dim3(LO_THREADS), 0, s, params, grads, m, v, blk_seg, blk_begin, blk_end,
-                     seg_norm2, lr_state, loss_scale_state, *hp);
+  hipLaunchKernelGGL(grad_prepare_kernel, dim3(nblk + 1), dim3(LO_THREADS), 0, s, params, grads, blk_seg, blk_begin, blk_end,
+                     seg_wd, hp->grad_scale, loss_scale_state, blk_partial, nblk, step_count, adam_t, lr_state, *hp);
+  hipLaunchKernelGGL(clip_adam_kernel, dim3(nblk + 1), dim3(LO_THREADS), 0, s, params, grads, m, v, blk_seg, blk_begin, blk_end,
+                     seg_first_blk, blk_partial, nblk, seg_norm2, step_count, adam_t, lr_state, loss_scale_state, *hp);
   IMM_CHECK_LAUNCH("imm_clip_adam_step");
   return 0;
 }

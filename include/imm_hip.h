@@ -376,7 +376,10 @@ int imm_weight_decay_loss(const float* params, const int32_t* blk_seg, const int
  * that were computed with their seeds multiplied by S (imm_perceptual_finalize): g is divided by S first; if any tensor's
  * norm is then not finite (an f16 gradient overflowed) the whole update is SKIPPED — weights, slots, step_count and adam_t
  * stay as they are — and S is halved (not below 1); after hp.scale_growth_interval clean steps in a row S doubles (up to
- * hp.scale_max).  The reference asserts on a NaN loss instead (cnn_train_multi.py:463); it has no reduced-precision mode. */
+ * hp.scale_max).  The reference asserts on a NaN loss instead (cnn_train_multi.py:463); it has no reduced-precision mode.
+ * "Not finite" is decided per chunk of the block table: a chunk whose sum of g^2 is NaN, inf or > 1e30.
+ * Two launches: the gradient pass (+ the learning rate), then the update, whose workgroups each rebuild their tensor's norm and
+ * the skip decision from the chunk sums (blk_partial f32[nblk]); lr_state is written by the first launch. */
 int imm_clip_adam_step(float* params, float* grads, float* m, float* v, const int32_t* blk_seg,
                        const int32_t* blk_begin, const int32_t* blk_end, int nblk, int nseg,
                        const int32_t* seg_first_blk, const float* seg_wd, float* blk_partial, float* seg_norm2,

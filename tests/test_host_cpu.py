@@ -110,8 +110,10 @@ def test_segment_and_job_tables_on_cpu():
     from imm_amd import ops
     tab = ops.SegmentTable([10, 20000, 3], [1e-5, 0.0, 0.0], 'cpu')
     assert tab.nseg == 3 and tab.total == 20013 and tab.offsets == [0, 10, 20010, 20013]
-    assert tab.seg_first_blk.tolist() == [0, 1, 4, 5] and tab.blk_begin.tolist() == [0, 10, 8202, 16394, 20010]
-    assert tab.blk_end.tolist() == [10, 8202, 16394, 20010, 20013] and tab.blk_seg.tolist() == [0, 1, 1, 1, 2]
+    ch = ops.SegmentTable.CHUNK
+    mid = list(range(10, 20010, ch))
+    assert tab.seg_first_blk.tolist() == [0, 1, 1 + len(mid), 2 + len(mid)] and tab.blk_begin.tolist() == [0] + mid + [20010]
+    assert tab.blk_end.tolist() == [10] + mid[1:] + [20010, 20013] and tab.blk_seg.tolist() == [0] + [1] * len(mid) + [2]
     jt = ops.JobTable([(1, 2, 3), (4, 5, 6)], [5000, 10], 2048, 'cpu')
     assert jt.blk_first.tolist() == [0, 3, 4] and jt.n_blocks == 4 and jt.jobs.shape == (2, 12)
     assert ops.same_pad_before(128, 3, 2) == (0, 64) and ops.same_pad_before(128, 7, 1) == (3, 128)
@@ -149,4 +151,5 @@ def test_ab_build_switches(tmp_path, monkeypatch):
     out = subprocess.run([sys.executable, '-c', code], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert out.returncode == 0, out.stderr.decode()[-1500:]
     lines = out.stdout.decode().split()
-    assert lines[0] == other and int(lines[1]) == 14
+    from imm_amd import _lib as L
+    assert lines[0] == other and int(lines[1]) == L.ABI_VERSION

@@ -1200,6 +1200,51 @@ def test_clip_adam_loss_scaling(ops):
     assert float(ls[0]) == 1.0 and float(ls[3]) == 1.0
 
 
+def test_clip_adam_many_workgroups(ops):
+    """The optimizer's two launches on a table of thousands of chunks (more workgroups than fit the chip at once; every one
+    of them rebuilds its tensor's norm and the skip decision from the chunk sums): same update as a table with 4x larger chunks
+    (only the summation order of the norms differs), counters advanced exactly once per step."""
+    sizes = [3 * 3 * 266 * 256, 256, 3 * 3 * 256 * 256, 5, 3 * 3 * 128 * 256 + 3, 1, 3 * 3 * 512 * 256]
+    wds = [1e-5, 0.0, 1e-5, 0.0, 1e-5, 0.0, 1e-5]
+    tabs = []
+    for chunk in (2048, 8192):
+        old = ops.SegmentTable.CHUNK
+        ops.SegmentTable.CHUNK = chunk
+        try:
+            tabs.append(ops.SegmentTable(sizes, wds, DEV))
+        finally:
+            ops.SegmentTable.CHUNK = old
+    assert tabs[0].nblk > 4 * 256 and tabs[0].nblk > 3 * tabs[1].nblk
+    g = torch.Generator().manual_seed(17)
+    p0 = (torch.randn(tabs[0].total, generator=g) * 0.3).to(DEV)
+    G = (torch.randn(tabs[0].total, generator=g) * 0.05).to(DEV)
+    hp = ops.OptHParams(lr_start=1e-3, lr_decay=0.95, lr_step=2, lr_multiple=1.0, beta1=0.9, beta2=0.999, eps=1e-8, clip=1.0,
+                        grad_scale=1.0, scale_growth_interval=0, scale_max=0.0)
+    res = []
+    for tab in tabs:
+        params, m, v = p0.clone(), torch.zeros_like(p0), torch.zeros_like(p0)
+        part = torch.empty(tab.nblk, device=DEV); norm2 = torch.empty(tab.nseg, device=DEV)
+        step = torch.zeros(1, dtype=torch.int32, device=DEV); adam_t = torch.zeros(1, dtype=torch.int32, device=DEV)
+        lrs = torch.zeros(2, device=DEV)
+        ls = torch.tensor([8.0, 0.0, 0.0, 0.0], device=DEV)
+        for it in range(4):
+            ops.clip_adam_step(params, G * 8.0 * (1.0 + it), m, v, tab, part, norm2, step, adam_t, lrs, hp, ls)
+            torch.cuda.synchronize()
+            assert int(step) == it + 1 and int(adam_t) == it + 1, it
+        assert ls.tolist() == [8.0, 4.0, 0.0, 0.0]
+        np.testing.assert_allclose(float(lrs[1]), 1e-3 * 0.95 ** 1, rtol=1e-6)        # step 3 (global_step 3 before): 3 // 2 = 1
+        res.append((params, m, v, norm2.clone()))
+    for a, b, name in zip(res[0], res[1], ('params', 'm', 'v', 'norm2')):
+        close(a, b, 1e-5, 1e-7, 'chunk 2048 vs 8192: ' + name)
+    # the norms themselves against torch
+    off = tabs[0].offsets
+    gl = G * 4.0
+    for i in range(len(sizes)):
+        # last step: g = G * 4 + wd * w_before_last_step; with wd = 1e-5 and |w| ~ 0.3 the wd part is < 1e-4 of the norm
+        ref = float((gl[off[i]:off[i + 1]].double() ** 2).sum())
+        np.testing.assert_allclose(float(res[0][3][i]), ref, rtol=2e-3)
+
+
 def test_perceptual_finalize_loss_scale(ops):
     """imm_perceptual_finalize with a loss scale: loss values unchanged, gradient coefficients x S exactly."""
     from imm_amd import _lib as L

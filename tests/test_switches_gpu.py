@@ -34,7 +34,10 @@ def base():
 
 
 def same(a, b, rel):
-    return all(abs(a[k] - b[k]) <= rel * abs(a[k]) for k in ('loss0', 'loss1', 'mu_abs_sum', 'params_abs_sum'))
+    # the landmarks of a freshly initialised model lie near 0 (their abs-sum is an ill-conditioned yardstick) and the two Adam
+    # updates before them are sign-like (|dw| ~ lr whatever the gradient's size): 5e-3 there
+    return all(abs(a[k] - b[k]) <= (5e-3 if k == 'mu_abs_sum' else rel) * abs(a[k])
+               for k in ('loss0', 'loss1', 'mu_abs_sum', 'params_abs_sum'))
 
 
 @pytest.mark.timeout(300)
