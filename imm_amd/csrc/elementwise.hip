@@ -305,6 +305,19 @@ __device__ __forceinline__ void slice32_reduce(const float* __restrict__ partial
   double a0[4] = {0.0, 0.0, 0.0, 0.0}, a1[4] = {0.0, 0.0, 0.0, 0.0};
   const float* base = partial + (int64_t)sidx * ldp + ch0 + q4;
   int b = rl;
+  // eight rows per trip, all eight 16-byte loads issued before the first add (the two-row loop below walked a 256-row table as
+  // eight L2 round trips in a row: ~4 of the 6-8 us of a small layer's launch); even rows -> a0, odd -> a1: the sums and
+  // their order are those of the two-row loop
+  for (; b + 7 * RL < nblk; b += 8 * RL) {
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = *(const float4*)(base + (int64_t)(b + u * RL) * NS * ldp);
+#pragma unroll
+    for (int u = 0; u < 8; u += 2) {
+      a0[0] += (double)v[u].x; a0[1] += (double)v[u].y; a0[2] += (double)v[u].z; a0[3] += (double)v[u].w;
+      a1[0] += (double)v[u + 1].x; a1[1] += (double)v[u + 1].y; a1[2] += (double)v[u + 1].z; a1[3] += (double)v[u + 1].w;
+    }
+  }
   for (; b + RL < nblk; b += 2 * RL) {
     const float4 v0 = *(const float4*)(base + (int64_t)b * NS * ldp), v1 = *(const float4*)(base + (int64_t)(b + RL) * NS * ldp);
     a0[0] += (double)v0.x; a0[1] += (double)v0.y; a0[2] += (double)v0.z; a0[3] += (double)v0.w;
@@ -335,6 +348,15 @@ __global__ __launch_bounds__(EW_THREADS) void bn_apply_fused_kernel(
   __shared__ double sums[64];
   __shared__ float ssc[32], ssh[32];
   const int tid = threadIdx.x, ch0 = blockIdx.y * 32;
+  const int q = tid & 3;                         // 16-byte chunk of the 64-byte slice of a pixel
+  const int64_t p0 = (int64_t)blockIdx.x * px_per_blk;
+  const int64_t p1 = p0 + px_per_blk < npix ? p0 + px_per_blk : npix;
+  // this thread's first two pixels are requested before the finalize prologue (its L2 round trips hide their latency)
+  const int64_t pf = p0 + (tid >> 2);
+  constexpr int PSTEP = EW_THREADS / 4;
+  uint4 raw0 = make_uint4(0, 0, 0, 0), raw1 = raw0;
+  if (up == nullptr && pf < p1) raw0 = *(const uint4*)(y + pf * ldy + ch0 + q * 8);
+  if (up == nullptr && pf + PSTEP < p1) raw1 = *(const uint4*)(y + (pf + PSTEP) * ldy + ch0 + q * 8);
   if (training) slice32_reduce<2>(partial, nblk, c, ch0, sums);
   if (tid < 32) {
     const int ch = ch0 + tid;
@@ -358,25 +380,41 @@ __global__ __launch_bounds__(EW_THREADS) void bn_apply_fused_kernel(
     if (blockIdx.x == 0) { scale[ch] = sc; shift[ch] = sh; mean_out[ch] = mean; rstd_out[ch] = rstd; }
   }
   __syncthreads();
-  const int q = tid & 3;                         // 16-byte chunk of the 64-byte slice of a pixel
   float sc[8], sh[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) { sc[i] = ssc[q * 8 + i]; sh[i] = ssh[q * 8 + i]; }
-  const int64_t p0 = (int64_t)blockIdx.x * px_per_blk;
-  const int64_t p1 = p0 + px_per_blk < npix ? p0 + px_per_blk : npix;
-  auto norm = [&](int64_t pp, float (&f)[8]) {
-    unpack8<ET>(*(const uint4*)(y + pp * ldy + ch0 + q * 8), f);
+  auto normq = [&](const uint4& rawq, float (&f)[8]) {
+    unpack8<ET>(rawq, f);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       f[i] = f[i] * sc[i] + sh[i];
       if (relu) f[i] = fmaxf(f[i], 0.f);
     }
   };
-  for (int64_t p = p0 + (tid >> 2); p < p1; p += EW_THREADS / 4) {
+  auto norm = [&](int64_t pp, float (&f)[8]) { normq(*(const uint4*)(y + pp * ldy + ch0 + q * 8), f); };
+  if (up == nullptr) {
+    // plain pass: two pixels per trip, the next trip's loads issued before this trip's stores
+    for (int64_t p = pf; p < p1; p += 2 * PSTEP) {
+      const bool two = p + PSTEP < p1;
+      uint4 n0 = make_uint4(0, 0, 0, 0), n1 = n0;
+      if (p + 2 * PSTEP < p1) n0 = *(const uint4*)(y + (p + 2 * PSTEP) * ldy + ch0 + q * 8);
+      if (p + 3 * PSTEP < p1) n1 = *(const uint4*)(y + (p + 3 * PSTEP) * ldy + ch0 + q * 8);
+      float f[8];
+      normq(raw0, f);
+      *(uint4*)(x + p * ldx + ch0 + q * 8) = pack8<ET>(f);
+      if (two) {
+        normq(raw1, f);
+        *(uint4*)(x + (p + PSTEP) * ldx + ch0 + q * 8) = pack8<ET>(f);
+      }
+      raw0 = n0; raw1 = n1;
+    }
+    return;
+  }
+  for (int64_t p = pf; p < p1; p += PSTEP) {
     float f[8];
     norm(p, f);
     *(uint4*)(x + p * ldx + ch0 + q * 8) = pack8<ET>(f);
-    if (up != nullptr) {
+    {
       // x2 bilinear up-sampling of the normalised activation in the same pass (tf.image.resize_images, legacy
       // align_corners=False, imm_model.py:175: out[2i] = in[i], out[2i+1] = (in[i] + in[min(i+1, n-1)]) / 2), from the
       // 16-bit values the separate kernel would read back (same arithmetic, same results)
@@ -742,22 +780,34 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_fused_kernel(
     const float* __restrict__ rstd, int relu, float* dgamma, float* dbeta, uint16_t* __restrict__ dy, int lddy, int px_per_blk) {
   __shared__ double sums[64];
   const int tid = threadIdx.x, ch0 = blockIdx.y * 32;
-  slice32_reduce<2>(partial, nblk, c, ch0, sums);
-  if (blockIdx.x == 0 && tid < 32) { dbeta[ch0 + tid] = (float)sums[tid]; dgamma[ch0 + tid] = (float)sums[32 + tid]; }
   const int q = tid & 3;
+  const int64_t p0 = (int64_t)blockIdx.x * px_per_blk;
+  const int64_t p1 = p0 + px_per_blk < npix ? p0 + px_per_blk : npix;
+  // this thread's first two pixels and its per-channel constants are requested before the finalize prologue (whose L2 round
+  // trips hide their latency)
+  const int64_t pf = p0 + (tid >> 2);
+  constexpr int PSTEP = EW_THREADS / 4;
+  uint4 d0 = make_uint4(0, 0, 0, 0), y0 = d0, d1 = d0, y1 = d0;
+  if (pf < p1) { d0 = *(const uint4*)(dout + pf * lddo + ch0 + q * 8); y0 = *(const uint4*)(y + pf * ldy + ch0 + q * 8); }
+  if (pf + PSTEP < p1) { d1 = *(const uint4*)(dout + (pf + PSTEP) * lddo + ch0 + q * 8); y1 = *(const uint4*)(y + (pf + PSTEP) * ldy + ch0 + q * 8); }
   float sc[8], sh[8], mu[8], rs[8], k0[8], k1[8], k2[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    const int l = q * 8 + i, ch = ch0 + l;
+    const int ch = ch0 + q * 8 + i;
     sc[i] = scale[ch]; sh[i] = shift[ch]; mu[i] = mean[ch]; rs[i] = rstd[ch];
-    k0[i] = gamma[ch] * rs[i]; k1[i] = (float)(sums[l] / count); k2[i] = (float)(sums[32 + l] / count);
+    k0[i] = gamma[ch] * rs[i];
   }
-  const int64_t p0 = (int64_t)blockIdx.x * px_per_blk;
-  const int64_t p1 = p0 + px_per_blk < npix ? p0 + px_per_blk : npix;
-  for (int64_t p = p0 + (tid >> 2); p < p1; p += EW_THREADS / 4) {
+  slice32_reduce<2>(partial, nblk, c, ch0, sums);
+  if (blockIdx.x == 0 && tid < 32) { dbeta[ch0 + tid] = (float)sums[tid]; dgamma[ch0 + tid] = (float)sums[32 + tid]; }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int l = q * 8 + i;
+    k1[i] = (float)(sums[l] / count); k2[i] = (float)(sums[32 + l] / count);
+  }
+  auto one = [&](const uint4& dq, const uint4& yq, int64_t p) {
     float d[8], v[8], o[8];
-    unpack8<ET>(*(const uint4*)(dout + p * lddo + ch0 + q * 8), d);
-    unpack8<ET>(*(const uint4*)(y + p * ldy + ch0 + q * 8), v);
+    unpack8<ET>(dq, d);
+    unpack8<ET>(yq, v);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       float dz = d[i];
@@ -766,6 +816,16 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_fused_kernel(
       o[i] = k0[i] * (dz - k1[i] - xhat * k2[i]);
     }
     *(uint4*)(dy + p * lddy + ch0 + q * 8) = pack8<ET>(o);
+  };
+  // two pixels per trip, the next trip's loads issued before this trip's stores
+  for (int64_t p = pf; p < p1; p += 2 * PSTEP) {
+    const bool two = p + PSTEP < p1;
+    uint4 nd0 = make_uint4(0, 0, 0, 0), ny0 = nd0, nd1 = nd0, ny1 = nd0;
+    if (p + 2 * PSTEP < p1) { nd0 = *(const uint4*)(dout + (p + 2 * PSTEP) * lddo + ch0 + q * 8); ny0 = *(const uint4*)(y + (p + 2 * PSTEP) * ldy + ch0 + q * 8); }
+    if (p + 3 * PSTEP < p1) { nd1 = *(const uint4*)(dout + (p + 3 * PSTEP) * lddo + ch0 + q * 8); ny1 = *(const uint4*)(y + (p + 3 * PSTEP) * ldy + ch0 + q * 8); }
+    one(d0, y0, p);
+    if (two) one(d1, y1, p + PSTEP);
+    d0 = nd0; y0 = ny0; d1 = nd1; y1 = ny1;
   }
 }
 
