@@ -143,7 +143,33 @@ __global__ __launch_bounds__(LO_THREADS) void masked_sse_f32_kernel(const float*
                                                                     float* __restrict__ partial) {
   __shared__ float red[4];
   float acc = 0.f;
-  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (int64_t)gridDim.x * blockDim.x) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 3) {
+    // RGB (the 'input' term of the perceptual loss): four pixels' loads in flight per thread, added in the order of the plain
+    // loop below (this launch sits on the one-lane path in front of the loss: 12.4 us as four dependent trips of scalar loads)
+    const bool a4 = lda == 4 && ((uintptr_t)a & 15) == 0, b4 = ldb == 4 && ((uintptr_t)b & 15) == 0;
+    for (; p + 3 * stride < npix; p += 4 * stride) {
+      float va[4][3], vb[4][3], mk[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t q = p + u * stride;
+        if (a4) { const float4 t = *(const float4*)(a + q * 4); va[u][0] = t.x; va[u][1] = t.y; va[u][2] = t.z; }
+        else { va[u][0] = a[q * lda]; va[u][1] = a[q * lda + 1]; va[u][2] = a[q * lda + 2]; }
+        if (b4) { const float4 t = *(const float4*)(b + q * 4); vb[u][0] = t.x; vb[u][1] = t.y; vb[u][2] = t.z; }
+        else { vb[u][0] = b[q * ldb]; vb[u][1] = b[q * ldb + 1]; vb[u][2] = b[q * ldb + 2]; }
+        mk[u] = mask ? mask[q] : 1.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float sq = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) { const float d = va[u][ch] - vb[u][ch]; sq += l1 ? fabsf(d) : d * d; }
+        acc += mk[u] * sq;
+      }
+    }
+  }
+  for (; p < npix; p += stride) {
     float sq = 0.f;
     for (int ch = 0; ch < c; ++ch) { const float d = a[p * lda + ch] - b[p * ldb + ch]; sq += l1 ? fabsf(d) : d * d; }
     acc += (mask ? mask[p] : 1.f) * sq;
@@ -212,6 +238,11 @@ __global__ __launch_bounds__(LO_THREADS) void perceptual_finalize_kernel(const f
   __shared__ double sse[16];
   __shared__ double wsum[LO_THREADS / 64][16];
   const int tid = threadIdx.x;
+  // the scalars of the tail, requested first (thread f owns feature f)
+  const float nel_f = tid < nfeat ? nel[tid] : 1.f;
+  const float agg_f = tid < nfeat ? agg[tid] : 1.f;
+  const float ls = (tid < nfeat && loss_scale) ? loss_scale[0] : 1.f;
+  const float wd = (tid == 0 && wd_loss) ? wd_loss[0] : 0.f;
   // every feature's partials in flight at once, one wave butterfly per feature, one barrier in all (was a load + an
   // 8-barrier tree per feature in sequence: 10.5 us on the critical path between the last error sum and the first gradient)
   double v[16];
@@ -237,32 +268,38 @@ __global__ __launch_bounds__(LO_THREADS) void perceptual_finalize_kernel(const f
     sse[tid] = t;
   }
   __syncthreads();
-  if (tid == 0) {
-    const float wd = wd_loss ? wd_loss[0] : 0.f;
-    // loss scaling (16-bit gradient storage with f16's range): every seed of the backward pass carries the factor S; the
-    // backward chain is linear in its seeds, imm_clip_adam_step divides the flat gradients by S again
-    const float ls = loss_scale ? loss_scale[0] : 1.f;
-    if (mode == IMM_LOSS_L2) {
-      const float m = (float)(sse[0] / (double)nel[0]);
+  // loss scaling (16-bit gradient storage with f16's range): every seed of the backward pass carries the factor S; the
+  // backward chain is linear in its seeds, imm_clip_adam_step divides the flat gradients by S again
+  if (mode == IMM_LOSS_L2) {
+    if (tid == 0) {
+      const float m = (float)(sse[0] / (double)nel_f);
       out[0] = m; out[nfeat] = m;
-      out[2 * nfeat] = ls * ((1000.f / 255.f) * 2.f / nel[0]);
+      out[2 * nfeat] = ls * ((1000.f / 255.f) * 2.f / nel_f);
       out[3 * nfeat] = 1000.f * m;
       out[3 * nfeat + 1] = wd;
       out[3 * nfeat + 2] = 1000.f * m / 255.f + wd;
-      return;
     }
+    return;
+  }
+  // one thread per feature (their nel / agg / scale loads are one round trip instead of nfeat dependent ones on thread 0:
+  // 18 -> 7 us between the last error sum and the first gradient launch); the terms are then added in feature order
+  __shared__ float terms[16];
+  if (tid < nfeat) {
+    const int f = tid;
+    const float m = (float)(sse[f] / (double)nel_f);
+    const float a = agg_f;
+    const float wl = a + 0.01f * (m - a);
+    const float term = m / wl;
+    out[f] = term;
+    out[nfeat + f] = m;
+    out[2 * nfeat + f] = ls * (1000.f * (1.f / wl - 0.01f * m / (wl * wl)) * (l1 ? 1.f : 2.f) / nel_f);
+    if (training) agg[f] = wl;
+    terms[f] = term;
+  }
+  __syncthreads();
+  if (tid == 0) {
     float rec = 0.f;
-    for (int f = 0; f < nfeat; ++f) {
-      const float m = (float)(sse[f] / (double)nel[f]);
-      const float a = agg[f];
-      const float wl = a + 0.01f * (m - a);
-      const float term = m / wl;
-      out[f] = term;
-      out[nfeat + f] = m;
-      out[2 * nfeat + f] = ls * (1000.f * (1.f / wl - 0.01f * m / (wl * wl)) * (l1 ? 1.f : 2.f) / nel[f]);
-      if (training) agg[f] = wl;
-      rec += term;
-    }
+    for (int f = 0; f < nfeat; ++f) rec += terms[f];
     rec *= 1000.f;
     out[3 * nfeat] = rec;
     out[3 * nfeat + 1] = wd;
