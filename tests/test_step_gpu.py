@@ -461,8 +461,8 @@ def test_gradient_parity_on_a_trained_model(dt):
     Measured over such builds: worst 0.095 .. 0.23, median 0.04 .. 0.07, worst cosine 0.98 .. 0.9955; tensor by tensor the
     engine sits at 0.9 .. 2.2 x the emulation where the emulation itself is small (0.03), within +-10 % where it is large:
     what is left is bf16 storage, not wiring.
-    f16 (BASELINE configs[4]; the reference is fp32, imm_model.py:97): the same test with the SAME bounds (against the oracle's
-    bf16 emulation).  Without loss scaling the stored dy tensors of the trained pose encoder underflow f16 (relative error up to
+    f16 (BASELINE configs[4]; the reference is fp32, imm_model.py:97): the same test with HALF the bounds (0.15 / cosine 0.99 /
+    median 0.05; still no further from the oracle than 1.5 x its bf16 emulation + 0.03).  Without loss scaling the stored dy tensors of the trained pose encoder underflow f16 (relative error up to
     3.6 on its first convolution, round 2); with the dynamic loss scale of imm_clip_adam_step the f16 engine has to be at
     least as close to the fp32 oracle as the bf16 engine is allowed to be, and no step of the 60 may be lost to an overflow
     after the first few (the scale search)."""
@@ -499,6 +499,9 @@ def test_gradient_parity_on_a_trained_model(dt):
     _oe, g_e = O.loss_and_grads(Pe, Se, inputs, cfg, act_round=bf)
     assert abs(float(eng.loss) - float(out_f['loss'])) / abs(float(out_f['loss'])) < 2e-3
     bad, rels, worst = [], [], (0.0, 1.0)
+    # f16 storage rounds 8x finer than bf16: measured worst 0.035, median 0.008, cosine 0.9994 (round 3) — held to half the
+    # bf16 bounds (which stay where the chaotic 60-step trajectory needs them, see above)
+    lim_rel, lim_cos, lim_med = (0.30, 0.97, 0.10) if dt == torch.bfloat16 else (0.15, 0.99, 0.05)
     gv = eng.named_gradients()            # loss scale divided out (f16); == gview for bf16
     for k, v in g_f.items():
         if k.endswith('/b') and (k[:-2] + '/gamma') in g_f:
@@ -513,12 +516,12 @@ def test_gradient_parity_on_a_trained_model(dt):
         rels.append(e)
         worst = (max(worst[0], e), min(worst[1], cos))
         print('TRAINED_GRAD %-48s rel %.4f cos %.5f  emul %.4f' % (k, e, cos, e_emul))
-        if e > 0.30 or cos < 0.97 or e > 1.5 * e_emul + 0.03:
+        if e > lim_rel or cos < lim_cos or e > 1.5 * e_emul + 0.03:
             bad.append((k, e, cos, e_emul))
     med = float(np.median(np.array(rels)))
     print('TRAINED_GRAD worst rel %.4f, worst cos %.5f, median rel %.4f' % (worst + (med,)))
     assert not bad, bad
-    assert med <= 0.10, med
+    assert med <= lim_med, med
 
 
 def test_backward_is_the_derivative_of_the_forward():
