@@ -47,16 +47,17 @@ __device__ __forceinline__ void wh_dma16(u32x4_t rsrc, uint32_t lds_addr, uint32
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
                :: "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
 }
-// same offset-robust chunk swizzle as conv_halo.hip (also conflict-free for the 8-byte transpose reads: the 8
-// pixels x 32 bytes a 32-lane half touches land on 8 distinct 32-byte bank windows)
+// Chunk swizzle of an LDS image [pixel][C8 chunks of 16 B], for the 8-byte transpose reads.  A 32-lane half of such a read takes
+// EIGHT pixels of one image row — x..x+3 and x+8..x+11 — times 32 bytes (16 channels), and the LDS serves 256 B = its 64 banks
+// per pass: the eight 32-byte windows must differ modulo 256 B.  Pixel stride 128 B (64 channels): even and odd pixels already
+// split the 256 B in halves, the chunk pair is XORed with (bit 1 of x) | (bit 3 of x) << 1; 64 B (32 channels): with bit 3 of x.
+// (Round 3.  Measured with SQ_LDS_BANK_CONFLICT: the swizzle of the forward halo kernels, ((pixel >> 1) & 3), and a first
+// replacement, pixel & 3, both give pixels x and x + 8 the same window — two passes per read, conflict cycles = half of
+// SQ_LDS_IDX_ACTIVE.)  It depends on the pixel's COLUMN only: a lane keeps one base address per (horizontal tap offset, first /
+// second read) and every read of the loop is base + immediate offset — the address arithmetic (3.3 VALU instructions per MFMA at
+// one wave per SIMD) leaves the loop.
 template <int C8>
-__device__ __forceinline__ int wh_swz(int row) { return C8 == 8 ? (((row >> 1) & 3) << 1) : (((row >> 2) & 1) << 1); }
-
-// byte offset inside an LDS image [row][C8 chunks of 16 B] of the 8-byte piece holding channels ch..ch+3 (ch % 4 == 0)
-template <int C8>
-__device__ __forceinline__ uint32_t wh_piece(int row, int ch) {
-  return (uint32_t)((row * C8 + ((ch >> 3) ^ wh_swz<C8>(row))) * 16 + (ch & 4) * 2);
-}
+__device__ __forceinline__ int wh_swzx(int x) { return C8 == 8 ? ((((x >> 1) & 1) | (((x >> 3) & 1) << 1)) << 1) : (((x >> 3) & 1) << 1); }
 
 struct WgradHaloArgs {
   const uint16_t* x; const uint16_t* dy; float* slab;
@@ -99,36 +100,60 @@ __device__ __forceinline__ void conv_wgrad_halo_body(const WgradHaloArgs& a, con
   const uint32_t lds_base = (uint32_t)(size_t)(lds_void_t*)smem;
   const int per_img = a.patches_x * a.patches_y;
 
+  // Per-lane halves of the DMA addresses, computed ONCE (they were ~250 VALU instructions per patch and wave, ahead of the patch's
+  // first MFMA): piece u of this wave is DMA instruction wid + 4u; a patch adds a scalar offset, and for X the image-border test.
+  constexpr int XU = X_DMA / 4, YU = Y_DMA / 4;
+  int x_iy[XU], x_ix[XU];            // input row / column of the piece's pixel relative to the patch's input origin
+  int x_rel[XU];                     // its byte offset relative to that origin (+ channel slice, swizzled chunk)
+  uint32_t y_rel[YU];
+  const int w_in = ST * a.w, h_in = ST * a.h;
+#pragma unroll
+  for (int u = 0; u < XU; ++u) {
+    const int hp = (wid + 4 * u) * X_PIX_PER_DMA + lane / XC8;
+    int iy, ix, col;
+    bool valid;
+    if constexpr (ST == 2) {
+      const int plane = hp / WH_S2_PP, rem = hp - plane * WH_S2_PP;
+      const int pi = rem / WH_S2_PW, pj = rem - pi * WH_S2_PW;
+      iy = 2 * pi + (plane >> 1); ix = 2 * pj + (plane & 1);
+      valid = rem < 9 * WH_S2_PW;
+      col = pj;
+    } else {
+      const int hy = hp / WH_HW, hx = hp - hy * WH_HW;
+      iy = hy - PT; ix = hx - PL;
+      valid = hp < HPIX;
+      col = hx;
+    }
+    const int sc = (lane % XC8) ^ wh_swzx<XC8>(col);
+    x_iy[u] = valid ? iy : (1 << 24);          // never inside an image
+    x_ix[u] = ix;
+    x_rel[u] = ((iy * w_in + ix) * a.ldx + ci0) * 2 + sc * 16;
+  }
+#pragma unroll
+  for (int u = 0; u < YU; ++u) {
+    const int p = (wid + 4 * u) * Y_PIX_PER_DMA + lane / YC8;       // patch pixel 0..127
+    const int ty = p >> 4, tx = p & 15;
+    const int sc = (lane % YC8) ^ wh_swzx<YC8>(tx);
+    y_rel[u] = (uint32_t)(((ty * a.w + tx) * a.lddy + co0) * 2 + sc * 16);
+  }
+
   auto issue = [&](int patch, int stage) {
     const int img = patch / per_img, pr = patch - img * per_img;
     const int y0 = (pr / a.patches_x) * WH_PH, x0 = (pr % a.patches_x) * WH_PW;
-    const uint32_t xs = (uint32_t)(img * (ST * a.h) * (ST * a.w)) * (uint32_t)(a.ldx * 2);   // a.h, a.w = OUTPUT map (input = ST x)
-    const uint32_t ys = (uint32_t)(img * a.h * a.w) * (uint32_t)(a.lddy * 2);
-    for (int i = wid; i < X_DMA; i += 4) {
-      const int hp = i * X_PIX_PER_DMA + lane / XC8;
-      int iy, ix;
-      bool ok;
-      if constexpr (ST == 2) {
-        const int plane = hp / WH_S2_PP, rem = hp - plane * WH_S2_PP;
-        const int pi = rem / WH_S2_PW, pj = rem - pi * WH_S2_PW;
-        iy = 2 * (y0 + pi) + (plane >> 1); ix = 2 * (x0 + pj) + (plane & 1);
-        ok = rem < 9 * WH_S2_PW && iy < ST * a.h && ix < ST * a.w;
-      } else {
-        const int hy = hp / WH_HW, hx = hp - hy * WH_HW;
-        iy = y0 - PT + hy; ix = x0 - PL + hx;
-        ok = (hp < HPIX) && ((unsigned)iy < (unsigned)a.h) && ((unsigned)ix < (unsigned)a.w);
-      }
-      const int sc = (lane % XC8) ^ wh_swz<XC8>(hp);
-      const uint32_t vo = ok ? (uint32_t)(((iy * (ST * a.w) + ix) * a.ldx + ci0) * 2 + sc * 16) : OOB;
-      wh_dma16(xr, __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)(stage * STAGE + i * 1024)), vo, xs);
+    const uint32_t xs = (uint32_t)(img * h_in * w_in) * (uint32_t)(a.ldx * 2);   // a.h, a.w = OUTPUT map (input = ST x)
+    const uint32_t ys = (uint32_t)(img * a.h * a.w) * (uint32_t)(a.lddy * 2) + (uint32_t)((y0 * a.w + x0) * a.lddy * 2);
+    const int py = ST * y0, px = ST * x0;
+    const int poff = (py * w_in + px) * a.ldx * 2;
+    const uint32_t lds_stage = lds_base + (uint32_t)(stage * STAGE + wid * 1024);
+#pragma unroll
+    for (int u = 0; u < XU; ++u) {
+      const bool ok = ((unsigned)(py + x_iy[u]) < (unsigned)h_in) && ((unsigned)(px + x_ix[u]) < (unsigned)w_in);
+      const uint32_t vo = ok ? (uint32_t)(x_rel[u] + poff) : OOB;
+      wh_dma16(xr, __builtin_amdgcn_readfirstlane(lds_stage + (uint32_t)(u * 4096)), vo, xs);
     }
-    for (int i = wid; i < Y_DMA; i += 4) {
-      const int p = i * Y_PIX_PER_DMA + lane / YC8;       // patch pixel 0..127
-      const int ty = p >> 4, tx = p & 15;
-      const int sc = (lane % YC8) ^ wh_swz<YC8>(p);
-      const uint32_t vo = (uint32_t)((((y0 + ty) * a.w + x0 + tx) * a.lddy + co0) * 2 + sc * 16);
-      wh_dma16(yr, __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)(stage * STAGE + X_BYTES + i * 1024)), vo, ys);
-    }
+#pragma unroll
+    for (int u = 0; u < YU; ++u)
+      wh_dma16(yr, __builtin_amdgcn_readfirstlane(lds_stage + (uint32_t)(X_BYTES + u * 4096)), y_rel[u], ys);
   };
 
   f32x4_t acc[NTAP][TNT];
@@ -142,6 +167,21 @@ __device__ __forceinline__ void conv_wgrad_halo_body(const WgradHaloArgs& a, con
   const int i16 = lane & 15, g = lane >> 4;
   const int k_row = g >> 1, k_x = (g & 1) * 8 + (i16 >> 2), ch4 = (i16 & 3) * 4;
   const char* lds_c = (const char*)smem;
+  // per-lane byte offsets inside a stage (see wh_swzx): X^T piece for horizontal tap offset e and first / second read (+4 pixels),
+  // dY^T piece of tile j; everything else of a read's address is a compile-time offset
+  constexpr int KXE = ST == 2 ? 2 : KW;                      // horizontal offsets inside a plane / the halo: kx >> 1 or kx
+  const int lx = k_row * (ST == 2 ? WH_S2_PW : WH_HW) + k_x, ly = k_row * WH_PW + k_x;
+  uint32_t xb[KXE][2], yb[TNT][2];
+#pragma unroll
+  for (int e = 0; e < KXE; ++e)
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+      xb[e][h] = (uint32_t)((lx * XC8 + (((wc * 16 + ch4) >> 3) ^ wh_swzx<XC8>(k_x + e + 4 * h))) * 16 + (ch4 & 4) * 2);
+#pragma unroll
+  for (int j = 0; j < TNT; ++j)
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+      yb[j][h] = (uint32_t)(X_BYTES + (ly * YC8 + (((((wn * TNT + j) * 16) + ch4) >> 3) ^ wh_swzx<YC8>(k_x + 4 * h))) * 16 + (ch4 & 4) * 2);
 
   const int n_mine = (bx < a.n_patches) ? (a.n_patches - bx + G - 1) / G : 0;
 #pragma unroll
@@ -157,8 +197,7 @@ __device__ __forceinline__ void conv_wgrad_halo_body(const WgradHaloArgs& a, con
       int ns = stage + NS - 1; if (ns >= NS) ns -= NS;
       issue(bx + (it + NS - 1) * G, ns);
     }
-    const char* Xl = lds_c + stage * STAGE;
-    const char* Yl = Xl + X_BYTES;
+    const char* Xl = lds_c + stage * STAGE;     // (the dY patch follows the X halo inside the stage: yb includes X_BYTES)
 
     // dY^T fragments of this wave's co tiles for the 4 k-steps of the patch: reused by all nine taps
     uint4 bfr[4][TNT];
@@ -166,10 +205,9 @@ __device__ __forceinline__ void conv_wgrad_halo_body(const WgradHaloArgs& a, con
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
       for (int j = 0; j < TNT; ++j) {
-        const int n0 = (wn * TNT + j) * 16;
-        const int p0 = (ks * 2 + k_row) * 16 + k_x;
-        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(Yl + wh_piece<YC8>(p0, n0 + ch4)));
-        const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(Yl + wh_piece<YC8>(p0 + 4, n0 + ch4)));
+        // pixel = ly + ks * 32 (+ 4)
+        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(Xl + yb[j][0] + ks * 32 * YC8 * 16));
+        const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(Xl + yb[j][1] + (ks * 32 + 4) * YC8 * 16));
         const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
         bfr[ks][j] = make_uint4(l2.x, l2.y, h2.x, h2.y);
       }
@@ -178,10 +216,12 @@ __device__ __forceinline__ void conv_wgrad_halo_body(const WgradHaloArgs& a, con
       const int ky = tap / KW, kx = tap % KW;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        const int hp = ST == 2 ? ((ky & 1) * 2 + (kx & 1)) * WH_S2_PP + (ks * 2 + k_row + (ky >> 1)) * WH_S2_PW + k_x + (kx >> 1)
-                               : (ks * 2 + k_row + ky) * WH_HW + k_x + kx;
-        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(Xl + wh_piece<XC8>(hp, wc * 16 + ch4)));
-        const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(Xl + wh_piece<XC8>(hp + 4, wc * 16 + ch4)));
+        // pixel = lx (this lane's part) + cp (compile-time part); its column = k_x + e (+ 4)
+        const int e = ST == 2 ? (kx >> 1) : kx;
+        const int cp = ST == 2 ? ((ky & 1) * 2 + (kx & 1)) * WH_S2_PP + (ks * 2 + (ky >> 1)) * WH_S2_PW + (kx >> 1)
+                               : (ks * 2 + ky) * WH_HW + kx;
+        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(Xl + xb[e][0] + cp * XC8 * 16));
+        const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(Xl + xb[e][1] + (cp + 4) * XC8 * 16));
         const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
         const uint4 af = make_uint4(l2.x, l2.y, h2.x, h2.y);
 #pragma unroll
