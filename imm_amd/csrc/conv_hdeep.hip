@@ -591,7 +591,8 @@ struct HdPlan { int ph, bn, n_patches, n_wg; bool map8, persist, row3; };
 static HdPlan hd_plan(const imm_conv_desc* d) {
   constexpr bool no_small = false;
   const int cus = hd_num_cu();
-  constexpr int small_below = 4;   // x CUs
+  constexpr int small_below = 2;   // x CUs (round 3: 4 -> 2.  128 -> 64 channels at 64x64 maps, batch 32 — renderer conv_5, VGG conv2_1's data
+                                   // gradient — as 512 tiles of 16x16x64 (8 waves) instead of 1024 of 8x16x64: -12 us per step, same box)
   constexpr bool no_big = false;
   HdPlan p;
   p.map8 = false; p.persist = false; p.row3 = false;
