@@ -36,6 +36,7 @@ def main():
     t_issue = (time.perf_counter() - t_all) * 1e3
     e1.record()
     ts.synchronize()
+    torch.cuda.synchronize()      # e0 / e1 sit on the caller's stream, which waits for the step's stream
     dev_ms = e0.elapsed_time(e1) / n
     print('device %.3f ms/step; host issue of %d steps %.2f ms total (%.3f ms/step); per-call host ms: first 8 %s ... last 4 %s' % (
         dev_ms, n, t_issue, t_issue / n, ['%.2f' % h for h in host[:8]], ['%.2f' % h for h in host[-4:]]))
