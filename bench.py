@@ -216,6 +216,34 @@ def cpu_baseline(budget_s=12.0):
             'legs': legs}
 
 
+def parity_vs_oracle(dev, batch=2):
+    """The second half of BASELINE.json's metric ("landmark MSE vs TF1 ref"): one training-mode forward pass of the HIP path on a
+    seeded batch of `batch` 128x128 images at K=10 against the CPU restatement of the TF1 graph (oracle/imm_oracle.py — TF 1.10
+    itself cannot run here) on the same inputs and the same seeded initial weights.  Part of the cpu_baseline leg
+    (the oracle is the checker, never the thing measured); ~1 s of CPU work."""
+    from oracle import imm_oracle as O
+    from imm_amd.models.imm_model import IMMModel
+    from imm_amd.utils.box import Box
+    cfg = O.default_model_config(N_MAPS)
+    inputs = O.synthetic_inputs(batch, IMAGE_SIZE, seed=0)
+    model = IMMModel(Box(dict(cfg)), dtype=torch.bfloat16, device=dev)
+    _, loss, _, tensors = model.build(inputs, True, output_tensors=True)
+    torch.cuda.synchronize()
+    P, S = O.init_params(cfg, IMAGE_SIZE)
+    with torch.no_grad():
+        ref = O.forward(P, S, inputs, cfg, training=True)
+    mu = tensors['gauss_yx'].detach().float().cpu()
+    d = mu - ref['gauss_yx']
+    pred = tensors['future_im_pred'].detach().float().cpu()
+    rp = ref['future_im_pred']
+    return {'reference': 'oracle/imm_oracle.py (fp32 torch-CPU restatement of the TF1 graph; parity unpinned against TF itself)',
+            'batch': batch, 'dtype': 'bf16 storage vs fp32',
+            'landmark_mse': float((d * d).mean()), 'mu_max_abs': float(d.abs().max()),
+            'loss_rel': abs(float(loss) - float(ref['loss'])) / abs(float(ref['loss'])),
+            'recon_rel_l2': float((pred - rp).norm() / rp.norm()),
+            'bounds': {'mu_max_abs': 1e-3, 'loss_rel': 1e-3, 'recon_rel_l2': 0.12}}
+
+
 # ---------------------------------------------------------------------------------------------------------
 def free_port():
     s = socket.socket()
@@ -254,6 +282,12 @@ def main():
     ap.add_argument('--force-dist', action='store_true', help='initialise the process group and run the split-graph + all-reduce path even at 1 GPU')
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend: 'nccl' (= RCCL on ROCm) or 'gloo' (tests)")
     ap.add_argument('--share-gpu', action='store_true', help='tests: let several ranks share one device (needs --backend gloo)')
+    ap.add_argument('--collective', choices=('pg', 'native', 'graph'), default=None,
+                    help="gradient exchange at N > 1: 'pg' torch.distributed all-reduce between two graphs (default), 'native' "
+                         "imm_rccl_allreduce on its own stream, 'graph' imm_rccl_allreduce captured into the step's single HIP graph "
+                         "(RCCL only); default: IMM_RCCL_GRAPH / IMM_RCCL_NATIVE, else pg")
+    ap.add_argument('--buckets', type=int, choices=(1, 2), default=None,
+                    help='all-reduce buckets (2: the renderer bucket travels while the encoders\' backward runs); default IMM_DP_BUCKETS or 1')
     ap.add_argument('--pmc-pass', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -294,8 +328,9 @@ def main():
     from imm_amd.models.imm_model import IMMModel
     from imm_amd.train.cnn_train_multi import TrainStep
 
-    model = IMMModel(model_config(N_MAPS), dtype=torch.bfloat16, device=dev, world_size=world)
-    ts = TrainStep(model, BATCH_PER_GPU, IMAGE_SIZE, world_size=world, use_graph=not args.no_graph, split_graphs=args.force_dist)
+    model = IMMModel(model_config(N_MAPS), dtype=torch.bfloat16, device=dev, world_size=world, dp_buckets=args.buckets)
+    ts = TrainStep(model, BATCH_PER_GPU, IMAGE_SIZE, world_size=world, use_graph=not args.no_graph, split_graphs=args.force_dist,
+                   collective=args.collective)
     eng = ts.engine
     inputs = synthetic_batch(BATCH_PER_GPU, IMAGE_SIZE, seed=rank, device=dev)
     eng.set_inputs(inputs['image'], inputs['future_image'], inputs['mask'])     # resident in HBM from here on
@@ -341,6 +376,15 @@ def main():
         lt = eng.loss.detach().clone().reshape(1).to(ctrl)
         dist.all_reduce(lt)
         loss = float(lt) / world
+
+    replicas_identical = None
+    if world > 1:
+        # data-parallel invariant: after the same number of updates from all-reduced gradients every rank holds the SAME bits
+        bits = eng.params.view(torch.int32).to(torch.int64)
+        chk = torch.stack([bits.sum(), (bits * (torch.arange(bits.numel(), device=bits.device) % 8191 + 1)).sum()]).to(ctrl)
+        got = [torch.zeros_like(chk) for _ in range(world)]
+        dist.all_gather(got, chk)
+        replicas_identical = all(bool(torch.equal(g, got[0])) for g in got)
 
     if rank == 0:
         # per-kernel timing with HIP events on the launch stream (eager pass; graph replay hides launches)
@@ -391,7 +435,7 @@ def main():
                        'global_batch': world * BATCH_PER_GPU, 'image_size': IMAGE_SIZE, 'n_maps': N_MAPS,
                        'parallelism': 'dp%d' % world, 'hip_graph': not args.no_graph,
                        'collective': ({'backend': dist.get_backend(), 'world_size': dist.get_world_size(),
-                                       'buckets': ts.buckets, 'graph_resident': bool(ts.graph_resident),
+                                       'mode': ts.collective, 'buckets': ts.buckets, 'graph_resident': bool(ts.graph_resident),
                                        'native_rccl': ts.native_comm is not None} if dist.is_initialized() else None),
                        'weights': 'seeded random init; synthetic VGG16 (vgg16.caffemodel.h5 unavailable offline)'},
             'roofline': roof,
@@ -403,11 +447,12 @@ def main():
                      'frac_of_peak': round(step_flops / (ms_per_step * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
                      'trainable_conv_tflops': round(sum(d[2] for d in tr) / (sum(d[1] for d in tr) * 1e-3) / 1e12, 1) if tr else None,
                      'sum_kernel_ms_eager': round(total_ms, 3), 'hbm_gb_per_step': hbm_gb_step, 'loss': round(loss, 3),
-                     'hbm_bytes_allocated': eng.memory_bytes()},
+                     'hbm_bytes_allocated': eng.memory_bytes(), 'replicas_identical': replicas_identical},
             'kernels': breakdown,
         }
         if (not args.no_cpu_baseline and world == 1) or args.cpu_baseline_full:
             out['cpu_baseline'] = cpu_baseline(0.0 if args.cpu_baseline_full else 12.0)
+            out['parity'] = parity_vs_oracle(dev)
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + '\n').encode())
     if dist.is_initialized():

@@ -20,7 +20,7 @@ CONV_BIAS, CONV_RELU, CONV_STATS, CONV_MASK, CONV_OUT_F32 = 1, 2, 4, 8, 16
 SSE_BLOCKS = 512
 OPTIMIZERS = {'adam': 0, 'adadelta': 1, 'adagrad': 2}      # IMM_OPT_* (scripts/train.py:97-104)
 GAUSS_MODES = {'rot': 0, 'flat': 1, 'ankush': 2}     # IMM_GAUSS_* (config key gauss_mode, imm_model.py:48-72)
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 
 class ImmHipError(RuntimeError):
@@ -99,6 +99,8 @@ _SIGS = {
     'imm_tps_warp': [_P, _I, _I, _I, _I, _I, _P, _I, _P, _P, _I, _P, _P, _I, _P],
     'imm_tps_warp_pad': [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P, _I, _P],
     'imm_conv2d_group': [_P, _I, _I, _P, _P, _P, _P, _P, _P],
+    'imm_conv2d_dgrad_s2_supported': [_I, _I, _I, _I, _I, _I],
+    'imm_conv2d_dgrad_s2': [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
     'imm_conv2d_group_stats_blocks': [_P, _I],
     'imm_upsample2x_bwd_bn': [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P],
     'imm_upsample2x_bwd_bn_blocks': [_I, _I, _I, _I],

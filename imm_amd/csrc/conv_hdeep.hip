@@ -83,9 +83,21 @@ __device__ __forceinline__ float hd_row_sum16(float x) {
 // the same interval cost only their own 0.11 us.  The ring is the nine tap stages of a slice (tap (ky, kx) of every slice lands
 // in stage 3 ky + kx; a row's three stages are refilled for the next slice right after the row's barrier), the next slice's halo
 // is requested after the FIRST row's barrier so that it has landed when the last row's barrier is passed.
-template <typename ET, int BN, int NW, int PH, bool MAP8 = false, int NSB_ = 0, bool PERSIST = false, bool ROW3 = false>
+//
+// S2D (round 4): the DATA GRADIENT of a 3x3 STRIDE-2 SAME convolution (encoder conv_3 / conv_5 / conv_7, imm_model.py:197,204,211;
+// padding 0 top / left, 1 bottom / right) as ONE launch over ONE dy halo.  Input pixel (2i+py, 2j+px) only receives
+// the filter taps ky = py (mod 2), kx = px (mod 2): four parity classes with 4 / 2 / 2 / 1 taps, each a dense sub-convolution of
+// dy.  The tile is an 8x16 patch of CLASS pixels (i, j) — i.e. a 16x32 patch of dx — with FOUR accumulator sets; the "input" is
+// dy with the ordinary 10x18 halo; the filter is the ordinary flipped data-gradient image (imm_pack_weights mode 1: tap t' =
+// (ky', kx') holds W[2-ky'][2-kx']), and tap t' simply accumulates into class (ky' & 1, kx' & 1) from halo offset
+// (min(ky', 1), min(kx', 1)): dy[i - (ky >> 1)][j - (kx >> 1)] with ky = 2 - ky'.  Nine taps of matrix work per tile — the
+// algorithmic count; the im2col forms it replaces ran four launches' worth of gathers at 1-7 % matrix duty with 6-39 VALU
+// instructions per MFMA (profiles/r03_v3_pmc_sq_ratios.txt).  The epilogue scatters class (py, px) to pixel (2i+py, 2j+px).
+template <typename ET, int BN, int NW, int PH, bool MAP8 = false, int NSB_ = 0, bool PERSIST = false, bool ROW3 = false, bool S2D = false>
 __global__ __launch_bounds__(NW * 64) void conv_hdeep_kernel(const HdArgs ha) {
   const ConvArgs& a = ha.c;
+  static_assert(!S2D || (!MAP8 && !PERSIST && NW == 4 && BN == 64), "stride-2 data gradient: 8x16 class patches x 64 channels, one tile per workgroup");
+  constexpr int NCLS = S2D ? 4 : 1;                    // accumulator sets (parity classes)
   static_assert((NW == 8 && PH == 16) || (NW == 4 && PH == 8), "wave (wm, wn) owns patch rows 4wm..4wm+3 x BN/2 channels");
   static_assert(!MAP8 || NW == 4, "two 8x8 images per 4-wave workgroup");
   static_assert(!(PERSIST && MAP8), "persistent tiles: 16x16 / 8x16 patches only");
@@ -189,7 +201,7 @@ __global__ __launch_bounds__(NW * 64) void conv_hdeep_kernel(const HdArgs ha) {
   // The accumulators START at the bias: its loads are issued here, behind the prologue DMA (an epilogue that begins with a
   // dependent global load costs its whole latency: ~0.6 us of the 2.2 us measured per tile), and the epilogue has no adds.
   const bool f_bias = a.flags & IMM_CONV_BIAS;
-  f32x4_t acc[MT][NT], bias4[NT];
+  f32x4_t acc[NCLS][MT][NT], bias4[NT];
   auto load_bias = [&](int n0_) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
@@ -199,9 +211,11 @@ __global__ __launch_bounds__(NW * 64) void conv_hdeep_kernel(const HdArgs ha) {
   };
   load_bias(e_n0);
 #pragma unroll
-  for (int i = 0; i < MT; ++i)
+  for (int c = 0; c < NCLS; ++c)
 #pragma unroll
-    for (int j = 0; j < NT; ++j) acc[i][j] = bias4[j];
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[c][i][j] = bias4[j];
 
   // per-lane fragment offsets (uint4 units): A = halo pixel (row wm*4 + i + ky, col frow + kx), B = filter row.  Persistent
   // tiles recompute them after every epilogue (11 registers that need not live through it).
@@ -233,7 +247,8 @@ __global__ __launch_bounds__(NW * 64) void conv_hdeep_kernel(const HdArgs ha) {
   //     ds_read (t+1, 0)
   //     MFMA (t, 1)
   uint4 af[2][MT], bf[2][NT];                          // [k-step][tile]
-  auto read_frags = [&](const int ks, const uint4* Hs, const uint4* Bs, const int ky, const int kx) __attribute__((always_inline)) {
+  auto read_frags = [&](const int ks, const uint4* Hs, const uint4* Bs, const int ky_, const int kx_) __attribute__((always_inline)) {
+    const int ky = S2D ? (ky_ > 0 ? 1 : 0) : ky_, kx = S2D ? (kx_ > 0 ? 1 : 0) : kx_;   // S2D: halo offset min(k', 1), see the header
 #pragma unroll
     for (int i = 0; i < MT; ++i) af[ks][i] = Hs[(aoff[kx] ^ (ks * 4)) + i * STEP_I + ky * STEP_KY];
 #pragma unroll
@@ -288,10 +303,11 @@ __global__ __launch_bounds__(NW * 64) void conv_hdeep_kernel(const HdArgs ha) {
             if (ky < 2) read_frags(0, Hc, smem + BRING_U4 + ((ky + 1) * 3) * B_U4, ky + 1, 0);
             else read_frags(0, Hnx, smem + BRING_U4, 0, 0);           // past the last slice: landed no-op data, never used
           }
+          const int cls = S2D ? ((ky & 1) * 2 + ((j >> 1) & 1)) : 0;     // parity class of tap (ky, kx = j >> 1)
 #pragma unroll
           for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int jj = 0; jj < NT; ++jj) acc[i][jj] = ET::mfma(bf[cur][jj], af[cur][i], acc[i][jj]);
+            for (int jj = 0; jj < NT; ++jj) acc[cls][i][jj] = ET::mfma(bf[cur][jj], af[cur][i], acc[cls][i][jj]);
 #pragma unroll
           for (int m = 0; m < MT * NT; ++m) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -327,10 +343,11 @@ __global__ __launch_bounds__(NW * 64) void conv_hdeep_kernel(const HdArgs ha) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
       read_frags(1, Hc, Bc, ky, kx);
+      const int cls = S2D ? ((ky & 1) * 2 + (kx & 1)) : 0;                                 // parity class of this tap
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = ET::mfma(bf[0][j], af[0][i], acc[i][j]);   // D[n][pixel]
+        for (int j = 0; j < NT; ++j) acc[cls][i][j] = ET::mfma(bf[0][j], af[0][i], acc[cls][i][j]);   // D[n][pixel]
       // issue order inside the region: 1 MFMA, 1 ds_read, <= 2 address ops, ... (non-MFMA issues ride in the pipe's shadow)
 #pragma unroll
       for (int m = 0; m < MT * NT; ++m) {
@@ -355,7 +372,7 @@ __global__ __launch_bounds__(NW * 64) void conv_hdeep_kernel(const HdArgs ha) {
       // time) rides in their shadow; the second quarter covers the halo piece, the rest the next tap's fragment reads.
       constexpr int QM = MT * NT / 4;
 #pragma unroll
-      for (int m = 0; m < QM; ++m) acc[m % MT][m / MT] = ET::mfma(bf[1][m / MT], af[1][m % MT], acc[m % MT][m / MT]);
+      for (int m = 0; m < QM; ++m) acc[cls][m % MT][m / MT] = ET::mfma(bf[1][m / MT], af[1][m % MT], acc[cls][m % MT][m / MT]);
       __builtin_amdgcn_sched_barrier(0);
       if (PERSIST && tp == 9 - HD_NSB && !next_slice && have_next) {          // t + NSB == T: the ring runs on into the next tile
 #pragma unroll
@@ -365,13 +382,13 @@ __global__ __launch_bounds__(NW * 64) void conv_hdeep_kernel(const HdArgs ha) {
       else issue_b(t + HD_NSB - T, bs, have_next);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int m = QM; m < 2 * QM; ++m) acc[m % MT][m / MT] = ET::mfma(bf[1][m / MT], af[1][m % MT], acc[m % MT][m / MT]);
+      for (int m = QM; m < 2 * QM; ++m) acc[cls][m % MT][m / MT] = ET::mfma(bf[1][m / MT], af[1][m % MT], acc[cls][m % MT][m / MT]);
       __builtin_amdgcn_sched_barrier(0);
       issue_halo_piece(next_slice ? cc + 1 : 0, hs_next, tp, (next_slice || have_next) && tp < NPIECE);   // ... and so does the halo
       // (k-step 0 of the next tap; not across a tile boundary: 32 fragment registers would stay live through the epilogue)
       if (!(PERSIST && tp == 8 && !next_slice)) read_frags(0, Hn, Bn, ntp / 3, ntp % 3);
 #pragma unroll
-      for (int m = 2 * QM; m < MT * NT; ++m) acc[m % MT][m / MT] = ET::mfma(bf[1][m / MT], af[1][m % MT], acc[m % MT][m / MT]);
+      for (int m = 2 * QM; m < MT * NT; ++m) acc[cls][m % MT][m / MT] = ET::mfma(bf[1][m / MT], af[1][m % MT], acc[cls][m % MT][m / MT]);
 #pragma unroll
       for (int m = 0; m < 2 * QM; ++m) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -418,7 +435,28 @@ __global__ __launch_bounds__(NW * 64) void conv_hdeep_kernel(const HdArgs ha) {
   typedef short s16x2_t __attribute__((ext_vector_type(2)));
   typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
   const s16x2_t zero2 = {0, 0}, one2 = {1, 1};
-  if ((a.flags & IMM_CONV_TAP_) && rows_exist) {
+  if constexpr (S2D) {
+    // ---- stride-2 data gradient: class (py, px) of tile pixel (row wm*4 + i, col frow) -> dx pixel (2 row + py, 2 col + px) ----
+    const int W2 = 2 * a.wo;
+#pragma unroll
+    for (int c = 0; c < NCLS; ++c) {
+      const int64_t mc = ((int64_t)img * (2 * a.ho) + 2 * (y0 + wm * 4) + (c >> 1)) * W2 + 2 * (x0 + frow) + (c & 1);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int64_t m = mc + (int64_t)i * 2 * W2;
+#pragma unroll
+        for (int h = 0; h < NT / 2; ++h) {
+          uint32_t w[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int j = 2 * h + (e >> 1), r = (e & 1) * 2;
+            w[e] = ET::pack2(acc[c][i][j][r], acc[c][i][j][r + 1]);
+          }
+          if (nb + 8 * h < a.co) *(uint4*)((uint16_t*)a.y + m * a.ldy + nb + 8 * h) = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+      }
+    }
+  } else if ((a.flags & IMM_CONV_TAP_) && rows_exist) {
     // ---- perceptual tap (imm_conv2d_tap): v = acc + c_k * lossmask[pixel] * (a_pred - a_gt), zero where a_pred <= 0 -----
     const float ck = a.tap_coef[a.tap_idx];
     const int hw = a.ho * a.wo, rr = a.tap_lmask ? a.tap_S / a.ho : 1;
@@ -437,7 +475,7 @@ __global__ __launch_bounds__(NW * 64) void conv_hdeep_kernel(const HdArgs ha) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int j = 2 * h + (e >> 1), r = (e & 1) * 2;
-          v[2 * e] = acc[i][j][r]; v[2 * e + 1] = acc[i][j][r + 1];
+          v[2 * e] = acc[0][i][j][r]; v[2 * e + 1] = acc[0][i][j][r + 1];
         }
         unpack8<ET>(*(const uint4*)(a.mask + m * a.ldmask + nb + 8 * h), fp);
         unpack8<ET>(*(const uint4*)(a.tap_gt + m * a.ldmask + nb + 8 * h), fg);
@@ -464,7 +502,7 @@ __global__ __launch_bounds__(NW * 64) void conv_hdeep_kernel(const HdArgs ha) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {                  // pair e = channels 2e, 2e+1 of the eight
           const int j = 2 * h + (e >> 1), r = (e & 1) * 2;
-          w[e] = ET::pack2(acc[i][j][r], acc[i][j][r + 1]);
+          w[e] = ET::pack2(acc[0][i][j][r], acc[0][i][j][r + 1]);
         }
         if (f_relu) {
 #pragma unroll
@@ -494,7 +532,7 @@ __global__ __launch_bounds__(NW * 64) void conv_hdeep_kernel(const HdArgs ha) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int j = 2 * h + (e >> 1), r = (e & 1) * 2;
-          v[2 * e] = acc[i][j][r]; v[2 * e + 1] = acc[i][j][r + 1];
+          v[2 * e] = acc[0][i][j][r]; v[2 * e + 1] = acc[0][i][j][r + 1];
         }
         if (f_relu) {
 #pragma unroll
@@ -558,7 +596,7 @@ __global__ __launch_bounds__(NW * 64) void conv_hdeep_kernel(const HdArgs ha) {
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
-      for (int j = 0; j < NT; ++j) acc[i][j] = bias4[j];
+      for (int j = 0; j < NT; ++j) acc[0][i][j] = bias4[j];
   }
   }   // tiles of this workgroup
 #ifdef IMM_HDEEP_PROFILE
@@ -639,17 +677,17 @@ bool imm_hdeep_applicable(const imm_conv_desc* d) {
 
 int imm_hdeep_stats_blocks(const imm_conv_desc* d) { return hd_plan(d).n_patches; }
 
-template <typename ET, int BN, int NW, int PH, bool MAP8 = false, int NSB_ = 0, bool PERSIST = false, bool ROW3 = false>
+template <typename ET, int BN, int NW, int PH, bool MAP8 = false, int NSB_ = 0, bool PERSIST = false, bool ROW3 = false, bool S2D = false>
 static void hd_launch_cfg(const HdArgs& ha, hipStream_t s) {
   constexpr int hstage = MAP8 ? 25 * 64 : HD_HSTAGE(PH), nsb = NSB_ ? NSB_ : MAP8 ? 3 : 4;
   constexpr int lds = (2 * hstage + 64 + nsb * BN * 8) * 16 + (PERSIST ? NW * BN * 4 : 0);   // + [NW/2][2][BN] f32 stats scratch
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)conv_hdeep_kernel<ET, BN, NW, PH, MAP8, NSB_, PERSIST, ROW3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)conv_hdeep_kernel<ET, BN, NW, PH, MAP8, NSB_, PERSIST, ROW3, S2D>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
   const int grid = PERSIST ? (ha.n_wg < hd_num_cu() ? ha.n_wg : hd_num_cu()) : ha.n_wg;
-  hipLaunchKernelGGL((conv_hdeep_kernel<ET, BN, NW, PH, MAP8, NSB_, PERSIST, ROW3>), dim3(grid), dim3(NW * 64), lds, s, ha);
+  hipLaunchKernelGGL((conv_hdeep_kernel<ET, BN, NW, PH, MAP8, NSB_, PERSIST, ROW3, S2D>), dim3(grid), dim3(NW * 64), lds, s, ha);
 }
 
 template <typename ET>
@@ -701,4 +739,45 @@ void imm_conv_hdeep_launch(int dtype, const imm_conv_desc* d, const ConvArgs& a,
   ha.c.x_bytes = (uint32_t)((int64_t)d->batch * d->hi * d->wi * d->ldx * 2);
   ha.c.wt_bytes = (uint32_t)((int64_t)d->co * d->kpad * 2);
   if (dtype == IMM_BF16) hd_launch<BF16>(p, ha, s); else hd_launch<F16>(p, ha, s);
+}
+
+// ---- stride-2 data gradient (S2D) ---------------------------------------------------------------------------------------------
+// d describes the CLASS grid as a same-size 3x3 convolution of dy: batch, hi = ho = dy rows, wi = wo = dy columns, ci = dy channels
+// entering the K loop (its pixel stride: padding channels hold zeros), co = dx channels, ldy = dx pixel stride; the output tensor
+// is [batch, 2 ho, 2 wo].  wt = the flipped data-gradient image (imm_pack_weights mode 1), rows >= co, row length kpad = 9 ci.
+bool imm_hdeep_s2d_applicable(const imm_conv_desc* d) {
+  static const bool off = imm_conv_disabled("s2d");
+  if (off) return false;
+  if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->updiv != 1 || d->pad_t != 1 || d->pad_l != 1) return false;
+  if (d->ci % 64 || d->ci < 64 || d->ldx != d->ci || d->kpad != 9 * d->ci) return false;
+  if (d->co % 8 || d->co < 8 || d->ldy % 8 || d->ldy < d->co) return false;
+  if (d->hi != d->ho || d->wi != d->wo || d->ho % 8 || d->wo % HD_PW) return false;
+  if (d->flags || d->out_scale > 1) return false;
+  const int64_t px = (int64_t)d->batch * d->hi * d->wi;
+  if (px * d->ldx * 2 >= (1LL << 31) || (int64_t)d->co * d->kpad * 2 >= (1LL << 31)) return false;
+  if (px * 4 * d->ldy * 2 >= (1LL << 40)) return false;
+  return true;
+}
+
+void imm_conv_hdeep_s2d_launch(int dtype, const imm_conv_desc* d, const ConvArgs& a, hipStream_t s) {
+  HdArgs ha;
+  ha.c = a;
+  ha.prof = nullptr;
+  ha.patches_x = d->wo / HD_PW; ha.patches_y = d->ho / 8;
+  ha.n_img = d->batch;
+  ha.n_patches = d->batch * ha.patches_x * ha.patches_y;
+  ha.c.n_nblk = (d->co + 63) / 64;
+  ha.n_wg = ha.n_patches * ha.c.n_nblk;
+  ha.c.x_bytes = (uint32_t)((int64_t)d->batch * d->hi * d->wi * d->ldx * 2);
+  ha.c.wt_bytes = (uint32_t)((int64_t)d->co * d->kpad * 2);
+  // one round of workgroups or less: the row-at-a-time schedule (119 KB of LDS, one workgroup per CU anyway); larger grids keep
+  // the 78 KB tap-at-a-time form
+  const bool row3 = ha.n_wg <= hd_num_cu();
+  if (dtype == IMM_BF16) {
+    if (row3) hd_launch_cfg<BF16, 64, 4, 8, false, 9, false, true, true>(ha, s);
+    else hd_launch_cfg<BF16, 64, 4, 8, false, 0, false, false, true>(ha, s);
+  } else {
+    if (row3) hd_launch_cfg<F16, 64, 4, 8, false, 9, false, true, true>(ha, s);
+    else hd_launch_cfg<F16, 64, 4, 8, false, 0, false, false, true>(ha, s);
+  }
 }

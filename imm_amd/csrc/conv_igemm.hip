@@ -21,6 +21,8 @@ void imm_conv_halo_launch(int dtype, const imm_conv_desc* d, const ConvArgs& a, 
 bool imm_hdeep_applicable(const imm_conv_desc* d);                                 // conv_hdeep.hip
 int imm_hdeep_stats_blocks(const imm_conv_desc* d);
 void imm_conv_hdeep_launch(int dtype, const imm_conv_desc* d, const ConvArgs& a, hipStream_t s);
+bool imm_hdeep_s2d_applicable(const imm_conv_desc* d);
+void imm_conv_hdeep_s2d_launch(int dtype, const imm_conv_desc* d, const ConvArgs& a, hipStream_t s);
 bool imm_halo2_applicable(const imm_conv_desc* d);                                 // conv_halo2.hip
 int imm_halo2_grid(const imm_conv_desc* d);
 void imm_conv_halo2_launch(int dtype, const imm_conv_desc* d, const ConvArgs& a, hipStream_t s);
@@ -385,6 +387,40 @@ extern "C" int imm_conv2d_tap(const imm_conv_desc* d, int dtype, const void* x, 
   a.tap_gt = (const uint16_t*)a_gt; a.tap_lmask = loss_mask; a.tap_coef = coef; a.tap_idx = idx; a.tap_S = S; a.tap_l1 = l1;
   imm_conv_hdeep_launch(dtype, &dd, a, (hipStream_t)stream);
   IMM_CHECK_LAUNCH("imm_conv2d_tap");
+  return 0;
+}
+
+// Data gradient of a 3x3 stride-2 SAME convolution in ONE launch over ONE dy halo (conv_hdeep.hip, S2D): the class grid is described
+// to the kernel as a same-size 3x3 convolution of dy whose four accumulator sets are scattered to the four parities of dx.
+static void s2d_desc(imm_conv_desc* d, int batch, int h, int w, int lddy, int c_dx, int lddx) {
+  *d = imm_conv_desc{};
+  d->batch = batch; d->hi = d->ho = h; d->wi = d->wo = w; d->ci = lddy; d->ldx = lddy; d->co = c_dx; d->ldy = lddx;
+  d->kh = d->kw = 3; d->stride = 1; d->pad_t = d->pad_l = 1; d->updiv = 1; d->kpad = 9 * lddy; d->flags = 0; d->ldmask = 0;
+  d->out_scale = 0; d->out_off_y = d->out_off_x = 0;
+}
+
+extern "C" int imm_conv2d_dgrad_s2_supported(int batch, int h, int w, int lddy, int c_dx, int lddx) {
+  if (batch <= 0 || h <= 0 || w <= 0 || lddy <= 0 || c_dx <= 0 || lddx <= 0 || lddy % 32) return 0;
+  imm_conv_desc d;
+  s2d_desc(&d, batch, h, w, lddy, c_dx, lddx);
+  return imm_hdeep_s2d_applicable(&d) ? 1 : 0;
+}
+
+extern "C" int imm_conv2d_dgrad_s2(const void* dy, int lddy, const void* wt, int kpad, void* dx, int lddx, int c_dx, int dtype,
+                                   int batch, int h, int w, void* stream) {
+  IMM_REQUIRE(dy && wt && dx, "conv_dgrad_s2: null tensor");
+  IMM_REQUIRE(dtype == IMM_BF16 || dtype == IMM_F16, "unknown dtype %d", dtype);
+  IMM_REQUIRE(((uintptr_t)dy % 16 == 0) && ((uintptr_t)wt % 16 == 0) && ((uintptr_t)dx % 16 == 0), "conv_dgrad_s2: 16-byte alignment");
+  if (!imm_conv2d_dgrad_s2_supported(batch, h, w, lddy, c_dx, lddx))
+    return imm_fail(IMM_E_UNSUPPORTED, "conv_dgrad_s2: batch %d, dy %dx%d x %d -> dx x %d (stride %d): needs h %% 8 == 0, w %% 16 == 0, "
+                    "lddy %% 64 == 0, c_dx %% 8 == 0, lddx %% 8 == 0", batch, h, w, lddy, c_dx, lddx);
+  IMM_REQUIRE(kpad == 9 * lddy, "conv_dgrad_s2: kpad=%d must be 9 * lddy (imm_pack_weights mode 1 with c_pad = lddy)", kpad);
+  imm_conv_desc d;
+  s2d_desc(&d, batch, h, w, lddy, c_dx, lddx);
+  ConvArgs a;
+  fill_args(a, &d, dy, wt, nullptr, dx, nullptr, nullptr);
+  imm_conv_hdeep_s2d_launch(dtype, &d, a, (hipStream_t)stream);
+  IMM_CHECK_LAUNCH("imm_conv2d_dgrad_s2");
   return 0;
 }
 

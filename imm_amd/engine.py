@@ -38,6 +38,7 @@ VGG_LAYERS = [('conv1_1', 1, 64), ('conv1_2', 64, 64), ('conv2_1', 64, 128), ('c
               ('conv4_1', 256, 512), ('conv4_2', 512, 512), ('conv4_3', 512, 512),
               ('conv5_1', 512, 512), ('conv5_2', 512, 512)]
 VGG_POOL_AFTER = ('conv1_2', 'conv2_2', 'conv3_3', 'conv4_3')
+WGRAD_MULTI_MAX_JOBS, WGRAD_MULTI_MAX_VARIANTS = 64, 16     # WGM_MAX_JOBS / WGM_MAX_LAUNCH of csrc/conv_wgrad.hip
 VGG_TAPS = {'conv1_2': 1, 'conv2_2': 2, 'conv3_2': 3, 'conv4_2': 4, 'conv5_2': 5}
 
 
@@ -137,7 +138,7 @@ class _ConvLayer:
 
 class IMMEngine:
     def __init__(self, cfg, batch, image_size, device='cuda:0', act_dtype=torch.bfloat16, seed=1, vgg_weights=None,
-                 hparams=None, world_size=1):
+                 hparams=None, world_size=1, dp_buckets=None):
         if cfg.gauss_mode not in L.GAUSS_MODES:
             raise ValueError('Unknown mode: ' + str(cfg.gauss_mode))       # imm_model.py:75
         if cfg.reconstruction_loss not in ('perceptual', 'l2'):
@@ -159,6 +160,10 @@ class IMMEngine:
         self.cfg, self.B, self.S, self.dev, self.dt = cfg, int(batch), int(image_size), torch.device(device), act_dtype
         self.K = int(cfg.n_maps)
         self.world_size = world_size
+        # gradient-exchange buckets the backward program is laid out for (1 = one all-reduce after the backward pass; 2 = the
+        # renderer's filter gradients are issued and reduced early so that their bucket can travel while the encoders' backward
+        # runs).  Decided HERE, once, and read back by TrainStep (IMM_DP_BUCKETS is only the default of this argument).
+        self.dp_buckets = int(dp_buckets if dp_buckets is not None else os.environ.get('IMM_DP_BUCKETS', '1'))
         self.use_mask = bool(cfg.loss_mask)
         self.n_cu, self.arch = ops.device_info()
         self._alloc_bytes = 0
@@ -409,7 +414,11 @@ class IMMEngine:
             lay.dd = None   # filled in backward()
             rows_d = ops.round_up(ci_real, 128)
             lay.s2 = ops.dgrad_s2_class_descs(B, H, W, ci_real, 0, lddy, lddy, k) if stride == 2 else None
-            if lay.s2 is not None:
+            # stride 2, 3x3: the four parity classes as ONE launch over one dy halo (imm_conv2d_dgrad_s2: LDS-halo deep-K kernel,
+            # four accumulator sets) where the shape is served; its filter image is the ordinary flipped one (mode 1)
+            lay.s2_fused = (lay.s2 is not None and k == 3 and lddy % 64 == 0 and ci_real % 8 == 0 and
+                            ops.conv2d_dgrad_s2_supported(B, fd.ho, fd.wo, lddy, ci_real, ci_real))
+            if lay.s2 is not None and not lay.s2_fused:
                 # parity-class decomposition: 4 sub-filters (2x2, 2x1, 1x2, 1x1 taps) instead of a 4x-redundant
                 # transposed gather over all 9 taps
                 lay.wt_s2 = []
@@ -495,7 +504,11 @@ class IMMEngine:
         # COLLECTED here and issued with the other layers' in one multi-problem launch per kernel variant (_flush_wgrads):
         # the per-layer launches (15-48 us each) leave the serial BN-backward -> data-gradient chain.
         self._wgrad_pending.append((lay, dy, lddy, flops))
-        if lay.needs_dgrad and dx is not None and getattr(lay, 's2', None) is not None:
+        if lay.needs_dgrad and dx is not None and getattr(lay, 's2_fused', False):
+            assert lddx % 8 == 0 and lddx >= lay.ci_real, (lddx, lay.ci_real)
+            self._add(self.prog_bwd, lambda: ops.conv2d_dgrad_s2(dy, lddy, lay.wt_d, dx, lddx, lay.ci_real, B, lay.Ho, lay.Wo),
+                      'conv_dgrad', flops, 2.0 * (npix * lddy + 4 * npix * lay.ci_real + 9 * lddy * lay.ci_real))
+        elif lay.needs_dgrad and dx is not None and getattr(lay, 's2', None) is not None:
             # stride 2: the four input-pixel parity classes as one grouped launch (falls back to four launches inside the
             # library when the members do not take a grouped tile)
             classes = ops.dgrad_s2_class_descs(B, lay.H, lay.W, lay.ci_real, lddx, lddy, lddy, k)
@@ -526,23 +539,38 @@ class IMMEngine:
         groups = OrderedDict()
         for lay, dy, lddy, flops in jobs:
             key, wps, units, pcu = ops.conv2d_wgrad_variant(lay.fd, lddy, self.dt)
-            groups.setdefault((key, pcu), []).append((lay, dy, lddy, wps, units))
-        multi_jobs = []
-        for (key, pcu), members in groups.items():
+            groups.setdefault((key, pcu), []).append((lay, dy, lddy, wps, units, flops))
+        # a multi-problem launch takes at most WGRAD_MULTI_MAX_JOBS jobs of WGRAD_MULTI_MAX_VARIANTS kernel variants (the library's
+        # table caps): deeper configurations are issued as several such launches instead of failing at engine build
+        chunks, cur, cur_jobs = [], [], 0
+        for gk, members in groups.items():
+            if cur and (cur_jobs + len(members) > WGRAD_MULTI_MAX_JOBS or len(cur) + 1 > WGRAD_MULTI_MAX_VARIANTS):
+                chunks.append(cur); cur, cur_jobs = [], 0
+            while len(members) > WGRAD_MULTI_MAX_JOBS:           # one variant with more members than a table holds
+                chunks.append([(gk, members[:WGRAD_MULTI_MAX_JOBS])]); members = members[WGRAD_MULTI_MAX_JOBS:]
+            cur.append((gk, members)); cur_jobs += len(members)
+        if cur:
+            chunks.append(cur)
+        for ci_, chunk in enumerate(chunks):
+            self._issue_wgrad_chunk(chunk, name if len(chunks) == 1 else '%s [%d/%d]' % (name, ci_ + 1, len(chunks)))
+
+    def _issue_wgrad_chunk(self, chunk, name):
+        multi_jobs, flops_total = [], 0.0
+        for (key, pcu), members in chunk:
             kind = key // 100000                    # 0 generic kernel (one launch per job), 1 transpose-read, 2 LDS-halo
             target = pcu * self.n_cu
             # shortest useful workgroup: 16 steps of 32 pixels / 2 (sliced) or 4 (whole-filter) patches of 128 pixels
-            floor_units = [16 if kind != 2 else (2 if wps > 1 else 4) for _l, _d, _ld, wps, _u in members]
+            floor_units = [16 if kind != 2 else (2 if wps > 1 else 4) for _l, _d, _ld, wps, _u, _f in members]
 
             def splits(u):
-                return [max(1, min(-(-units // u), max(1, units // fl))) for (_l, _d, _ld, _w, units), fl in zip(members, floor_units)]
+                return [max(1, min(-(-units // u), max(1, units // fl))) for (_l, _d, _ld, _w, units, _f), fl in zip(members, floor_units)]
             if kind == 0:
-                ns = [max(1, min(-(-target // wps), max(1, units // 16))) for _l, _d, _ld, wps, units in members]
+                ns = [max(1, min(-(-target // wps), max(1, units // 16))) for _l, _d, _ld, wps, units, _f in members]
             else:
                 # the shortest common workgroup length whose total stays WITHIN the target: all workgroups of a group are equally
                 # long, so one full round of resident workgroups is ideal and a single workgroup beyond it doubles the launch
                 # (measured: 258 one-per-CU workgroups on 256 CUs, 84 us instead of ~45)
-                u = max(units for _l, _d, _ld, _w, units in members)
+                u = max(units for _l, _d, _ld, _w, units, _f in members)
                 ns = splits(u)
                 while u > 1:
                     u2 = max(1, int(u / 1.05)) if u > 64 else u - 1
@@ -550,8 +578,9 @@ class IMMEngine:
                     if sum(n * m[3] for n, m in zip(ns2, members)) > target:
                         break
                     u, ns = u2, ns2
-            for (lay, dy, lddy, wps, units), nsplit in zip(members, ns):
+            for (lay, dy, lddy, wps, units, flops), nsplit in zip(members, ns):
                 lay.nsplit = nsplit
+                flops_total += flops
                 lay.slab = self._zeros(nsplit, lay.fd.kpad, lay.co)
                 multi_jobs.append((lay.fd, lay.x, dy, lddy, lay.slab, nsplit))
                 gw = self.gview[lay.scope + '/w']
@@ -560,7 +589,7 @@ class IMMEngine:
         multi = ops.WgradMulti(multi_jobs, self.dt)
         self._wgrad_multis = getattr(self, '_wgrad_multis', []) + [multi]
         self._cur_scope = name
-        self._add(self.prog_bwd, lambda: ops.conv2d_wgrad_multi(multi), 'conv_wgrad', sum(j[3] for j in jobs), name=name)
+        self._add(self.prog_bwd, lambda: ops.conv2d_wgrad_multi(multi), 'conv_wgrad', flops_total, name=name)
 
     def _build_network(self):
         cfg, B, S, K, dt = self.cfg, self.B, self.S, self.K, self.dt
@@ -917,7 +946,7 @@ class IMMEngine:
         self.n_bwd_bucket0 = None
         # (The renderer's grouped launches as a third lane beside the encoders' backward chains: 3.37 -> 3.48 ms — the matrix-heavy
         # workgroups take the CUs the latency-bound BN / data-gradient chains need; round 3, same box.)
-        if int(os.environ.get('IMM_DP_BUCKETS', '1')) >= 2:
+        if self.dp_buckets >= 2:
             for scope, fn in self._colsum_pending:       # the renderer head's bias gradient belongs to this bucket
                 self._add(self.prog_bwd, fn, 'colsum', name=scope)
             self._colsum_pending = []

@@ -35,7 +35,7 @@ def colorize_landmark_maps(maps):
 
 class IMMModel(BaseModel):
     def __init__(self, config, global_step=None, dtype=torch.bfloat16, name='IMMModel', device=None, seed=1,
-                 vgg_weights=None, hparams=None, world_size=1):
+                 vgg_weights=None, hparams=None, world_size=1, dp_buckets=None):
         super(IMMModel, self).__init__(dtype, name)
         self._config = config
         self._global_step = global_step
@@ -63,6 +63,7 @@ class IMMModel(BaseModel):
         self._vgg_weights = vgg_weights
         self._hparams = hparams
         self._world_size = world_size
+        self._dp_buckets = dp_buckets
         self._engines = {}
         self.engine = None
 
@@ -70,9 +71,11 @@ class IMMModel(BaseModel):
         """The loss needs the perceptual network: a missing perceptual.net_file is an error (the reference's dd.io.load
         raises), never a silent fall-back to random weights."""
         cfg = self._config
-        comp = list(getattr(getattr(cfg, 'perceptual', None), 'comp', []) or [])
-        if getattr(cfg, 'reconstruction_loss', 'perceptual') != 'perceptual' or all(n == 'input' for n in comp):
-            return       # no VGG layer is tapped: the reference only opens net_file inside the perceptual branch (imm_model.py:376-387)
+        if getattr(cfg, 'reconstruction_loss', 'perceptual') != 'perceptual':
+            return       # 'l2' (imm_model.py:385-387) never touches the perceptual network
+        # The perceptual branch opens net_file UNCONDITIONALLY (imm_model.py:124-127: build_vgg16(ims, pretrained_file=...) before
+        # any feature is selected), so a missing file fails in the reference even for perceptual.comp == ['input'], where no VGG
+        # layer is evaluated: same here.
         if hasattr(self, '_vgg_missing'):
             missing = self._vgg_missing
             raise FileNotFoundError("perceptual.net_file %r does not exist (set it to the vgg16.caffemodel.h5 / .npz file, or to "
@@ -97,7 +100,8 @@ class IMMModel(BaseModel):
         if key not in self._engines:
             dev = self._device or ('cuda:%d' % torch.cuda.current_device())
             eng = IMMEngine(self._config, batch, size, device=dev, act_dtype=self.dtype, seed=self._seed,
-                            vgg_weights=self._vgg_weights, hparams=self._hparams, world_size=self._world_size)
+                            vgg_weights=self._vgg_weights, hparams=self._hparams, world_size=self._world_size,
+                            dp_buckets=self._dp_buckets)
             src = master if master is not None else self.engine
             if src is not None:
                 self._mirror(eng, src)

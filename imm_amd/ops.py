@@ -516,6 +516,17 @@ def conv2d_group(group, x, y, stats=None, mask=None):
          _p(y), _p(stats), _p(mask), _s())
 
 
+def conv2d_dgrad_s2_supported(batch, h, w, lddy, c_dx, lddx):
+    """dy [batch,h,w] with pixel stride lddy -> dx [batch,2h,2w,c_dx]: served by the one-launch four-class kernel?"""
+    return bool(L.load().imm_conv2d_dgrad_s2_supported(batch, h, w, lddy, c_dx, lddx))
+
+
+def conv2d_dgrad_s2(dy, lddy, wt, dx, lddx, c_dx, batch, h, w):
+    """Data gradient of a 3x3 stride-2 SAME convolution as ONE launch (imm_conv2d_dgrad_s2): wt = the mode-1 packed image
+    [rows >= c_dx][9 * lddy]."""
+    call('imm_conv2d_dgrad_s2', _p(dy), lddy, _p(wt), int(wt.shape[1]), _p(dx), lddx, c_dx, dtype_enum(dy.dtype), batch, h, w, _s())
+
+
 def conv2d_group_stats_blocks(group):
     n = L.load().imm_conv2d_group_stats_blocks(C.cast(group.descs, C.c_void_p), group.n)
     if n <= 0:

@@ -81,36 +81,51 @@ def mean_tower_loss(loss, world_size, group=None):
 class TrainStep:
     """One rank's training step: fwd+bwd graph -> gradient all-reduce -> clip+Adam graph."""
 
-    def __init__(self, model, batch_per_rank, image_size, world_size=1, use_graph=True, group=None, split_graphs=False):
+    COLLECTIVES = ('pg', 'native', 'graph')
+
+    def __init__(self, model, batch_per_rank, image_size, world_size=1, use_graph=True, group=None, split_graphs=False,
+                 collective=None):
+        """collective (how the gradient exchange of a multi-rank step is issued; identical sums):
+             'pg'      torch.distributed.all_reduce on the process group's stream between the two graphs (default)
+             'native'  imm_rccl_allreduce of the C-ABI on a stream of this object, ordered by events (the process group then
+                       only carries the 128-byte unique id at start-up)
+             'graph'   imm_rccl_allreduce issued on the CAPTURING stream between the backward and the optimizer launches: a
+                       step at N > 1 is ONE graph launch, like at N = 1 (needs use_graph)
+           None = IMM_RCCL_GRAPH=1 -> 'graph', IMM_RCCL_NATIVE=1 -> 'native', else 'pg' (the environment only supplies the
+           default of this argument).  The bucket count is the one the ENGINE was built for (IMMModel(dp_buckets=...) /
+           IMM_DP_BUCKETS at engine construction): it fixes the layout of the backward program and is read back from it."""
         self.model = model
         self.world_size = world_size
         # two graphs with the all-reduce in between (always for world_size > 1; selectable at 1 to test that path)
         self.split = split_graphs or world_size > 1
-        # ONE bucket by default: [fwd + bwd graph] -> all-reduce of the flat gradient buffer -> [clip + Adam graph].
-        # IMM_DP_BUCKETS=2 (opt-in): the renderer's gradients (the tail of the flat buffer, 43 % of the 16.6 MB) are all-reduced
-        # on RCCL's stream while the encoders' backward graph still runs, the encoder bucket follows it.  The asynchronous
-        # two-bucket branch has only ever run with gloo on one device (where it degenerates to synchronous host bounces); it
-        # stays opt-in until a >= 2-GPU RCCL run has compared its update with the one-bucket update.
         self.group = group
         model.require_vgg()                       # training against a missing perceptual network is an error, not a fallback
         self.engine = model._get_engine(batch_per_rank, image_size)
         model._master = self.engine               # the engine whose variables are trained; others mirror it (eval batches)
-        self.buckets = int(os.environ.get('IMM_DP_BUCKETS', '1'))
-        if self.buckets >= 2 and self.engine.n_bwd_bucket0 is None:
-            raise ValueError('IMM_DP_BUCKETS=2 must be set before the engine is built (it places the renderer gradients\' early reduction)')
+        # ONE bucket by default: [fwd + bwd graph] -> all-reduce of the flat gradient buffer -> [clip + Adam graph].
+        # Two buckets (opt-in): the renderer's gradients (the tail of the flat buffer, 43 % of the 16.6 MB) are all-reduced
+        # on RCCL's stream while the encoders' backward graph still runs, the encoder bucket follows it.  The asynchronous
+        # two-bucket branch has only ever run with gloo on one device (where it degenerates to synchronous host bounces); it
+        # stays opt-in until a >= 2-GPU RCCL run has compared its update with the one-bucket update.
+        self.buckets = 2 if self.engine.n_bwd_bucket0 is not None else 1
         if abs(self.engine.hp.grad_scale - 1.0 / world_size) > 1e-9:
             raise ValueError('engine was built for world_size %g' % (1.0 / self.engine.hp.grad_scale))
         self.use_graph = use_graph
-        # IMM_RCCL_NATIVE=1: the collective goes through the C-ABI (imm_rccl_allreduce, include/imm_hip.h) on a stream of
-        # this object instead of through torch.distributed's process group (which then only carries the 128-byte
-        # unique id at start-up).  Same sums; default off until it has run on a multi-GPU box.
-        # IMM_RCCL_GRAPH=1 (implies IMM_RCCL_NATIVE): the collective is a node of the step's HIP graph — imm_rccl_allreduce is
-        # issued on the capturing stream between the backward and the optimizer launches, so a step at N > 1 is ONE graph
-        # launch, like at N = 1 (no second graph, no host-side collective call per step).  Validated with a one-rank
-        # communicator on the single-GPU test box; multi-GPU timing has to come from a node (DESIGN.md §7).
-        self.graph_resident = self.split and use_graph and os.environ.get('IMM_RCCL_GRAPH', '0') != '0'
+        if collective is None:
+            collective = ('graph' if os.environ.get('IMM_RCCL_GRAPH', '0') != '0' else
+                          'native' if os.environ.get('IMM_RCCL_NATIVE', '0') != '0' else 'pg')
+        if collective not in self.COLLECTIVES:
+            raise ValueError('collective must be one of %r, got %r' % (self.COLLECTIVES, collective))
+        if collective == 'graph' and not use_graph:
+            raise ValueError("collective 'graph' needs use_graph=True")
+        if collective == 'graph' and self.buckets >= 2:
+            raise ValueError("collective 'graph' is the one-bucket, one-graph form: build the engine with dp_buckets=1")
+        self.collective = collective if self.split else None
+        # 'graph' has been validated with a one-rank communicator on the single-GPU test box only; multi-GPU timing has to come
+        # from a node (DESIGN.md §7)
+        self.graph_resident = self.split and use_graph and collective == 'graph'
         self.native_comm = None
-        if self.split and (self.graph_resident or os.environ.get('IMM_RCCL_NATIVE', '0') != '0'):
+        if self.split and collective in ('native', 'graph'):
             rank = dist.get_rank(group) if dist.is_initialized() else 0
             with torch.cuda.device(self.engine.dev):
                 self.native_comm = ops.RcclComm(rank, world_size, group)
@@ -343,14 +358,17 @@ def train_loop(opts, train_step, data_iter, num_steps, log_every=10, checkpoint_
     n_image = int(opts.get('n_image_summary', 100) or 0)      # image summaries: every n_image steps (upstream: every summary)
     n_test = int(opts.get('n_test') or 0)
     n_ckpt = int(opts.get('n_checkpoint') or 0)
-    for step in range(start_step, num_steps):
+    scaled = getattr(eng, 'loss_scale_state', None) is not None
+    step = start_step
+    while step < num_steps:
         t0 = time.time()
         loss = train_step.step(next(data_iter))
         n_seen += opts['batch_size']
         do_log = (step - start_step) % log_every == 0
         do_sum = bool(n_summary) and step % n_summary == 0      # the same on every rank: the loss mean is a collective
+        synced = False
         if do_log or do_sum:
-            train_step.synchronize()
+            train_step.synchronize(); synced = True
             loss_value = mean_tower_loss(loss, train_step.world_size, train_step.group)   # every rank takes part
             assert loss_value == loss_value, 'Model diverged with loss = NaN'
             dt = time.time() - t0
@@ -364,15 +382,24 @@ def train_loop(opts, train_step, data_iter, num_steps, log_every=10, checkpoint_
                                             'examples_per_sec': opts['batch_size'] / dt}, step, images=images)
                 summary_writer.flush()
         if test_dataset is not None and model is not None and n_test and step % n_test == 0:
-            train_step.synchronize()
+            train_step.synchronize(); synced = True
             if rank == 0:
                 run_test_pass(model, test_dataset, step, summary_writer)
             if train_step.world_size > 1:
                 torch.distributed.barrier(group=train_step.group)
         if checkpoint_fn is not None and n_ckpt and step % n_ckpt == 0:
-            train_step.synchronize()
+            train_step.synchronize(); synced = True
             if rank == 0:
                 checkpoint_fn(step)
+        step += 1
+        if scaled and (synced or step >= num_steps):
+            # f16 storage with a dynamic loss scale: an update whose gradients overflowed is SKIPPED on the device (weights,
+            # slots, global_step and Adam's t untouched; imm_clip_adam_step) — the host's count follows the device's
+            # global_step, so checkpoints / summaries carry the saved global_step and the run ends with global_step ==
+            # num_steps.  (The forward-side running averages — BN moving statistics, loss normalisers — do advance on a
+            # skipped step: they belong to the forward pass, which ran.)  Read only where the loop synchronises anyway.
+            train_step.synchronize()
+            step = int(eng.step_count)
     train_step.synchronize()
     if rank == 0:
         print('Avg. samples per second %.2f' % (n_seen / max(time.time() - t_start, 1e-9)))

@@ -378,6 +378,9 @@ def optimizer_slots(engine):
     return [('adam_m', '/Adam'), ('adam_v', '/Adam_1')]
 
 
+LOSS_SCALE_VAR = 'imm_amd/loss_scale_state'
+
+
 def engine_to_tf(engine, with_optimizer=True):
     """{TF variable name: numpy array} of an engine: model variables, BN moving statistics, loss normalisers, global_step
     and (optionally) Adam's slots `<var>/Adam`, `<var>/Adam_1`, `beta1_power`, `beta2_power` (tf.train.AdamOptimizer)."""
@@ -394,6 +397,10 @@ def engine_to_tf(engine, with_optimizer=True):
             for i, (name, shape, _wd) in enumerate(engine.spec):
                 o0, o1 = engine.tab.offsets[i], engine.tab.offsets[i + 1]
                 out[tf_variable_name(name) + suffix] = flat[o0:o1].reshape(shape)
+        if getattr(engine, 'loss_scale_state', None) is not None:
+            # not a TensorFlow variable (the reference computes in fp32): the dynamic loss scale of f16 storage and its
+            # clean-step counter, so that a resume continues at the scale the run had reached
+            out[LOSS_SCALE_VAR] = engine.loss_scale_state.cpu().numpy().astype(np.float32)
         if getattr(engine, 'optim', 'adam') != 'adam':
             return out
         # tf.train.AdamOptimizer: beta_power starts at beta and is multiplied by beta after every apply => beta^(t+1) after
@@ -422,7 +429,7 @@ def load_tf_checkpoint(engine, prefix, restore_optim=False, ignore_missing_vars=
     missing = [n for n in needed if n not in have]
     if missing and not ignore_missing_vars:
         raise KeyError('%s lacks %d variables (e.g. %s); pass ignore_missing_vars to skip them' % (prefix, len(missing), missing[0]))
-    data = read_bundle(prefix, names=set(needed) | {'global_step', 'beta1_power', 'beta2_power'})
+    data = read_bundle(prefix, names=set(needed) | {'global_step', 'beta1_power', 'beta2_power', LOSS_SCALE_VAR})
     params = engine.named_parameters()
     for k, n in want_params.items():
         if n in data:
@@ -452,6 +459,8 @@ def load_tf_checkpoint(engine, prefix, restore_optim=False, ignore_missing_vars=
                 if bp == 0.0:
                     t = max(t, 1 << 20)
         engine.adam_t.fill_(t)
+        if getattr(engine, 'loss_scale_state', None) is not None and LOSS_SCALE_VAR in data:
+            engine.loss_scale_state.copy_(torch.from_numpy(np.asarray(data[LOSS_SCALE_VAR], dtype=np.float32).reshape(-1)))
     else:
         engine.reset_optimizer_slots()
     if reset_global_step >= 0:

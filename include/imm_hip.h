@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define IMM_ABI_VERSION 14   /* 14: loss scaling (imm_perceptual_finalize, imm_clip_adam_step, imm_opt_hparams) */
+#define IMM_ABI_VERSION 15   /* 15: imm_conv2d_dgrad_s2; entry points removed since 14 (imm_bn_bwd_reduce_finalize, ...) finally counted */
 
 enum imm_dtype { IMM_BF16 = 0, IMM_F16 = 1 };
 
@@ -112,6 +112,17 @@ int imm_wgrad_reduce_multi(const int64_t* jobs, const int32_t* blk_first, int n_
 int imm_conv2d_group(const imm_conv_desc* descs, int n, int dtype, const void* x, const void* const* wts, void* y,
                      float* stats_partial, const void* mask_ref, void* stream);
 int imm_conv2d_group_stats_blocks(const imm_conv_desc* descs, int n);
+/* The data gradient of a 3x3 STRIDE-2 SAME convolution (encoder conv_3 / conv_5 / conv_7, imm_model.py:197,204,211:
+ * tf.nn.conv2d_backprop_input at those nn_utils.py:100 call sites) as ONE launch over ONE halo of dy: input pixel (2i+py, 2j+px)
+ * receives only the taps of its parity class (4 / 2 / 2 / 1 of the nine); a workgroup keeps four accumulator sets for an 8x16
+ * patch of class pixels and scatters them to the 16x32 patch of dx.  Replaces the four imm_conv2d_group class launches (same
+ * values up to accumulation order).  dy 16-bit [batch,h,w], pixel stride lddy = the channels entering the K loop (multiple of
+ * 64; channels beyond the real count hold zeros); wt = the flipped image of imm_pack_weights mode 1 (kh = kw = 3, c_pad = lddy:
+ * rows >= c_dx, row length kpad = 9 * lddy); dx 16-bit [batch,2h,2w], pixel stride lddx, channels [0, c_dx) written
+ * (c_dx % 8 == 0).  h % 8 == 0, w % 16 == 0.  imm_conv2d_dgrad_s2_supported: 1 when the shape is served, else 0. */
+int imm_conv2d_dgrad_s2_supported(int batch, int h, int w, int lddy, int c_dx, int lddx);
+int imm_conv2d_dgrad_s2(const void* dy, int lddy, const void* wt, int kpad, void* dx, int lddx, int c_dx, int dtype, int batch,
+                        int h, int w, void* stream);
 /* y[m][n] = epilogue( sum_k gather(x)[m][k] * wt[n][k] ).  stats_partial: [n_mblocks][2][co] f32
  * with n_mblocks = imm_conv_stats_blocks(desc).  Replaces tf.nn.conv2d+bias_add (nn_utils.py:100,108),
  * vgg conv+bias+relu (vgg16.py:182-189,230) and their data gradients.

@@ -145,6 +145,8 @@ def main(args):
         if args.restore_optim and 'adam_m' in ck:
             eng.adam_m.copy_(ck['adam_m']); eng.adam_v.copy_(ck['adam_v'])
             eng.adam_t.fill_(int(ck.get('adam_t', ck.get('step', 0))))
+            if eng.loss_scale_state is not None and ck.get('loss_scale_state') is not None:
+                eng.loss_scale_state.copy_(ck['loss_scale_state'])      # dynamic loss scale S + its clean-step counter (f16 storage)
         else:
             eng.reset_optimizer_slots()
     elif args.checkpoint is not None:
@@ -169,6 +171,7 @@ def main(args):
         path = osp.join(train_config.logdir, 'model.ckpt-%d.pt' % n)
         torch.save({'params': eng.named_parameters(), 'state': eng.named_state(), 'adam_m': eng.adam_m.cpu(),
                     'adam_v': eng.adam_v.cpu(), 'step': int(eng.step_count), 'adam_t': int(eng.adam_t),
+                    'loss_scale_state': None if eng.loss_scale_state is None else eng.loss_scale_state.cpu(),
                     'vgg_weights': getattr(step.model, 'vgg_source', 'unknown')}, path)
         print('saved', path)
         if args.tf_checkpoints:

@@ -11,7 +11,6 @@ sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
 
 def rank_main(rank, world, port, buckets, ret):
-    os.environ['IMM_DP_BUCKETS'] = str(buckets)
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0')
     import torch.distributed as dist
     torch.cuda.set_device(0)
@@ -20,7 +19,7 @@ def rank_main(rank, world, port, buckets, ret):
     from imm_amd.train import cnn_train_multi as M
     full, _t = T._towers()
     mine = M.split_inputs(full, world, rank)
-    ts = M.TrainStep(T._model(world), T.B_GLOBAL // world, T.S_IMG, world_size=world, use_graph=True)
+    ts = M.TrainStep(T._model(world, buckets), T.B_GLOBAL // world, T.S_IMG, world_size=world, use_graph=True)
     eng = ts.engine
     log = []
     orig = M.average_gradients

@@ -27,10 +27,10 @@ bf = lambda t: t.to(torch.bfloat16).to(torch.float32)
 B_GLOBAL, S_IMG, N_STEPS = 4, 128, 2
 
 
-def _model(world):
+def _model(world, buckets=None):
     from imm_amd.models.imm_model import IMMModel
     from imm_amd.utils.box import Box
-    return IMMModel(Box(dict(O.default_model_config(10))), dtype=torch.bfloat16, device=DEV, world_size=world)
+    return IMMModel(Box(dict(O.default_model_config(10))), dtype=torch.bfloat16, device=DEV, world_size=world, dp_buckets=buckets)
 
 
 def _towers():
@@ -42,20 +42,12 @@ def _towers():
 def emulate_two_towers(n_steps, buckets=1):
     """Single process: engines A and B are the two towers; A carries the variables (B is refreshed from A every step, like
     TF's reuse_variables), the flat gradient buffers are added on the device, A applies the update.
-    `buckets`: the engines are built the way a rank with IMM_DP_BUCKETS=<buckets> builds them (with two buckets the renderer's
+    `buckets`: the engines are built the way a rank with dp_buckets=<buckets> builds them (with two buckets the renderer's
     filter gradients are issued and reduced early, with other split counts: the same sums in another order)."""
     _full, towers = _towers()
     per = B_GLOBAL // 2
-    old = os.environ.get('IMM_DP_BUCKETS')
-    os.environ['IMM_DP_BUCKETS'] = str(buckets)
-    try:
-        mA, mB = _model(2), _model(2)
-        A, Bn = mA._get_engine(per, S_IMG), mB._get_engine(per, S_IMG)
-    finally:
-        if old is None:
-            del os.environ['IMM_DP_BUCKETS']
-        else:
-            os.environ['IMM_DP_BUCKETS'] = old
+    mA, mB = _model(2, buckets), _model(2, buckets)
+    A, Bn = mA._get_engine(per, S_IMG), mB._get_engine(per, S_IMG)
     losses = []
     for it in range(n_steps):
         if it > 0:       # tower B reads tower A's variables; its BN moving statistics / loss normalisers stay its own (:155)
@@ -127,7 +119,6 @@ def test_two_engines_equal_the_two_tower_reference(emu):
 
 def _rank_main(rank, world, port, ret, buckets):
     sys.path.insert(0, ROOT)
-    os.environ['IMM_DP_BUCKETS'] = str(buckets)
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0')
     import torch.distributed as dist
     torch.cuda.set_device(0)
@@ -135,7 +126,7 @@ def _rank_main(rank, world, port, ret, buckets):
     from imm_amd.train.cnn_train_multi import TrainStep, mean_tower_loss, split_inputs
     full, _t = _towers()
     mine = split_inputs(full, world, rank)
-    model = _model(world)
+    model = _model(world, buckets)
     ts = TrainStep(model, B_GLOBAL // world, S_IMG, world_size=world, use_graph=True)
     assert ts.split and ts.buckets == buckets, (ts.split, ts.buckets)     # default 1; 2 = overlapped buckets (opt-in)
     losses = []
@@ -189,4 +180,32 @@ def test_bench_self_spawns_two_ranks(tmp_path):
     d = json.loads(lines[0])
     assert d['n_gpus'] == 2 and d['config']['global_batch'] == 64 and d['config']['parallelism'] == 'dp2'
     assert d['config']['collective']['world_size'] == 2 and d['config']['collective']['buckets'] == 1
+    assert d['config']['collective']['mode'] == 'pg' and d['step']['replicas_identical'] is True
     assert d['value'] > 0 and d['scaling'] == 'weak' and np.isfinite(d['step']['loss'])
+
+
+@pytest.mark.timeout(1500)
+def test_bench_self_spawns_eight_ranks(tmp_path):
+    """The configuration the driver's scaling run ends with — `bench.py --gpus 8`: world 8, global batch 256 (BASELINE.json
+    configs[2]), grad_scale 1/8, the self-spawn — executed for real, with gloo standing in for RCCL and the eight ranks sharing the
+    one GPU of the test box (8 x 3.2 GB of engine buffers).  Nothing about speed is read from it; what is checked is that eight
+    ranks rendezvous, run the split-graph path, and end with bit-identical parameters after the all-reduced updates."""
+    import json
+    import subprocess
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    if torch.cuda.mem_get_info(0)[0] < 40 * 2 ** 30:
+        pytest.skip('needs ~30 GB of free HBM for eight co-resident engines')
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '3', '--warmup', '1', '--windows', '1',
+                          '--spin-seconds', '0', '--backend', 'gloo', '--share-gpu', '--no-cpu-baseline', '--no-pmc', '--collective', 'pg'],
+                         env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1400)
+    assert out.returncode == 0, out.stderr.decode()[-3000:]
+    lines = [l for l in out.stdout.decode().splitlines() if l.strip().startswith('{')]
+    assert len(lines) == 1, out.stdout.decode()[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 8 and d['config']['global_batch'] == 256 and d['config']['parallelism'] == 'dp8'
+    c = d['config']['collective']
+    assert c['world_size'] == 8 and c['buckets'] == 1 and c['mode'] == 'pg' and c['backend'] == 'gloo'
+    assert d['value'] > 0 and d['scaling'] == 'weak' and np.isfinite(d['step']['loss'])
+    assert d['step']['replicas_identical'] is True

@@ -238,6 +238,73 @@ def test_conv_dgrad_stride2_parity_classes(ops, H, ci, co, dt):
     close(dx, gx, 1e-2, 2e-3, 'dgrad_s2_classes')       # every pixel written exactly once (no NaN left)
 
 
+S2D_CASES = [
+    # B, H (input side = 2 x dy side), ci (dx channels), co (dy channels), tag
+    (32, 128, 32, 64, 'enc_conv3_full_size_1024_tiles'),       # more tiles than CUs: tap-at-a-time form; dx channels < the 64-wide block
+    (32, 64, 64, 128, 'enc_conv5_full_size_256_tiles'),        # one round of tiles: row-at-a-time form, two 64-channel slices
+    (32, 32, 128, 256, 'enc_conv7_full_size_two_nblocks'),     # four slices, two channel blocks
+    (2, 32, 64, 128, 'four_tiles'),
+    (3, 64, 40, 64, 'odd_batch_dx40'),                         # c_dx = 40: a partly filled channel block
+    (1, 32, 8, 192, 'dx8_three_slices'),
+    (5, 64, 200, 64, 'dx200_four_nblocks_ragged'),
+]
+
+
+@pytest.mark.parametrize('case', S2D_CASES, ids=[c[-1] for c in S2D_CASES])
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16], ids=['bf16', 'f16'])
+def test_conv_dgrad_stride2_one_launch(ops, case, dt):
+    """imm_conv2d_dgrad_s2: the data gradient of a 3x3 stride-2 SAME convolution (encoder conv_3/5/7) as one launch with four
+    accumulator sets over one dy halo, against autograd of the oracle's convolution on the same 16-bit values and against the
+    four class launches it replaces (same sums in another order)."""
+    B, H, ci, co, _tag = case
+    k = 3
+    w = rnd((k, k, ci, co), 13, 0.05, dt)
+    xr = torch.zeros(B, H, H, ci, requires_grad=True)
+    yref = O.conv2d_same(xr, w.float(), None, 2)
+    dy = rnd(tuple(yref.shape), 14, 1.0, dt)
+    (gx,) = torch.autograd.grad(yref, xr, dy.float())
+    h = H // 2
+    assert ops.conv2d_dgrad_s2_supported(B, h, h, co, ci, ci)
+    rows = ops.round_up(ci, 128)
+    wd = w.float().to(DEV).contiguous()
+    wt = torch.zeros(rows, 9 * co, dtype=dt, device=DEV)
+    ops.pack_weights(wd, wt, 1, k, k, ci, co, co, rows, 9 * co)
+    dx = torch.full((B, H, H, ci), float('nan'), dtype=dt, device=DEV)
+    dyd = dy.to(DEV).contiguous()
+    ops.conv2d_dgrad_s2(dyd, co, wt, dx, ci, ci, B, h, h)
+    torch.cuda.synchronize()
+    close(dx, gx, 1e-2, 2e-3, 'dgrad_s2_one_launch')           # every pixel written exactly once (no NaN left)
+    # the four class launches
+    dx4 = torch.full((B, H, H, ci), float('nan'), dtype=dt, device=DEV)
+    for d, mode in ops.dgrad_s2_class_descs(B, H, H, ci, ci, co, co, k):
+        wt_c = torch.zeros(rows, d.kpad, dtype=dt, device=DEV)
+        ops.pack_weights(wd, wt_c, mode, k, k, ci, co, co, rows, d.kpad)
+        ops.conv2d(d, dyd, wt_c, None, dx4)
+    torch.cuda.synchronize()
+    close(dx, dx4, 2.0 ** -7 if dt == torch.bfloat16 else 2.0 ** -10, 1e-4, 'dgrad_s2_one_launch vs class launches')
+    # padded output stride: channels beyond c_dx are left alone
+    if ci % 32:
+        ld = ops.round_up(ci, 32)
+        dxp = torch.full((B, H, H, ld), 7.0, dtype=dt, device=DEV)
+        ops.conv2d_dgrad_s2(dyd, co, wt, dxp, ld, ci, B, h, h)
+        torch.cuda.synchronize()
+        assert torch.equal(dxp[..., :ci], dx) and bool((dxp[..., ci:] == 7.0).all())
+
+
+def test_conv_dgrad_stride2_one_launch_rejects_unserved_shapes(ops):
+    assert not ops.conv2d_dgrad_s2_supported(2, 8, 8, 64, 32, 32)        # dy columns % 16
+    assert not ops.conv2d_dgrad_s2_supported(2, 12, 16, 64, 32, 32)      # dy rows % 8
+    assert not ops.conv2d_dgrad_s2_supported(2, 16, 16, 32, 32, 32)      # dy channels % 64
+    assert not ops.conv2d_dgrad_s2_supported(2, 16, 16, 64, 12, 16)      # dx channels % 8
+    assert ops.conv2d_dgrad_s2_supported(2, 16, 16, 64, 32, 32)
+    dy = torch.zeros(2, 8, 8, 64, dtype=torch.bfloat16, device=DEV)
+    wt = torch.zeros(128, 576, dtype=torch.bfloat16, device=DEV)
+    dx = torch.zeros(2, 16, 16, 32, dtype=torch.bfloat16, device=DEV)
+    from imm_amd import _lib as L
+    with pytest.raises(L.ImmHipError):
+        ops.conv2d_dgrad_s2(dy, 64, wt, dx, 32, 32, 2, 8, 8)
+
+
 @pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16], ids=['bf16', 'f16'])
 @pytest.mark.parametrize('B,H,cin,cout,l1', [(32, 16, 512, 512, False), (8, 32, 256, 256, False), (4, 32, 256, 256, True),
                                               (33, 8, 512, 512, False)],

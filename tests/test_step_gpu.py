@@ -21,11 +21,11 @@ DEV = 'cuda:0'
 bf = lambda t: t.to(torch.bfloat16).to(torch.float32)
 
 
-def make(batch, K=10, S=128, seed_in=0):
+def make(batch, K=10, S=128, seed_in=0, dp_buckets=None):
     from imm_amd.models.imm_model import IMMModel
     from imm_amd.utils.box import Box
     cfg = O.default_model_config(K)
-    model = IMMModel(Box(dict(cfg)), dtype=torch.bfloat16, device=DEV)
+    model = IMMModel(Box(dict(cfg)), dtype=torch.bfloat16, device=DEV, dp_buckets=dp_buckets)
     inputs = O.synthetic_inputs(batch, S, seed=seed_in)
     eng = model._get_engine(batch, S)
     P, St = O.init_params(cfg, S)
@@ -597,32 +597,41 @@ def test_backward_is_the_derivative_of_the_forward():
 
 
 def test_native_rccl_exchange_single_rank(monkeypatch):
-    """IMM_RCCL_NATIVE=1: the gradient exchange through the C-ABI (imm_rccl_unique_id / init / allreduce / destroy) on the
-    communication stream of TrainStep — a one-rank RCCL communicator on the test box (sum over one rank = identity), so
-    the step must equal the plain single-GPU step bit for bit, with one bucket and with two overlapped buckets."""
+    """collective='native' / 'graph': the gradient exchange through the C-ABI (imm_rccl_unique_id / init / allreduce / destroy) on
+    the communication stream of TrainStep resp. as a node of the step's one graph — a one-rank RCCL communicator on the test box
+    (sum over one rank = identity), so the step must equal the plain single-GPU step bit for bit, with one bucket and with two
+    overlapped buckets.  The modes are chosen by ARGUMENT (IMMModel(dp_buckets=...), TrainStep(collective=...)); the last case
+    goes through the environment variables, which only supply those arguments' defaults."""
     if not torch.cuda.is_available():
         pytest.skip('no GPU')
     from imm_amd.train.cnn_train_multi import TrainStep
     res = {}
-    # the engine is built per bucket mode (IMM_DP_BUCKETS=2 issues and reduces the renderer's filter gradients early: the same
+    for v in ('IMM_RCCL_NATIVE', 'IMM_DP_BUCKETS', 'IMM_RCCL_GRAPH'):
+        monkeypatch.delenv(v, raising=False)
+    # the engine is built per bucket mode (two buckets: the renderer's filter gradients are issued and reduced early: the same
     # sums in another order), so every mode is compared with the plain single-graph step of an engine built the same way
-    for native, buckets, in_graph in ((False, 1, False), (True, 1, False), (True, 1, True), (False, 2, False), (True, 2, False)):
-        monkeypatch.setenv('IMM_RCCL_NATIVE', '1' if native else '0')
-        monkeypatch.setenv('IMM_DP_BUCKETS', str(buckets))
-        monkeypatch.setenv('IMM_RCCL_GRAPH', '1' if in_graph else '0')     # the collective as a node of the step's ONE graph
-        cfg, model, eng, inputs, P, St = make(4)
-        ts = TrainStep(model, 4, 128, world_size=1, use_graph=True, split_graphs=native)
-        assert (ts.native_comm is not None) == native and ts.graph_resident == in_graph
+    for native, buckets, in_graph, via_env in ((False, 1, False, False), (True, 1, False, False), (True, 1, True, False),
+                                               (False, 2, False, False), (True, 2, False, False), (True, 2, False, True)):
+        if via_env:
+            monkeypatch.setenv('IMM_RCCL_NATIVE', '1'); monkeypatch.setenv('IMM_DP_BUCKETS', str(buckets))
+            cfg, model, eng, inputs, P, St = make(4)
+            ts = TrainStep(model, 4, 128, world_size=1, use_graph=True, split_graphs=True)
+        else:
+            cfg, model, eng, inputs, P, St = make(4, dp_buckets=buckets)
+            ts = TrainStep(model, 4, 128, world_size=1, use_graph=True, split_graphs=native,
+                           collective='graph' if in_graph else 'native' if native else 'pg')
+        assert (ts.native_comm is not None) == native and ts.graph_resident == in_graph and ts.buckets == buckets
+        assert ts.collective == (None if not native else 'graph' if in_graph else 'native')
         for it in range(3):
             loss = ts.step(inputs)
         ts.synchronize()
-        res[(native, buckets, in_graph)] = (float(loss), eng.params.clone())
+        res[(native, buckets, in_graph, via_env)] = (float(loss), eng.params.clone())
         if native:
             ts.native_comm.destroy()
         if in_graph:
             assert len(ts._graphs) == 1
     for key, (loss, params) in res.items():
-        ref = res[(False, key[1], False)]
+        ref = res[(False, key[1], False, False)]
         assert loss == ref[0] and torch.equal(params, ref[1]), key
     # and the two engine builds agree to rounding
-    assert abs(res[(False, 1, False)][0] - res[(False, 2, False)][0]) <= 1e-5 * abs(res[(False, 1, False)][0])
+    assert abs(res[(False, 1, False, False)][0] - res[(False, 2, False, False)][0]) <= 1e-5 * abs(res[(False, 1, False, False)][0])
