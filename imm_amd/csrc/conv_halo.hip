@@ -42,6 +42,11 @@ __device__ __forceinline__ int halo_swz(int row) { return C8 == 8 ? (((row >> 1)
 struct HaloArgs {
   ConvArgs c;
   int n_patches, patches_x, patches_y;    // per image: patches_x * patches_y
+  // NOL (normalise on load, round 4): x is the RAW 16-bit output y of the preceding convolution of a conv + batch-norm + ReLU block
+  // (tf.layers.batch_normalization + relu, nn_utils.py:201-209); the input of THIS convolution is relu(scale[c] * y + shift[c]),
+  // which is never stored: the affine + ReLU is applied once per halo pixel to the LDS tile after its DMA has landed (out-of-image
+  // halo pixels stay zero: the zero padding is of the normalised tensor).  scale / shift: f32 [CI] from imm_bn_finalize.
+  const float* nol_scale; const float* nol_shift; int nol_relu;
 };
 
 // S2: 3x3 STRIDE-2 forward (encoder conv_3: 32 -> 64 channels at 128^2 -> 64^2, imm_model.py:197; TF SAME on an even side pads
@@ -54,7 +59,7 @@ struct HaloArgs {
 #define HALO_S2_PW 17            // plane width  (33 columns -> 17 even + 16 odd)
 #define HALO_S2_PP 160           // plane pitch in pixels (9 x 17 = 153, padded)
 #define HALO_S2_HP 640           // 4 planes
-template <typename ET, int CI, int BN, bool S2 = false>
+template <typename ET, int CI, int BN, bool S2 = false, bool NOL = false>
 __global__ __launch_bounds__(256) void conv_halo_kernel(const HaloArgs ha) {
   const ConvArgs& a = ha.c;
   constexpr int HP = S2 ? HALO_S2_HP : HALO_HP;    // halo pixels per stage
@@ -67,7 +72,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const HaloArgs ha) {
   constexpr int W_DMA = 9 * BN / PIX_PER_DMA;      // instructions for the whole filter
   constexpr int W_U4 = 9 * BN * C8;                // uint4 of the filter image
   constexpr int H_U4 = HP * C8;                    // uint4 per halo stage
-  extern __shared__ __attribute__((aligned(16))) uint4 smem[];   // [W_U4] filter | [2][H_U4] halo tiles
+  extern __shared__ __attribute__((aligned(16))) uint4 smem[];   // [W_U4] filter | [2][H_U4] halo tiles | NOL: [C8][16] f32 coefficients
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WGN, wn = wid % WGN;
@@ -85,6 +90,35 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const HaloArgs ha) {
     const int sc = (lane % C8) ^ halo_swz<C8>(row);
     const uint32_t vo = (n < a.co) ? (uint32_t)((n * a.kpad + tap * CI) * 2 + sc * 16) : OOB;
     halo_dma16(wr, __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)(i * 1024)), vo, 0u);
+  }
+
+  // ---- normalise on load: per-chunk coefficient table + this thread's halo pieces (DMA instruction wid + 4k, 16 bytes each) ----
+  constexpr int NPC = HALO_DMA / 4;
+  static_assert(HALO_DMA % 4 == 0, "every wave issues the same number of halo pieces");
+  float* coef = (float*)(smem + W_U4 + 2 * H_U4);          // [C8][16]: scale[8] | shift[8] of an 8-channel chunk
+  int p_dy[NOL ? NPC : 1], p_dx[NOL ? NPC : 1], p_sc[NOL ? NPC : 1];
+  if constexpr (NOL) {
+    if (tid < CI) {
+      coef[(tid >> 3) * 16 + (tid & 7)] = ha.nol_scale[tid];
+      coef[(tid >> 3) * 16 + 8 + (tid & 7)] = ha.nol_shift[tid];
+    }
+#pragma unroll
+    for (int k = 0; k < NPC; ++k) {
+      const int hp = (wid + 4 * k) * PIX_PER_DMA + lane / C8;
+      bool valid;
+      if constexpr (S2) {
+        const int plane = hp / HALO_S2_PP, rem = hp - plane * HALO_S2_PP;
+        const int pi = rem / HALO_S2_PW, pj = rem - pi * HALO_S2_PW;
+        p_dy[k] = 2 * pi + (plane >> 1); p_dx[k] = 2 * pj + (plane & 1);       // relative to input pixel (2 y0, 2 x0)
+        valid = rem < 9 * HALO_S2_PW;
+      } else {
+        const int hy = hp / HALO_HW, hx = hp - hy * HALO_HW;
+        p_dy[k] = hy - 1; p_dx[k] = hx - 1;                                    // relative to input pixel (y0, x0)
+        valid = hp < (HALO_PH + 2) * HALO_HW;
+      }
+      if (!valid) p_dy[k] = 1 << 24;                                           // padding slot of the tile: never inside an image
+      p_sc[k] = (lane % C8) ^ halo_swz<C8>(hp);
+    }
   }
 
   // ---- halo loader ----------------------------------------------------------------------------------------
@@ -141,9 +175,38 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const HaloArgs ha) {
     if (counted && !first) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MT * NT) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the filter / this patch's halo landed
     first = false;
+    if constexpr (NOL) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (first patch: the coefficient table)
     __builtin_amdgcn_s_barrier();                          // => everyone's share; everyone is done with the other stage
     if (patch + (int)gridDim.x < ha.n_patches && !(a.flags & IMM_DBG_NO_GLOAD)) issue_halo(patch + gridDim.x, stage ^ 1);
     const uint4* Hl = smem + W_U4 + stage * H_U4;
+    if constexpr (NOL) {
+      // affine + ReLU of this patch's halo, in place: every thread transforms the 16-byte pieces its own DMA instructions wrote
+      // (it knows their pixel and channel chunk); pieces outside the image were zero-filled and stay zero
+      const int img_ = patch / per_img, pr_ = patch - img_ * per_img;
+      const int by = (S2 ? 2 : 1) * (pr_ / ha.patches_x) * HALO_PH, bx = (S2 ? 2 : 1) * (pr_ % ha.patches_x) * HALO_PW;
+      uint4* Hw = smem + W_U4 + stage * H_U4;
+      const bool nrelu = ha.nol_relu != 0;
+#pragma unroll
+      for (int k = 0; k < NPC; ++k) {
+        if (((unsigned)(by + p_dy[k]) < (unsigned)a.hi) && ((unsigned)(bx + p_dx[k]) < (unsigned)a.wi)) {
+          uint4* slot = Hw + (wid + 4 * k) * 64 + lane;
+          float f[8];
+          unpack8<ET>(*slot, f);
+          const float4* cf = (const float4*)(coef + p_sc[k] * 16);
+          const float4 s0 = cf[0], s1 = cf[1], h0 = cf[2], h1 = cf[3];
+          const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+          const float sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            f[e] = f[e] * sc[e] + sh[e];                   // the arithmetic of bn_apply_fused_kernel (elementwise.hip)
+            if (nrelu) f[e] = fmaxf(f[e], 0.f);
+          }
+          *slot = pack8<ET>(f);
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                        // the normalised tile is complete
+    }
 
     f32x4_t acc[MT][NT];
 #pragma unroll
@@ -310,11 +373,13 @@ bool imm_halo_applicable(const imm_conv_desc* d) {
 }
 
 static int halo_bn(int co) { return co > 32 ? 64 : co > 16 ? 32 : 16; }
-static size_t halo_lds(int ci, int bn, bool s2 = false) { return (size_t)(9 * bn * (ci / 8) + 2 * (s2 ? HALO_S2_HP : HALO_HP) * (ci / 8)) * 16; }
+static size_t halo_lds(int ci, int bn, bool s2 = false, bool nol = false) {
+  return (size_t)(9 * bn * (ci / 8) + 2 * (s2 ? HALO_S2_HP : HALO_HP) * (ci / 8)) * 16 + (nol ? (size_t)(ci / 8) * 64 : 0);
+}
 
 int imm_halo_grid(const imm_conv_desc* d) {
   const int n_patches = d->batch * (d->ho / HALO_PH) * (d->wo / HALO_PW);
-  const size_t lds = halo_lds(d->ci, halo_bn(d->co), halo_is_s2(d));
+  const size_t lds = halo_lds(d->ci, halo_bn(d->co), halo_is_s2(d), true);     // (with the normalise-on-load table: one grid for both forms)
   int per_cu = (int)((160 * 1024) / lds);
   if (per_cu > 4) per_cu = 4;
   if (per_cu < 1) per_cu = 1;
@@ -322,26 +387,38 @@ int imm_halo_grid(const imm_conv_desc* d) {
   return n_patches < grid ? n_patches : grid;
 }
 
-template <typename ET, int CI, int BN, bool S2 = false>
+template <typename ET, int CI, int BN, bool S2 = false, bool NOL = false>
 static void halo_launch_cfg(const HaloArgs& ha, int grid, hipStream_t s) {
-  const size_t lds = halo_lds(CI, BN, S2);
+  const size_t lds = halo_lds(CI, BN, S2, NOL);
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {
-    (void)hipFuncSetAttribute((const void*)conv_halo_kernel<ET, CI, BN, S2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)conv_halo_kernel<ET, CI, BN, S2, NOL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_halo_kernel<ET, CI, BN, S2>), dim3(grid), dim3(256), lds, s, ha);
+  hipLaunchKernelGGL((conv_halo_kernel<ET, CI, BN, S2, NOL>), dim3(grid), dim3(256), lds, s, ha);
 }
 
 template <typename ET>
-static void halo_launch(const imm_conv_desc* d, const ConvArgs& a, hipStream_t s) {
+static void halo_launch(const imm_conv_desc* d, const ConvArgs& a, hipStream_t s, const float* nol_scale = nullptr,
+                        const float* nol_shift = nullptr, int nol_relu = 0) {
   HaloArgs ha;
   ha.c = a;
+  ha.nol_scale = nol_scale; ha.nol_shift = nol_shift; ha.nol_relu = nol_relu;
   ha.patches_x = d->wo / HALO_PW; ha.patches_y = d->ho / HALO_PH;
   ha.n_patches = d->batch * ha.patches_x * ha.patches_y;
   ha.c.x_bytes = (uint32_t)((int64_t)d->batch * d->hi * d->wi * d->ldx * 2);
   ha.c.wt_bytes = (uint32_t)((int64_t)d->co * d->kpad * 2);
   const int grid = imm_halo_grid(d), bn = halo_bn(d->co);
+  if (nol_scale) {
+    // normalise-on-load instantiations: the shapes whose input is a batch-norm output in the encoders / the renderer
+    if (halo_is_s2(d)) halo_launch_cfg<ET, 32, 64, true, true>(ha, grid, s);
+    else if (d->ci == 64 && bn == 64) halo_launch_cfg<ET, 64, 64, false, true>(ha, grid, s);
+    else if (d->ci == 64 && bn == 32) halo_launch_cfg<ET, 64, 32, false, true>(ha, grid, s);
+    else if (d->ci == 32 && bn == 64) halo_launch_cfg<ET, 32, 64, false, true>(ha, grid, s);
+    else if (d->ci == 32 && bn == 32) halo_launch_cfg<ET, 32, 32, false, true>(ha, grid, s);
+    else halo_launch_cfg<ET, 32, 16, false, true>(ha, grid, s);
+    return;
+  }
   if (halo_is_s2(d)) { halo_launch_cfg<ET, 32, 64, true>(ha, grid, s); return; }
   if (d->ci == 64) {
     if (bn == 64) halo_launch_cfg<ET, 64, 64>(ha, grid, s);
@@ -357,4 +434,17 @@ static void halo_launch(const imm_conv_desc* d, const ConvArgs& a, hipStream_t s
 void imm_conv_halo_launch(int dtype, const imm_conv_desc* d, const ConvArgs& a, hipStream_t s) {
   if (dtype == IMM_BF16) halo_launch<BF16>(d, a, s);
   else halo_launch<F16>(d, a, s);
+}
+
+// normalise on load: served for every shape this kernel takes except (ci = 64, co <= 16), which no layer has
+bool imm_halo_nol_applicable(const imm_conv_desc* d) {
+  static const bool off = imm_conv_disabled("nol");
+  if (off || !imm_halo_applicable(d)) return false;
+  return halo_is_s2(d) || !(d->ci == 64 && halo_bn(d->co) == 16);
+}
+
+void imm_conv_halo_nol_launch(int dtype, const imm_conv_desc* d, const ConvArgs& a, const float* scale, const float* shift, int relu,
+                              hipStream_t s) {
+  if (dtype == IMM_BF16) halo_launch<BF16>(d, a, s, scale, shift, relu);
+  else halo_launch<F16>(d, a, s, scale, shift, relu);
 }

@@ -454,15 +454,18 @@ def test_gradient_parity_on_a_trained_model(dt):
     ill conditioned (test_gradient_parity); after 60 Adam steps on a smooth batch the fp32 oracle agrees with an fp64 run of
     itself to 1.3e-4 on every tensor (tests/diag_grad_conditioning.py), so a mis-scaled or mis-wired gradient anywhere in
     the backward chain would show.  Bound for the bf16 engine against the fp32 oracle at the SAME trained parameters and
-    state: EVERY trainable tensor within 0.30 relative L2, cosine >= 0.97 and no further from the fp32 oracle than 1.5 x the
-    oracle's own bf16-storage emulation + 0.03 (the emulation rounds weights and forward activations; the engine also stores
-    every gradient tensor in bf16); median over the tensors <= 0.10.  The 60-step trajectory is chaotic: numerically
+    state: EVERY trainable tensor no further from the fp32 oracle than 1.25 x the oracle's own bf16-storage emulation + 0.03 (the
+    emulation rounds weights and forward activations; the engine also stores every gradient tensor in bf16) AND within 0.30
+    relative L2 / cosine >= 0.97 — the absolute pair being waived for a tensor only when the emulation itself is outside it in
+    this trained state and the engine is at least as close to the fp32 oracle as the emulation (round 4: a rounding-order change
+    in one data-gradient kernel landed the trajectory in a state whose first pose-encoder beta is at 0.387 for the emulation,
+    0.378 for the engine); median over the tensors <= 0.10.  The 60-step trajectory is chaotic: numerically
     equivalent builds (another summation order of the batch-norm partial rows is enough) end in different trained states.
     Measured over such builds: worst 0.095 .. 0.23, median 0.04 .. 0.07, worst cosine 0.98 .. 0.9955; tensor by tensor the
     engine sits at 0.9 .. 2.2 x the emulation where the emulation itself is small (0.03), within +-10 % where it is large:
     what is left is bf16 storage, not wiring.
     f16 (BASELINE configs[4]; the reference is fp32, imm_model.py:97): the same test with HALF the bounds (0.15 / cosine 0.99 /
-    median 0.05; still no further from the oracle than 1.5 x its bf16 emulation + 0.03).  Without loss scaling the stored dy tensors of the trained pose encoder underflow f16 (relative error up to
+    median 0.05; still no further from the oracle than 1.25 x its bf16 emulation + 0.03).  Without loss scaling the stored dy tensors of the trained pose encoder underflow f16 (relative error up to
     3.6 on its first convolution, round 2); with the dynamic loss scale of imm_clip_adam_step the f16 engine has to be at
     least as close to the fp32 oracle as the bf16 engine is allowed to be, and no step of the 60 may be lost to an overflow
     after the first few (the scale search)."""
@@ -513,11 +516,20 @@ def test_gradient_parity_on_a_trained_model(dt):
         e = float((a - b).norm() / b.norm())
         cos = float((a * b).sum() / (a.norm() * b.norm()))
         e_emul = rel(g_e[k], v)
+        c = g_e[k].detach().double().flatten()
+        cos_emul = float((c * b).sum() / (c.norm() * b.norm()))
         rels.append(e)
         worst = (max(worst[0], e), min(worst[1], cos))
-        print('TRAINED_GRAD %-48s rel %.4f cos %.5f  emul %.4f' % (k, e, cos, e_emul))
-        if e > lim_rel or cos < lim_cos or e > 1.5 * e_emul + 0.03:
-            bad.append((k, e, cos, e_emul))
+        print('TRAINED_GRAD %-48s rel %.4f cos %.5f  emul %.4f cos %.5f' % (k, e, cos, e_emul, cos_emul))
+        # (i) tensor by tensor the engine stays with the oracle's own bf16-storage emulation: 1.25 x + 0.03 (measured
+        #     ratios 0.9 .. 1.2 where the emulation is large, up to 2.2 where it is ~0.03); (ii) the absolute bounds — unless the emulation itself is outside them for this tensor of this
+        #     trained state (the 60-step trajectory is chaotic: a rounding-order change in any kernel lands in another state, and
+        #     the first pose-encoder layer of some states is ill conditioned: round 4 met beta at 0.378 with the emulation at
+        #     0.387): then the engine must be at least as close to the fp32 oracle as the emulation is
+        tight = e <= 1.25 * e_emul + 0.03
+        absolute = (e <= lim_rel and cos >= lim_cos) or (e <= e_emul and cos >= cos_emul - 1e-3)
+        if not (tight and absolute):
+            bad.append((k, e, cos, e_emul, cos_emul))
     med = float(np.median(np.array(rels)))
     print('TRAINED_GRAD worst rel %.4f, worst cos %.5f, median rel %.4f' % (worst + (med,)))
     assert not bad, bad
