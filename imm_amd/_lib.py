@@ -35,7 +35,8 @@ class ConvDesc(C.Structure):
 
 class WgradJob(C.Structure):
     _fields_ = [('desc', ConvDesc), ('x', C.c_void_p), ('dy', C.c_void_p), ('slab', C.c_void_p), ('lddy', C.c_int32),
-                ('nsplit', C.c_int32)]
+                ('nsplit', C.c_int32), ('x_scale', C.c_void_p), ('x_shift', C.c_void_p), ('x_relu', C.c_int32),
+                ('reserved', C.c_int32)]
 
 
 class OptHParams(C.Structure):
@@ -99,6 +100,9 @@ _SIGS = {
     'imm_tps_warp': [_P, _I, _I, _I, _I, _I, _P, _I, _P, _P, _I, _P, _P, _I, _P],
     'imm_tps_warp_pad': [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P, _I, _P],
     'imm_conv2d_group': [_P, _I, _I, _P, _P, _P, _P, _P, _P],
+    'imm_conv2d_nol_supported': [C.POINTER(ConvDesc)],
+    'imm_conv2d_nol_stats_blocks': [C.POINTER(ConvDesc)],
+    'imm_conv2d_nol': [C.POINTER(ConvDesc), _I, _P, _P, _P, _I, _P, _P, _P, _P, _P],
     'imm_conv2d_dgrad_s2_supported': [_I, _I, _I, _I, _I, _I],
     'imm_conv2d_dgrad_s2': [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
     'imm_conv2d_group_stats_blocks': [_P, _I],

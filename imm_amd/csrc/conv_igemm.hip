@@ -21,6 +21,9 @@ void imm_conv_halo_launch(int dtype, const imm_conv_desc* d, const ConvArgs& a, 
 bool imm_hdeep_applicable(const imm_conv_desc* d);                                 // conv_hdeep.hip
 int imm_hdeep_stats_blocks(const imm_conv_desc* d);
 void imm_conv_hdeep_launch(int dtype, const imm_conv_desc* d, const ConvArgs& a, hipStream_t s);
+bool imm_halo_nol_applicable(const imm_conv_desc* d);
+void imm_conv_halo_nol_launch(int dtype, const imm_conv_desc* d, const ConvArgs& a, const float* scale, const float* shift, int relu,
+                              hipStream_t s);
 bool imm_hdeep_s2d_applicable(const imm_conv_desc* d);
 void imm_conv_hdeep_s2d_launch(int dtype, const imm_conv_desc* d, const ConvArgs& a, hipStream_t s);
 bool imm_halo2_applicable(const imm_conv_desc* d);                                 // conv_halo2.hip
@@ -387,6 +390,34 @@ extern "C" int imm_conv2d_tap(const imm_conv_desc* d, int dtype, const void* x, 
   a.tap_gt = (const uint16_t*)a_gt; a.tap_lmask = loss_mask; a.tap_coef = coef; a.tap_idx = idx; a.tap_S = S; a.tap_l1 = l1;
   imm_conv_hdeep_launch(dtype, &dd, a, (hipStream_t)stream);
   IMM_CHECK_LAUNCH("imm_conv2d_tap");
+  return 0;
+}
+
+// Normalise on load (conv_halo.hip): the batch-norm apply pass of the block in front of this convolution folded into its halo tile.
+extern "C" int imm_conv2d_nol_supported(const imm_conv_desc* d) {
+  if (!d || validate_desc(d)) return 0;
+  if (d->flags & (IMM_CONV_MASK | IMM_CONV_RELU | 0xfe0)) return 0;
+  return imm_halo_nol_applicable(d) ? 1 : 0;
+}
+
+extern "C" int imm_conv2d_nol_stats_blocks(const imm_conv_desc* d) {
+  if (!imm_conv2d_nol_supported(d)) return imm_fail(IMM_E_UNSUPPORTED, "conv_nol: shape not served by the LDS-halo kernel");
+  return imm_halo_grid(d);
+}
+
+extern "C" int imm_conv2d_nol(const imm_conv_desc* d, int dtype, const void* x_raw, const float* x_scale, const float* x_shift,
+                              int x_relu, const void* wt, const float* bias, void* y, float* stats_partial, void* stream) {
+  if (validate_desc(d)) return IMM_E_INVALID;
+  IMM_REQUIRE(x_raw && x_scale && x_shift && wt && y, "conv_nol: null tensor");
+  IMM_REQUIRE(dtype == IMM_BF16 || dtype == IMM_F16, "unknown dtype %d", dtype);
+  IMM_REQUIRE(!(d->flags & IMM_CONV_BIAS) || bias, "conv_nol: bias flag without bias");
+  IMM_REQUIRE(!(d->flags & IMM_CONV_STATS) || stats_partial, "conv_nol: stats flag without buffer");
+  IMM_REQUIRE(((uintptr_t)x_raw % 16 == 0) && ((uintptr_t)wt % 16 == 0) && ((uintptr_t)y % 16 == 0), "conv_nol: 16-byte alignment");
+  if (!imm_conv2d_nol_supported(d)) return imm_fail(IMM_E_UNSUPPORTED, "conv_nol: shape not served by the LDS-halo kernel");
+  ConvArgs a;
+  fill_args(a, d, x_raw, wt, bias, y, stats_partial, nullptr);
+  imm_conv_halo_nol_launch(dtype, d, a, x_scale, x_shift, x_relu, (hipStream_t)stream);
+  IMM_CHECK_LAUNCH("imm_conv2d_nol");
   return 0;
 }
 

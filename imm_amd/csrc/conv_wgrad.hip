@@ -301,7 +301,7 @@ void imm_wgrad_tr_launch(int dtype, const imm_conv_desc* d, const void* x, const
 bool imm_wgrad_halo_applicable(const imm_conv_desc* d, int lddy);          // conv_wgrad_halo.hip
 int imm_wgrad_halo_splits(const imm_conv_desc* d, int lddy);
 void imm_wgrad_halo_launch(int dtype, const imm_conv_desc* d, const void* x, const void* dy, int lddy, float* slab,
-                           int nsplit, hipStream_t s);
+                           int nsplit, hipStream_t s, const float* nol_scale, const float* nol_shift, int nol_relu);
 
 extern "C" int imm_conv2d_wgrad_splits(const imm_conv_desc* d, int lddy) {
   if (!d) return IMM_E_INVALID;
@@ -319,7 +319,7 @@ extern "C" int imm_conv2d_wgrad(const imm_conv_desc* d, int dtype, const void* x
   IMM_REQUIRE(d->wo % 2 == 0, "wgrad: output width must be even (pixel pairs)");
   IMM_REQUIRE(((uintptr_t)x % 16 == 0) && ((uintptr_t)dy % 16 == 0) && ((uintptr_t)slab % 16 == 0), "wgrad: alignment");
   if (imm_wgrad_halo_applicable(d, lddy) && nsplit == imm_wgrad_halo_splits(d, lddy) && (dtype == IMM_BF16 || dtype == IMM_F16)) {
-    imm_wgrad_halo_launch(dtype, d, x, dy, lddy, slab, nsplit, (hipStream_t)stream);
+    imm_wgrad_halo_launch(dtype, d, x, dy, lddy, slab, nsplit, (hipStream_t)stream, nullptr, nullptr, 0);
     IMM_CHECK_LAUNCH("imm_conv2d_wgrad(halo)");
     return 0;
   }
@@ -347,7 +347,8 @@ int imm_wgrad_halo_variant(const imm_conv_desc* d, int lddy);
 int imm_wgrad_halo_blocks(const imm_conv_desc* d, int lddy, int* n_patches);
 int imm_wgrad_halo_args_bytes();
 int imm_wgrad_halo_per_cu(int variant);
-int imm_wgrad_halo_fill(const imm_conv_desc* d, const void* x, const void* dy, int lddy, float* slab, int nsplit, void* out, int* steps);
+int imm_wgrad_halo_fill(const imm_conv_desc* d, const void* x, const void* dy, int lddy, float* slab, int nsplit, void* out, int* steps,
+                        const float* nol_scale, const float* nol_shift, int nol_relu);
 void imm_wgrad_halo_launch_multi(int dtype, int variant, const void* tab_dev, const int* first_dev, int n, int blocks, hipStream_t s);
 
 namespace {
@@ -388,6 +389,7 @@ extern "C" int64_t imm_conv2d_wgrad_multi_table_bytes(int n) {
 extern "C" int imm_conv2d_wgrad_variant(const imm_conv_desc* d, int lddy, int dtype, int* wg_per_split, int* units, int* wg_per_cu) {
   IMM_REQUIRE(d && lddy >= d->co, "wgrad_variant: args");
   imm_wgrad_job j; j.desc = *d; j.lddy = lddy; j.nsplit = 1; j.x = j.dy = nullptr; j.slab = nullptr;
+  j.x_scale = j.x_shift = nullptr; j.x_relu = 0;
   int kind, variant;
   wgm_classify(&j, dtype, &kind, &variant);
   int wps = 1, un = 1, pcu = 2;                                // transpose-read / generic kernels: 65 KB of LDS, two per CU
@@ -417,6 +419,10 @@ extern "C" int imm_conv2d_wgrad_multi_plan(const imm_wgrad_job* jobs, int n, int
   for (int i = 0; i < n; ++i) {
     if (wgm_check_job(&jobs[i])) return IMM_E_INVALID;
     wgm_classify(&jobs[i], dtype, &kind[i], &variant[i]);
+    IMM_REQUIRE((jobs[i].x_scale == nullptr) == (jobs[i].x_shift == nullptr), "wgrad_multi_plan: job %d: x_scale / x_shift come together", i);
+    IMM_REQUIRE(jobs[i].x_scale == nullptr || kind[i] == WGM_HALO,
+                "wgrad_multi_plan: job %d: normalise-on-load (x_scale) is served by the LDS-halo filter-gradient kernels only "
+                "(imm_conv2d_wgrad_variant / 100000 == 2)", i);
     done[i] = false;
   }
   int64_t off = WGM_HEADER;
@@ -444,7 +450,9 @@ extern "C" int imm_conv2d_wgrad_multi_plan(const imm_wgrad_job* jobs, int n, int
     char tmp[WGM_MAX_JOBS][WGM_ARG_STRIDE];
     for (int k = 0; k < m; ++k) {
       const imm_wgrad_job* j = &jobs[idx[k]];
-      blocks[k] = (kind[i] == WGM_TR ? imm_wgrad_tr_fill : imm_wgrad_halo_fill)(&j->desc, j->x, j->dy, j->lddy, j->slab, j->nsplit, tmp[k], &steps[k]);
+      blocks[k] = kind[i] == WGM_TR ? imm_wgrad_tr_fill(&j->desc, j->x, j->dy, j->lddy, j->slab, j->nsplit, tmp[k], &steps[k])
+                                    : imm_wgrad_halo_fill(&j->desc, j->x, j->dy, j->lddy, j->slab, j->nsplit, tmp[k], &steps[k], j->x_scale,
+                                                          j->x_shift, j->x_relu);
     }
     int order[WGM_MAX_JOBS];
     for (int k = 0; k < m; ++k) order[k] = k;

@@ -65,6 +65,10 @@ struct WgradHaloArgs {
   int n_patches, patches_x, patches_y;
   int nsplit, nci, nco;          // grid of the member (multi-problem launches)
   uint32_t x_bytes, dy_bytes;
+  // normalise on load (round 4): x is the RAW output y of the conv + batch-norm + ReLU block in front of this convolution; the
+  // tensor the forward pass convolved, relu(scale[c] * y + shift[c]), is rebuilt in the LDS halo (conv_halo.hip does the same on
+  // the forward side), so it never exists in HBM.  NULL = x is the stored activation.
+  const float* nol_scale; const float* nol_shift; int nol_relu;
 };
 
 // CI input channels, CO = channels of the dY rows that are staged (32 or 64; co <= CO real ones).
@@ -88,7 +92,9 @@ __device__ __forceinline__ void conv_wgrad_halo_body(const WgradHaloArgs& a, con
   constexpr int X_BYTES = WH_HP_ * CI * 2, Y_BYTES = 128 * CO * 2, STAGE = X_BYTES + Y_BYTES;
   constexpr int LPP = X_DMA / 4 + Y_DMA / 4;           // DMA instructions per wave and patch
   static_assert(X_DMA % 4 == 0 && Y_DMA % 4 == 0 && NS >= 2 && (NS - 2) * LPP < 64, "uniform per-wave DMA count");
-  extern __shared__ __attribute__((aligned(16))) uint4 smem[];   // NS stages of [X halo | dY patch]
+  extern __shared__ __attribute__((aligned(16))) uint4 smem[];   // NS stages of [X halo | dY patch] | [CI/8][16] f32 normalise-on-load table
+  const bool nol = a.nol_scale != nullptr;
+  float* coef = (float*)((char*)smem + NS * STAGE);
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wc = wid % WC, wn = wid / WC;
@@ -105,6 +111,7 @@ __device__ __forceinline__ void conv_wgrad_halo_body(const WgradHaloArgs& a, con
   constexpr int XU = X_DMA / 4, YU = Y_DMA / 4;
   int x_iy[XU], x_ix[XU];            // input row / column of the piece's pixel relative to the patch's input origin
   int x_rel[XU];                     // its byte offset relative to that origin (+ channel slice, swizzled chunk)
+  int x_sc[XU];                      // the 8-channel chunk of the slice that lands in this lane's 16-byte slot (normalise on load)
   uint32_t y_rel[YU];
   const int w_in = ST * a.w, h_in = ST * a.h;
 #pragma unroll
@@ -128,6 +135,11 @@ __device__ __forceinline__ void conv_wgrad_halo_body(const WgradHaloArgs& a, con
     x_iy[u] = valid ? iy : (1 << 24);          // never inside an image
     x_ix[u] = ix;
     x_rel[u] = ((iy * w_in + ix) * a.ldx + ci0) * 2 + sc * 16;
+    x_sc[u] = sc;
+  }
+  if (nol && tid < CI) {
+    coef[(tid >> 3) * 16 + (tid & 7)] = a.nol_scale[ci0 + tid];
+    coef[(tid >> 3) * 16 + 8 + (tid & 7)] = a.nol_shift[ci0 + tid];
   }
 #pragma unroll
   for (int u = 0; u < YU; ++u) {
@@ -192,12 +204,42 @@ __device__ __forceinline__ void conv_wgrad_halo_body(const WgradHaloArgs& a, con
     // patches it .. min(it+NS-2, n_mine-1) are in flight; patch `it` must have landed (this wave's share, then everyone's)
     if (it + NS - 2 < n_mine) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * LPP) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (nol) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (first patch: the coefficient table)
     __builtin_amdgcn_s_barrier();
     if (it + NS - 1 < n_mine) {      // into the stage patch it-1 occupied: every wave is past its reads (the barrier above)
       int ns = stage + NS - 1; if (ns >= NS) ns -= NS;
       issue(bx + (it + NS - 1) * G, ns);
     }
     const char* Xl = lds_c + stage * STAGE;     // (the dY patch follows the X halo inside the stage: yb includes X_BYTES)
+    if (nol) {
+      // affine + ReLU of this patch's X halo, in place: every thread transforms the 16-byte pieces its own DMA instructions wrote
+      // (pixel and channel chunk known); pieces outside the image were zero-filled and stay zero
+      const int patch_ = bx + it * G;
+      const int img_ = patch_ / per_img, pr_ = patch_ - img_ * per_img;
+      const int py_ = ST * (pr_ / a.patches_x) * WH_PH, px_ = ST * (pr_ % a.patches_x) * WH_PW;
+      char* Xw = (char*)smem + stage * STAGE + wid * 1024 + lane * 16;
+      const bool nrelu = a.nol_relu != 0;
+#pragma unroll
+      for (int u = 0; u < XU; ++u) {
+        if (((unsigned)(py_ + x_iy[u]) < (unsigned)h_in) && ((unsigned)(px_ + x_ix[u]) < (unsigned)w_in)) {
+          uint4* slot = (uint4*)(Xw + u * 4096);
+          float f[8];
+          unpack8<ET>(*slot, f);
+          const float4* cf = (const float4*)(coef + x_sc[u] * 16);
+          const float4 s0 = cf[0], s1 = cf[1], h0 = cf[2], h1 = cf[3];
+          const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+          const float sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            f[e] = f[e] * sc[e] + sh[e];                   // the arithmetic of bn_apply_fused_kernel (elementwise.hip)
+            if (nrelu) f[e] = fmaxf(f[e], 0.f);
+          }
+          *slot = pack8<ET>(f);
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
 
     // dY^T fragments of this wave's co tiles for the 4 k-steps of the patch: reused by all nine taps
     uint4 bfr[4][TNT];
@@ -378,7 +420,7 @@ template <typename ET, int CI, int CO, int KH = 3, int KW = 3, int ST = 1>
 static void wh_launch_cfg(const WgradHaloArgs& a, dim3 grid, hipStream_t s) {
   constexpr int stage = WhRing<CI, CO, KH, KW, ST>::stage;
   constexpr int NS = WhRing<CI, CO, KH, KW, ST>::NS;
-  constexpr int lds = NS * stage;
+  constexpr int lds = NS * stage + CI * 8;             // + the normalise-on-load coefficient table
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {
     (void)hipFuncSetAttribute((const void*)conv_wgrad_halo_kernel<ET, CI, CO, NS, KH, KW, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -388,8 +430,9 @@ static void wh_launch_cfg(const WgradHaloArgs& a, dim3 grid, hipStream_t s) {
 }
 
 static WgradHaloArgs wh_fill(const imm_conv_desc* d, const void* x, const void* dy, int lddy, float* slab, int nsplit,
-                             const WhPlan& pl) {
+                             const WhPlan& pl, const float* nol_scale = nullptr, const float* nol_shift = nullptr, int nol_relu = 0) {
   WgradHaloArgs a;
+  a.nol_scale = nol_scale; a.nol_shift = nol_shift; a.nol_relu = nol_relu;
   a.x = (const uint16_t*)x; a.dy = (const uint16_t*)dy; a.slab = slab;
   a.batch = d->batch; a.h = d->ho; a.w = d->wo; a.ldx = d->ldx; a.lddy = lddy; a.co = d->co; a.kpad = d->kpad;
   a.ci_total = d->ci;
@@ -402,10 +445,10 @@ static WgradHaloArgs wh_fill(const imm_conv_desc* d, const void* x, const void* 
 }
 
 void imm_wgrad_halo_launch(int dtype, const imm_conv_desc* d, const void* x, const void* dy, int lddy, float* slab,
-                           int nsplit, hipStream_t s) {
+                           int nsplit, hipStream_t s, const float* nol_scale, const float* nol_shift, int nol_relu) {
   WhPlan pl;
   (void)wh_plan(d, lddy, &pl);
-  const WgradHaloArgs a = wh_fill(d, x, dy, lddy, slab, nsplit, pl);
+  const WgradHaloArgs a = wh_fill(d, x, dy, lddy, slab, nsplit, pl, nol_scale, nol_shift, nol_relu);
   const dim3 grid(nsplit, pl.nci, pl.nco);
 #define WH_GO(ET_) \
   do { \
@@ -435,10 +478,10 @@ int imm_wgrad_halo_blocks(const imm_conv_desc* d, int lddy, int* n_patches) {
 }
 int imm_wgrad_halo_args_bytes() { return (int)sizeof(WgradHaloArgs); }
 int imm_wgrad_halo_fill(const imm_conv_desc* d, const void* x, const void* dy, int lddy, float* slab, int nsplit, void* out,
-                        int* steps) {
+                        int* steps, const float* nol_scale, const float* nol_shift, int nol_relu) {
   WhPlan pl;
   (void)wh_plan(d, lddy, &pl);
-  const WgradHaloArgs a = wh_fill(d, x, dy, lddy, slab, nsplit, pl);
+  const WgradHaloArgs a = wh_fill(d, x, dy, lddy, slab, nsplit, pl, nol_scale, nol_shift, nol_relu);
   memcpy(out, &a, sizeof(a));
   if (steps) *steps = (a.n_patches + nsplit - 1) / nsplit * 4 * (pl.cs / 16);     // ~ matrix work per workgroup
   return nsplit * pl.nci * pl.nco;
@@ -451,7 +494,7 @@ template <typename ET, int CI, int CO, int KH = 3, int KW = 3, int ST = 1>
 static void wh_launch_multi_cfg(const WgradHaloArgs* tab, const int* first, int n, int blocks, hipStream_t s) {
   constexpr int stage = WhRing<CI, CO, KH, KW, ST>::stage;
   constexpr int NS = WhRing<CI, CO, KH, KW, ST>::NS;
-  constexpr int lds = NS * stage;
+  constexpr int lds = NS * stage + CI * 8;             // + the normalise-on-load coefficient table
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {
     (void)hipFuncSetAttribute((const void*)conv_wgrad_halo_multi_kernel<ET, CI, CO, NS, KH, KW, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);

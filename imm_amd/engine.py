@@ -323,14 +323,34 @@ class IMMEngine:
         (and their backward passes) are independent chains of small kernels that do not fill 256 CUs on their own."""
         prog.append(_Launch(None, what))
 
+    def _nol_consumer_ok(self, H, W, ci, ldx, co, k, stride, bn, out_f32):
+        """Can a convolution of this geometry take the RAW output of the conv + BN + ReLU block in front of it (normalise on
+        load)?  Both readers of the normalised tensor must rebuild it in LDS: the forward convolution (imm_conv2d_nol) and
+        its filter gradient (an LDS-halo variant of imm_conv2d_wgrad_multi).  IMM_CONV_DISABLE=nol turns the path off."""
+        if k != 3 or ci != ldx:
+            return False
+        ldy = ops.round_up(co, 4) if out_f32 else ops.round_up(co, 8)
+        flags = L.CONV_BIAS | (L.CONV_OUT_F32 if out_f32 else 0) | (L.CONV_STATS if bn else 0)
+        fd = ops.fwd_desc(self.B, H, W, ci, ldx, co, ldy, k, stride, flags)
+        if not ops.conv2d_nol_supported(fd):
+            return False
+        lddy = ldy if not out_f32 else ops.round_up(co, 32)
+        key, _wps, _units, _pcu = ops.conv2d_wgrad_variant(fd, lddy, self.dt)
+        return key // 100000 == 2
+
     def _conv_block(self, scope, x, H, W, ci_real, ci_pad, ldx, co, k, stride, bn, relu, needs_dgrad,
-                    out=None, ldo=None, out_f32=False, kw=None, up2x=False, fwd_launch=True):
+                    out=None, ldo=None, out_f32=False, kw=None, up2x=False, fwd_launch=True, nol_src=None, defer_apply=False):
         """Registers forward launches now and returns a layer record whose .backward(d_out, dx) registers the
-        backward launches later (in reverse order)."""
+        backward launches later (in reverse order).
+        nol_src: the conv + BN + ReLU block in front of this convolution whose normalised output is NOT stored: x is its raw
+        conv output y, and this convolution (and its filter gradient) apply relu(scale * y + shift) on load.
+        defer_apply: this block is such a producer — statistics and a finalize launch, no apply pass, no `out`."""
         B, dt, dev = self.B, self.dt, self.dev
         self._cur_scope = scope
         lay = _ConvLayer()
         lay.scope, lay.bn, lay.relu, lay.x, lay.ldx = scope, bn, relu, x, ldx
+        lay.nol_src = nol_src
+        assert nol_src is None or (nol_src.bn and x is nol_src.y and ldx == nol_src.ldy)
         kw = k if kw is None else kw      # kw != k only for the tap-unrolled first encoder conv (7x1 over 21 channels)
         lay.ci_real, lay.ci_pad, lay.co, lay.k, lay.stride, lay.H, lay.W, lay.kw = ci_real, ci_pad, co, k, stride, H, W, kw
         flags = L.CONV_BIAS | (L.CONV_OUT_F32 if out_f32 else 0)
@@ -348,19 +368,23 @@ class IMMEngine:
         lay.y = self._zeros(B, fd.ho, fd.wo, ldy, dtype=torch.float32 if out_f32 else dt)
         flops = 2.0 * npix * k * kw * ci_real * co
         if bn:
-            nblk = ops.conv_stats_blocks(fd)
+            nblk = ops.conv_stats_blocks(fd) if nol_src is None else ops.conv2d_nol_stats_blocks(fd)
             lay.stats = self._zeros(nblk, 2, co)
             lay.scale, lay.shift, lay.mean, lay.rstd = (self._zeros(co) for _ in range(4))
             mm, mv = self._zeros(co), self._zeros(co)
             mv.fill_(1.0)
             self.state[scope + '/moving_mean'], self.state[scope + '/moving_variance'] = mm, mv
             gamma, beta = self.pview[scope + '/gamma'], self.pview[scope + '/beta']
-            if out is None:
+            if out is None and not defer_apply:
                 out, ldo = self._act(B, fd.ho, fd.wo, co), co
             lay.out, lay.ldo = out, ldo
 
             def f_conv():
-                ops.conv2d(fd if self._training else fd_eval, x, lay.wt, b, lay.y, lay.stats if self._training else None)
+                if nol_src is not None:
+                    ops.conv2d_nol(fd if self._training else fd_eval, x, nol_src.scale, nol_src.shift, nol_src.relu, lay.wt, b, lay.y,
+                                   lay.stats if self._training else None)
+                else:
+                    ops.conv2d(fd if self._training else fd_eval, x, lay.wt, b, lay.y, lay.stats if self._training else None)
 
             def f_fin():
                 ops.bn_finalize(lay.stats, nblk, co, npix, gamma, beta, BN_EPS, BN_MOMENTUM, self._training, mm, mv,
@@ -368,7 +392,14 @@ class IMMEngine:
             cbytes = 2.0 * (B * H * W * ci_pad + npix * co + fd.kpad * co)
             self._add(self.prog_fwd, f_conv, 'conv_fwd', flops, cbytes)
             lay.up = None
-            if nblk <= 256 and co % 32 == 0:
+            if defer_apply:
+                # normalise on load: the consumers rebuild relu(scale * y + shift) in LDS, so the apply pass (read y, write out:
+                # 4 B per element of HBM traffic) is gone; what is left of the batch norm's forward is this finalize of the
+                # partial rows (one workgroup per 32 channels; <= 768 rows: the producers are persistent kernels)
+                assert up2x is False and out is None
+                lay.out, lay.ldo = None, None
+                self._add(self.prog_fwd, f_fin, 'bn_finalize')
+            elif nblk <= 256 and co % 32 == 0:
                 # few partial rows: the finalize is redone by every workgroup of the apply pass (one launch, one kernel
                 # boundary and a 6-9 us latency chain less per layer); the renderer's x2 up-sampling rides along
                 if up2x:
@@ -399,7 +430,10 @@ class IMMEngine:
         else:
             lay.out, lay.ldo = lay.y, ldy
             lay.fwd_flops = flops
-            if fwd_launch:      # (the pose head's convolution is part of the fused imm_pose_head_fwd launch instead)
+            if fwd_launch and nol_src is not None:
+                self._add(self.prog_fwd, lambda: ops.conv2d_nol(fd_eval, x, nol_src.scale, nol_src.shift, nol_src.relu, lay.wt, b, lay.y),
+                          'conv_fwd', flops, 2.0 * (B * H * W * ci_pad + fd.kpad * co) + npix * co * (4.0 if out_f32 else 2.0))
+            elif fwd_launch:      # (the pose head's convolution is part of the fused imm_pose_head_fwd launch instead)
                 self._add(self.prog_fwd, lambda: ops.conv2d(fd_eval, x, lay.wt, b, lay.y), 'conv_fwd', flops,
                           2.0 * (B * H * W * ci_pad + fd.kpad * co) + npix * co * (4.0 if out_f32 else 2.0))
 
@@ -582,7 +616,9 @@ class IMMEngine:
                 lay.nsplit = nsplit
                 flops_total += flops
                 lay.slab = self._zeros(nsplit, lay.fd.kpad, lay.co)
-                multi_jobs.append((lay.fd, lay.x, dy, lddy, lay.slab, nsplit))
+                ns_ = getattr(lay, 'nol_src', None)
+                multi_jobs.append((lay.fd, lay.x, dy, lddy, lay.slab, nsplit,
+                                   None if ns_ is None else (ns_.scale, ns_.shift, ns_.relu)))
                 gw = self.gview[lay.scope + '/w']
                 job = (lay.slab.data_ptr(), gw.data_ptr(), nsplit, lay.k * lay.kw, lay.ci_pad, lay.ci_real, lay.co, lay.fd.kpad)
                 self._reduce_jobs.append((job, lay.k * lay.kw * lay.ci_real * lay.co))
@@ -619,15 +655,31 @@ class IMMEngine:
                       0.0, B * S * S * (12.0 + 2.0 * ld1), name=scope + '/pack')
             layers, x, H, ci_real, ci_pad, ldx = [], xin, S, 3 * k1, ld1, ld1
             spec = encoder_spec(nf)
+            # normalise on load: block i keeps only its raw conv output when the next convolution (its ONLY reader, forward
+            # and filter gradient) can rebuild the normalised tensor in LDS — the high-resolution layers, where the apply
+            # pass is pure HBM traffic (conv_2, conv_3, conv_4 of each encoder at 128x128 / 64x64)
+            hs, h_ = [], S
+            for (_k, _ci, _co, st) in spec:
+                hs.append(h_); h_ = -(-h_ // st)
+            defer = [i + 1 < len(spec) and self._nol_consumer_ok(hs[i + 1], hs[i + 1], spec[i][2], ops.round_up(spec[i][2], 8),
+                                                               spec[i + 1][2], spec[i + 1][0], spec[i + 1][3], True, False)
+                     for i in range(len(spec))]
+            prev = None
             for i, (k, ci, co, stride) in enumerate(spec):
                 last = i == len(spec) - 1
                 out, ldo = (None, None)
                 if last and scope == 'model/image_encoder' and He == 16:
                     out, ldo = self.joint, Cj       # conv_8 writes straight into the concat buffer
+                nol_src = prev if (prev is not None and prev.out is None) else None
                 lay = self._conv_block('%s/encoder/conv_%d' % (scope, i + 1), x, H, H, ci_real, ci_pad, ldx, co, k,
-                                       stride, True, True, needs_dgrad=(i > 0), out=out, ldo=ldo, kw=(1 if i == 0 else None))
+                                       stride, True, True, needs_dgrad=(i > 0), out=out, ldo=ldo, kw=(1 if i == 0 else None),
+                                       nol_src=nol_src, defer_apply=defer[i])
                 layers.append(lay)
-                x, H, ci_real, ci_pad, ldx = lay.out, lay.Ho, co, co, lay.ldo
+                prev = lay
+                if lay.out is None:
+                    x, H, ci_real, ci_pad, ldx = lay.y, lay.Ho, co, co, lay.ldy
+                else:
+                    x, H, ci_real, ci_pad, ldx = lay.out, lay.Ho, co, co, lay.ldo
             return layers
 
         self._mark(self.prog_fwd, 'fork')
@@ -674,12 +726,23 @@ class IMMEngine:
         self.ren, self.ren_up = [], []
         x, H, ci_real, ci_pad, ldx = self.joint, 16, 8 * nf + K, Cj, Cj
         rspec = renderer_spec(cfg, S, n_renderer_out(cfg))
+        prev = None
         for i, (k, ci, co, bn, up) in enumerate(rspec):
             assert ci == ci_real, (ci, ci_real)
+            # normalise on load (see build_encoder): a block that is not up-sampled and whose next convolution takes the raw tensor
+            defer = False
+            if bn and not up and i + 1 < len(rspec) and co % 8 == 0:
+                k2, _ci2, co2, bn2, _up2 = rspec[i + 1]
+                defer = self._nol_consumer_ok(H, H, co, co, co2, k2, 1, bn2, not bn2)
+            nol_src = prev if (prev is not None and prev.bn and prev.out is None) else None
             lay = self._conv_block('model/renderer/conv_%d' % (i + 1), x, H, H, ci_real, ci_pad, ldx, co, k, 1, bn, bn,
-                                   needs_dgrad=True, out_f32=not bn, up2x=bool(up and bn))
+                                   needs_dgrad=True, out_f32=not bn, up2x=bool(up and bn), nol_src=nol_src, defer_apply=defer)
             self.ren.append(lay)
-            x, ci_real, ci_pad, ldx = lay.out, co, co, lay.ldo
+            prev = lay
+            if lay.bn and lay.out is None:
+                x, ci_real, ci_pad, ldx = lay.y, co, co, lay.ldy
+            else:
+                x, ci_real, ci_pad, ldx = lay.out, co, co, lay.ldo
             if up:
                 ub = getattr(lay, 'up', None)
                 if ub is None:       # not taken by the fused finalize + apply + up-sample pass

@@ -194,17 +194,21 @@ def conv2d_wgrad_variant(desc, lddy, dtype):
 
 
 class WgradMulti(object):
-    """Planned multi-problem filter-gradient launch: jobs = [(desc, x, dy, lddy, slab, nsplit)].  Keeps the host table, its
-    device copy and the operand tensors alive."""
+    """Planned multi-problem filter-gradient launch: jobs = [(desc, x, dy, lddy, slab, nsplit[, (x_scale, x_shift, x_relu)])];
+    the optional triple = normalise on load (x is the raw output of the conv + BN + ReLU block in front of the layer).  Keeps
+    the host table, its device copy and the operand tensors alive."""
 
     def __init__(self, jobs, dtype):
         n = len(jobs)
-        self.keep = [t for j in jobs for t in (j[1], j[2], j[4])]
+        self.keep = [t for j in jobs for t in (j[1], j[2], j[4])] + [t for j in jobs if len(j) > 6 and j[6] for t in j[6][:2]]
         arr = (L.WgradJob * n)()
-        for i, (desc, x, dy, lddy, slab, nsplit) in enumerate(jobs):
+        for i, job in enumerate(jobs):
+            desc, x, dy, lddy, slab, nsplit = job[:6]
             arr[i].desc = desc
             arr[i].x, arr[i].dy, arr[i].slab = x.data_ptr(), dy.data_ptr(), slab.data_ptr()
             arr[i].lddy, arr[i].nsplit = int(lddy), int(nsplit)
+            if len(job) > 6 and job[6]:
+                arr[i].x_scale, arr[i].x_shift, arr[i].x_relu = job[6][0].data_ptr(), job[6][1].data_ptr(), int(bool(job[6][2]))
         nbytes = L.load().imm_conv2d_wgrad_multi_table_bytes(n)
         if nbytes <= 0:
             raise L.ImmHipError('imm_conv2d_wgrad_multi_table_bytes(%d)' % n)
@@ -514,6 +518,24 @@ class ConvGroup(object):
 def conv2d_group(group, x, y, stats=None, mask=None):
     call('imm_conv2d_group', C.cast(group.descs, C.c_void_p), group.n, dtype_enum(x.dtype), _p(x), C.cast(group.ptrs, C.c_void_p),
          _p(y), _p(stats), _p(mask), _s())
+
+
+def conv2d_nol_supported(desc):
+    """imm_conv2d_nol (normalise on load) serves this forward convolution?"""
+    return bool(L.load().imm_conv2d_nol_supported(C.byref(desc)))
+
+
+def conv2d_nol_stats_blocks(desc):
+    n = L.load().imm_conv2d_nol_stats_blocks(C.byref(desc))
+    if n <= 0:
+        raise L.ImmHipError('imm_conv2d_nol_stats_blocks: ' + L.load().imm_last_error().decode())
+    return n
+
+
+def conv2d_nol(desc, x_raw, x_scale, x_shift, x_relu, wt, bias, y, stats=None):
+    """Convolution of relu(x_scale * x_raw + x_shift) without that tensor being stored (imm_conv2d_nol)."""
+    call('imm_conv2d_nol', C.byref(desc), dtype_enum(x_raw.dtype), _p(x_raw), _p(x_scale), _p(x_shift), int(bool(x_relu)), _p(wt),
+         _p(bias), _p(y), _p(stats), _s())
 
 
 def conv2d_dgrad_s2_supported(batch, h, w, lddy, c_dx, lddx):

@@ -23,7 +23,8 @@
 extern "C" {
 #endif
 
-#define IMM_ABI_VERSION 15   /* 15: imm_conv2d_dgrad_s2; entry points removed since 14 (imm_bn_bwd_reduce_finalize, ...) finally counted */
+#define IMM_ABI_VERSION 15   /* 15: imm_conv2d_dgrad_s2, imm_conv2d_nol, imm_wgrad_job.x_scale/x_shift/x_relu; entry points removed
+                                  since 14 (imm_bn_bwd_reduce_finalize, imm_conv2d_stats_workspace_bytes) finally counted */
 
 enum imm_dtype { IMM_BF16 = 0, IMM_F16 = 1 };
 
@@ -112,6 +113,18 @@ int imm_wgrad_reduce_multi(const int64_t* jobs, const int32_t* blk_first, int n_
 int imm_conv2d_group(const imm_conv_desc* descs, int n, int dtype, const void* x, const void* const* wts, void* y,
                      float* stats_partial, const void* mask_ref, void* stream);
 int imm_conv2d_group_stats_blocks(const imm_conv_desc* descs, int n);
+/* Normalise on load: the convolution of a conv + batch-norm + ReLU block's output WITHOUT that output ever being stored
+ * (tf.layers.batch_normalization + tf.nn.relu feeding the next tf.nn.conv2d, nn_utils.py:201-209 -> :100).  x_raw is the 16-bit
+ * output y of the PRECEDING convolution; this convolution reads relu(x_scale[c] * y + x_shift[c]) (x_relu != 0; zero padding is of
+ * the normalised tensor), the affine + ReLU being applied once per halo pixel in LDS after the tile's DMA.  x_scale / x_shift:
+ * f32 [ci] as written by imm_bn_finalize.  Everything else as imm_conv2d (bias, IMM_CONV_STATS partial rows — their count is
+ * imm_conv2d_nol_stats_blocks(desc), not imm_conv_stats_blocks).  Served by the LDS-halo kernel of conv_halo.hip: 3x3, ci in
+ * {32, 64}, co <= 64, stride 1 at >= 64x64 maps, or the 32 -> 64-channel stride-2 form; imm_conv2d_nol_supported(desc) = 1 / 0.
+ * Results equal imm_bn_apply_relu + imm_conv2d up to the convolution's accumulation order. */
+int imm_conv2d_nol_supported(const imm_conv_desc* desc_host);
+int imm_conv2d_nol_stats_blocks(const imm_conv_desc* desc_host);
+int imm_conv2d_nol(const imm_conv_desc* desc_host, int dtype, const void* x_raw, const float* x_scale, const float* x_shift,
+                   int x_relu, const void* wt, const float* bias, void* y, float* stats_partial, void* stream);
 /* The data gradient of a 3x3 STRIDE-2 SAME convolution (encoder conv_3 / conv_5 / conv_7, imm_model.py:197,204,211:
  * tf.nn.conv2d_backprop_input at those nn_utils.py:100 call sites) as ONE launch over ONE halo of dy: input pixel (2i+py, 2j+px)
  * receives only the taps of its parity class (4 / 2 / 2 / 1 of the nine); a workgroup keeps four accumulator sets for an 8x16
@@ -168,6 +181,12 @@ typedef struct imm_wgrad_job {
   imm_conv_desc desc;          /* the FORWARD convolution */
   const void* x; const void* dy; float* slab;
   int32_t lddy, nsplit;
+  /* normalise on load (imm_conv2d_nol below): x is the RAW output of the conv + batch-norm + ReLU block in front of this
+   * convolution and the filter gradient is taken against relu(x_scale[c] * x + x_shift[c]) (x_relu != 0), rebuilt in LDS.
+   * NULL / NULL / 0 = x is the stored activation.  Only for jobs whose variant is an LDS-halo kernel
+   * (imm_conv2d_wgrad_variant(...) / 100000 == 2); imm_conv2d_wgrad_multi_plan refuses others. */
+  const float* x_scale; const float* x_shift;
+  int32_t x_relu, reserved;
 } imm_wgrad_job;
 int64_t imm_conv2d_wgrad_multi_table_bytes(int n);
 int imm_conv2d_wgrad_variant(const imm_conv_desc* desc_host, int lddy, int dtype, int* wg_per_split_host, int* units_host,

@@ -238,6 +238,133 @@ def test_conv_dgrad_stride2_parity_classes(ops, H, ci, co, dt):
     close(dx, gx, 1e-2, 2e-3, 'dgrad_s2_classes')       # every pixel written exactly once (no NaN left)
 
 
+NOL_CASES = [
+    # B, H, ci, co, stride, out_f32, tag           (the shapes whose input is a batch-norm output: encoder conv_2/3/4, renderer conv_6/8)
+    (2, 128, 32, 32, 1, False, 'enc_conv2_32_32'),
+    (2, 128, 32, 64, 2, False, 'enc_conv3_stride2'),
+    (2, 64, 64, 64, 1, False, 'enc_conv4_64_64'),
+    (3, 64, 64, 32, 1, False, 'halo_64_32'),
+    (1, 128, 32, 9, 1, True, 'ren_conv8_f32_head'),
+    (70, 64, 32, 64, 1, False, 'many_patches_32_64'),
+    (33, 64, 32, 64, 2, False, 'stride2_many_patches'),
+]
+
+
+def _nol_inputs(B, H, ci, dt, seed):
+    """raw conv output y (16-bit), per-channel scale (both signs) / shift, and the normalised tensor the stand-alone apply pass
+    stores: relu(scale * y + shift) rounded to 16 bits."""
+    from imm_amd import ops as _ops
+    y = rnd((B, H, H, ci), seed, 1.0, dt).to(DEV).contiguous()
+    g = torch.Generator().manual_seed(seed + 1)
+    scale = (torch.randn(ci, generator=g) * 0.8 + 0.3).to(DEV)
+    shift = (torch.randn(ci, generator=g) * 0.7 + 0.4).to(DEV)      # mostly positive: relu(shift) != 0, so a normalised padding pixel shows
+    out = torch.empty_like(y)
+    _ops.bn_apply_relu(y, B * H * H, ci, ci, scale, shift, True, out, ci)
+    torch.cuda.synchronize()
+    return y, scale, shift, out
+
+
+@pytest.mark.parametrize('case', NOL_CASES, ids=[c[-1] for c in NOL_CASES])
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16], ids=['bf16', 'f16'])
+def test_conv_norm_on_load(ops, case, dt):
+    """imm_conv2d_nol: the convolution reads the RAW output of the conv + BN + ReLU block in front of it and applies the affine +
+    ReLU in its LDS halo tile — against the two-launch path (imm_bn_apply_relu, then imm_conv2d on the stored tensor: same
+    16-bit operands, accumulation order may differ) and against the oracle convolution of that tensor; the batch-norm partial
+    sums of ITS output too."""
+    from imm_amd import _lib as L
+    B, H, ci, co, stride, out_f32, _tag = case
+    y, scale, shift, out = _nol_inputs(B, H, ci, dt, 900)
+    w = rnd((3, 3, ci, co), 902, 0.05, dt)
+    bias = rnd((co,), 903, 0.1, torch.float32).float()
+    flags = L.CONV_BIAS | L.CONV_STATS | (L.CONV_OUT_F32 if out_f32 else 0)
+    ldy = ops.round_up(co, 4 if out_f32 else 8)
+    desc = ops.fwd_desc(B, H, H, ci, ci, co, ldy, 3, stride, flags)
+    assert ops.conv2d_nol_supported(desc)
+    rows = ops.round_up(co, 128)
+    wt = torch.zeros(rows, desc.kpad, dtype=dt, device=DEV)
+    ops.pack_weights(w.float().to(DEV).contiguous(), wt, 0, 3, 3, ci, co, ci, rows, desc.kpad)
+    bd = bias.to(DEV)
+    odt = torch.float32 if out_f32 else dt
+    z_nol = torch.full((B, desc.ho, desc.wo, ldy), float('nan'), dtype=odt, device=DEV)
+    st_nol = torch.full((ops.conv2d_nol_stats_blocks(desc), 2, co), float('nan'), dtype=torch.float32, device=DEV)
+    ops.conv2d_nol(desc, y, scale, shift, True, wt, bd, z_nol, st_nol)
+    z_ref = torch.full((B, desc.ho, desc.wo, ldy), float('nan'), dtype=odt, device=DEV)
+    st_ref = torch.full((ops.conv_stats_blocks(desc), 2, co), float('nan'), dtype=torch.float32, device=DEV)
+    ops.conv2d(desc, out, wt, bd, z_ref, st_ref)
+    torch.cuda.synchronize()
+    zo = O.conv2d_same(out.float().cpu(), w.float(), bias, stride)
+    close(z_nol[..., :co], zo, 1e-2 if not out_f32 else 2e-3, 2e-3, 'conv_nol vs oracle')
+    close(z_nol[..., :co], z_ref[..., :co], (2.0 ** -7 if dt == torch.bfloat16 else 2.0 ** -10) if not out_f32 else 1e-4, 1e-4,
+          'conv_nol vs apply + conv')
+    close(st_nol.sum(0), st_ref.sum(0), 2e-4, 2e-4, 'conv_nol batch-norm partial sums')
+    # without the ReLU (a block built with relu = False)
+    ops.conv2d_nol(desc, y, scale, shift, False, wt, bd, z_nol, st_nol)
+    out2 = torch.empty_like(y)
+    ops.bn_apply_relu(y, B * H * H, ci, ci, scale, shift, False, out2, ci)
+    ops.conv2d(desc, out2, wt, bd, z_ref, st_ref)
+    torch.cuda.synchronize()
+    close(z_nol[..., :co], z_ref[..., :co], (2.0 ** -7 if dt == torch.bfloat16 else 2.0 ** -10) if not out_f32 else 1e-4, 1e-4,
+          'conv_nol (no relu) vs apply + conv')
+
+
+def test_conv_norm_on_load_rejects_unserved_shapes(ops):
+    from imm_amd import _lib as L
+    assert not ops.conv2d_nol_supported(ops.fwd_desc(2, 32, 32, 128, 128, 128, 128, 3, 1, L.CONV_BIAS))     # deep layer: hdeep
+    assert not ops.conv2d_nol_supported(ops.fwd_desc(2, 64, 64, 64, 64, 128, 128, 3, 2, L.CONV_BIAS))       # stride 2 from 64 channels
+    assert not ops.conv2d_nol_supported(ops.fwd_desc(2, 128, 128, 32, 32, 32, 32, 3, 1, L.CONV_BIAS | L.CONV_RELU))
+    d = ops.fwd_desc(2, 32, 32, 128, 128, 128, 128, 3, 1, L.CONV_BIAS)
+    x = torch.zeros(2, 32, 32, 128, dtype=torch.bfloat16, device=DEV)
+    v = torch.zeros(128, device=DEV)
+    with pytest.raises(L.ImmHipError):
+        ops.conv2d_nol(d, x, v, v, True, torch.zeros(128, d.kpad, dtype=torch.bfloat16, device=DEV), v, torch.empty_like(x))
+    # a filter-gradient job with normalise-on-load must be an LDS-halo variant
+    d8 = ops.fwd_desc(2, 8, 8, 128, 128, 128, 128, 3, 1, 0)            # 8x8 maps: the transpose-read kernel's job
+    assert ops.conv2d_wgrad_variant(d8, 128, torch.bfloat16)[0] // 100000 != 2
+    x8 = torch.zeros(2, 8, 8, 128, dtype=torch.bfloat16, device=DEV)
+    slab = torch.zeros(2, d8.kpad, 128, device=DEV)
+    with pytest.raises(L.ImmHipError):
+        ops.WgradMulti([(d8, x8, x8, 128, slab, 2, (v, v, True))], torch.bfloat16)
+
+
+NOL_WGRAD_CASES = [
+    # B, H, ci, co, lddy, stride, nsplit, tag
+    (2, 128, 32, 32, 32, 1, 5, 'enc_conv2'),
+    (2, 128, 32, 64, 64, 2, 4, 'enc_conv3_stride2'),
+    (3, 64, 64, 64, 64, 1, 6, 'enc_conv4'),
+    (1, 128, 32, 9, 32, 1, 3, 'ren_conv8_head'),
+]
+
+
+@pytest.mark.parametrize('case', NOL_WGRAD_CASES, ids=[c[-1] for c in NOL_WGRAD_CASES])
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16], ids=['bf16', 'f16'])
+def test_conv_wgrad_norm_on_load(ops, case, dt):
+    """imm_conv2d_wgrad_multi with imm_wgrad_job.x_scale / x_shift: the filter gradient against relu(scale * y + shift) rebuilt in
+    the LDS halo from the raw tensor y == the same job on the stored normalised tensor (same 16-bit operands, same split count:
+    the slabs must agree to rounding of identical sums), and == autograd of the oracle convolution."""
+    B, H, ci, co, lddy, stride, nsplit, _tag = case
+    y, scale, shift, out = _nol_inputs(B, H, ci, dt, 950)
+    wr = torch.zeros(3, 3, ci, co, requires_grad=True)
+    zref = O.conv2d_same(out.float().cpu(), wr, None, stride)
+    dz = rnd(tuple(zref.shape), 952, 1.0, dt)
+    (gw,) = torch.autograd.grad(zref, wr, dz.float())
+    desc = ops.fwd_desc(B, H, H, ci, ci, co, lddy, 3, stride, 0)
+    key, _wps, _units, _pcu = ops.conv2d_wgrad_variant(desc, lddy, dt)
+    assert key // 100000 == 2, key
+    dzd = padded(dz, lddy)
+    res = []
+    for nol in (True, False):
+        slab = torch.full((nsplit, desc.kpad, co), float('nan'), dtype=torch.float32, device=DEV)
+        job = (desc, y, dzd, lddy, slab, nsplit, (scale, shift, True)) if nol else (desc, out, dzd, lddy, slab, nsplit)
+        ops.conv2d_wgrad_multi(ops.WgradMulti([job], dt))
+        dw = torch.full((3, 3, ci, co), float('nan'), dtype=torch.float32, device=DEV)
+        ops.conv2d_wgrad_reduce(slab, nsplit, 3, 3, ci, ci, co, desc.kpad, dw)
+        torch.cuda.synchronize()
+        res.append(dw)
+    close(res[0], gw, 2e-3, 5e-4, 'wgrad_nol vs oracle')
+    close(res[0], res[1], 1e-5, 1e-6, 'wgrad_nol vs wgrad on the stored tensor')
+    print('WGRAD_NOL bitwise equal to the stored-tensor job:', bool(torch.equal(res[0], res[1])))
+
+
 S2D_CASES = [
     # B, H (input side = 2 x dy side), ci (dx channels), co (dy channels), tag
     (32, 128, 32, 64, 'enc_conv3_full_size_1024_tiles'),       # more tiles than CUs: tap-at-a-time form; dx channels < the 64-wide block
