@@ -222,6 +222,12 @@ class IMMEngine:
         self.prog_pack, self.prog_fwd, self.prog_bwd, self.prog_opt = [], [], [], []
         # IMM_TWO_STREAMS=0: everything on one stream (A/B of the two-lane schedule; the results are identical)
         self.two_streams = os.environ.get('IMM_TWO_STREAMS', '1') != '0'
+        # IMM_NOL=1: normalise on load (round 4) — the batch-norm apply pass of a block folded into the LDS halo tiles of its two
+        # readers (next convolution forward, its filter gradient) where both are LDS-halo kernels: encoder conv_1..3, renderer
+        # conv_5 / conv_7.  Built, parity-tested, and MEASURED SLOWER on the step (3.137 -> 3.216 ms, same box, DESIGN.md item 47:
+        # the affine + ReLU costs ~3.5 VALU instructions per element at one wave per SIMD with nothing to hide them behind —
+        # forward convolutions +5..8 us for 11..15 us of apply pass saved, filter gradients +100 us), so it is off by default.
+        self.nol = os.environ.get('IMM_NOL', '0') != '0'
         # IMM_DEBUG_SKIP_TAGS=tag,tag: timing experiment only (results become wrong): drop every launch whose tag is listed, to
         # measure how much of the step's critical path a kernel class occupies under graph replay / stream concurrency
         self._skip_tags = set(t for t in os.environ.get('IMM_DEBUG_SKIP_TAGS', '').split(',') if t)
@@ -327,7 +333,7 @@ class IMMEngine:
         """Can a convolution of this geometry take the RAW output of the conv + BN + ReLU block in front of it (normalise on
         load)?  Both readers of the normalised tensor must rebuild it in LDS: the forward convolution (imm_conv2d_nol) and
         its filter gradient (an LDS-halo variant of imm_conv2d_wgrad_multi).  IMM_CONV_DISABLE=nol turns the path off."""
-        if k != 3 or ci != ldx:
+        if not self.nol or k != 3 or ci != ldx:
             return False
         ldy = ops.round_up(co, 4) if out_f32 else ops.round_up(co, 8)
         flags = L.CONV_BIAS | (L.CONV_OUT_F32 if out_f32 else 0) | (L.CONV_STATS if bn else 0)

@@ -1,6 +1,6 @@
 """Every IMM_* environment switch the product path still reads, exercised in both positions: the
 kernel-dispatch ablation list IMM_CONV_DISABLE (each specialised kernel family off -> the layer falls back to the next more
-general kernel, same numbers to accumulation order), IMM_TWO_STREAMS, IMM_DEBUG_STAMPS, IMM_DEBUG_SKIP_TAGS.  The switches are
+general kernel, same numbers to accumulation order), IMM_NOL, IMM_TWO_STREAMS, IMM_DEBUG_STAMPS, IMM_DEBUG_SKIP_TAGS.  The switches are
 read once per process (static dispatch tables / engine construction), hence the child processes (tests/_switch_probe.py).
 IMM_DP_BUCKETS, IMM_RCCL_NATIVE and IMM_RCCL_GRAPH have their tests in test_dp_gpu.py / test_step_gpu.py; IMM_HIP_LIB and
 IMM_HIPCC_FLAGS (A/B builds) in test_host_cpu.py."""
@@ -41,12 +41,21 @@ def same(a, b, rel):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize('names', ['halo,halo2,hdeep,deepk', 'group,group32', 'wgrad_tr,wgrad_halo'])
+@pytest.mark.parametrize('names', ['halo,halo2,hdeep,deepk', 'group,group32', 'wgrad_tr,wgrad_halo', 's2d', 's2d,group,group32'])
 def test_conv_disable_falls_back_to_the_general_kernels(base, names):
     """IMM_CONV_DISABLE: with the specialised kernels out of the dispatch every layer runs on the im2col / generic kernels —
     the same step to accumulation order (loss 1e-4, parameters after two updates 1e-4 of their abs-sum)."""
     got = probe(IMM_CONV_DISABLE=names)
     assert same(base, got, 2e-4), (names, base, got)
+
+
+@pytest.mark.timeout(300)
+def test_normalise_on_load_is_the_same_step(base):
+    """IMM_NOL=1: the apply passes of encoder conv_1..3 / renderer conv_5, conv_7 folded into their readers' LDS tiles
+    (imm_conv2d_nol, imm_wgrad_job.x_scale): fewer launches, the same step to accumulation order."""
+    got = probe(IMM_NOL=1)
+    assert got['n_launches'] <= base['n_launches'], (got['n_launches'], base['n_launches'])
+    assert same(base, got, 2e-4), (base, got)
 
 
 @pytest.mark.timeout(300)

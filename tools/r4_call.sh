@@ -15,6 +15,8 @@ for st in "$@"; do
     full) timeout 1200 python -m pytest tests -m gpu -q > $out/full.log 2>&1 ;;
     ab)   bash tools/ab_trees.sh 2 --steps 200 --warmup 20 > $out/ab.log 2>&1 ;;
     bench) timeout 400 python bench.py > $out/bench.json 2> $out/bench.err ;;
+    dumpold) (cd build_ab/old && IMM_BENCH_DUMP=1 timeout 300 python bench.py --no-cpu-baseline --no-pmc --steps 50 > ../../$out/dumpold.json 2> ../../$out/dumpold.err) ;;
+    dumpnonol) IMM_CONV_DISABLE=nol IMM_BENCH_DUMP=1 timeout 300 python bench.py --no-cpu-baseline --no-pmc --steps 50 > $out/dumpnonol.json 2> $out/dumpnonol.err ;;
     dump) IMM_BENCH_DUMP=1 timeout 300 python bench.py --no-cpu-baseline --no-pmc --steps 50 > $out/dump.json 2> $out/dump.err ;;
     *) echo "unknown stage $st" ;;
   esac
