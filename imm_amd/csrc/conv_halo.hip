@@ -59,9 +59,18 @@ struct HaloArgs {
 #define HALO_S2_PW 17            // plane width  (33 columns -> 17 even + 16 odd)
 #define HALO_S2_PP 160           // plane pitch in pixels (9 x 17 = 153, padded)
 #define HALO_S2_HP 640           // 4 planes
-template <typename ET, int CI, int BN, bool S2 = false, bool NOL = false>
+// S2D (round 4): the DATA GRADIENT of a 3x3 stride-2 SAME convolution whose whole flipped filter fits the LDS (encoder conv_3:
+// dy 64 channels -> dx 32 channels at 128x128, imm_model.py:197) as one launch: four accumulator sets (the input-pixel parity
+// classes, see conv_hdeep.hip S2D for the index algebra: tap t' = (ky', kx') of the mode-1 filter image accumulates into class
+// (ky' & 1, kx' & 1) from halo offset (min(ky', 1), min(kx', 1))), scattered to pixel (2i + py, 2j + px) of dx.  The deep-K
+// kernel serves the same operation for the wider layers; here the layer is HBM-bound (50 MB for 4.8 GFLOP) and a persistent
+// workgroup with the filter resident and the next halo in flight is what it wants (hdeep S2D: 1024 one-tile workgroups in four
+// rounds, 32 us).
+template <typename ET, int CI, int BN, bool S2 = false, bool NOL = false, bool S2D = false>
 __global__ __launch_bounds__(256) void conv_halo_kernel(const HaloArgs ha) {
   const ConvArgs& a = ha.c;
+  static_assert(!S2D || (!S2 && !NOL), "stride-2 data gradient: plain stride-1 halo of dy");
+  constexpr int NCLS = S2D ? 4 : 1;
   constexpr int HP = S2 ? HALO_S2_HP : HALO_HP;    // halo pixels per stage
   constexpr int C8 = CI / 8;                       // 16-byte chunks per pixel / filter row
   constexpr int KS = CI / 32;                      // MFMA k-steps per tap
@@ -170,9 +179,10 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const HaloArgs ha) {
   // while the stores (HBM write latency) are still allowed in flight.  Only valid when every tile is ONE store
   // instruction (all 4 channels in range, no mask loads in between); otherwise drain completely.
   const bool counted = (a.co % 4 == 0) && (a.co == BN) && !f_mask;
+  constexpr int N_STORES = MT * NT * NCLS;                 // store instructions per wave and patch
   bool first = true;
   for (; patch < ha.n_patches; patch += gridDim.x) {
-    if (counted && !first) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MT * NT) : "memory");
+    if (counted && !first) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_STORES) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the filter / this patch's halo landed
     first = false;
     if constexpr (NOL) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (first patch: the coefficient table)
@@ -208,22 +218,26 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const HaloArgs ha) {
       __builtin_amdgcn_s_barrier();                        // the normalised tile is complete
     }
 
-    f32x4_t acc[MT][NT];
+    f32x4_t acc[NCLS][MT][NT];
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+    for (int c = 0; c < NCLS; ++c)
 #pragma unroll
-      for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[c][i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     if (!(a.flags & IMM_DBG_NO_MFMA))
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int ky = tap / 3, kx = tap % 3;
+      const int cls = S2D ? ((ky & 1) * 2 + (kx & 1)) : 0;               // parity class this tap feeds
+      const int rky = S2D ? (ky > 0 ? 1 : 0) : ky, rkx = S2D ? (kx > 0 ? 1 : 0) : kx;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         uint4 af[MT], bf[NT];
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
           const int hp = S2 ? ((ky & 1) * 2 + (kx & 1)) * HALO_S2_PP + (wm * MT + i + (ky >> 1)) * HALO_S2_PW + frow + (kx >> 1)
-                            : (wm * MT + i + ky) * HALO_HW + frow + kx;
+                            : (wm * MT + i + rky) * HALO_HW + frow + rkx;
           af[i] = Hl[hp * C8 + ((ks * 4 + fchunk) ^ halo_swz<C8>(hp))];
         }
 #pragma unroll
@@ -234,7 +248,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const HaloArgs ha) {
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
-          for (int j = 0; j < NT; ++j) acc[i][j] = ET::mfma(bf[j], af[i], acc[i][j]);   // D[n][pixel]
+          for (int j = 0; j < NT; ++j) acc[cls][i][j] = ET::mfma(bf[j], af[i], acc[cls][i][j]);   // D[n][pixel]
       }
     }
 
@@ -243,8 +257,33 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const HaloArgs ha) {
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        for (int j = 0; j < NT; ++j) t += acc[0][i][j][0] + acc[0][i][j][1] + acc[0][i][j][2] + acc[0][i][j][3];
       if (t == 123456.789f) ((float*)a.y)[0] = t;
+      stage ^= 1;
+      continue;
+    }
+    if constexpr (S2D) {
+      // class (py, px) of tile pixel (row wm*MT + i, column lane & 15) -> pixel (2 row + py, 2 column + px) of the [2 ho, 2 wo] map
+      const int img2 = patch / per_img, pr2 = patch - img2 * per_img;
+      const int ty0 = (pr2 / ha.patches_x) * HALO_PH, tx0 = (pr2 % ha.patches_x) * HALO_PW;
+      const int W2 = 2 * a.wo;
+#pragma unroll
+      for (int c = 0; c < NCLS; ++c)
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const int64_t m = ((int64_t)img2 * (2 * a.ho) + 2 * (ty0 + wm * MT + i) + (c >> 1)) * W2 + 2 * (tx0 + (lane & 15)) + (c & 1);
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            const int n = wn * TN + j * 16 + 4 * (lane >> 4);
+            uint16_t* yp = (uint16_t*)a.y + m * a.ldy + n;
+            const uint2 v2 = make_uint2(ET::pack2(acc[c][i][j][0], acc[c][i][j][1]), ET::pack2(acc[c][i][j][2], acc[c][i][j][3]));
+            if (n + 3 < a.co) *(uint2*)yp = v2;
+            else {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) if (n + r < a.co) yp[r] = ET::from_f32(acc[c][i][j][r]);
+            }
+          }
+        }
       stage ^= 1;
       continue;
     }
@@ -262,7 +301,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const HaloArgs ha) {
         float v[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          v[r] = acc[i][j][r] + bv[j][r];
+          v[r] = acc[0][i][j][r] + bv[j][r];
           if (f_relu) v[r] = fmaxf(v[r], 0.f);
         }
         if (!mok) continue;
@@ -387,15 +426,15 @@ int imm_halo_grid(const imm_conv_desc* d) {
   return n_patches < grid ? n_patches : grid;
 }
 
-template <typename ET, int CI, int BN, bool S2 = false, bool NOL = false>
+template <typename ET, int CI, int BN, bool S2 = false, bool NOL = false, bool S2D = false>
 static void halo_launch_cfg(const HaloArgs& ha, int grid, hipStream_t s) {
   const size_t lds = halo_lds(CI, BN, S2, NOL);
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {
-    (void)hipFuncSetAttribute((const void*)conv_halo_kernel<ET, CI, BN, S2, NOL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)conv_halo_kernel<ET, CI, BN, S2, NOL, S2D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_halo_kernel<ET, CI, BN, S2, NOL>), dim3(grid), dim3(256), lds, s, ha);
+  hipLaunchKernelGGL((conv_halo_kernel<ET, CI, BN, S2, NOL, S2D>), dim3(grid), dim3(256), lds, s, ha);
 }
 
 template <typename ET>
@@ -447,4 +486,30 @@ void imm_conv_halo_nol_launch(int dtype, const imm_conv_desc* d, const ConvArgs&
                               hipStream_t s) {
   if (dtype == IMM_BF16) halo_launch<BF16>(d, a, s, scale, shift, relu);
   else halo_launch<F16>(d, a, s, scale, shift, relu);
+}
+
+// ---- stride-2 data gradient with the whole flipped filter in LDS (S2D): dy with 64 channels -> dx with <= 32 channels ----
+// d = the class grid as a same-size 3x3 convolution of dy (see imm_hdeep_s2d_applicable); wt = imm_pack_weights mode 1 image.
+bool imm_halo_s2d_applicable(const imm_conv_desc* d) {
+  static const bool off = imm_conv_disabled("s2d_halo");
+  if (off) return false;
+  if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->updiv != 1 || d->pad_t != 1 || d->pad_l != 1) return false;
+  if (d->ci != 64 || d->ldx != 64 || d->kpad != 9 * 64 || d->co > 32 || d->co < 4 || d->co % 4 || d->ldy % 4 || d->ldy < d->co) return false;
+  if (d->hi != d->ho || d->wi != d->wo || d->ho % HALO_PH || d->wo % HALO_PW || d->ho * d->wo < 32 * 32) return false;
+  if (d->flags || d->out_scale > 1) return false;
+  return (int64_t)d->batch * d->hi * d->wi * d->ldx * 2 < (1LL << 31);
+}
+
+void imm_conv_halo_s2d_launch(int dtype, const imm_conv_desc* d, const ConvArgs& a, hipStream_t s) {
+  HaloArgs ha;
+  ha.c = a;
+  ha.nol_scale = nullptr; ha.nol_shift = nullptr; ha.nol_relu = 0;
+  ha.patches_x = d->wo / HALO_PW; ha.patches_y = d->ho / HALO_PH;
+  ha.n_patches = d->batch * ha.patches_x * ha.patches_y;
+  ha.c.x_bytes = (uint32_t)((int64_t)d->batch * d->hi * d->wi * d->ldx * 2);
+  ha.c.wt_bytes = (uint32_t)((int64_t)d->co * d->kpad * 2);
+  const int cus = halo_num_cu();                       // 84 KB of LDS: one persistent workgroup per CU
+  const int grid = ha.n_patches < cus ? ha.n_patches : cus;
+  if (dtype == IMM_BF16) halo_launch_cfg<BF16, 64, 32, false, false, true>(ha, grid, s);
+  else halo_launch_cfg<F16, 64, 32, false, false, true>(ha, grid, s);
 }

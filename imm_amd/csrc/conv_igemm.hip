@@ -24,6 +24,8 @@ void imm_conv_hdeep_launch(int dtype, const imm_conv_desc* d, const ConvArgs& a,
 bool imm_halo_nol_applicable(const imm_conv_desc* d);
 void imm_conv_halo_nol_launch(int dtype, const imm_conv_desc* d, const ConvArgs& a, const float* scale, const float* shift, int relu,
                               hipStream_t s);
+bool imm_halo_s2d_applicable(const imm_conv_desc* d);
+void imm_conv_halo_s2d_launch(int dtype, const imm_conv_desc* d, const ConvArgs& a, hipStream_t s);
 bool imm_hdeep_s2d_applicable(const imm_conv_desc* d);
 void imm_conv_hdeep_s2d_launch(int dtype, const imm_conv_desc* d, const ConvArgs& a, hipStream_t s);
 bool imm_halo2_applicable(const imm_conv_desc* d);                                 // conv_halo2.hip
@@ -434,7 +436,7 @@ extern "C" int imm_conv2d_dgrad_s2_supported(int batch, int h, int w, int lddy, 
   if (batch <= 0 || h <= 0 || w <= 0 || lddy <= 0 || c_dx <= 0 || lddx <= 0 || lddy % 32) return 0;
   imm_conv_desc d;
   s2d_desc(&d, batch, h, w, lddy, c_dx, lddx);
-  return imm_hdeep_s2d_applicable(&d) ? 1 : 0;
+  return (imm_halo_s2d_applicable(&d) || imm_hdeep_s2d_applicable(&d)) ? 1 : 0;
 }
 
 extern "C" int imm_conv2d_dgrad_s2(const void* dy, int lddy, const void* wt, int kpad, void* dx, int lddx, int c_dx, int dtype,
@@ -450,7 +452,9 @@ extern "C" int imm_conv2d_dgrad_s2(const void* dy, int lddy, const void* wt, int
   s2d_desc(&d, batch, h, w, lddy, c_dx, lddx);
   ConvArgs a;
   fill_args(a, &d, dy, wt, nullptr, dx, nullptr, nullptr);
-  imm_conv_hdeep_s2d_launch(dtype, &d, a, (hipStream_t)stream);
+  // the whole flipped filter in LDS where it fits (dy 64 channels -> dx <= 32: encoder conv_3, HBM-bound), the deep-K kernel otherwise
+  if (imm_halo_s2d_applicable(&d)) imm_conv_halo_s2d_launch(dtype, &d, a, (hipStream_t)stream);
+  else imm_conv_hdeep_s2d_launch(dtype, &d, a, (hipStream_t)stream);
   IMM_CHECK_LAUNCH("imm_conv2d_dgrad_s2");
   return 0;
 }

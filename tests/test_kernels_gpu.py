@@ -371,6 +371,11 @@ S2D_CASES = [
     (32, 64, 64, 128, 'enc_conv5_full_size_256_tiles'),        # one round of tiles: row-at-a-time form, two 64-channel slices
     (32, 32, 128, 256, 'enc_conv7_full_size_two_nblocks'),     # four slices, two channel blocks
     (2, 32, 64, 128, 'four_tiles'),
+    # dy 64 channels -> dx <= 32 channels: the whole flipped filter in LDS, persistent workgroups (conv_halo.hip S2D)
+    (2, 64, 32, 64, 'halo_form_small'),
+    (70, 64, 32, 64, 'halo_form_many_patches_per_workgroup'),
+    (1, 64, 12, 64, 'halo_form_dx12'),
+    (5, 128, 20, 64, 'halo_form_dx20'),
     (3, 64, 40, 64, 'odd_batch_dx40'),                         # c_dx = 40: a partly filled channel block
     (1, 32, 8, 192, 'dx8_three_slices'),
     (5, 64, 200, 64, 'dx200_four_nblocks_ragged'),
