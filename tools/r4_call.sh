@@ -18,6 +18,11 @@ for st in "$@"; do
     dumpold) (cd build_ab/old && IMM_BENCH_DUMP=1 timeout 300 python bench.py --no-cpu-baseline --no-pmc --steps 50 > ../../$out/dumpold.json 2> ../../$out/dumpold.err) ;;
     dumpnonol) IMM_CONV_DISABLE=nol IMM_BENCH_DUMP=1 timeout 300 python bench.py --no-cpu-baseline --no-pmc --steps 50 > $out/dumpnonol.json 2> $out/dumpnonol.err ;;
     dump) IMM_BENCH_DUMP=1 timeout 300 python bench.py --no-cpu-baseline --no-pmc --steps 50 > $out/dump.json 2> $out/dump.err ;;
+    prof) bash tools/make_profiles.sh ${tag} > $out/prof.log 2>&1 ;;
+    ratios) bash tools/pmc_ratios.sh > $out/pmc_sq_ratios.txt 2> $out/ratios.err ;;
+    configs) timeout 500 python tools/bench_configs.py --json $out/configs.json > /dev/null 2> $out/configs.log ;;
+    timeline) IMM_DEBUG_STAMPS=marks timeout 300 python tools/graph_timeline.py > $out/phase_timeline.txt 2> $out/timeline.err ;;
+    trace1) (cd /tmp && rocprofv3 --kernel-trace --output-format csv -d /tmp/trace1 -- python $PWD/bench.py --steps 10 --warmup 3 --windows 1 --spin-seconds 0 --no-cpu-baseline --no-pmc > /dev/null 2>&1); python tools/rocprof_csv.py /tmp/trace1 > $out/kernel_trace_one_step.txt 2>&1 ;;
     *) echo "unknown stage $st" ;;
   esac
   echo "STAGE $st rc=$? $(( $(date +%s) - t0 )) s" | tee -a $out/stages.log
