@@ -100,6 +100,9 @@ _SIGS = {
     'imm_tps_warp': [_P, _I, _I, _I, _I, _I, _P, _I, _P, _P, _I, _P, _P, _I, _P],
     'imm_tps_warp_pad': [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P, _I, _P],
     'imm_conv2d_group': [_P, _I, _I, _P, _P, _P, _P, _P, _P],
+    'imm_conv_first_supported': [_I, _I, _I, _I],
+    'imm_conv_first_stats_blocks': [_I, _I],
+    'imm_conv_first': [_P, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P],
     'imm_conv2d_nol_supported': [C.POINTER(ConvDesc)],
     'imm_conv2d_nol_stats_blocks': [C.POINTER(ConvDesc)],
     'imm_conv2d_nol': [C.POINTER(ConvDesc), _I, _P, _P, _P, _I, _P, _P, _P, _P, _P],

@@ -1,0 +1,253 @@
+// conv_first.hip — the first encoder convolution (7x7, 3 -> 32 channels, stride 1, SAME; imm/models/imm_model.py:190 through
+// nn_utils.py:100,108) straight from the f32 image.
+//
+// Since round 1 this layer runs as a 7x1 convolution over the image with its seven horizontal taps unrolled into 21 (+11 zero)
+// channels (imm_pack_image_taps), which made it an ordinary 32-channel layer for the LDS-halo kernels — at the price of a 16-bit
+// [B,S,S,32] copy of the image written by a pass of its own and read back by the convolution: per encoder 12 us of packing in front
+// of the 128x128 layer and 67 MB of HBM traffic for a 6 MB image, at the head of both forward lanes.  Here the tap-unrolled tile is
+// built in LDS instead: a persistent workgroup loads the (8+6) x (16+6) f32 halo of an 8x16-pixel patch (3.7 KB, coalesced rows,
+// requested one patch ahead), rounds it to 16 bits, gathers the [14 x 16 pixels][32 channels] operand tile from it and runs the
+// seven vertical taps as 7 k-steps of v_mfma_f32_16x16x32 against the filter image resident in LDS (the same packed image
+// Wt[n][ky*32 + kx*3 + c] the 7x1 form uses, so the arithmetic is unchanged: same 16-bit operands, f32 accumulation).  Epilogue =
+// conv_halo.hip's: bias, 16-bit NHWC store, batch-norm partial sums accumulated over the workgroup's patches (one row per
+// workgroup).  The packed copy is still produced for the layer's filter gradient, but off the forward chain.
+#include "conv_common.h"
+
+#define CF_PH 8
+#define CF_PW 16
+#define CF_K 7
+#define CF_PAD 3
+#define CF_TR (CF_PH + CF_K - 1)          // tile rows 14
+#define CF_SW (CF_PW + CF_K - 1)          // staging columns 22
+#define CF_BN 32
+
+struct ConvFirstArgs {
+  const float* img; const uint16_t* wt; const float* bias; uint16_t* y; float* stats;
+  int batch, s, co, ldy, kpad, flags;
+  int n_patches, patches_x, patches_y;
+};
+
+// chunk swizzle of 64-byte rows (4 chunks): a ds_read_b128 of 16 consecutive rows x 4 chunks is conflict-free (conv_halo.hip)
+__device__ __forceinline__ int cf_swz(int row) { return ((row >> 2) & 1) << 1; }
+
+template <typename ET>
+__global__ __launch_bounds__(256) void conv_first_kernel(const ConvFirstArgs a) {
+  constexpr int MT = 2, NT = 2;                      // wave w: patch rows 2w, 2w+1 x 32 channels
+  constexpr int W_U4 = CF_K * CF_BN * 4;             // filter image: row = ky*32 + n, 4 chunks
+  constexpr int T_U4 = CF_TR * CF_PW * 4;            // operand tile: row = pixel (r*16 + x), 4 chunks
+  constexpr int N_ELEM = CF_TR * CF_SW * 3;          // f32 values of a halo (924)
+  constexpr int N_LD = (N_ELEM + 255) / 256;         // loads per thread (4)
+  __shared__ __attribute__((aligned(16))) uint4 Wl[W_U4];
+  __shared__ __attribute__((aligned(16))) uint4 Tl[T_U4];
+  __shared__ __attribute__((aligned(16))) uint16_t Sl[CF_TR * CF_SW * 4];     // 16-bit halo, 4 slots per pixel (3 used)
+  __shared__ float red[4 * 2 * CF_BN];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int frow = lane & 15, fchunk = lane >> 4;
+  const int S = a.s;
+  const int per_img = a.patches_x * a.patches_y;
+
+  // ---- filter image -> LDS (once) ------------------------------------------------------------------------------------
+  for (int idx = tid; idx < W_U4; idx += 256) {
+    const int row = idx >> 2, q = idx & 3;
+    const int tap = row / CF_BN, n = row - tap * CF_BN;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (n < a.co) v = *(const uint4*)(a.wt + (int64_t)n * a.kpad + tap * 32 + q * 8);
+    Wl[row * 4 + (q ^ cf_swz(row))] = v;
+  }
+
+  // ---- halo loader: element e = r*66 + t of the [14][22][3] f32 halo, this thread's e = tid + 256 u ----------------------
+  float pre[N_LD];
+  auto load_halo = [&](int patch) {
+    const int img = patch / per_img, pr = patch - img * per_img;
+    const int y0 = (pr / a.patches_x) * CF_PH - CF_PAD, x0 = (pr % a.patches_x) * CF_PW - CF_PAD;
+    const float* base = a.img + (int64_t)img * S * S * 3;
+#pragma unroll
+    for (int u = 0; u < N_LD; ++u) {
+      const int e = tid + 256 * u;
+      const int r = e / (CF_SW * 3), t = e - r * (CF_SW * 3);
+      const int iy = y0 + r, ix = x0 + t / 3;
+      const bool ok = e < N_ELEM && (unsigned)iy < (unsigned)S && (unsigned)ix < (unsigned)S;
+      pre[u] = ok ? base[((int64_t)iy * S + x0) * 3 + t] : 0.f;
+    }
+  };
+
+  const bool f_bias = a.flags & IMM_CONV_BIAS, f_stats = a.flags & IMM_CONV_STATS;
+  float s1[NT][4], s2[NT][4], bv[NT][4];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      s1[j][r] = 0.f; s2[j][r] = 0.f;
+      const int n = j * 16 + 4 * fchunk + r;
+      bv[j][r] = (f_bias && n < a.co) ? a.bias[n] : 0.f;
+    }
+
+  int patch = blockIdx.x;
+  if (patch < a.n_patches) load_halo(patch);
+  for (; patch < a.n_patches; patch += gridDim.x) {
+    // 16-bit halo: S[r][px][c]
+#pragma unroll
+    for (int u = 0; u < N_LD; ++u) {
+      const int e = tid + 256 * u;
+      if (e < N_ELEM) {
+        const int r = e / (CF_SW * 3), t = e - r * (CF_SW * 3);
+        const int px = t / 3, c = t - px * 3;
+        Sl[(r * CF_SW + px) * 4 + c] = ET::from_f32(pre[u]);
+      }
+    }
+    __syncthreads();            // halo complete; every wave is past the previous patch's reads of the operand tile
+    // operand tile: chunk q of pixel (r, x) = unrolled channels 8q .. 8q+7, channel ch = kx*3 + c <- S[r][x + kx][c], ch >= 21: 0
+    for (int idx = tid; idx < T_U4; idx += 256) {
+      const int pix = idx >> 2, q = idx & 3;
+      const int r = pix >> 4, x = pix & 15;
+      const uint16_t* src = Sl + (r * CF_SW + x) * 4;
+      uint32_t w[4];
+#pragma unroll
+      for (int e2 = 0; e2 < 4; ++e2) {
+        uint32_t lo = 0, hi = 0;
+        const int ch0 = q * 8 + 2 * e2, ch1 = ch0 + 1;
+        if (ch0 < 3 * CF_K) lo = src[(ch0 / 3) * 4 + ch0 % 3];
+        if (ch1 < 3 * CF_K) hi = src[(ch1 / 3) * 4 + ch1 % 3];
+        w[e2] = lo | (hi << 16);
+      }
+      Tl[pix * 4 + (q ^ cf_swz(pix))] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    __syncthreads();            // tile complete (also: the filter image, first patch)
+    const int next = patch + gridDim.x;
+    if (next < a.n_patches) load_halo(next);          // in flight during the matrix work and the stores below
+
+    f32x4_t acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ky = 0; ky < CF_K; ++ky) {
+      uint4 af[MT], bf[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int hp = (wid * MT + i + ky) * CF_PW + frow;
+        af[i] = Tl[hp * 4 + (fchunk ^ cf_swz(hp))];
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int row = ky * CF_BN + j * 16 + frow;
+        bf[j] = Wl[row * 4 + (fchunk ^ cf_swz(row))];
+      }
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = ET::mfma(bf[j], af[i], acc[i][j]);   // D[n][pixel]
+    }
+
+    // ---- store: lane = pixel (row wid*MT + i, column lane & 15), 4 consecutive channels -----------------------------
+    const int img = patch / per_img, pr = patch - img * per_img;
+    const int y0 = (pr / a.patches_x) * CF_PH, x0 = (pr % a.patches_x) * CF_PW;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int64_t m = ((int64_t)img * S + y0 + wid * MT + i) * S + x0 + frow;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int n = j * 16 + 4 * fchunk;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + bv[j][r];
+        if (f_stats) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { s1[j][r] += v[r]; s2[j][r] += v[r] * v[r]; }
+        }
+        uint16_t* yp = a.y + m * a.ldy + n;
+        if (n + 3 < a.co) *(uint2*)yp = make_uint2(ET::pack2(v[0], v[1]), ET::pack2(v[2], v[3]));
+        else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) if (n + r < a.co) yp[r] = ET::from_f32(v[r]);
+        }
+      }
+    }
+  }
+
+  if (f_stats) {
+    // per-workgroup partial sums: 16 pixel lanes -> the four waves -> one row of (sum, sum of squares) per workgroup
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+          s1[j][r] += __shfl_xor(s1[j][r], o, 64);
+          s2[j][r] += __shfl_xor(s2[j][r], o, 64);
+        }
+      }
+    if (frow == 0) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int nl = j * 16 + 4 * fchunk + r;
+          red[(wid * 2 + 0) * CF_BN + nl] = s1[j][r];
+          red[(wid * 2 + 1) * CF_BN + nl] = s2[j][r];
+        }
+    }
+    __syncthreads();
+    if (tid < CF_BN && tid < a.co) {
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) { t1 += red[(w * 2 + 0) * CF_BN + tid]; t2 += red[(w * 2 + 1) * CF_BN + tid]; }
+      a.stats[((int64_t)blockIdx.x * 2 + 0) * a.co + tid] = t1;
+      a.stats[((int64_t)blockIdx.x * 2 + 1) * a.co + tid] = t2;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+static int cf_num_cu() {
+  static int n = 0;
+  if (n == 0) {
+    hipDeviceProp_t p; int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
+    else (void)hipGetLastError();
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
+
+static int cf_grid(int batch, int s) {
+  const int n_patches = batch * (s / CF_PH) * (s / CF_PW);
+  const int grid = 3 * cf_num_cu();                 // ~34 KB of LDS and 4 waves per workgroup: three per CU cover each other's barriers
+  return n_patches < grid ? n_patches : grid;
+}
+
+extern "C" int imm_conv_first_supported(int batch, int s, int co, int ldy) {
+  static const bool off = imm_conv_disabled("first");
+  if (off) return 0;
+  if (batch <= 0 || s < 16 || s % CF_PW || co < 4 || co > CF_BN || co % 4 || ldy < co || ldy % 4) return 0;
+  return ((int64_t)batch * s * s * 3 < (1LL << 31)) ? 1 : 0;
+}
+
+extern "C" int imm_conv_first_stats_blocks(int batch, int s) { return (batch > 0 && s >= 16 && s % CF_PW == 0) ? cf_grid(batch, s) : IMM_E_INVALID; }
+
+extern "C" int imm_conv_first(const float* image, const void* wt, int kpad, const float* bias, void* y, int ldy, float* stats_partial,
+                              int dtype, int batch, int s, int co, int flags, void* stream) {
+  IMM_REQUIRE(image && wt && y, "conv_first: null tensor");
+  IMM_REQUIRE(dtype == IMM_BF16 || dtype == IMM_F16, "unknown dtype %d", dtype);
+  if (!imm_conv_first_supported(batch, s, co, ldy))
+    return imm_fail(IMM_E_UNSUPPORTED, "conv_first: batch %d side %d co %d ldy %d: needs side %% 16 == 0, co <= 32, co %% 4 == 0", batch, s, co, ldy);
+  IMM_REQUIRE(kpad >= CF_K * 32 && kpad % 8 == 0, "conv_first: kpad=%d must hold 7 taps x 32 unrolled channels (imm_pack_weights, kh 7, kw 1, c_pad 32)", kpad);
+  IMM_REQUIRE(!(flags & ~(IMM_CONV_BIAS | IMM_CONV_STATS)), "conv_first: flags 0x%x (bias and batch-norm sums only)", flags);
+  IMM_REQUIRE(!(flags & IMM_CONV_BIAS) || bias, "conv_first: bias flag without bias");
+  IMM_REQUIRE(!(flags & IMM_CONV_STATS) || stats_partial, "conv_first: stats flag without buffer");
+  IMM_REQUIRE(((uintptr_t)wt % 16 == 0) && ((uintptr_t)y % 8 == 0) && ((uintptr_t)image % 4 == 0), "conv_first: alignment");
+  ConvFirstArgs a;
+  a.img = image; a.wt = (const uint16_t*)wt; a.bias = bias; a.y = (uint16_t*)y; a.stats = stats_partial;
+  a.batch = batch; a.s = s; a.co = co; a.ldy = ldy; a.kpad = kpad; a.flags = flags;
+  a.patches_x = s / CF_PW; a.patches_y = s / CF_PH; a.n_patches = batch * a.patches_x * a.patches_y;
+  const int grid = cf_grid(batch, s);
+  if (dtype == IMM_BF16) hipLaunchKernelGGL((conv_first_kernel<BF16>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((conv_first_kernel<F16>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  IMM_CHECK_LAUNCH("imm_conv_first");
+  return 0;
+}

@@ -345,12 +345,15 @@ class IMMEngine:
         return key // 100000 == 2
 
     def _conv_block(self, scope, x, H, W, ci_real, ci_pad, ldx, co, k, stride, bn, relu, needs_dgrad,
-                    out=None, ldo=None, out_f32=False, kw=None, up2x=False, fwd_launch=True, nol_src=None, defer_apply=False):
+                    out=None, ldo=None, out_f32=False, kw=None, up2x=False, fwd_launch=True, nol_src=None, defer_apply=False,
+                    first_src=None):
         """Registers forward launches now and returns a layer record whose .backward(d_out, dx) registers the
         backward launches later (in reverse order).
         nol_src: the conv + BN + ReLU block in front of this convolution whose normalised output is NOT stored: x is its raw
         conv output y, and this convolution (and its filter gradient) apply relu(scale * y + shift) on load.
-        defer_apply: this block is such a producer — statistics and a finalize launch, no apply pass, no `out`."""
+        defer_apply: this block is such a producer — statistics and a finalize launch, no apply pass, no `out`.
+        first_src: the f32 image behind the tap-unrolled input x of the first encoder convolution: the forward launch reads IT
+        (imm_conv_first builds the unrolled tile in LDS); x is then only the filter gradient's operand."""
         B, dt, dev = self.B, self.dt, self.dev
         self._cur_scope = scope
         lay = _ConvLayer()
@@ -374,7 +377,8 @@ class IMMEngine:
         lay.y = self._zeros(B, fd.ho, fd.wo, ldy, dtype=torch.float32 if out_f32 else dt)
         flops = 2.0 * npix * k * kw * ci_real * co
         if bn:
-            nblk = ops.conv_stats_blocks(fd) if nol_src is None else ops.conv2d_nol_stats_blocks(fd)
+            nblk = (ops.conv_first_stats_blocks(B, H) if first_src is not None else
+                    ops.conv_stats_blocks(fd) if nol_src is None else ops.conv2d_nol_stats_blocks(fd))
             lay.stats = self._zeros(nblk, 2, co)
             lay.scale, lay.shift, lay.mean, lay.rstd = (self._zeros(co) for _ in range(4))
             mm, mv = self._zeros(co), self._zeros(co)
@@ -386,7 +390,10 @@ class IMMEngine:
             lay.out, lay.ldo = out, ldo
 
             def f_conv():
-                if nol_src is not None:
+                if first_src is not None:
+                    ops.conv_first(first_src, lay.wt, b, lay.y, ldy, lay.stats if self._training else None, B, H, co,
+                                   L.CONV_BIAS | (L.CONV_STATS if self._training else 0))
+                elif nol_src is not None:
                     ops.conv2d_nol(fd if self._training else fd_eval, x, nol_src.scale, nol_src.shift, nol_src.relu, lay.wt, b, lay.y,
                                    lay.stats if self._training else None)
                 else:
@@ -657,8 +664,16 @@ class IMMEngine:
             k1 = encoder_spec(nf)[0][0]
             ld1 = ops.round_up(3 * k1, 32)
             xin = self._act(B, S, S, ld1)
-            self._add(self.prog_fwd, lambda: ops.pack_image_taps(src, xin, B, S, S, k1, (k1 - 1) // 2, ld1), 'pack_image',
-                      0.0, B * S * S * (12.0 + 2.0 * ld1), name=scope + '/pack')
+            f_pack = (lambda: ops.pack_image_taps(src, xin, B, S, S, k1, (k1 - 1) // 2, ld1), 'pack_image',
+                      0.0, B * S * S * (12.0 + 2.0 * ld1), scope + '/pack')
+            # imm_conv_first reads the f32 image itself: the tap-unrolled copy is then only the operand of conv_1's filter gradient
+            # (the end of the backward pass) and its packing leaves the head of the forward chain for the tail of the shorter lane
+            co1 = encoder_spec(nf)[0][2]
+            direct = k1 == 7 and ld1 == 32 and ops.conv_first_supported(B, S, co1, ops.round_up(co1, 8))
+            if direct:
+                self._deferred_packs.append(f_pack)
+            else:
+                self._add(self.prog_fwd, f_pack[0], f_pack[1], f_pack[2], f_pack[3], name=f_pack[4])
             layers, x, H, ci_real, ci_pad, ldx = [], xin, S, 3 * k1, ld1, ld1
             spec = encoder_spec(nf)
             # normalise on load: block i keeps only its raw conv output when the next convolution (its ONLY reader, forward
@@ -679,7 +694,7 @@ class IMMEngine:
                 nol_src = prev if (prev is not None and prev.out is None) else None
                 lay = self._conv_block('%s/encoder/conv_%d' % (scope, i + 1), x, H, H, ci_real, ci_pad, ldx, co, k,
                                        stride, True, True, needs_dgrad=(i > 0), out=out, ldo=ldo, kw=(1 if i == 0 else None),
-                                       nol_src=nol_src, defer_apply=defer[i])
+                                       nol_src=nol_src, defer_apply=defer[i], first_src=(src if (i == 0 and direct) else None))
                 layers.append(lay)
                 prev = lay
                 if lay.out is None:
@@ -688,6 +703,7 @@ class IMMEngine:
                     x, H, ci_real, ci_pad, ldx = lay.out, lay.Ho, co, co, lay.ldo
             return layers
 
+        self._deferred_packs = []
         self._mark(self.prog_fwd, 'fork')
         self._cur_lane = 1                      # image encoder: side stream, concurrent with the pose encoder
         # the weight-decay term of the loss depends on the parameters only: computed here, beside the (longer) pose branch,
@@ -727,6 +743,14 @@ class IMMEngine:
             self._add(self.prog_fwd, lambda: ops.softargmax_gauss_fwd(self.heat, self.ldh, B, He, He, K, self.inv_std, 16,
                                                                       self.mu, self.py, self.px, gview, Cj, dt, cfg.gauss_mode), 'bottleneck')
 
+        if self._deferred_packs:
+            # the tap-unrolled image copies (filter-gradient operands of the two first convolutions): at the tail of the image-encoder
+            # lane, which is shorter than the pose lane by the pose head
+            self._cur_lane = 1
+            for fn, tag, fl, nb, nm in self._deferred_packs:
+                self._cur_scope = nm
+                self._add(self.prog_fwd, fn, tag, fl, nb, name=nm)
+            self._cur_lane = 0
         self._mark(self.prog_fwd, 'join')
         # ---- renderer ---------------------------------------------------------------------------------
         self.ren, self.ren_up = [], []

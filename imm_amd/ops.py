@@ -520,6 +520,23 @@ def conv2d_group(group, x, y, stats=None, mask=None):
          _p(y), _p(stats), _p(mask), _s())
 
 
+def conv_first_supported(batch, s, co, ldy):
+    return bool(L.load().imm_conv_first_supported(batch, s, co, ldy))
+
+
+def conv_first_stats_blocks(batch, s):
+    n = L.load().imm_conv_first_stats_blocks(batch, s)
+    if n <= 0:
+        raise L.ImmHipError('imm_conv_first_stats_blocks(%d, %d)' % (batch, s))
+    return n
+
+
+def conv_first(image, wt, bias, y, ldy, stats, batch, s, co, flags):
+    """First encoder convolution (7x7 over RGB) straight from the f32 image (imm_conv_first); wt = the 7x1 packed filter image."""
+    call('imm_conv_first', _p(image), _p(wt), int(wt.shape[1]), _p(bias), _p(y), ldy, _p(stats), dtype_enum(y.dtype), batch, s, co,
+         flags, _s())
+
+
 def conv2d_nol_supported(desc):
     """imm_conv2d_nol (normalise on load) serves this forward convolution?"""
     return bool(L.load().imm_conv2d_nol_supported(C.byref(desc)))

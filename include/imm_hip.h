@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define IMM_ABI_VERSION 15   /* 15: imm_conv2d_dgrad_s2, imm_conv2d_nol, imm_wgrad_job.x_scale/x_shift/x_relu; entry points removed
+#define IMM_ABI_VERSION 15   /* 15: imm_conv2d_dgrad_s2, imm_conv2d_nol, imm_conv_first, imm_wgrad_job.x_scale/x_shift/x_relu; entry points removed
                                   since 14 (imm_bn_bwd_reduce_finalize, imm_conv2d_stats_workspace_bytes) finally counted */
 
 enum imm_dtype { IMM_BF16 = 0, IMM_F16 = 1 };
@@ -277,6 +277,17 @@ int imm_pack_image(const float* src, void* dst, int dtype, int64_t npix, void* s
  * (imm_model.py:190) into a 7x1 convolution over 32 channels with identical arithmetic. */
 int imm_pack_image_taps(const float* src, void* dst, int dtype, int batch, int h, int w, int kw, int pad_l, int ld,
                         void* stream);
+
+/* The first encoder convolution (7x7, 3 -> co <= 32 channels, stride 1, SAME + bias: imm_model.py:190 through nn_utils.py:100,108)
+ * straight from the f32 image [batch,s,s,3]: the tap-unrolled operand tile of the 7x1 form above is built in LDS per 8x16-pixel
+ * patch instead of being written to HBM by imm_pack_image_taps and read back.  wt = the SAME packed filter image the 7x1 form uses
+ * (imm_pack_weights mode 0, kh 7, kw 1, ci_real 21, c_pad 32: row length kpad >= 224), so the arithmetic (16-bit operands, f32
+ * accumulation) is unchanged.  y 16-bit [batch,s,s] with pixel stride ldy; flags: IMM_CONV_BIAS, IMM_CONV_STATS (partial rows
+ * [imm_conv_first_stats_blocks(batch, s)][2][co]).  s % 16 == 0, co % 4 == 0.  imm_conv_first_supported: 1 / 0. */
+int imm_conv_first_supported(int batch, int s, int co, int ldy);
+int imm_conv_first_stats_blocks(int batch, int s);
+int imm_conv_first(const float* image, const void* wt, int kpad, const float* bias, void* y, int ldy, float* stats_partial, int dtype,
+                   int batch, int s, int co, int flags, void* stream);
 
 /* ---- landmark bottleneck (imm_model.py:252-264 soft-argmax, :34-78 get_gaussian_maps) ---------- */
 /* gauss_mode (config key gauss_mode, imm_model.py:48-72): 'rot' exp(-((y-mu_y)^2+(x-mu_x)^2)*inv_std^2) (every shipped

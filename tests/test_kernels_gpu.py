@@ -1094,6 +1094,59 @@ def test_first_conv_as_tap_unrolled_7x1(ops, B, S):
     close(dw, gw, 2e-3, 5e-4, 'wgrad7x1')
 
 
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16], ids=['bf16', 'f16'])
+@pytest.mark.parametrize('B,S,co', [(2, 128, 32), (33, 64, 32), (1, 256, 32), (3, 32, 20)],
+                         ids=['128px', 'many_patches_64px', '256px', 'co20_32px'])
+def test_first_conv_from_the_f32_image(ops, B, S, co, dt):
+    """imm_conv_first: the 7x7x3 first encoder convolution straight from the f32 image (tap-unrolled tile built in LDS) against
+    the oracle convolution of the 16-bit-rounded image and against the two-launch form it replaces on the forward chain
+    (imm_pack_image_taps + the 7x1 convolution): same 16-bit operands, so outputs and batch-norm sums agree to rounding."""
+    from imm_amd import _lib as L
+    g = torch.Generator().manual_seed(77)
+    src = torch.rand(B, S, S, 3, generator=g) * 255
+    w = rnd((7, 7, 3, co), 57, 0.01, torch.float32)
+    bias = rnd((co,), 59, 0.5, torch.float32)
+    srcd = src.to(DEV).contiguous()
+    ldy = ops.round_up(co, 8)
+    assert ops.conv_first_supported(B, S, co, ldy)
+    wt = torch.zeros(128, 224, dtype=dt, device=DEV)
+    ops.pack_weights(w.to(DEV).contiguous(), wt, 0, 7, 1, 21, co, 32, 128, 224)
+    y = torch.full((B, S, S, ldy), float('nan'), dtype=dt, device=DEV)
+    stats = torch.full((ops.conv_first_stats_blocks(B, S), 2, co), float('nan'), dtype=torch.float32, device=DEV)
+    ops.conv_first(srcd, wt, bias.to(DEV), y, ldy, stats, B, S, co, L.CONV_BIAS | L.CONV_STATS)
+    # the form it replaces
+    xin = torch.empty(B, S, S, 32, dtype=dt, device=DEV)
+    ops.pack_image_taps(srcd, xin, B, S, S, 7, 3, 32)
+    d2 = ops.fwd_desc(B, S, S, 32, 32, co, ldy, 7, 1, L.CONV_BIAS | L.CONV_STATS, kw=1)
+    stats2 = torch.full((ops.conv_stats_blocks(d2), 2, co), float('nan'), dtype=torch.float32, device=DEV)
+    y2 = torch.full((B, S, S, ldy), float('nan'), dtype=dt, device=DEV)
+    ops.conv2d(d2, xin, wt, bias.to(DEV), y2, stats2)
+    torch.cuda.synchronize()
+    ref = O.conv2d_same(src.to(dt).float(), w.to(dt).float(), bias, 1)
+    close(y[..., :co], ref, 1e-2, 2e-3, 'conv_first vs oracle')
+    close(y[..., :co], y2[..., :co], 2.0 ** -7 if dt == torch.bfloat16 else 2.0 ** -10, 1e-4, 'conv_first vs pack + 7x1 conv')
+    close(stats.sum(0), stats2.sum(0), 2e-4, 2e-4, 'conv_first batch-norm partial sums')
+    if ldy > co:
+        assert bool(torch.isnan(y[..., co:].float()).all())          # padding channels are left alone
+    # no bias, no sums (the inference form)
+    y3 = torch.full((B, S, S, ldy), float('nan'), dtype=dt, device=DEV)
+    ops.conv_first(srcd, wt, None, y3, ldy, None, B, S, co, 0)
+    torch.cuda.synchronize()
+    close(y3[..., :co], ref - bias, 1e-2, 2e-3, 'conv_first without bias')
+
+
+def test_first_conv_from_the_f32_image_rejects_unserved_shapes(ops):
+    from imm_amd import _lib as L
+    assert not ops.conv_first_supported(2, 72, 32, 32)       # side % 16
+    assert not ops.conv_first_supported(2, 64, 64, 64)       # more than 32 filters
+    assert not ops.conv_first_supported(2, 64, 30, 32)       # co % 4
+    img = torch.zeros(2, 72, 72, 3, device=DEV)
+    wt = torch.zeros(128, 224, dtype=torch.bfloat16, device=DEV)
+    y = torch.zeros(2, 72, 72, 32, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(L.ImmHipError):
+        ops.conv_first(img, wt, None, y, 32, None, 2, 72, 32, 0)
+
+
 def test_pack_image(ops):
     src = torch.rand(5, 7, 7, 3) * 255
     dst = torch.empty(5, 7, 7, 8, dtype=torch.bfloat16, device=DEV)
