@@ -39,7 +39,10 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const ConvFirstArgs a) 
   constexpr int N_LD = (N_ELEM + 255) / 256;         // loads per thread (4)
   __shared__ __attribute__((aligned(16))) uint4 Wl[W_U4];
   __shared__ __attribute__((aligned(16))) uint4 Tl[T_U4];
-  __shared__ __attribute__((aligned(16))) uint16_t Sl[CF_TR * CF_SW * 4];     // 16-bit halo, 4 slots per pixel (3 used)
+  // 16-bit halo, rows of 22 pixels x 3 channels PACKED: the unrolled channels kx*3 + c of tile pixel (r, x) are then the 21
+  // CONSECUTIVE values Sl[r][3x .. 3x+20] (channel kx*3 + c of pixel x = channel c of pixel x + kx = element 3(x+kx) + c)
+  constexpr int SROW = CF_SW * 3 + 6;               // 72: row pitch (u16), the over-read of a row's last chunks stays inside the array
+  __shared__ __attribute__((aligned(16))) uint16_t Sl[CF_TR * SROW + 8];
   __shared__ float red[4 * 2 * CF_BN];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -56,21 +59,38 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const ConvFirstArgs a) 
     Wl[row * 4 + (q ^ cf_swz(row))] = v;
   }
 
-  // ---- halo loader: element e = r*66 + t of the [14][22][3] f32 halo, this thread's e = tid + 256 u ----------------------
+  // ---- halo loader: element e = r*66 + t of the [14][22][3] f32 halo, this thread's e = tid + 256 u.  Everything that does not
+  // depend on the patch is computed once (the first version recomputed divisions and gather addresses per patch and was
+  // VALU-bound: 33 us for the layer, ~3000 cycles per patch and wave) ----------------------------------------------------------
   float pre[N_LD];
+  int e_r[N_LD], e_px[N_LD], e_off[N_LD], e_lds[N_LD];
+#pragma unroll
+  for (int u = 0; u < N_LD; ++u) {
+    const int e = tid + 256 * u;
+    const int r = e / (CF_SW * 3), t = e - r * (CF_SW * 3);
+    e_r[u] = e < N_ELEM ? r : (1 << 24);             // (never inside an image)
+    e_px[u] = t / 3;
+    e_off[u] = r * S * 3 + t;                         // relative to the f32 element of halo pixel (0, 0)
+    e_lds[u] = r * SROW + t;
+  }
   auto load_halo = [&](int patch) {
     const int img = patch / per_img, pr = patch - img * per_img;
     const int y0 = (pr / a.patches_x) * CF_PH - CF_PAD, x0 = (pr % a.patches_x) * CF_PW - CF_PAD;
-    const float* base = a.img + (int64_t)img * S * S * 3;
+    const float* base = a.img + ((int64_t)img * S * S + (int64_t)y0 * S + x0) * 3;
 #pragma unroll
     for (int u = 0; u < N_LD; ++u) {
-      const int e = tid + 256 * u;
-      const int r = e / (CF_SW * 3), t = e - r * (CF_SW * 3);
-      const int iy = y0 + r, ix = x0 + t / 3;
-      const bool ok = e < N_ELEM && (unsigned)iy < (unsigned)S && (unsigned)ix < (unsigned)S;
-      pre[u] = ok ? base[((int64_t)iy * S + x0) * 3 + t] : 0.f;
+      const bool ok = (unsigned)(y0 + e_r[u]) < (unsigned)S && (unsigned)(x0 + e_px[u]) < (unsigned)S;
+      pre[u] = ok ? base[e_off[u]] : 0.f;
     }
   };
+  // operand-tile builder: this thread's chunks are (pixel (tid >> 2) + 64 u, q = tid & 3), u = 0 .. 3 (pixel < 224): source
+  // = 8 consecutive halo values from Sl[(r0 + 4u) * SROW + 3x + 8q]; q = 3 (channels 24..31) is all zero and q = 2 holds
+  // channels 16..20 + three zeros: the zero parts are written once, below
+  const int t_q = tid & 3, t_pix0 = tid >> 2;
+  const int t_src0 = (t_pix0 >> 4) * SROW + 3 * (t_pix0 & 15) + 8 * t_q;
+  for (int idx = tid; idx < T_U4; idx += 256) Tl[idx] = make_uint4(0, 0, 0, 0);
+  for (int idx = tid; idx < (CF_TR * SROW + 8) / 2; idx += 256) ((uint32_t*)Sl)[idx] = 0u;
+  __syncthreads();              // (the zero fill is ordered before the first patch's halo values)
 
   const bool f_bias = a.flags & IMM_CONV_BIAS, f_stats = a.flags & IMM_CONV_STATS;
   float s1[NT][4], s2[NT][4], bv[NT][4];
@@ -86,32 +106,24 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const ConvFirstArgs a) 
   int patch = blockIdx.x;
   if (patch < a.n_patches) load_halo(patch);
   for (; patch < a.n_patches; patch += gridDim.x) {
-    // 16-bit halo: S[r][px][c]
+    // 16-bit halo (values outside the image were loaded as zeros)
 #pragma unroll
-    for (int u = 0; u < N_LD; ++u) {
-      const int e = tid + 256 * u;
-      if (e < N_ELEM) {
-        const int r = e / (CF_SW * 3), t = e - r * (CF_SW * 3);
-        const int px = t / 3, c = t - px * 3;
-        Sl[(r * CF_SW + px) * 4 + c] = ET::from_f32(pre[u]);
-      }
-    }
+    for (int u = 0; u < N_LD; ++u)
+      if (e_r[u] < CF_TR) Sl[e_lds[u]] = ET::from_f32(pre[u]);
     __syncthreads();            // halo complete; every wave is past the previous patch's reads of the operand tile
-    // operand tile: chunk q of pixel (r, x) = unrolled channels 8q .. 8q+7, channel ch = kx*3 + c <- S[r][x + kx][c], ch >= 21: 0
-    for (int idx = tid; idx < T_U4; idx += 256) {
-      const int pix = idx >> 2, q = idx & 3;
-      const int r = pix >> 4, x = pix & 15;
-      const uint16_t* src = Sl + (r * CF_SW + x) * 4;
-      uint32_t w[4];
+    // operand tile: chunk q of pixel (r, x) = unrolled channels 8q .. 8q+7 = Sl[r][3x + 8q ..+7] (q = 2: five values, q = 3: none)
+    if (t_q < 3) {
 #pragma unroll
-      for (int e2 = 0; e2 < 4; ++e2) {
-        uint32_t lo = 0, hi = 0;
-        const int ch0 = q * 8 + 2 * e2, ch1 = ch0 + 1;
-        if (ch0 < 3 * CF_K) lo = src[(ch0 / 3) * 4 + ch0 % 3];
-        if (ch1 < 3 * CF_K) hi = src[(ch1 / 3) * 4 + ch1 % 3];
-        w[e2] = lo | (hi << 16);
+      for (int u = 0; u < 4; ++u) {
+        const int pix = t_pix0 + 64 * u;
+        if (pix < CF_TR * CF_PW) {
+          const uint16_t* src = Sl + t_src0 + 4 * u * SROW;
+          const uint32_t w0 = (uint32_t)src[0] | ((uint32_t)src[1] << 16), w1 = (uint32_t)src[2] | ((uint32_t)src[3] << 16);
+          uint32_t w2 = (uint32_t)src[4] | ((uint32_t)src[5] << 16), w3 = (uint32_t)src[6] | ((uint32_t)src[7] << 16);
+          if (t_q == 2) { w2 &= 0xffffu; w3 = 0u; }      // channels 21, 22, 23 do not exist
+          Tl[pix * 4 + (t_q ^ cf_swz(pix))] = make_uint4(w0, w1, w2, w3);
+        }
       }
-      Tl[pix * 4 + (q ^ cf_swz(pix))] = make_uint4(w[0], w[1], w[2], w[3]);
     }
     __syncthreads();            // tile complete (also: the filter image, first patch)
     const int next = patch + gridDim.x;
@@ -217,7 +229,7 @@ static int cf_num_cu() {
 
 static int cf_grid(int batch, int s) {
   const int n_patches = batch * (s / CF_PH) * (s / CF_PW);
-  const int grid = 3 * cf_num_cu();                 // ~34 KB of LDS and 4 waves per workgroup: three per CU cover each other's barriers
+  const int grid = 2 * cf_num_cu();                 // ~33 KB of LDS and 4 waves per workgroup; two per CU (512 partial rows, as the 7x1 form)
   return n_patches < grid ? n_patches : grid;
 }
 
