@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const ConvFirstArgs a) 
   // ---- halo loader: element e = r*66 + t of the [14][22][3] f32 halo, this thread's e = tid + 256 u.  Everything that does not
   // depend on the patch is computed once (the first version recomputed divisions and gather addresses per patch and was
   // VALU-bound: 33 us for the layer, ~3000 cycles per patch and wave) ----------------------------------------------------------
-  float pre[N_LD];
+  float pre[N_LD], pre2[N_LD];                       // the halos of the next two patches of this workgroup, in flight
   int e_r[N_LD], e_px[N_LD], e_off[N_LD], e_lds[N_LD];
 #pragma unroll
   for (int u = 0; u < N_LD; ++u) {
@@ -73,15 +73,22 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const ConvFirstArgs a) 
     e_off[u] = r * S * 3 + t;                         // relative to the f32 element of halo pixel (0, 0)
     e_lds[u] = r * SROW + t;
   }
-  auto load_halo = [&](int patch) {
+  auto load_halo = [&](int patch, float (&dst)[N_LD]) {
     const int img = patch / per_img, pr = patch - img * per_img;
     const int y0 = (pr / a.patches_x) * CF_PH - CF_PAD, x0 = (pr % a.patches_x) * CF_PW - CF_PAD;
     const float* base = a.img + ((int64_t)img * S * S + (int64_t)y0 * S + x0) * 3;
 #pragma unroll
     for (int u = 0; u < N_LD; ++u) {
       const bool ok = (unsigned)(y0 + e_r[u]) < (unsigned)S && (unsigned)(x0 + e_px[u]) < (unsigned)S;
-      pre[u] = ok ? base[e_off[u]] : 0.f;
+      dst[u] = ok ? base[e_off[u]] : 0.f;
     }
+  };
+  // LDS-only barrier: a __syncthreads would also drain vmcnt, i.e. wait for the previous patch's output stores and for the halo
+  // loads requested ahead — the layer is a chain of short patches (3.7 KB in, 8 KB out, 28 MFMAs per wave) and was latency-bound
+  // that way (32 us; 4 us per patch and workgroup)
+  auto lds_barrier = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
   };
   // operand-tile builder: this thread's chunks are (pixel (tid >> 2) + 64 u, q = tid & 3), u = 0 .. 3 (pixel < 224): source
   // = 8 consecutive halo values from Sl[(r0 + 4u) * SROW + 3x + 8q]; q = 3 (channels 24..31) is all zero and q = 2 holds
@@ -104,13 +111,15 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const ConvFirstArgs a) 
     }
 
   int patch = blockIdx.x;
-  if (patch < a.n_patches) load_halo(patch);
-  for (; patch < a.n_patches; patch += gridDim.x) {
+  const int G = (int)gridDim.x;
+  if (patch < a.n_patches) load_halo(patch, pre);
+  if (patch + G < a.n_patches) load_halo(patch + G, pre2);
+  for (; patch < a.n_patches; patch += G) {
     // 16-bit halo (values outside the image were loaded as zeros)
 #pragma unroll
     for (int u = 0; u < N_LD; ++u)
       if (e_r[u] < CF_TR) Sl[e_lds[u]] = ET::from_f32(pre[u]);
-    __syncthreads();            // halo complete; every wave is past the previous patch's reads of the operand tile
+    lds_barrier();              // halo complete; every wave is past the previous patch's reads of the operand tile
     // operand tile: chunk q of pixel (r, x) = unrolled channels 8q .. 8q+7 = Sl[r][3x + 8q ..+7] (q = 2: five values, q = 3: none)
     if (t_q < 3) {
 #pragma unroll
@@ -125,9 +134,10 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const ConvFirstArgs a) 
         }
       }
     }
-    __syncthreads();            // tile complete (also: the filter image, first patch)
-    const int next = patch + gridDim.x;
-    if (next < a.n_patches) load_halo(next);          // in flight during the matrix work and the stores below
+    lds_barrier();              // tile complete (also: the filter image, first patch)
+#pragma unroll
+    for (int u = 0; u < N_LD; ++u) pre[u] = pre2[u];
+    if (patch + 2 * G < a.n_patches) load_halo(patch + 2 * G, pre2);     // two patches ahead
 
     f32x4_t acc[MT][NT];
 #pragma unroll
@@ -229,7 +239,7 @@ static int cf_num_cu() {
 
 static int cf_grid(int batch, int s) {
   const int n_patches = batch * (s / CF_PH) * (s / CF_PW);
-  const int grid = 2 * cf_num_cu();                 // ~33 KB of LDS and 4 waves per workgroup; two per CU (512 partial rows, as the 7x1 form)
+  const int grid = 4 * cf_num_cu();                 // ~31 KB of LDS and 4 waves per workgroup: four per CU keep enough patches in flight
   return n_patches < grid ? n_patches : grid;
 }
 
