@@ -30,7 +30,9 @@ struct ConvFirstArgs {
 // chunk swizzle of 64-byte rows (4 chunks): a ds_read_b128 of 16 consecutive rows x 4 chunks is conflict-free (conv_halo.hip)
 __device__ __forceinline__ int cf_swz(int row) { return ((row >> 2) & 1) << 1; }
 
-template <typename ET>
+// FULL: co == 32 (every shipped configuration) — compile-time, so that the patch loop is straight-line code and hipcc can COUNT the
+// outstanding stores at the loop's back edge instead of draining vmcnt to zero there
+template <typename ET, bool FULL>
 __global__ __launch_bounds__(256) void conv_first_kernel(const ConvFirstArgs a) {
   constexpr int MT = 2, NT = 2;                      // wave w: patch rows 2w, 2w+1 x 32 channels
   constexpr int W_U4 = CF_K * CF_BN * 4;             // filter image: row = ky*32 + n, 4 chunks
@@ -73,14 +75,19 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const ConvFirstArgs a) 
     e_off[u] = r * S * 3 + t;                         // relative to the f32 element of halo pixel (0, 0)
     e_lds[u] = r * SROW + t;
   }
+  // branch-free: buffer loads whose offset is out of range for halo elements outside the image return 0 (a conditional global
+  // load is a divergent branch per element, and hipcc then drains vmcnt to zero at the loop's back edge: every patch waited for
+  // its own output stores)
+  const __amdgpu_buffer_rsrc_t ir = __builtin_amdgcn_make_buffer_rsrc((void*)a.img, 0, (int)((int64_t)a.batch * S * S * 12), 0x00020000);
   auto load_halo = [&](int patch, float (&dst)[N_LD]) {
     const int img = patch / per_img, pr = patch - img * per_img;
     const int y0 = (pr / a.patches_x) * CF_PH - CF_PAD, x0 = (pr % a.patches_x) * CF_PW - CF_PAD;
-    const float* base = a.img + ((int64_t)img * S * S + (int64_t)y0 * S + x0) * 3;
+    const int pbase = ((img * S + y0) * S + x0) * 3;              // f32 element of halo pixel (0, 0); may be negative
 #pragma unroll
     for (int u = 0; u < N_LD; ++u) {
       const bool ok = (unsigned)(y0 + e_r[u]) < (unsigned)S && (unsigned)(x0 + e_px[u]) < (unsigned)S;
-      dst[u] = ok ? base[e_off[u]] : 0.f;
+      const uint32_t vo = ok ? (uint32_t)((pbase + e_off[u]) * 4) : 0x80000000u;
+      dst[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ir, vo, 0, 0));
     }
   };
   // LDS-only barrier: a __syncthreads would also drain vmcnt, i.e. wait for the previous patch's output stores and for the halo
@@ -100,6 +107,7 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const ConvFirstArgs a) 
   __syncthreads();              // (the zero fill is ordered before the first patch's halo values)
 
   const bool f_bias = a.flags & IMM_CONV_BIAS, f_stats = a.flags & IMM_CONV_STATS;
+  constexpr bool full = FULL;                       // every lane's four channels exist: one 8-byte store per tile, no per-lane tests
   float s1[NT][4], s2[NT][4], bv[NT][4];
 #pragma unroll
   for (int j = 0; j < NT; ++j)
@@ -180,7 +188,8 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const ConvFirstArgs a) 
           for (int r = 0; r < 4; ++r) { s1[j][r] += v[r]; s2[j][r] += v[r] * v[r]; }
         }
         uint16_t* yp = a.y + m * a.ldy + n;
-        if (n + 3 < a.co) *(uint2*)yp = make_uint2(ET::pack2(v[0], v[1]), ET::pack2(v[2], v[3]));
+        if constexpr (full) *(uint2*)yp = make_uint2(ET::pack2(v[0], v[1]), ET::pack2(v[2], v[3]));
+        else if (n + 3 < a.co) *(uint2*)yp = make_uint2(ET::pack2(v[0], v[1]), ET::pack2(v[2], v[3]));
         else {
 #pragma unroll
           for (int r = 0; r < 4; ++r) if (n + r < a.co) yp[r] = ET::from_f32(v[r]);
@@ -247,7 +256,7 @@ extern "C" int imm_conv_first_supported(int batch, int s, int co, int ldy) {
   static const bool off = imm_conv_disabled("first");
   if (off) return 0;
   if (batch <= 0 || s < 16 || s % CF_PW || co < 4 || co > CF_BN || co % 4 || ldy < co || ldy % 4) return 0;
-  return ((int64_t)batch * s * s * 3 < (1LL << 31)) ? 1 : 0;
+  return ((int64_t)batch * s * s * 12 < (1LL << 31)) ? 1 : 0;      // (the image is addressed through a buffer descriptor)
 }
 
 extern "C" int imm_conv_first_stats_blocks(int batch, int s) { return (batch > 0 && s >= 16 && s % CF_PW == 0) ? cf_grid(batch, s) : IMM_E_INVALID; }
@@ -268,8 +277,14 @@ extern "C" int imm_conv_first(const float* image, const void* wt, int kpad, cons
   a.batch = batch; a.s = s; a.co = co; a.ldy = ldy; a.kpad = kpad; a.flags = flags;
   a.patches_x = s / CF_PW; a.patches_y = s / CF_PH; a.n_patches = batch * a.patches_x * a.patches_y;
   const int grid = cf_grid(batch, s);
-  if (dtype == IMM_BF16) hipLaunchKernelGGL((conv_first_kernel<BF16>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL((conv_first_kernel<F16>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  const bool full = co == CF_BN;
+  if (dtype == IMM_BF16) {
+    if (full) hipLaunchKernelGGL((conv_first_kernel<BF16, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((conv_first_kernel<BF16, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  } else {
+    if (full) hipLaunchKernelGGL((conv_first_kernel<F16, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((conv_first_kernel<F16, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  }
   IMM_CHECK_LAUNCH("imm_conv_first");
   return 0;
 }
