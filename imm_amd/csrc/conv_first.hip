@@ -30,42 +30,24 @@ struct ConvFirstArgs {
 // chunk swizzle of 64-byte rows (4 chunks): a ds_read_b128 of 16 consecutive rows x 4 chunks is conflict-free (conv_halo.hip)
 __device__ __forceinline__ int cf_swz(int row) { return ((row >> 2) & 1) << 1; }
 
-// FULL: co == 32 (every shipped configuration) — compile-time: every lane then issues exactly MT*NT output stores per patch, which is
-// what makes the counted s_waitcnt of the loop exact.
-//
-// Memory pipeline (what three earlier versions of this loop taught, 33 -> 27 us for the layer against the 33 us of the two launches
-// it replaces): a patch is 3.7 KB in, 8 KB out and 28 MFMAs per wave, so the loop is a latency chain unless the halo of patch k+2
-// is in flight while patch k is computed and nobody waits for output stores.  With ordinary loads hipcc decides the waits, and it
-// drains vmcnt to zero wherever loads and stores are both outstanding (its counter model treats mixed event types as unordered) or
-// a branch sits in between.  So the halo goes HBM -> LDS by DMA (buffer_load_dword ... lds: no register results, nothing for
-// the compiler to wait for) from inline asm, EXACTLY four DMA instructions per wave and patch (beyond the last patch: no-op pieces
-// with out-of-range offsets), and the loop waits with a counted vmcnt: after the four DMA instructions of patch k come the stores
-// of patch k-2 (4), the DMA of patch k+1 (4) and the stores of patch k-1 (4) -> vmcnt(12) (8 / 4 for the first two patches).
-typedef __attribute__((address_space(3))) void cf_lds_void_t;
-typedef __attribute__((ext_vector_type(4))) unsigned int cf_u32x4_t;
-__device__ __forceinline__ void cf_dma4(cf_u32x4_t rsrc, uint32_t lds_addr, uint32_t voff) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds" :: "s"(lds_addr), "v"(voff), "s"(rsrc) : "memory");
-}
-
+// FULL: co == 32 (every shipped configuration) — compile-time, so that the patch loop is straight-line code and hipcc can COUNT the
+// outstanding stores at the loop's back edge instead of draining vmcnt to zero there
 template <typename ET, bool FULL>
 __global__ __launch_bounds__(256) void conv_first_kernel(const ConvFirstArgs a) {
   constexpr int MT = 2, NT = 2;                      // wave w: patch rows 2w, 2w+1 x 32 channels
   constexpr int W_U4 = CF_K * CF_BN * 4;             // filter image: row = ky*32 + n, 4 chunks
   constexpr int T_U4 = CF_TR * CF_PW * 4;            // operand tile: row = pixel (r*16 + x), 4 chunks
-  constexpr int FROW = CF_SW * 3;                    // f32 values per halo row (66): pixel-major, channels packed
-  constexpr int N_ELEM = CF_TR * FROW;               // f32 values of a halo (924)
-  constexpr int N_LD = 4, F_STAGE = 256 * N_LD;      // DMA instructions per wave and patch; floats per halo stage (1024 >= 924 + over-read)
-  constexpr int NSF = 3;                             // halo stages: computing k, landed or landing k+1, landing k+2
-  static_assert(N_ELEM + 8 <= F_STAGE, "halo + the tile builder's over-read fit a stage");
+  constexpr int N_ELEM = CF_TR * CF_SW * 3;          // f32 values of a halo (924)
+  constexpr int N_LD = (N_ELEM + 255) / 256;         // loads per thread (4)
   __shared__ __attribute__((aligned(16))) uint4 Wl[W_U4];
   __shared__ __attribute__((aligned(16))) uint4 Tl[T_U4];
-  // f32 halo stages, element e = r*66 + 3*px + c: the unrolled channels kx*3 + c of tile pixel (r, x) are the 21 CONSECUTIVE values
-  // F[r*66 + 3x .. +20] (channel kx*3 + c of pixel x = channel c of pixel x + kx)
-  __shared__ __attribute__((aligned(16))) float Fl[NSF * F_STAGE];
+  // 16-bit halo, rows of 22 pixels x 3 channels PACKED: the unrolled channels kx*3 + c of tile pixel (r, x) are then the 21
+  // CONSECUTIVE values Sl[r][3x .. 3x+20] (channel kx*3 + c of pixel x = channel c of pixel x + kx = element 3(x+kx) + c)
+  constexpr int SROW = CF_SW * 3 + 6;               // 72: row pitch (u16), the over-read of a row's last chunks stays inside the array
+  __shared__ __attribute__((aligned(16))) uint16_t Sl[CF_TR * SROW + 8];
   __shared__ float red[4 * 2 * CF_BN];
 
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int frow = lane & 15, fchunk = lane >> 4;
   const int S = a.s;
   const int per_img = a.patches_x * a.patches_y;
@@ -78,38 +60,54 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const ConvFirstArgs a) 
     if (n < a.co) v = *(const uint4*)(a.wt + (int64_t)n * a.kpad + tap * 32 + q * 8);
     Wl[row * 4 + (q ^ cf_swz(row))] = v;
   }
-  for (int idx = tid; idx < T_U4; idx += 256) Tl[idx] = make_uint4(0, 0, 0, 0);     // (chunk 3 of every pixel stays zero)
 
-  // ---- halo loader: this lane's element of DMA instruction u of wave wid is e = 256 u + 64 wid + lane ----------------
-  int e_r[N_LD], e_px[N_LD], e_off[N_LD];
+  // ---- halo loader: element e = r*66 + t of the [14][22][3] f32 halo, this thread's e = tid + 256 u.  Everything that does not
+  // depend on the patch is computed once (the first version recomputed divisions and gather addresses per patch and was
+  // VALU-bound: 33 us for the layer, ~3000 cycles per patch and wave) ----------------------------------------------------------
+  float pre[N_LD], pre2[N_LD];                       // the halos of the next two patches of this workgroup, in flight
+  int e_r[N_LD], e_px[N_LD], e_off[N_LD], e_lds[N_LD];
 #pragma unroll
   for (int u = 0; u < N_LD; ++u) {
-    const int e = 256 * u + 64 * wid + lane;
-    const int r = e / FROW, t = e - r * FROW;
-    e_r[u] = e < N_ELEM ? r : (1 << 24);             // (slots beyond the halo: never inside an image -> zero fill)
+    const int e = tid + 256 * u;
+    const int r = e / (CF_SW * 3), t = e - r * (CF_SW * 3);
+    e_r[u] = e < N_ELEM ? r : (1 << 24);             // (never inside an image)
     e_px[u] = t / 3;
-    e_off[u] = (r * S * 3 + t) * 4;                   // byte offset relative to the f32 element of halo pixel (0, 0)
+    e_off[u] = r * S * 3 + t;                         // relative to the f32 element of halo pixel (0, 0)
+    e_lds[u] = r * SROW + t;
   }
-  const uint64_t ia = (uint64_t)a.img;
-  const cf_u32x4_t ir = {(uint32_t)ia, (uint32_t)(ia >> 32) & 0xffffu, (uint32_t)((int64_t)a.batch * S * S * 12), 0x00020000u};
-  const uint32_t f_base = (uint32_t)(size_t)(cf_lds_void_t*)Fl;
-  auto issue_halo = [&](int patch, int stage) {
-    const bool real = patch < a.n_patches;
+  // branch-free: buffer loads whose offset is out of range for halo elements outside the image return 0 (a conditional global
+  // load is a divergent branch per element, and hipcc then drains vmcnt to zero at the loop's back edge: every patch waited for
+  // its own output stores)
+  const __amdgpu_buffer_rsrc_t ir = __builtin_amdgcn_make_buffer_rsrc((void*)a.img, 0, (int)((int64_t)a.batch * S * S * 12), 0x00020000);
+  auto load_halo = [&](int patch, float (&dst)[N_LD]) {
     const int img = patch / per_img, pr = patch - img * per_img;
     const int y0 = (pr / a.patches_x) * CF_PH - CF_PAD, x0 = (pr % a.patches_x) * CF_PW - CF_PAD;
-    const int pbase = ((img * S + y0) * S + x0) * 12;             // byte offset of halo pixel (0, 0); may be negative
+    const int pbase = ((img * S + y0) * S + x0) * 3;              // f32 element of halo pixel (0, 0); may be negative
 #pragma unroll
     for (int u = 0; u < N_LD; ++u) {
-      const bool ok = real && (unsigned)(y0 + e_r[u]) < (unsigned)S && (unsigned)(x0 + e_px[u]) < (unsigned)S;
-      cf_dma4(ir, f_base + (uint32_t)((stage * F_STAGE + 256 * u + 64 * wid) * 4), ok ? (uint32_t)(pbase + e_off[u]) : 0x80000000u);
+      const bool ok = (unsigned)(y0 + e_r[u]) < (unsigned)S && (unsigned)(x0 + e_px[u]) < (unsigned)S;
+      const uint32_t vo = ok ? (uint32_t)((pbase + e_off[u]) * 4) : 0x80000000u;
+      dst[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ir, vo, 0, 0));
     }
   };
-  // operand-tile builder: this thread's chunks are (pixel (tid >> 2) + 64 u, q = tid & 3), u = 0 .. 3 (pixel < 224); source = 8
-  // consecutive f32 from F[(r0 + 4u)*66 + 3x + 8q]; q = 3 (channels 24..31) is all zero, q = 2 holds channels 16..20 + three zeros
+  // LDS-only barrier: a __syncthreads would also drain vmcnt, i.e. wait for the previous patch's output stores and for the halo
+  // loads requested ahead — the layer is a chain of short patches (3.7 KB in, 8 KB out, 28 MFMAs per wave) and was latency-bound
+  // that way (32 us; 4 us per patch and workgroup)
+  auto lds_barrier = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+  // operand-tile builder: this thread's chunks are (pixel (tid >> 2) + 64 u, q = tid & 3), u = 0 .. 3 (pixel < 224): source
+  // = 8 consecutive halo values from Sl[(r0 + 4u) * SROW + 3x + 8q]; q = 3 (channels 24..31) is all zero and q = 2 holds
+  // channels 16..20 + three zeros: the zero parts are written once, below
   const int t_q = tid & 3, t_pix0 = tid >> 2;
-  const int t_src0 = (t_pix0 >> 4) * FROW + 3 * (t_pix0 & 15) + 8 * t_q;
+  const int t_src0 = (t_pix0 >> 4) * SROW + 3 * (t_pix0 & 15) + 8 * t_q;
+  for (int idx = tid; idx < T_U4; idx += 256) Tl[idx] = make_uint4(0, 0, 0, 0);
+  for (int idx = tid; idx < (CF_TR * SROW + 8) / 2; idx += 256) ((uint32_t*)Sl)[idx] = 0u;
+  __syncthreads();              // (the zero fill is ordered before the first patch's halo values)
 
   const bool f_bias = a.flags & IMM_CONV_BIAS, f_stats = a.flags & IMM_CONV_STATS;
+  constexpr bool full = FULL;                       // every lane's four channels exist: one 8-byte store per tile, no per-lane tests
   float s1[NT][4], s2[NT][4], bv[NT][4];
 #pragma unroll
   for (int j = 0; j < NT; ++j)
@@ -119,48 +117,35 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const ConvFirstArgs a) 
       const int n = j * 16 + 4 * fchunk + r;
       bv[j][r] = (f_bias && n < a.co) ? a.bias[n] : 0.f;
     }
-  // everything loaded so far (filter image, bias) has ARRIVED before the loop: its waits must not land inside it
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-  for (int j = 0; j < NT; ++j)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(bv[j][r]));
 
+  int patch = blockIdx.x;
   const int G = (int)gridDim.x;
-  const int n_mine = ((int)blockIdx.x < a.n_patches) ? (a.n_patches - (int)blockIdx.x + G - 1) / G : 0;
-  issue_halo(blockIdx.x, 0);
-  issue_halo(blockIdx.x + G, 1);
-  int stage = 0;
-  for (int it = 0; it < n_mine; ++it) {
-    const int patch = blockIdx.x + it * G;
-    // this wave's share of the halo of patch `it` has landed (then, with the barrier, everyone's)
-    if (!FULL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // (co < 32: the store count per patch varies — drain)
-    else if (it == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_LD) : "memory");
-    else if (it == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_LD + MT * NT) : "memory");
-    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_LD + 2 * MT * NT) : "memory");
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();            // halo complete; every wave is past the previous patch's reads of the operand tile
-    // operand tile: chunk q of pixel (r, x) = unrolled channels 8q .. 8q+7 = F[r*66 + 3x + 8q ..+7], rounded to 16 bits
+  if (patch < a.n_patches) load_halo(patch, pre);
+  if (patch + G < a.n_patches) load_halo(patch + G, pre2);
+  for (; patch < a.n_patches; patch += G) {
+    // 16-bit halo (values outside the image were loaded as zeros)
+#pragma unroll
+    for (int u = 0; u < N_LD; ++u)
+      if (e_r[u] < CF_TR) Sl[e_lds[u]] = ET::from_f32(pre[u]);
+    lds_barrier();              // halo complete; every wave is past the previous patch's reads of the operand tile
+    // operand tile: chunk q of pixel (r, x) = unrolled channels 8q .. 8q+7 = Sl[r][3x + 8q ..+7] (q = 2: five values, q = 3: none)
     if (t_q < 3) {
-      const float* Fs = Fl + stage * F_STAGE + t_src0;
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int pix = t_pix0 + 64 * u;
         if (pix < CF_TR * CF_PW) {
-          const float* src = Fs + 4 * u * FROW;
-          const uint32_t w0 = ET::pack2(src[0], src[1]), w1 = ET::pack2(src[2], src[3]);
-          uint32_t w2 = ET::pack2(src[4], src[5]), w3 = ET::pack2(src[6], src[7]);
+          const uint16_t* src = Sl + t_src0 + 4 * u * SROW;
+          const uint32_t w0 = (uint32_t)src[0] | ((uint32_t)src[1] << 16), w1 = (uint32_t)src[2] | ((uint32_t)src[3] << 16);
+          uint32_t w2 = (uint32_t)src[4] | ((uint32_t)src[5] << 16), w3 = (uint32_t)src[6] | ((uint32_t)src[7] << 16);
           if (t_q == 2) { w2 &= 0xffffu; w3 = 0u; }      // channels 21, 22, 23 do not exist
           Tl[pix * 4 + (t_q ^ cf_swz(pix))] = make_uint4(w0, w1, w2, w3);
         }
       }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();            // tile complete (also: the filter image, first patch); stage (it+2) % 3 is free
-    {
-      int s2_ = stage + 2; if (s2_ >= NSF) s2_ -= NSF;
-      issue_halo(patch + 2 * G, s2_);        // two patches ahead (a no-op piece per instruction beyond the last patch)
-    }
+    lds_barrier();              // tile complete (also: the filter image, first patch)
+#pragma unroll
+    for (int u = 0; u < N_LD; ++u) pre[u] = pre2[u];
+    if (patch + 2 * G < a.n_patches) load_halo(patch + 2 * G, pre2);     // two patches ahead
 
     f32x4_t acc[MT][NT];
 #pragma unroll
@@ -203,7 +188,7 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const ConvFirstArgs a) 
           for (int r = 0; r < 4; ++r) { s1[j][r] += v[r]; s2[j][r] += v[r] * v[r]; }
         }
         uint16_t* yp = a.y + m * a.ldy + n;
-        if constexpr (FULL) *(uint2*)yp = make_uint2(ET::pack2(v[0], v[1]), ET::pack2(v[2], v[3]));
+        if constexpr (full) *(uint2*)yp = make_uint2(ET::pack2(v[0], v[1]), ET::pack2(v[2], v[3]));
         else if (n + 3 < a.co) *(uint2*)yp = make_uint2(ET::pack2(v[0], v[1]), ET::pack2(v[2], v[3]));
         else {
 #pragma unroll
@@ -211,9 +196,7 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const ConvFirstArgs a) 
         }
       }
     }
-    if (++stage == NSF) stage = 0;
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // trailing no-op pieces: no LDS-DMA may outlive the workgroup
 
   if (f_stats) {
     // per-workgroup partial sums: 16 pixel lanes -> the four waves -> one row of (sum, sum of squares) per workgroup

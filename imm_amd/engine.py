@@ -669,7 +669,10 @@ class IMMEngine:
             # imm_conv_first reads the f32 image itself: the tap-unrolled copy is then only the operand of conv_1's filter gradient
             # (the end of the backward pass) and its packing leaves the head of the forward chain for the tail of the shorter lane
             co1 = encoder_spec(nf)[0][2]
-            direct = k1 == 7 and ld1 == 32 and ops.conv_first_supported(B, S, co1, ops.round_up(co1, 8))
+            # (IMM_CONV_FIRST=1: built, bit-compatible, measured NEUTRAL on the step — 26.7 us against 12 + 20 us for the two launches it
+            # takes off the chain, whose packing pass still runs at the lane's tail; DESIGN.md item 49 — so the default stays the 7x1 form)
+            direct = (os.environ.get('IMM_CONV_FIRST', '0') != '0' and k1 == 7 and ld1 == 32 and
+                      ops.conv_first_supported(B, S, co1, ops.round_up(co1, 8)))
             if direct:
                 self._deferred_packs.append(f_pack)
             else:

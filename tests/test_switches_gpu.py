@@ -1,6 +1,6 @@
 """Every IMM_* environment switch the product path still reads, exercised in both positions: the
 kernel-dispatch ablation list IMM_CONV_DISABLE (each specialised kernel family off -> the layer falls back to the next more
-general kernel, same numbers to accumulation order), IMM_NOL, IMM_TWO_STREAMS, IMM_DEBUG_STAMPS, IMM_DEBUG_SKIP_TAGS.  The switches are
+general kernel, same numbers to accumulation order), IMM_NOL, IMM_CONV_FIRST, IMM_TWO_STREAMS, IMM_DEBUG_STAMPS, IMM_DEBUG_SKIP_TAGS.  The switches are
 read once per process (static dispatch tables / engine construction), hence the child processes (tests/_switch_probe.py).
 IMM_DP_BUCKETS, IMM_RCCL_NATIVE and IMM_RCCL_GRAPH have their tests in test_dp_gpu.py / test_step_gpu.py; IMM_HIP_LIB and
 IMM_HIPCC_FLAGS (A/B builds) in test_host_cpu.py."""
@@ -55,6 +55,15 @@ def test_normalise_on_load_is_the_same_step(base):
     (imm_conv2d_nol, imm_wgrad_job.x_scale): fewer launches, the same step to accumulation order."""
     got = probe(IMM_NOL=1)
     assert got['n_launches'] <= base['n_launches'], (got['n_launches'], base['n_launches'])
+    assert same(base, got, 2e-4), (base, got)
+
+
+@pytest.mark.timeout(300)
+def test_first_convolution_from_the_image_is_the_same_step(base):
+    """IMM_CONV_FIRST=1: conv_1 of both encoders straight from the f32 image (imm_conv_first), the tap-unrolled copies packed at the
+    tail of the image-encoder lane for the filter gradients: the same step to accumulation order."""
+    got = probe(IMM_CONV_FIRST=1)
+    assert got['n_launches'] == base['n_launches']
     assert same(base, got, 2e-4), (base, got)
 
 
