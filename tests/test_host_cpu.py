@@ -153,3 +153,25 @@ def test_ab_build_switches(tmp_path, monkeypatch):
     lines = out.stdout.decode().split()
     from imm_amd import _lib as L
     assert lines[0] == other and int(lines[1]) == L.ABI_VERSION
+
+
+def test_every_entry_point_named_in_the_documents_exists():
+    """INTEGRATION.md, DESIGN.md and README.md may only name `imm_*` entry points the header declares (round 3's INTEGRATION.md still
+    listed two that had been removed).  A name passes when it is an exported symbol or a documented prefix / family form of one
+    (`imm_graph_`, `imm_upsample2x_fwd/bwd` -> `imm_upsample2x_fwd`); names of modules, files and fixtures are listed here."""
+    import re
+    hdr = open(os.path.join(ROOT, 'include', 'imm_hip.h')).read()
+    exported = set(re.findall(r'\b(imm_[a-z0-9_]+)\s*\(', hdr))
+    types = set(re.findall(r'\b(imm_[a-z0-9_]+)\b', hdr)) - exported            # enums / structs / struct fields
+    not_abi = {'imm_amd', 'imm_hip', 'imm_model', 'imm_oracle', 'imm_step_golden', 'imm_ref_cpu', 'imm_pmc_', 'imm_mi355x'}
+    bad = []
+    for doc in ('INTEGRATION.md', 'DESIGN.md', 'README.md'):
+        text = open(os.path.join(ROOT, doc)).read()
+        for name in sorted(set(re.findall(r'\bimm_[a-z0-9_]+', text))):
+            if name in exported or name in types or name in not_abi or name.rstrip('_') in not_abi:
+                continue
+            if any(e.startswith(name) for e in exported):       # family / prefix forms
+                continue
+            bad.append((doc, name))
+    assert not bad, bad
+    assert len(exported) == 88 and ('%d entry points' % len(exported)) in open(os.path.join(ROOT, 'INTEGRATION.md')).read()
