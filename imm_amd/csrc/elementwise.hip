@@ -413,7 +413,7 @@ __global__ __launch_bounds__(EW_THREADS) void bn_apply_fused_kernel(
   for (int64_t p = pf; p < p1; p += PSTEP) {
     float f[8];
     norm(p, f);
-    *(uint4*)(x + p * ldx + ch0 + q * 8) = pack8<ET>(f);
+    if (x != nullptr) *(uint4*)(x + p * ldx + ch0 + q * 8) = pack8<ET>(f);      // (nobody reads the un-sampled tensor of an up-sampled block)
     {
       // x2 bilinear up-sampling of the normalised activation in the same pass (tf.image.resize_images, legacy
       // align_corners=False, imm_model.py:175: out[2i] = in[i], out[2i+1] = (in[i] + in[min(i+1, n-1)]) / 2), from the
@@ -456,11 +456,11 @@ extern "C" int imm_bn_apply_fused(const float* partial, int nblk, int c, int64_t
                                   float eps, float momentum, int training, float* moving_mean, float* moving_var, float* scale,
                                   float* shift, float* mean, float* rstd, const void* y, int dtype, int ldy, int relu,
                                   void* x_out, int ldx, void* up2x_out, int ldu, int h, int w, void* stream) {
-  IMM_REQUIRE(gamma && beta && moving_mean && moving_var && scale && shift && mean && rstd && y && x_out, "bn_apply_fused: null");
+  IMM_REQUIRE(gamma && beta && moving_mean && moving_var && scale && shift && mean && rstd && y && (x_out || up2x_out), "bn_apply_fused: null");
   IMM_REQUIRE(!training || (partial && nblk > 0), "bn_apply_fused: training needs partial sums");
   IMM_REQUIRE(c > 0 && c % 32 == 0 && count > 0, "bn_apply_fused: C=%d must be a multiple of 32", c);
   EW_REQUIRE_VEC(c, ldy, "bn_apply_fused(y)");
-  EW_REQUIRE_VEC(c, ldx, "bn_apply_fused(x)");
+  if (x_out) EW_REQUIRE_VEC(c, ldx, "bn_apply_fused(x)");
   if (up2x_out) {
     EW_REQUIRE_VEC(c, ldu, "bn_apply_fused(up2x)");
     IMM_REQUIRE(h > 0 && w > 0 && count % ((int64_t)h * w) == 0, "bn_apply_fused: up-sampling needs the map size (h=%d w=%d)", h, w);

@@ -417,9 +417,13 @@ class IMMEngine:
                 # boundary and a 6-9 us latency chain less per layer); the renderer's x2 up-sampling rides along
                 if up2x:
                     lay.up = self._act(B, 2 * fd.ho, 2 * fd.wo, co)
+                # an up-sampled block's own normalised tensor has no reader (the next convolution and its filter gradient read the
+                # up-sampled one, the batch-norm backward reads y): only `up` is written (IMM_DEBUG_KEEP_OUT=1 keeps it for diagnosis)
+                x_w = None if (lay.up is not None and os.environ.get('IMM_DEBUG_KEEP_OUT', '0') == '0') else out
+                lay.out_stale = x_w is None          # (lay.out stays allocated but is never written)
                 self._add(self.prog_fwd, lambda: ops.bn_apply_fused(lay.stats, nblk, co, npix, gamma, beta, BN_EPS, BN_MOMENTUM,
                                                                     self._training, mm, mv, lay.scale, lay.shift, lay.mean, lay.rstd,
-                                                                    lay.y, ldy, relu, out, ldo, lay.up, co, fd.ho, fd.wo),
+                                                                    lay.y, ldy, relu, x_w, ldo, lay.up, co, fd.ho, fd.wo),
                           'bn_apply', 0.0, npix * co * (4.0 + (8.0 if lay.up is not None else 0.0)))
             elif co % 32 == 0:
                 # many partial rows: 32-row groups are summed by rows/32 workgroups in parallel, the fused apply pass finishes

@@ -212,7 +212,8 @@ int imm_bn_apply_relu(const void* y, int dtype, int64_t npix, int c, int ldy, co
  * workgroup owns a 32-channel slice x a pixel range and redoes the finalize of its slice from the rows (fixed order: the same
  * scale / shift in every workgroup), workgroup (0, slice) writes scale / shift / mean / rstd and the moving statistics.
  * up2x_out != NULL: the x2 bilinear up-sampling that follows the block in the renderer (imm_model.py:175) is written in the
- * same pass, [B, 2h, 2w] with pixel stride ldu, from the 16-bit values of x_out (bitwise = imm_upsample2x_fwd(x_out)). */
+ * same pass, [B, 2h, 2w] with pixel stride ldu, from the 16-bit values of x_out (bitwise = imm_upsample2x_fwd(x_out)); x_out may then
+ * be NULL (only the up-sampled tensor is written: the renderer's next convolution and its filter gradient read that one). */
 int imm_bn_apply_fused(const float* partial, int nblk, int c, int64_t count, const float* gamma, const float* beta, float eps,
                        float momentum, int training, float* moving_mean, float* moving_var, float* scale, float* shift,
                        float* mean, float* rstd, const void* y, int dtype, int ldy, int relu, void* x_out, int ldx,

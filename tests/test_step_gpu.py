@@ -102,9 +102,10 @@ def test_layerwise_forward_diagnostics(fwd2):
         for lays in (eng.enc_im, eng.enc_pose, eng.ren):
             for lay in lays:
                 ref = acts[lay.scope]
-                if lay.bn and lay.out is None:
-                    # normalise on load: the block's normalised output is never stored (its consumers rebuild it in LDS);
-                    # materialise it here with the stand-alone apply pass from the same scale / shift
+                if lay.bn and (lay.out is None or getattr(lay, 'out_stale', False)):
+                    # the block's normalised output is never stored (normalise on load: its consumers rebuild it in LDS; an
+                    # up-sampled renderer block: only the up-sampled tensor has readers); materialise it here with the
+                    # stand-alone apply pass from the same scale / shift
                     from imm_amd import ops as _ops
                     tmp = torch.empty_like(lay.y)
                     _ops.bn_apply_relu(lay.y, lay.npix, lay.co, lay.ldy, lay.scale, lay.shift, lay.relu, tmp, lay.ldy)
