@@ -418,8 +418,8 @@ class IMMEngine:
                 if up2x:
                     lay.up = self._act(B, 2 * fd.ho, 2 * fd.wo, co)
                 # an up-sampled block's own normalised tensor has no reader (the next convolution and its filter gradient read the
-                # up-sampled one, the batch-norm backward reads y): only `up` is written (IMM_DEBUG_KEEP_OUT=1 keeps it for diagnosis)
-                x_w = None if (lay.up is not None and os.environ.get('IMM_DEBUG_KEEP_OUT', '0') == '0') else out
+                # up-sampled one, the batch-norm backward reads y): only `up` is written
+                x_w = None if lay.up is not None else out
                 lay.out_stale = x_w is None          # (lay.out stays allocated but is never written)
                 self._add(self.prog_fwd, lambda: ops.bn_apply_fused(lay.stats, nblk, co, npix, gamma, beta, BN_EPS, BN_MOMENTUM,
                                                                     self._training, mm, mv, lay.scale, lay.shift, lay.mean, lay.rstd,
