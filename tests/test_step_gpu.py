@@ -657,3 +657,33 @@ def test_native_rccl_exchange_single_rank(monkeypatch):
         assert loss == ref[0] and torch.equal(params, ref[1]), key
     # and the two engine builds agree to rounding
     assert abs(res[(False, 1, False, False)][0] - res[(False, 2, False, False)][0]) <= 1e-5 * abs(res[(False, 1, False, False)][0])
+
+
+def test_train_loop_follows_the_device_step_when_updates_are_skipped(capsys):
+    """f16 storage with a loss scale that starts far too high: the first updates overflow and are SKIPPED on the device (weights,
+    slots and global_step untouched).  train_loop's host count follows the device's global_step, so the run ends with global_step ==
+    num_steps (more iterations than steps), checkpoints carry the saved global_step, and the loss stays finite."""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    from imm_amd.models.imm_model import IMMModel
+    from imm_amd.train import cnn_train_multi as tru
+    from imm_amd.utils.box import Box
+    model = IMMModel(Box(dict(O.default_model_config(10))), dtype=torch.float16, device=DEV, hparams={'loss_scale': 2.0 ** 22})
+    ts = tru.TrainStep(model, 2, 128, world_size=1, use_graph=True)
+    inputs = O.synthetic_inputs(2, 128, seed=0)
+    fed, saved = [0], []
+
+    def batches():
+        while True:
+            fed[0] += 1
+            yield inputs
+    tru.train_loop({'batch_size': 2, 'n_summary': 0, 'n_test': 0, 'n_checkpoint': 2}, ts, batches(), 6, log_every=1,
+                   checkpoint_fn=lambda step: saved.append((step, int(ts.engine.step_count))))
+    eng = ts.engine
+    skipped = int(eng.loss_scale_state[2])
+    assert skipped >= 1 and int(eng.step_count) == 6 and int(eng.adam_t) == 6
+    assert fed[0] == 6 + skipped                               # one extra iteration per skipped update
+    assert all(s % 2 == 0 for s, _ in saved) and saved[-1][0] == 4
+    # a checkpoint written "at step s" holds global_step s + 1 (the update of step s has been applied) or s (it was skipped)
+    assert all(dev in (s, s + 1) for s, dev in saved), saved
+    assert torch.isfinite(eng.params).all() and float(eng.loss) == float(eng.loss)

@@ -80,3 +80,34 @@ def test_missing_variables_follow_the_reference_switch(tmp_path):
     T.write_bundle(prefix, tensors)
     with pytest.raises(ValueError, match='shape'):
         T.load_tf_checkpoint(eng, prefix)
+
+
+def test_f16_loss_scale_state_travels_with_the_optimizer_slots(tmp_path):
+    """f16 storage: the dynamic loss scale S and its clean-step counter are saved as an extra (non-TensorFlow) variable and come
+    back with --restore-optim, so that a resume continues at the scale the run had reached; a restore without the
+    optimizer starts the scale afresh like the slots."""
+    from imm_amd.models.imm_model import IMMModel
+    from imm_amd.train.cnn_train_multi import TrainStep
+    from imm_amd.utils import tf_checkpoint as T
+    from imm_amd.utils.box import Box
+
+    def model(seed, ls):
+        return IMMModel(Box(dict(O.default_model_config(10))), dtype=torch.float16, device=DEV, seed=seed, hparams={'loss_scale': ls})
+    m = model(1, 2.0 ** 22)                       # far too large: the first steps overflow, S is halved, updates are skipped
+    ts = TrainStep(m, 2, 128, world_size=1, use_graph=False)
+    inputs = O.synthetic_inputs(2, 128, seed=0)
+    for _ in range(8):
+        ts.step(inputs)
+    ts.synchronize()
+    eng = m.engine
+    state = eng.loss_scale_state.tolist()
+    assert state[2] >= 1.0 and state[0] < 2.0 ** 22 and int(eng.step_count) == 8 - int(state[2]), state
+    prefix = str(tmp_path / 'model.ckpt-f16')
+    T.save_tf_checkpoint(eng, prefix)
+    assert T.LOSS_SCALE_VAR in T.list_bundle(prefix)
+    fresh = model(5, 4096.0)._get_engine(2, 128)
+    T.load_tf_checkpoint(fresh, prefix, restore_optim=True)
+    assert fresh.loss_scale_state.tolist() == state and int(fresh.step_count) == int(eng.step_count) and int(fresh.adam_t) == int(eng.adam_t)
+    other = model(6, 4096.0)._get_engine(2, 128)
+    T.load_tf_checkpoint(other, prefix, restore_optim=False)
+    assert other.loss_scale_state.tolist()[0] == 4096.0 and int(other.adam_t) == 0
