@@ -30,24 +30,44 @@ struct ConvFirstArgs {
 // chunk swizzle of 64-byte rows (4 chunks): a ds_read_b128 of 16 consecutive rows x 4 chunks is conflict-free (conv_halo.hip)
 __device__ __forceinline__ int cf_swz(int row) { return ((row >> 2) & 1) << 1; }
 
-// FULL: co == 32 (every shipped configuration) — compile-time, so that the patch loop is straight-line code and hipcc can COUNT the
-// outstanding stores at the loop's back edge instead of draining vmcnt to zero there
+// FULL: co == 32 (every shipped configuration) — compile-time: every lane then issues exactly MT*NT output stores per patch, which is
+// what makes the counted s_waitcnt of the loop exact.
+//
+// Memory pipeline (what three earlier versions of this loop taught, 33 -> 27 us for the layer against the 33 us of the two launches
+// it replaces): a patch is 3.7 KB in, 8 KB out and 28 MFMAs per wave, so the loop is a latency chain unless the halo of patch k+2
+// is in flight while patch k is computed and nobody waits for output stores.  With ordinary loads hipcc decides the waits, and it
+// drains vmcnt to zero wherever loads and stores are both outstanding (its counter model treats mixed event types as unordered) or
+// a branch sits in between.  So the halo loads are issued from inline asm (buffer_load_dword into registers the compiler does not
+// track), EXACTLY four per lane and patch (beyond the last patch: out-of-range offsets, which return zeros), into two register sets
+// that alternate, and the loop waits with a counted vmcnt: after the four loads of patch k come the stores of patch k-2 (4), the
+// loads of patch k+1 (4) and the stores of patch k-1 (4) -> vmcnt(12) (8 / 4 for the first two patches).  (A version with the
+// halo by 4-byte LDS-DMA pieces was slower, 37 us: that path wants 16-byte pieces.)
+typedef __attribute__((ext_vector_type(4))) unsigned int cf_u32x4_t;
+// asynchronous: `dst` is valid only after an s_waitcnt that covers this load AND a cf_arrived() on it (which stops the compiler from
+// reading the register any earlier)
+__device__ __forceinline__ void cf_load(float& dst, cf_u32x4_t rsrc, uint32_t voff) {
+  asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(dst) : "v"(voff), "s"(rsrc) : "memory");
+}
+__device__ __forceinline__ void cf_arrived(float& v) { asm volatile("" : "+v"(v) :: "memory"); }
+
 template <typename ET, bool FULL>
 __global__ __launch_bounds__(256) void conv_first_kernel(const ConvFirstArgs a) {
   constexpr int MT = 2, NT = 2;                      // wave w: patch rows 2w, 2w+1 x 32 channels
   constexpr int W_U4 = CF_K * CF_BN * 4;             // filter image: row = ky*32 + n, 4 chunks
   constexpr int T_U4 = CF_TR * CF_PW * 4;            // operand tile: row = pixel (r*16 + x), 4 chunks
-  constexpr int N_ELEM = CF_TR * CF_SW * 3;          // f32 values of a halo (924)
-  constexpr int N_LD = (N_ELEM + 255) / 256;         // loads per thread (4)
+  constexpr int FROW = CF_SW * 3;                    // f32 values per halo row (66): pixel-major, channels packed
+  constexpr int N_ELEM = CF_TR * FROW;               // f32 values of a halo (924)
+  constexpr int N_LD = 4;                            // loads per lane and patch (256 lanes x 4 >= 924)
+  constexpr int SROW = FROW + 6;                     // 72: 16-bit halo row pitch (the over-read of a row's last chunks stays inside)
   __shared__ __attribute__((aligned(16))) uint4 Wl[W_U4];
   __shared__ __attribute__((aligned(16))) uint4 Tl[T_U4];
-  // 16-bit halo, rows of 22 pixels x 3 channels PACKED: the unrolled channels kx*3 + c of tile pixel (r, x) are then the 21
-  // CONSECUTIVE values Sl[r][3x .. 3x+20] (channel kx*3 + c of pixel x = channel c of pixel x + kx = element 3(x+kx) + c)
-  constexpr int SROW = CF_SW * 3 + 6;               // 72: row pitch (u16), the over-read of a row's last chunks stays inside the array
+  // 16-bit halo, rows of 22 pixels x 3 channels PACKED: the unrolled channels kx*3 + c of tile pixel (r, x) are the 21 CONSECUTIVE
+  // values S[r][3x .. 3x+20] (channel kx*3 + c of pixel x = channel c of pixel x + kx = element 3(x+kx) + c)
   __shared__ __attribute__((aligned(16))) uint16_t Sl[CF_TR * SROW + 8];
   __shared__ float red[4 * 2 * CF_BN];
 
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int frow = lane & 15, fchunk = lane >> 4;
   const int S = a.s;
   const int per_img = a.patches_x * a.patches_y;
@@ -60,54 +80,41 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const ConvFirstArgs a) 
     if (n < a.co) v = *(const uint4*)(a.wt + (int64_t)n * a.kpad + tap * 32 + q * 8);
     Wl[row * 4 + (q ^ cf_swz(row))] = v;
   }
+  for (int idx = tid; idx < T_U4; idx += 256) Tl[idx] = make_uint4(0, 0, 0, 0);     // (chunk 3 of every pixel stays zero)
+  for (int idx = tid; idx < (CF_TR * SROW + 8) / 2; idx += 256) ((uint32_t*)Sl)[idx] = 0u;
+  __syncthreads();              // (the zero fill is ordered before the first patch's halo values)
 
-  // ---- halo loader: element e = r*66 + t of the [14][22][3] f32 halo, this thread's e = tid + 256 u.  Everything that does not
-  // depend on the patch is computed once (the first version recomputed divisions and gather addresses per patch and was
-  // VALU-bound: 33 us for the layer, ~3000 cycles per patch and wave) ----------------------------------------------------------
-  float pre[N_LD], pre2[N_LD];                       // the halos of the next two patches of this workgroup, in flight
+  // ---- halo loader: this lane's element u of the [14][22][3] f32 halo is e = tid + 256 u ------------------------------
   int e_r[N_LD], e_px[N_LD], e_off[N_LD], e_lds[N_LD];
 #pragma unroll
   for (int u = 0; u < N_LD; ++u) {
     const int e = tid + 256 * u;
-    const int r = e / (CF_SW * 3), t = e - r * (CF_SW * 3);
-    e_r[u] = e < N_ELEM ? r : (1 << 24);             // (never inside an image)
+    const int r = e / FROW, t = e - r * FROW;
+    e_r[u] = e < N_ELEM ? r : (1 << 24);             // (elements beyond the halo: never inside an image -> zeros)
     e_px[u] = t / 3;
-    e_off[u] = r * S * 3 + t;                         // relative to the f32 element of halo pixel (0, 0)
-    e_lds[u] = r * SROW + t;
+    e_off[u] = (r * S * 3 + t) * 4;                   // byte offset relative to the f32 element of halo pixel (0, 0)
+    e_lds[u] = e < N_ELEM ? r * SROW + t : CF_TR * SROW + (tid & 7);      // (beyond the halo: a dump slot nobody reads)
   }
-  // branch-free: buffer loads whose offset is out of range for halo elements outside the image return 0 (a conditional global
-  // load is a divergent branch per element, and hipcc then drains vmcnt to zero at the loop's back edge: every patch waited for
-  // its own output stores)
-  const __amdgpu_buffer_rsrc_t ir = __builtin_amdgcn_make_buffer_rsrc((void*)a.img, 0, (int)((int64_t)a.batch * S * S * 12), 0x00020000);
-  auto load_halo = [&](int patch, float (&dst)[N_LD]) {
+  const uint64_t ia = (uint64_t)a.img;
+  const cf_u32x4_t ir = {(uint32_t)ia, (uint32_t)(ia >> 32) & 0xffffu, (uint32_t)((int64_t)a.batch * S * S * 12), 0x00020000u};
+  float bufA[N_LD], bufB[N_LD];                      // the halos of the next two patches of this workgroup, in flight
+  auto issue_halo = [&](int patch, float (&buf)[N_LD]) __attribute__((always_inline)) {
+    const bool real = patch < a.n_patches;
     const int img = patch / per_img, pr = patch - img * per_img;
     const int y0 = (pr / a.patches_x) * CF_PH - CF_PAD, x0 = (pr % a.patches_x) * CF_PW - CF_PAD;
-    const int pbase = ((img * S + y0) * S + x0) * 3;              // f32 element of halo pixel (0, 0); may be negative
+    const int pbase = ((img * S + y0) * S + x0) * 12;             // byte offset of halo pixel (0, 0); may be negative
 #pragma unroll
     for (int u = 0; u < N_LD; ++u) {
-      const bool ok = (unsigned)(y0 + e_r[u]) < (unsigned)S && (unsigned)(x0 + e_px[u]) < (unsigned)S;
-      const uint32_t vo = ok ? (uint32_t)((pbase + e_off[u]) * 4) : 0x80000000u;
-      dst[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ir, vo, 0, 0));
+      const bool ok = real && (unsigned)(y0 + e_r[u]) < (unsigned)S && (unsigned)(x0 + e_px[u]) < (unsigned)S;
+      cf_load(buf[u], ir, ok ? (uint32_t)(pbase + e_off[u]) : 0x80000000u);
     }
   };
-  // LDS-only barrier: a __syncthreads would also drain vmcnt, i.e. wait for the previous patch's output stores and for the halo
-  // loads requested ahead — the layer is a chain of short patches (3.7 KB in, 8 KB out, 28 MFMAs per wave) and was latency-bound
-  // that way (32 us; 4 us per patch and workgroup)
-  auto lds_barrier = [&]() {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-  };
-  // operand-tile builder: this thread's chunks are (pixel (tid >> 2) + 64 u, q = tid & 3), u = 0 .. 3 (pixel < 224): source
-  // = 8 consecutive halo values from Sl[(r0 + 4u) * SROW + 3x + 8q]; q = 3 (channels 24..31) is all zero and q = 2 holds
-  // channels 16..20 + three zeros: the zero parts are written once, below
+  // operand-tile builder: this thread's chunks are (pixel (tid >> 2) + 64 u, q = tid & 3), u = 0 .. 3 (pixel < 224); source = 8
+  // consecutive 16-bit values from S[(r0 + 4u)*SROW + 3x + 8q]; q = 3 (channels 24..31) is all zero, q = 2: channels 16..20 + zeros
   const int t_q = tid & 3, t_pix0 = tid >> 2;
   const int t_src0 = (t_pix0 >> 4) * SROW + 3 * (t_pix0 & 15) + 8 * t_q;
-  for (int idx = tid; idx < T_U4; idx += 256) Tl[idx] = make_uint4(0, 0, 0, 0);
-  for (int idx = tid; idx < (CF_TR * SROW + 8) / 2; idx += 256) ((uint32_t*)Sl)[idx] = 0u;
-  __syncthreads();              // (the zero fill is ordered before the first patch's halo values)
 
   const bool f_bias = a.flags & IMM_CONV_BIAS, f_stats = a.flags & IMM_CONV_STATS;
-  constexpr bool full = FULL;                       // every lane's four channels exist: one 8-byte store per tile, no per-lane tests
   float s1[NT][4], s2[NT][4], bv[NT][4];
 #pragma unroll
   for (int j = 0; j < NT; ++j)
@@ -117,18 +124,31 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const ConvFirstArgs a) 
       const int n = j * 16 + 4 * fchunk + r;
       bv[j][r] = (f_bias && n < a.co) ? a.bias[n] : 0.f;
     }
-
-  int patch = blockIdx.x;
-  const int G = (int)gridDim.x;
-  if (patch < a.n_patches) load_halo(patch, pre);
-  if (patch + G < a.n_patches) load_halo(patch + G, pre2);
-  for (; patch < a.n_patches; patch += G) {
-    // 16-bit halo (values outside the image were loaded as zeros)
+  // everything loaded so far (filter image, bias) has ARRIVED before the loop: its waits must not land inside it
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int u = 0; u < N_LD; ++u)
-      if (e_r[u] < CF_TR) Sl[e_lds[u]] = ET::from_f32(pre[u]);
-    lds_barrier();              // halo complete; every wave is past the previous patch's reads of the operand tile
-    // operand tile: chunk q of pixel (r, x) = unrolled channels 8q .. 8q+7 = Sl[r][3x + 8q ..+7] (q = 2: five values, q = 3: none)
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(bv[j][r]));
+
+  const int G = (int)gridDim.x;
+  const int n_mine = ((int)blockIdx.x < a.n_patches) ? (a.n_patches - (int)blockIdx.x + G - 1) / G : 0;
+  issue_halo(blockIdx.x, bufA);
+  issue_halo(blockIdx.x + G, bufB);
+  // one patch: `buf` holds its halo (requested TWO patches ago) and is refilled for the patch two ahead; the two register sets alternate
+  auto do_patch = [&](const int it, float (&buf)[N_LD]) __attribute__((always_inline)) {
+    const int patch = blockIdx.x + it * G;
+    // the four loads of this patch have arrived (see the header for the counts)
+    if (!FULL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // (co < 32: the store count per patch varies — drain)
+    else if (it == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_LD) : "memory");
+    else if (it == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_LD + MT * NT) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_LD + 2 * MT * NT) : "memory");
+#pragma unroll
+    for (int u = 0; u < N_LD; ++u) cf_arrived(buf[u]);
+#pragma unroll
+    for (int u = 0; u < N_LD; ++u) Sl[e_lds[u]] = ET::from_f32(buf[u]);         // 16-bit halo (outside the image: zeros)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();            // halo complete; every wave is past the previous patch's reads of the operand tile
     if (t_q < 3) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -142,10 +162,9 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const ConvFirstArgs a) 
         }
       }
     }
-    lds_barrier();              // tile complete (also: the filter image, first patch)
-#pragma unroll
-    for (int u = 0; u < N_LD; ++u) pre[u] = pre2[u];
-    if (patch + 2 * G < a.n_patches) load_halo(patch + 2 * G, pre2);     // two patches ahead
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();            // tile complete (also: the filter image, first patch)
+    issue_halo(patch + 2 * G, buf);          // two patches ahead (out-of-range offsets beyond the last patch: the count stays exact)
 
     f32x4_t acc[MT][NT];
 #pragma unroll
@@ -188,7 +207,7 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const ConvFirstArgs a) 
           for (int r = 0; r < 4; ++r) { s1[j][r] += v[r]; s2[j][r] += v[r] * v[r]; }
         }
         uint16_t* yp = a.y + m * a.ldy + n;
-        if constexpr (full) *(uint2*)yp = make_uint2(ET::pack2(v[0], v[1]), ET::pack2(v[2], v[3]));
+        if constexpr (FULL) *(uint2*)yp = make_uint2(ET::pack2(v[0], v[1]), ET::pack2(v[2], v[3]));
         else if (n + 3 < a.co) *(uint2*)yp = make_uint2(ET::pack2(v[0], v[1]), ET::pack2(v[2], v[3]));
         else {
 #pragma unroll
@@ -196,7 +215,14 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const ConvFirstArgs a) 
         }
       }
     }
+  };
+  for (int it = 0; it < n_mine; it += 2) {
+    do_patch(it, bufA);
+    if (it + 1 < n_mine) do_patch(it + 1, bufB);
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the trailing look-ahead loads
+#pragma unroll
+  for (int u = 0; u < N_LD; ++u) { cf_arrived(bufA[u]); cf_arrived(bufB[u]); }
 
   if (f_stats) {
     // per-workgroup partial sums: 16 pixel lanes -> the four waves -> one row of (sum, sum of squares) per workgroup
