@@ -687,3 +687,46 @@ def test_train_loop_follows_the_device_step_when_updates_are_skipped(capsys):
     # a checkpoint written "at step s" holds global_step s + 1 (the update of step s has been applied) or s (it was skipped)
     assert all(dev in (s, s + 1) for s, dev in saved), saved
     assert torch.isfinite(eng.params).all() and float(eng.loss) == float(eng.loss)
+
+
+def test_filter_gradient_launches_are_chunked_by_the_table_caps(monkeypatch):
+    """imm_conv2d_wgrad_multi takes at most 64 jobs of 16 kernel variants per table: the engine issues a deeper
+    configuration's filter gradients as several multi-problem launches instead of failing at build.  Forced here with caps of 5
+    jobs / 2 variants on the ordinary model: more launches, the same gradients (other split counts: f32 sums in another order)."""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    import imm_amd.engine as E
+    cfg, model, eng, inputs, P, St = make(2)
+    monkeypatch.setattr(E, 'WGRAD_MULTI_MAX_JOBS', 5)
+    monkeypatch.setattr(E, 'WGRAD_MULTI_MAX_VARIANTS', 2)
+    _c, _m, eng2, _i, _P, _S = make(2)
+    n1 = sum(1 for l in eng.prog_bwd if l.tag == 'conv_wgrad')
+    n2 = sum(1 for l in eng2.prog_bwd if l.tag == 'conv_wgrad')
+    assert n1 == 1 and n2 >= 5, (n1, n2)
+    for e in (eng, eng2):
+        e.set_inputs(inputs['image'].to(DEV), inputs['future_image'].to(DEV), inputs['mask'].to(DEV))
+        e.forward(True); e.backward()
+    torch.cuda.synchronize()
+    assert float(eng.loss) == float(eng2.loss)
+    g1, g2 = eng.grads, eng2.grads
+    assert float((g1 - g2).norm() / g1.norm()) < 1e-5
+    for name in ('model/renderer/conv_8/w', 'model/image_encoder/encoder/conv_1/w', 'model/pose_encoder/encoder/conv_5/w'):
+        a, b = eng.gview[name], eng2.gview[name]
+        assert float((a - b).norm() / a.norm()) < 1e-4, name
+
+
+def test_train_step_argument_checks():
+    """TrainStep(collective=...): unknown names, 'graph' without graph capture, 'graph' with two buckets are refused at construction."""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    from imm_amd.train.cnn_train_multi import TrainStep
+    cfg, model, eng, inputs, P, St = make(2)
+    with pytest.raises(ValueError):
+        TrainStep(model, 2, 128, collective='ring')
+    with pytest.raises(ValueError):
+        TrainStep(model, 2, 128, use_graph=False, collective='graph')
+    cfg2, model2, eng2, _i, _P, _S = make(2, dp_buckets=2)
+    with pytest.raises(ValueError):
+        TrainStep(model2, 2, 128, split_graphs=True, collective='graph')
+    ts = TrainStep(model, 2, 128)                       # single rank, no split: no collective at all
+    assert ts.collective is None and ts.buckets == 1 and ts.native_comm is None
