@@ -110,7 +110,7 @@ template <typename ET, int BN, int NW, int PH, bool MAP8 = false, int NSB_ = 0, 
 __global__ __launch_bounds__(NW * 64) void conv_hdeep_kernel(const HdArgs ha) {
   const ConvArgs& a = ha.c;
   static_assert(!S2D || (!MAP8 && !PERSIST && NW == 4 && BN == 64), "stride-2 data gradient: 8x16 class patches x 64 channels, one tile per workgroup");
-  static_assert(!WIDE || (!S2D && !MAP8 && !PERSIST && NW == 8 && PH == 16 && BN == 128), "wide tile: 16x32 pixels x 128 channels, 8 waves");
+  static_assert(!WIDE || (!S2D && !MAP8 && !PERSIST && !ROW3 && NW == 8 && PH == 16 && BN == 128), "wide tile: 16x32 pixels x 128 channels, 8 waves");
   constexpr int NCLS = S2D ? 4 : WIDE ? 2 : 1;         // accumulator sets (parity classes / column halves)
   constexpr int C8 = WIDE ? 4 : 8;                     // 16-byte chunks per LDS pixel / filter row (K slice = 8 C8 channels)
   constexpr int HW_ = WIDE ? 34 : HD_HW;               // halo width in pixels
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(NW * 64) void conv_hdeep_kernel(const HdArgs ha) {
             if (ky < 2) read_frags(0, Hc, smem + BRING_U4 + ((ky + 1) * 3) * B_U4, ky + 1, 0);
             else read_frags(0, Hnx, smem + BRING_U4, 0, 0);           // past the last slice: landed no-op data, never used
           }
-          const int cls = S2D ? ((ky & 1) * 2 + ((j >> 1) & 1)) : WIDE ? (j & 1) : 0;     // parity class of tap (ky, kx = j >> 1) / WIDE: column half
+          const int cls = S2D ? ((ky & 1) * 2 + ((j >> 1) & 1)) : 0;     // parity class of tap (ky, kx = j >> 1)
 #pragma unroll
           for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -757,13 +757,7 @@ static void hd_launch(const HdPlan& p, const HdArgs& ha, hipStream_t s) {
   // (119 KB of LDS: one workgroup per CU — only where the grid leaves it at one per CU anyway; with more tiles than CUs the
   // 78 KB tap-at-a-time form keeps two co-resident: 32x32 128->128, 512 tiles, 14.2 vs 17.1 us)
   const bool one_wave = p.n_wg <= hd_num_cu();
-  if (p.wide) {
-    // one tile per CU or fewer: a barrier interval of a whole filter row (3 taps x 2 column halves = 96 MFMAs per wave; nine 8 KB tap
-    // stages resident: 151 KB of LDS) — the experiment of DESIGN.md §9: what capped the 16x16 tiles was the per-tap interval
-    if (one_wave) hd_launch_cfg<ET, 128, 8, 16, false, 9, false, true, false, true>(ha, s);
-    else hd_launch_cfg<ET, 128, 8, 16, false, 0, false, false, false, true>(ha, s);
-    return;
-  }
+  if (p.wide) { hd_launch_cfg<ET, 128, 8, 16, false, 0, false, false, false, true>(ha, s); return; }
   if (p.map8 && row3 && one_wave) hd_launch_cfg<ET, 64, 4, 8, true, 9, false, true>(ha, s);
   else if (p.ph == 8 && p.bn == 64 && !p.map8 && row3 && one_wave) hd_launch_cfg<ET, 64, 4, 8, false, 9, false, true>(ha, s);
   else if (p.map8) hd_launch_cfg<ET, 64, 4, 8, true>(ha, s);
