@@ -44,9 +44,6 @@ __device__ __forceinline__ void hd_dma16(u32x4_t rsrc, uint32_t lds_addr, uint32
 }
 // halo pixel -> chunk swizzle (same as conv_halo2.hip): a ds_read_b128 of 16 consecutive pixels is conflict-free
 __device__ __forceinline__ int hd_swz(int hx) { return ((hx >> 1) & 3) << 1; }
-// ... for 128-byte pixels (8 chunks) resp. 64-byte pixels / rows (4 chunks: conv_halo.hip's swizzle, as a function of the column — a
-// row of 34 such pixels is 2176 B = 8 x 256 B + 128 B, a constant shift of the bank pattern per row)
-template <int C8> __device__ __forceinline__ int hd_aswz(int hx) { return C8 == 8 ? hd_swz(hx) : (((hx >> 2) & 1) << 1); }
 // Filter stage in LDS: row = output channel of the BN block (128 B = 8 chunks), chunk XOR-swizzled by hd_bswz.  The MFMA
 // B-operand row rho of tile j is NOT channel 16j + rho but channel (rho>>2)*4NT + 4j + (rho&3) of the wave's TN = 16 NT
 // channels: then a lane (which holds D rows 4q..4q+3 of every tile) owns 4NT CONSECUTIVE channels of its pixel — 16-byte
@@ -96,25 +93,11 @@ __device__ __forceinline__ float hd_row_sum16(float x) {
 // (min(ky', 1), min(kx', 1)): dy[i - (ky >> 1)][j - (kx >> 1)] with ky = 2 - ky'.  Nine taps of matrix work per tile — the
 // algorithmic count; the im2col forms it replaces ran four launches' worth of gathers at 1-7 % matrix duty with 6-39 VALU
 // instructions per MFMA (profiles/r03_v3_pmc_sq_ratios.txt).  The epilogue scatters class (py, px) to pixel (2i+py, 2j+px).
-//
-// WIDE (round 4): what bounds the 16x16x128 tile on the VGG layers is the L2 -> LDS DMA path, not the matrix pipe (DESIGN.md §9:
-// 4.6 GB per step at 5.7 TB/s; 204 FLOP per DMA byte, 78 % of the bytes are filter taps re-fetched by every tile).  The WIDE tile is
-// 16 x 32 pixels x 128 channels on 32-CHANNEL K slices: halo stage 18 x 34 pixels x 64 B = 39 KB, tap stage 128 rows x 64 B = 8 KB,
-// 340 FLOP per DMA byte.  It re-uses this kernel's pipeline unchanged by re-reading its two K-steps per tap as the two 16-column
-// HALVES of the patch (one K-step of 32 channels per tap): fragment set / MFMA group 0 = columns 0-15, group 1 = columns 16-31, two
-// accumulator sets; the filter fragments are read per half (same LDS bytes per MFMA as before).  LDS images have 4 chunks per pixel /
-// filter row (conv_halo.hip's 64-byte swizzle), the filter rows map to MFMA rows plainly (8-byte stores in a simple epilogue: bias,
-// ReLU, ReLU-backward mask — the VGG forward layers and their untapped data gradients).
-template <typename ET, int BN, int NW, int PH, bool MAP8 = false, int NSB_ = 0, bool PERSIST = false, bool ROW3 = false, bool S2D = false,
-          bool WIDE = false>
+template <typename ET, int BN, int NW, int PH, bool MAP8 = false, int NSB_ = 0, bool PERSIST = false, bool ROW3 = false, bool S2D = false>
 __global__ __launch_bounds__(NW * 64) void conv_hdeep_kernel(const HdArgs ha) {
   const ConvArgs& a = ha.c;
   static_assert(!S2D || (!MAP8 && !PERSIST && NW == 4 && BN == 64), "stride-2 data gradient: 8x16 class patches x 64 channels, one tile per workgroup");
-  static_assert(!WIDE || (!S2D && !MAP8 && !PERSIST && !ROW3 && NW == 8 && PH == 16 && BN == 128), "wide tile: 16x32 pixels x 128 channels, 8 waves");
-  constexpr int NCLS = S2D ? 4 : WIDE ? 2 : 1;         // accumulator sets (parity classes / column halves)
-  constexpr int C8 = WIDE ? 4 : 8;                     // 16-byte chunks per LDS pixel / filter row (K slice = 8 C8 channels)
-  constexpr int HW_ = WIDE ? 34 : HD_HW;               // halo width in pixels
-  constexpr int PXI = 64 / C8;                         // pixels (rows) per 1-KB DMA instruction
+  constexpr int NCLS = S2D ? 4 : 1;                    // accumulator sets (parity classes)
   static_assert((NW == 8 && PH == 16) || (NW == 4 && PH == 8), "wave (wm, wn) owns patch rows 4wm..4wm+3 x BN/2 channels");
   static_assert(!MAP8 || NW == 4, "two 8x8 images per 4-wave workgroup");
   static_assert(!(PERSIST && MAP8), "persistent tiles: 16x16 / 8x16 patches only");
@@ -122,13 +105,13 @@ __global__ __launch_bounds__(NW * 64) void conv_hdeep_kernel(const HdArgs ha) {
   constexpr int HD_NSB = NSB_ ? NSB_ : MAP8 ? 3 : 4;   // filter-slice ring depth (MAP8: 3 keeps two workgroups per CU)
   constexpr int NPIECE = MAP8 ? 7 : 6;                 // halo DMA pieces per wave and slice
   constexpr int TN = BN / 2, MT = 4, NT = TN / 16;
-  constexpr int B_I = BN / (PXI * NW);                 // filter DMA instructions per wave and tap (BN rows / rows per instruction / NW waves)
-  constexpr int SLOTS = MAP8 ? 200 : (PH + 2) * HW_;   // halo pixels
-  constexpr int HINSTR = (SLOTS + PXI - 1) / PXI, HSTAGE = HINSTR * 64;
+  constexpr int B_I = BN / (8 * NW);                   // filter DMA instructions per wave and tap (BN rows / 8 / NW waves)
+  constexpr int SLOTS = MAP8 ? 200 : HD_SLOTS(PH);     // halo pixels
+  constexpr int HINSTR = (SLOTS + 7) / 8, HSTAGE = HINSTR * 64;
   static_assert(B_I >= 1 && NPIECE * NW >= HINSTR && (ROW3 || NPIECE <= 11 - HD_NSB), "halo pieces per wave cover the halo and land in time");
   // fragment row strides (uint4 units): output tile row i, vertical tap ky
-  constexpr int STEP_I = MAP8 ? 160 : HW_ * C8, STEP_KY = MAP8 ? 80 : HW_ * C8;
-  constexpr int B_U4 = BN * C8;                        // uint4 per filter stage
+  constexpr int STEP_I = MAP8 ? 160 : (HD_HW * 128) / 16, STEP_KY = MAP8 ? 80 : (HD_HW * 128) / 16;
+  constexpr int B_U4 = BN * 8;                         // uint4 per filter stage
   constexpr int WN_STEADY = (HD_NSB - 2) * (B_I + 1);  // outstanding VMEM allowed at the top of a tap (see header)
   extern __shared__ __attribute__((aligned(16))) uint4 smem[];   // [2][HSTAGE] halo | [64] dump | [HD_NSB][B_U4] filter
   constexpr int DUMP_U4 = 2 * HSTAGE, BRING_U4 = DUMP_U4 + 64;
@@ -161,37 +144,36 @@ __global__ __launch_bounds__(NW * 64) void conv_hdeep_kernel(const HdArgs ha) {
     // MAP8: `patch` is a pair of images (2*patch, 2*patch + 1), origin (0, 0)
     img = MAP8 ? 2 * patch : patch / per_img;
     const int pr = MAP8 ? 0 : patch - img * per_img;
-    y0 = MAP8 ? 0 : (pr / ha.patches_x) * PH; x0 = MAP8 ? 0 : (pr % ha.patches_x) * (WIDE ? 2 * HD_PW : HD_PW);
+    y0 = MAP8 ? 0 : (pr / ha.patches_x) * PH; x0 = MAP8 ? 0 : (pr % ha.patches_x) * HD_PW;
     n0 = nblk * BN;
   };
   auto halo_offsets = [&](int img, int y0, int x0) {
 #pragma unroll
     for (int k = 0; k < NPIECE; ++k) {
-      const int hp = (wid + NW * k) * PXI + lane / C8;
+      const int hp = (wid + NW * k) * 8 + (lane >> 3);
       int hy, hx, il = 0;                                // halo row / column (, image of the pair)
       if (MAP8) { il = hp / 100; const int rr = hp - il * 100; hy = rr / 10; hx = rr - hy * 10; }
-      else { hy = hp / HW_; hx = hp - hy * HW_; }
+      else { hy = hp / HD_HW; hx = hp - hy * HD_HW; }
       const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
       const bool ok = hp < SLOTS && (unsigned)iy < (unsigned)a.hi && (unsigned)ix < (unsigned)a.wi && (!MAP8 || img + il < ha.n_img);
-      h_voff[k] = ok ? (uint32_t)(((il * a.hi + iy) * a.wi + ix) * a.ldx * 2 + (((lane & (C8 - 1)) ^ hd_aswz<C8>(hx)) * 16)) : HD_OOB;
+      h_voff[k] = ok ? (uint32_t)(((il * a.hi + iy) * a.wi + ix) * a.ldx * 2 + (((lane & 7) ^ hd_swz(hx)) * 16)) : HD_OOB;
     }
     h_soff = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(img * a.hi * a.wi) * (uint32_t)(a.ldx * 2)));
   };
   auto filter_offsets = [&](int n0, uint32_t (&bv)[B_I]) {
 #pragma unroll
     for (int j = 0; j < B_I; ++j) {
-      const int r = (wid * B_I + j) * PXI + lane / C8;
-      const int bsw = WIDE ? hd_aswz<4>(r) : hd_bswz<NT>(r);
-      bv[j] = (n0 + r < a.co) ? (uint32_t)((n0 + r) * a.kpad * 2 + (((lane & (C8 - 1)) ^ bsw) * 16)) : HD_OOB;
+      const int r = (wid * B_I + j) * 8 + (lane >> 3);
+      bv[j] = (n0 + r < a.co) ? (uint32_t)((n0 + r) * a.kpad * 2 + (((lane & 7) ^ hd_bswz<NT>(r)) * 16)) : HD_OOB;
     }
   };
-  const int ncc = WIDE ? (a.ci8 >> 2) : (a.ci8 >> 3);  // 64-channel (WIDE: 32-channel) K slices
+  const int ncc = a.ci8 >> 3;                          // 64-channel slices
   const int T = ncc * 9;                               // taps per tile
   // filter tap t (< T) of the loader's tile -> ring stage; real = false: a no-op piece that keeps the per-tap DMA count exact
   auto issue_b = [&](int t, int stage, bool real) {
     // tap t = slice cc, tap index tp: filter columns [tp*ci + cc*64, +64) of Wt[n][kpad]
     const int cc = t / 9, tp = t - cc * 9;
-    const uint32_t soff = (uint32_t)((tp * (a.ci8 << 3) + cc * (8 * C8)) * 2);
+    const uint32_t soff = (uint32_t)((tp * (a.ci8 << 3) + cc * 64) * 2);
 #pragma unroll
     for (int j = 0; j < B_I; ++j)
       hd_dma16(wr, lds_base + (uint32_t)((BRING_U4 + stage * B_U4 + (wid * B_I + j) * 64) * 16), real ? b_voff[j] : HD_OOB, soff);
@@ -201,7 +183,7 @@ __global__ __launch_bounds__(NW * 64) void conv_hdeep_kernel(const HdArgs ha) {
     const int i = wid + NW * k;
     const bool exists = real && i < HINSTR;
     const uint32_t dst = exists ? (uint32_t)((hs * HSTAGE + i * 64) * 16) : (uint32_t)(DUMP_U4 * 16);
-    hd_dma16(xr, lds_base + dst, exists ? h_voff[k < NPIECE ? k : 0] : HD_OOB, h_soff + (uint32_t)(cc * (16 * C8)));
+    hd_dma16(xr, lds_base + dst, exists ? h_voff[k < NPIECE ? k : 0] : HD_OOB, h_soff + (uint32_t)(cc * 128));
   };
 
   const int G = PERSIST ? (int)gridDim.x : 1;
@@ -223,8 +205,7 @@ __global__ __launch_bounds__(NW * 64) void conv_hdeep_kernel(const HdArgs ha) {
   auto load_bias = [&](int n0_) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-      // (WIDE: plain row mapping — the lane's four channels of tile j are j*16 + 4q .. +3)
-      const float4 b4 = f_bias ? *(const float4*)(a.bias + n0_ + wn * TN + (WIDE ? j * 16 + q * 4 : q * (4 * NT) + j * 4)) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 b4 = f_bias ? *(const float4*)(a.bias + n0_ + wn * TN + q * (4 * NT) + j * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
       bias4[j] = f32x4_t{b4.x, b4.y, b4.z, b4.w};
     }
   };
@@ -243,14 +224,13 @@ __global__ __launch_bounds__(NW * 64) void conv_hdeep_kernel(const HdArgs ha) {
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
       if (MAP8) aoff[kx] = (wm * 100 + (frow >> 3) * 10 + (frow & 7) + kx) * 8 + (q ^ hd_swz((frow & 7) + kx));
-      else aoff[kx] = (wm * 4 * HW_ + frow + kx) * C8 + (q ^ hd_aswz<C8>(frow + kx));
+      else aoff[kx] = (wm * 4 * HD_HW + frow + kx) * 8 + (q ^ hd_swz(frow + kx));
     }
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
-        boff[j][ks] = WIDE ? (wn * TN + j * 16 + frow) * 4 + (q ^ hd_aswz<4>(wn * TN + j * 16 + frow))
-                           : hd_bidx<NT>(wn * TN + (frow >> 2) * (4 * NT) + j * 4 + (frow & 3), ks * 4 + q);
+        boff[j][ks] = hd_bidx<NT>(wn * TN + (frow >> 2) * (4 * NT) + j * 4 + (frow & 3), ks * 4 + q);
   };
   frag_offsets();
 
@@ -270,7 +250,7 @@ __global__ __launch_bounds__(NW * 64) void conv_hdeep_kernel(const HdArgs ha) {
   auto read_frags = [&](const int ks, const uint4* Hs, const uint4* Bs, const int ky_, const int kx_) __attribute__((always_inline)) {
     const int ky = S2D ? (ky_ > 0 ? 1 : 0) : ky_, kx = S2D ? (kx_ > 0 ? 1 : 0) : kx_;   // S2D: halo offset min(k', 1), see the header
 #pragma unroll
-    for (int i = 0; i < MT; ++i) af[ks][i] = Hs[(WIDE ? aoff[kx] + ks * (HD_PW * 4) : (aoff[kx] ^ (ks * 4))) + i * STEP_I + ky * STEP_KY];
+    for (int i = 0; i < MT; ++i) af[ks][i] = Hs[(aoff[kx] ^ (ks * 4)) + i * STEP_I + ky * STEP_KY];
 #pragma unroll
     for (int j = 0; j < NT; ++j) bf[ks][j] = Bs[boff[j][ks]];
   };
@@ -364,7 +344,6 @@ __global__ __launch_bounds__(NW * 64) void conv_hdeep_kernel(const HdArgs ha) {
       __builtin_amdgcn_sched_barrier(0);
       read_frags(1, Hc, Bc, ky, kx);
       const int cls = S2D ? ((ky & 1) * 2 + (kx & 1)) : 0;                                 // parity class of this tap
-      const int cls1 = WIDE ? 1 : cls;                                                     // (WIDE: "K-step" 1 = the right column half)
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -393,7 +372,7 @@ __global__ __launch_bounds__(NW * 64) void conv_hdeep_kernel(const HdArgs ha) {
       // time) rides in their shadow; the second quarter covers the halo piece, the rest the next tap's fragment reads.
       constexpr int QM = MT * NT / 4;
 #pragma unroll
-      for (int m = 0; m < QM; ++m) acc[cls1][m % MT][m / MT] = ET::mfma(bf[1][m / MT], af[1][m % MT], acc[cls1][m % MT][m / MT]);
+      for (int m = 0; m < QM; ++m) acc[cls][m % MT][m / MT] = ET::mfma(bf[1][m / MT], af[1][m % MT], acc[cls][m % MT][m / MT]);
       __builtin_amdgcn_sched_barrier(0);
       if (PERSIST && tp == 9 - HD_NSB && !next_slice && have_next) {          // t + NSB == T: the ring runs on into the next tile
 #pragma unroll
@@ -403,13 +382,13 @@ __global__ __launch_bounds__(NW * 64) void conv_hdeep_kernel(const HdArgs ha) {
       else issue_b(t + HD_NSB - T, bs, have_next);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int m = QM; m < 2 * QM; ++m) acc[cls1][m % MT][m / MT] = ET::mfma(bf[1][m / MT], af[1][m % MT], acc[cls1][m % MT][m / MT]);
+      for (int m = QM; m < 2 * QM; ++m) acc[cls][m % MT][m / MT] = ET::mfma(bf[1][m / MT], af[1][m % MT], acc[cls][m % MT][m / MT]);
       __builtin_amdgcn_sched_barrier(0);
       issue_halo_piece(next_slice ? cc + 1 : 0, hs_next, tp, (next_slice || have_next) && tp < NPIECE);   // ... and so does the halo
       // (k-step 0 of the next tap; not across a tile boundary: 32 fragment registers would stay live through the epilogue)
       if (!(PERSIST && tp == 8 && !next_slice)) read_frags(0, Hn, Bn, ntp / 3, ntp % 3);
 #pragma unroll
-      for (int m = 2 * QM; m < MT * NT; ++m) acc[cls1][m % MT][m / MT] = ET::mfma(bf[1][m / MT], af[1][m % MT], acc[cls1][m % MT][m / MT]);
+      for (int m = 2 * QM; m < MT * NT; ++m) acc[cls][m % MT][m / MT] = ET::mfma(bf[1][m / MT], af[1][m % MT], acc[cls][m % MT][m / MT]);
 #pragma unroll
       for (int m = 0; m < 2 * QM; ++m) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -456,34 +435,7 @@ __global__ __launch_bounds__(NW * 64) void conv_hdeep_kernel(const HdArgs ha) {
   typedef short s16x2_t __attribute__((ext_vector_type(2)));
   typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
   const s16x2_t zero2 = {0, 0}, one2 = {1, 1};
-  if constexpr (WIDE) {
-    // ---- wide tile: accumulator set c = columns 16c .. 16c+15; lane = pixel (row wm*4 + i, column 16c + frow), channels j*16 + 4q .. +3 ----
-    const bool f_relu_w = a.flags & IMM_CONV_RELU, f_mask_w = a.flags & IMM_CONV_MASK;
-    const s16x2_t zero2w = {0, 0}, one2w = {1, 1};
-#pragma unroll
-    for (int c = 0; c < NCLS; ++c)
-#pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        const int64_t m = ((int64_t)img * a.ho + y0 + wm * 4 + i) * a.wo + x0 + 16 * c + frow;
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          const int n = n0 + wn * TN + j * 16 + 4 * q;
-          uint32_t w0 = ET::pack2(acc[c][i][j][0], acc[c][i][j][1]), w1 = ET::pack2(acc[c][i][j][2], acc[c][i][j][3]);
-          if (f_relu_w) {
-            w0 = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2_t, w0), zero2w));
-            w1 = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2_t, w1), zero2w));
-          }
-          if (f_mask_w) {
-            const uint2 mk = *(const uint2*)(a.mask + m * a.ldmask + n);
-            const s16x2_t p0 = __builtin_elementwise_min(__builtin_elementwise_max(__builtin_bit_cast(s16x2_t, mk.x), zero2w), one2w);
-            const s16x2_t p1 = __builtin_elementwise_min(__builtin_elementwise_max(__builtin_bit_cast(s16x2_t, mk.y), zero2w), one2w);
-            w0 = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2_t, w0) * __builtin_bit_cast(u16x2_t, p0));
-            w1 = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2_t, w1) * __builtin_bit_cast(u16x2_t, p1));
-          }
-          *(uint2*)((uint16_t*)a.y + m * a.ldy + n) = make_uint2(w0, w1);
-        }
-      }
-  } else if constexpr (S2D) {
+  if constexpr (S2D) {
     // ---- stride-2 data gradient: class (py, px) of tile pixel (row wm*4 + i, col frow) -> dx pixel (2 row + py, 2 col + px) ----
     const int W2 = 2 * a.wo;
 #pragma unroll
@@ -672,28 +624,16 @@ static int hd_num_cu() {
 //   16 x 16 x 64 when THAT does;
 //   else 8 x 16 x 64 (4 waves, two workgroups per CU) when the map height allows — the small-grid layers (16x16 maps of
 //   a 32-image batch: 32 patches) otherwise leave half the chip idle.
-struct HdPlan { int ph, bn, n_patches, n_wg; bool map8, persist, row3, wide; };
+struct HdPlan { int ph, bn, n_patches, n_wg; bool map8, persist, row3; };
 
-static HdPlan hd_plan(const imm_conv_desc* d, bool allow_wide = true) {
+static HdPlan hd_plan(const imm_conv_desc* d) {
   constexpr bool no_small = false;
   const int cus = hd_num_cu();
   constexpr int small_below = 2;   // x CUs (round 3: 4 -> 2.  128 -> 64 channels at 64x64 maps, batch 32 — renderer conv_5, VGG conv2_1's data
                                    // gradient — as 512 tiles of 16x16x64 (8 waves) instead of 1024 of 8x16x64: -12 us per step, same box)
   constexpr bool no_big = false;
   HdPlan p;
-  p.map8 = false; p.persist = false; p.row3 = false; p.wide = false;
-  // The wide tile (16 x 32 pixels x 128 channels on 32-channel K slices, 340 instead of 204 FLOP per L2 -> LDS byte) where its
-  // epilogue serves the launch (bias / ReLU / ReLU-backward mask) and its grid gives every CU a tile: the 64x64 and 32x32 maps of the
-  // VGG16 forward pass at 2 x 32 images and conv2_2's data gradient
-  {
-    static const bool wide_off = imm_conv_disabled("wide");
-    const int npw = (d->ho % 16 == 0 && d->wo % 32 == 0) ? d->batch * (d->ho / 16) * (d->wo / 32) : 0;
-    const bool epi_ok = !(d->flags & ~(IMM_CONV_BIAS | IMM_CONV_RELU | IMM_CONV_MASK));
-    if (allow_wide && !wide_off && npw > 0 && d->co % 128 == 0 && epi_ok && npw * (d->co / 128) >= cus) {
-      p.ph = 16; p.bn = 128; p.wide = true; p.n_patches = npw; p.n_wg = npw * (d->co / 128);
-      return p;
-    }
-  }
+  p.map8 = false; p.persist = false; p.row3 = false;
   if (d->ho == 8 && d->wo == 8) {                      // two whole 8x8 images per (4-wave) workgroup
     p.ph = 8; p.bn = 64; p.map8 = true;
     p.n_patches = (d->batch + 1) / 2;
@@ -737,18 +677,17 @@ bool imm_hdeep_applicable(const imm_conv_desc* d) {
 
 int imm_hdeep_stats_blocks(const imm_conv_desc* d) { return hd_plan(d).n_patches; }
 
-template <typename ET, int BN, int NW, int PH, bool MAP8 = false, int NSB_ = 0, bool PERSIST = false, bool ROW3 = false, bool S2D = false,
-          bool WIDE = false>
+template <typename ET, int BN, int NW, int PH, bool MAP8 = false, int NSB_ = 0, bool PERSIST = false, bool ROW3 = false, bool S2D = false>
 static void hd_launch_cfg(const HdArgs& ha, hipStream_t s) {
-  constexpr int hstage = WIDE ? ((PH + 2) * 34 + 15) / 16 * 64 : MAP8 ? 25 * 64 : HD_HSTAGE(PH), nsb = NSB_ ? NSB_ : MAP8 ? 3 : 4;
-  constexpr int lds = (2 * hstage + 64 + nsb * BN * (WIDE ? 4 : 8)) * 16 + (PERSIST ? NW * BN * 4 : 0);   // + [NW/2][2][BN] f32 stats scratch
+  constexpr int hstage = MAP8 ? 25 * 64 : HD_HSTAGE(PH), nsb = NSB_ ? NSB_ : MAP8 ? 3 : 4;
+  constexpr int lds = (2 * hstage + 64 + nsb * BN * 8) * 16 + (PERSIST ? NW * BN * 4 : 0);   // + [NW/2][2][BN] f32 stats scratch
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)conv_hdeep_kernel<ET, BN, NW, PH, MAP8, NSB_, PERSIST, ROW3, S2D, WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)conv_hdeep_kernel<ET, BN, NW, PH, MAP8, NSB_, PERSIST, ROW3, S2D>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
   const int grid = PERSIST ? (ha.n_wg < hd_num_cu() ? ha.n_wg : hd_num_cu()) : ha.n_wg;
-  hipLaunchKernelGGL((conv_hdeep_kernel<ET, BN, NW, PH, MAP8, NSB_, PERSIST, ROW3, S2D, WIDE>), dim3(grid), dim3(NW * 64), lds, s, ha);
+  hipLaunchKernelGGL((conv_hdeep_kernel<ET, BN, NW, PH, MAP8, NSB_, PERSIST, ROW3, S2D>), dim3(grid), dim3(NW * 64), lds, s, ha);
 }
 
 template <typename ET>
@@ -757,7 +696,6 @@ static void hd_launch(const HdPlan& p, const HdArgs& ha, hipStream_t s) {
   // (119 KB of LDS: one workgroup per CU — only where the grid leaves it at one per CU anyway; with more tiles than CUs the
   // 78 KB tap-at-a-time form keeps two co-resident: 32x32 128->128, 512 tiles, 14.2 vs 17.1 us)
   const bool one_wave = p.n_wg <= hd_num_cu();
-  if (p.wide) { hd_launch_cfg<ET, 128, 8, 16, false, 0, false, false, false, true>(ha, s); return; }
   if (p.map8 && row3 && one_wave) hd_launch_cfg<ET, 64, 4, 8, true, 9, false, true>(ha, s);
   else if (p.ph == 8 && p.bn == 64 && !p.map8 && row3 && one_wave) hd_launch_cfg<ET, 64, 4, 8, false, 9, false, true>(ha, s);
   else if (p.map8) hd_launch_cfg<ET, 64, 4, 8, true>(ha, s);
@@ -792,8 +730,8 @@ void imm_conv_hdeep_launch(int dtype, const imm_conv_desc* d, const ConvArgs& a,
     atexit(hd_prof_dump);
   }
   ha.prof = prof ? hd_prof_buf : nullptr;
-  const HdPlan p = hd_plan(d, !(a.flags & IMM_CONV_TAP_));      // (the perceptual-tap epilogue lives in the 16x16 tiles)
-  ha.patches_x = p.map8 ? 1 : d->wo / (p.wide ? 2 * HD_PW : HD_PW); ha.patches_y = p.map8 ? 1 : d->ho / p.ph;
+  const HdPlan p = hd_plan(d);
+  ha.patches_x = p.map8 ? 1 : d->wo / HD_PW; ha.patches_y = p.map8 ? 1 : d->ho / p.ph;
   ha.n_img = d->batch;
   ha.n_patches = p.n_patches;
   ha.c.n_nblk = d->co / p.bn;

@@ -238,38 +238,6 @@ def test_conv_dgrad_stride2_parity_classes(ops, H, ci, co, dt):
     close(dx, gx, 1e-2, 2e-3, 'dgrad_s2_classes')       # every pixel written exactly once (no NaN left)
 
 
-WIDE_CASES = [
-    # B, H, ci, co, mask, tag        (conv_hdeep's 16x32-pixel x 128-channel tile on 32-channel K slices: >= one tile per CU)
-    (64, 32, 256, 256, False, 'vgg_conv3_2_fwd_256_tiles'),
-    (64, 64, 64, 128, False, 'vgg_conv2_1_fwd_two_rounds_two_slices'),
-    (32, 64, 128, 128, True, 'vgg_conv2_2_dgrad_shape_with_relu_mask'),
-    (33, 64, 64, 128, True, 'ragged_tile_count_mask'),
-]
-
-
-@pytest.mark.parametrize('case', WIDE_CASES, ids=[c[-1] for c in WIDE_CASES])
-@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16], ids=['bf16', 'f16'])
-def test_conv_wide_tile(ops, case, dt):
-    """The wide tile of conv_hdeep.hip (what the VGG16 forward layers at 64x64 / 32x32 and conv2_2's data gradient run on at the
-    benchmark batch): bias + ReLU, resp. the ReLU-backward mask, against the oracle convolution — and against the 16x16 tiles
-    (the same launch with the wide tile taken out of the dispatch would need another process: compared here through the oracle)."""
-    from imm_amd import _lib as L
-    B, H, ci, co, with_mask, _tag = case
-    x = rnd((B, H, H, ci), 31, 1.0, dt)
-    w = rnd((3, 3, ci, co), 32, 0.03, dt)
-    if with_mask:
-        mref = rnd((B, H, H, co), 33, 1.0, dt).to(DEV).contiguous()
-        y, _st, _d = run_conv(ops, x, w, None, 3, 1, co, ci, False, extra_flags=L.CONV_MASK, mask=mref)
-        ref = O.conv2d_same(x.float(), w.float(), None, 1) * (mref.float().cpu() > 0)
-        close(y, ref, 1e-2 if dt == torch.bfloat16 else 2e-3, 2e-3, 'wide tile, masked')
-        assert float(y.float()[mref.float() <= 0].abs().max()) == 0.0
-    else:
-        bias = rnd((co,), 34, 0.3, torch.float32).float()
-        y, _st, _d = run_conv(ops, x, w, bias, 3, 1, co, ci, False, extra_flags=L.CONV_RELU)
-        ref = torch.relu(O.conv2d_same(x.float(), w.float(), bias, 1))
-        close(y, ref, 1e-2 if dt == torch.bfloat16 else 2e-3, 2e-3, 'wide tile, bias + relu')
-
-
 NOL_CASES = [
     # B, H, ci, co, stride, out_f32, tag           (the shapes whose input is a batch-norm output: encoder conv_2/3/4, renderer conv_6/8)
     (2, 128, 32, 32, 1, False, 'enc_conv2_32_32'),

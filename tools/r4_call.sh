@@ -9,7 +9,6 @@ for st in "$@"; do
   case $st in
     s2d)  timeout 300 python -m pytest tests/test_kernels_gpu.py -q -x -k "stride2" > $out/s2d.log 2>&1 ;;
     newtests) timeout 600 python -m pytest tests/test_tf_checkpoint_gpu.py tests/test_step_gpu.py -q -k "loss_scale_state or follows_the_device" > $out/newtests.log 2>&1 ;;
-    wide) timeout 600 python -m pytest tests/test_kernels_gpu.py -q -k "wide_tile or conv_forward or conv_dgrad" > $out/wide.log 2>&1 ;;
     first) timeout 300 python -m pytest tests/test_kernels_gpu.py -q -k "first_conv" > $out/first.log 2>&1 ;;
     nol)  timeout 400 python -m pytest tests/test_kernels_gpu.py -q -k "nol or norm_on_load" > $out/nol.log 2>&1 ;;
     kern) timeout 600 python -m pytest tests/test_kernels_gpu.py -q > $out/kern.log 2>&1 ;;
