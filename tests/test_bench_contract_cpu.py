@@ -19,7 +19,7 @@ def test_bench_line_has_the_contract_keys():
               'data', 'config', 'roofline', 'cpu_baseline'):
         assert k in d, (k, path)
     base = json.load(open(os.path.join(ROOT, 'BASELINE.json')))
-    assert d['metric'] in base['metric'] and d['unit'] == 'images/s' and d['higher_is_better'] is True and d['scaling'] == 'weak'
+    assert d['metric'] in base['metric'].replace('\u00d7', 'x') and d['unit'] == 'images/s' and d['higher_is_better'] is True and d['scaling'] == 'weak'
     assert d['vs_baseline'] is None and base['published'] == {}              # no published number for this metric
     assert d['dtype'] == 'bf16' and d['data'] == 'synthetic' and 'workload' in d['config'] and 'model' not in d['config']
     assert abs(d['value'] - d['config']['global_batch'] / d['ms_per_step'] * 1e3) <= 1e-3 * d['value']
