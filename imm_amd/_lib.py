@@ -20,7 +20,7 @@ CONV_BIAS, CONV_RELU, CONV_STATS, CONV_MASK, CONV_OUT_F32 = 1, 2, 4, 8, 16
 SSE_BLOCKS = 512
 OPTIMIZERS = {'adam': 0, 'adadelta': 1, 'adagrad': 2}      # IMM_OPT_* (scripts/train.py:97-104)
 GAUSS_MODES = {'rot': 0, 'flat': 1, 'ankush': 2}     # IMM_GAUSS_* (config key gauss_mode, imm_model.py:48-72)
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 
 class ImmHipError(RuntimeError):
@@ -60,6 +60,7 @@ _SIGS = {
     'imm_wgrad_reduce_multi': [_P, _P, _I, _I, _P],
     'imm_conv2d': [C.POINTER(ConvDesc), _I, _P, _P, _P, _P, _P, _P, _P],
     'imm_conv_stats_blocks': [C.POINTER(ConvDesc)],
+    'imm_conv2d_variant': [C.POINTER(ConvDesc), _I],
     'imm_conv2d_tap_supported': [C.POINTER(ConvDesc)],
     'imm_conv2d_tap': [C.POINTER(ConvDesc), _I, _P, _P, _P, _P, _P, _I, _P, _I, _P, _I, _I, _P],
     'imm_conv2d_wgrad': [C.POINTER(ConvDesc), _I, _P, _P, _I, _P, _I, _P],

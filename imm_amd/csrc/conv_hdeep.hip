@@ -677,6 +677,18 @@ bool imm_hdeep_applicable(const imm_conv_desc* d) {
 
 int imm_hdeep_stats_blocks(const imm_conv_desc* d) { return hd_plan(d).n_patches; }
 
+static bool hd_takes_hdeep6(const imm_conv_desc* d, const HdPlan& p);
+// imm_conv2d_variant: 6 * 100000 + persist for the six-k-steps-per-barrier kernel (conv_hdeep6.hip), else
+// 5 * 100000 + map8 * 40000 + row-at-a-time * 20000 + persistent * 10000 + channel block * 10 + waves
+int imm_hdeep_variant(const imm_conv_desc* d) {
+  const HdPlan p = hd_plan(d);
+  if (hd_takes_hdeep6(d, p)) return 600000 + (p.persist ? 1 : 0);
+  const bool one_wave = p.n_wg <= hd_num_cu();
+  const bool row3 = (p.map8 && one_wave) || (p.ph == 8 && p.bn == 64 && !p.map8 && one_wave) || (p.ph == 16 && p.bn == 64 && p.row3);
+  const bool persist = !row3 && !p.map8 && p.ph == 16 && p.persist;
+  return 500000 + (p.map8 ? 40000 : 0) + (row3 ? 20000 : 0) + (persist ? 10000 : 0) + p.bn * 10 + (p.ph == 16 ? 8 : 4);
+}
+
 template <typename ET, int BN, int NW, int PH, bool MAP8 = false, int NSB_ = 0, bool PERSIST = false, bool ROW3 = false, bool S2D = false>
 static void hd_launch_cfg(const HdArgs& ha, hipStream_t s) {
   constexpr int hstage = MAP8 ? 25 * 64 : HD_HSTAGE(PH), nsb = NSB_ ? NSB_ : MAP8 ? 3 : 4;
@@ -721,6 +733,14 @@ static void hd_prof_dump() {
             i > 1 ? (double)((host[i] & mask) - (host[i - 1] & mask)) / 100.0 : 0.0);
 }
 
+bool imm_hdeep6_enabled();                                                           // conv_hdeep6.hip
+void imm_conv_hdeep6_launch(int dtype, const ConvArgs& a, int n_patches, int patches_x, int patches_y, int n_wg, bool persist, int cus,
+                            hipStream_t s);
+// the 16x16x128 tile without batch-norm partial sums runs the six-k-steps-per-barrier form (conv_hdeep6.hip)
+static bool hd_takes_hdeep6(const imm_conv_desc* d, const HdPlan& p) {
+  return p.ph == 16 && p.bn == 128 && !p.map8 && !(d->flags & IMM_CONV_STATS) && imm_hdeep6_enabled();
+}
+
 void imm_conv_hdeep_launch(int dtype, const imm_conv_desc* d, const ConvArgs& a, hipStream_t s) {
   HdArgs ha;
   ha.c = a;
@@ -738,6 +758,10 @@ void imm_conv_hdeep_launch(int dtype, const imm_conv_desc* d, const ConvArgs& a,
   ha.n_wg = p.n_wg;
   ha.c.x_bytes = (uint32_t)((int64_t)d->batch * d->hi * d->wi * d->ldx * 2);
   ha.c.wt_bytes = (uint32_t)((int64_t)d->co * d->kpad * 2);
+  if (hd_takes_hdeep6(d, p)) {
+    imm_conv_hdeep6_launch(dtype, ha.c, ha.n_patches, ha.patches_x, ha.patches_y, ha.n_wg, p.persist, hd_num_cu(), s);
+    return;
+  }
   if (dtype == IMM_BF16) hd_launch<BF16>(p, ha, s); else hd_launch<F16>(p, ha, s);
 }
 

@@ -20,6 +20,7 @@ int imm_halo_grid(const imm_conv_desc* d);
 void imm_conv_halo_launch(int dtype, const imm_conv_desc* d, const ConvArgs& a, hipStream_t s);
 bool imm_hdeep_applicable(const imm_conv_desc* d);                                 // conv_hdeep.hip
 int imm_hdeep_stats_blocks(const imm_conv_desc* d);
+int imm_hdeep_variant(const imm_conv_desc* d);
 void imm_conv_hdeep_launch(int dtype, const imm_conv_desc* d, const ConvArgs& a, hipStream_t s);
 bool imm_halo_nol_applicable(const imm_conv_desc* d);
 void imm_conv_halo_nol_launch(int dtype, const imm_conv_desc* d, const ConvArgs& a, const float* scale, const float* shift, int relu,
@@ -350,6 +351,22 @@ static int conv_launch(const imm_conv_desc* d, const void* x, const void* wt, co
   else launch_cfg<ET, 128, 16, 4, 1>(a, fast, s);
   IMM_CHECK_LAUNCH("imm_conv2d");
   return 0;
+}
+
+// Which kernel imm_conv2d runs for a descriptor (the twin of imm_conv2d_wgrad_variant): family * 100000 + tile variant, following
+// conv_launch's order exactly.  Families: 1 conv_igemm (BK = 32, register-staged), 2 conv_igemm64 (BK = 64, LDS-DMA ring),
+// 3 conv_halo (filter in LDS), 4 conv_halo2 (filter in registers), 5 conv_hdeep (LDS halo, tap / row at a time), 6 conv_hdeep6.
+extern "C" int imm_conv2d_variant(const imm_conv_desc* d, int dtype) {
+  if (validate_desc(d)) return IMM_E_INVALID;
+  IMM_REQUIRE(dtype == IMM_BF16 || dtype == IMM_F16, "unknown dtype %d", dtype);
+  if (imm_halo2_applicable(d)) return 400000 + (d->kw == 1 ? 10000 : 0) + d->ci * 100 + (d->co > 32 ? 64 : 32);
+  if (imm_halo_applicable(d)) return 300000 + (d->stride == 2 ? 10000 : 0) + d->ci * 100 + (d->co > 32 ? 64 : d->co > 16 ? 32 : 16);
+  if (imm_hdeep_applicable(d)) return imm_hdeep_variant(d);
+  const TileCfg t = pick_tile((int64_t)d->batch * d->ho * d->wo, d->co);
+  const int64_t xb = (int64_t)d->batch * d->hi * d->wi * d->ldx * 2, wb = (int64_t)d->co * d->kpad * 2;
+  const bool fast = (d->ci % 32 == 0) && xb < (1LL << 31) && wb < (1LL << 31);
+  const bool deep = fast && (d->ci % 64 == 0) && t.bn >= 64 && !(d->flags & 0xf00) && !imm_conv_disabled("deepk");
+  return (deep ? 200000 : 100000) + (fast ? 10000 : 0) + (t.bm / 16) * 100 + t.bn / 16;
 }
 
 extern "C" int imm_conv2d(const imm_conv_desc* d, int dtype, const void* x, const void* wt, const float* bias,

@@ -183,6 +183,18 @@ def conv2d_wgrad(desc, x, dy, lddy, slab, nsplit):
     call('imm_conv2d_wgrad', C.byref(desc), dtype_enum(x.dtype), _p(x), _p(dy), lddy, _p(slab), nsplit, _s())
 
 
+CONV_FAMILIES = {1: 'igemm', 2: 'igemm64', 3: 'halo', 4: 'halo2', 5: 'hdeep', 6: 'hdeep6'}
+
+
+def conv2d_variant(desc, dtype):
+    """(family name, variant key) of the kernel imm_conv2d dispatches `desc` to (imm_conv2d_variant: family * 100000 + tile
+    variant; families in CONV_FAMILIES) — what a test asserts to prove that the kernel a case is named after is the one that ran."""
+    key = L.load().imm_conv2d_variant(C.byref(desc), dtype_enum(dtype))
+    if key < 0:
+        raise L.ImmHipError('imm_conv2d_variant: ' + L.load().imm_last_error().decode())
+    return CONV_FAMILIES[key // 100000], key
+
+
 def conv2d_wgrad_variant(desc, lddy, dtype):
     """(variant key, workgroups per pixel split, length in units, resident workgroups per CU) of a layer's filter-gradient
     kernel: jobs with the same key share a launch of imm_conv2d_wgrad_multi."""

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define IMM_ABI_VERSION 15   /* 15: imm_conv2d_dgrad_s2, imm_conv2d_nol, imm_conv_first, imm_wgrad_job.x_scale/x_shift/x_relu; entry points removed
+#define IMM_ABI_VERSION 16   /* 16: imm_conv2d_variant.  15: imm_conv2d_dgrad_s2, imm_conv2d_nol, imm_conv_first, imm_wgrad_job.x_scale/x_shift/x_relu; entry points removed
                                   since 14 (imm_bn_bwd_reduce_finalize, imm_conv2d_stats_workspace_bytes) finally counted */
 
 enum imm_dtype { IMM_BF16 = 0, IMM_F16 = 1 };
@@ -147,6 +147,12 @@ int imm_conv2d_dgrad_s2(const void* dy, int lddy, const void* wt, int kpad, void
 int imm_conv2d(const imm_conv_desc* desc_host, int dtype, const void* x, const void* wt, const float* bias,
                void* y, float* stats_partial, const void* mask_ref, void* stream);
 int imm_conv_stats_blocks(const imm_conv_desc* desc_host);
+/* Which kernel imm_conv2d dispatches `desc` to: family * 100000 + tile variant (>= 100000; negative = invalid descriptor).
+ * Families: 1 conv_igemm (im2col, BK = 32), 2 conv_igemm64 (im2col, BK = 64, LDS-DMA ring), 3 conv_halo (LDS halo, filter in LDS),
+ * 4 conv_halo2 (LDS halo, filter in registers), 5 conv_hdeep (LDS halo of a 64-channel slice, filter taps streamed), 6 conv_hdeep6
+ * (the 16x16x128 tile on 32-channel slices, six k-steps per barrier).  The twin of imm_conv2d_wgrad_variant: tests assert that the
+ * kernel a case is named after is the one that ran; tools/layer_table.py prints it per layer.  Host-only, no launch. */
+int imm_conv2d_variant(const imm_conv_desc* desc_host, int dtype);
 /* imm_conv2d of a data gradient (no bias / ReLU / statistics) that ENTERS a tapped activation of the frozen VGG16 (conv3_2, conv4_2 of
  * imm_model.py:124-147), with the perceptual tap folded into its epilogue:
  *     y = [a_pred > 0] * ( round16(conv) + coef[idx] * loss_mask[pixel] * (a_pred - a_gt) )        (sign(a_pred - a_gt) with l1)

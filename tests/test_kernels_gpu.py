@@ -86,7 +86,7 @@ CONV_CASES = [
     # more tiles than CUs: one persistent workgroup per CU walks them (ragged: some take two tiles, some one; one / two slices)
     (20, 64, 128, 128, 128, 3, 1, False, 'hdeep_persistent_ragged'),
     (9, 64, 64, 64, 256, 3, 1, False, 'hdeep_persistent_one_slice_two_nblk'),
-    (70, 32, 128, 128, 64, 3, 1, False, 'hdeep_persistent_bn64'),
+    (130, 32, 128, 128, 64, 3, 1, False, 'hdeep_persistent_bn64'),   # 520 16x16x64 tiles >= 2 x CUs: 8 waves, persistent
     # small grids: 8x16 patches, 4 waves, two workgroups per CU
     (32, 16, 128, 128, 256, 3, 1, False, 'hdeep_small_patch'),
     (5, 40, 64, 64, 64, 3, 1, False, 'hdeep_small_patch_h40'),
@@ -94,6 +94,31 @@ CONV_CASES = [
     (64, 8, 512, 512, 512, 3, 1, False, 'hdeep_map8'),
     (33, 8, 128, 128, 256, 3, 1, False, 'hdeep_map8_odd_batch'),
 ]
+
+
+# The kernel family imm_conv2d must dispatch each case to on a 256-CU part (imm_conv2d_variant): a case named after a kernel proves
+# nothing unless that kernel is the one that ran.  Tags without an entry fall to the im2col kernels.
+CONV_FAMILY = {
+    'tile128x64': 'halo2', 'halo_64_64': 'halo2', 'halo_32_32': 'halo2', 'halo_64_32': 'halo2', 'halo_32_64_many_patches': 'halo2',
+    'halo_32_9_f32': 'halo', 'halo_s2_128px': 'halo', 'halo_s2_64px_many_patches': 'halo', 'halo_s2_co48': 'halo',
+    'hdeep_bn128_one_slice': 'hdeep6', 'hdeep_bn128_whole_image_patches': 'hdeep6', 'hdeep_persistent_ragged': 'hdeep6',
+    'hdeep_persistent_one_slice_two_nblk': 'hdeep6',
+    'hdeep_bn64_two_slices': 'hdeep', 'hdeep_three_slices': 'hdeep', 'hdeep_persistent_bn64': 'hdeep', 'hdeep_small_patch': 'hdeep',
+    'hdeep_map8': 'hdeep',
+    # below the deep-K LDS-halo kernel's minimum grid (100 workgroups): the BK = 64 im2col kernel
+    'hdeep_small_patch_h40': 'igemm64', 'hdeep_map8_odd_batch': 'igemm64', 'ragged_m100': 'igemm64', 'vgg5': 'igemm64',
+    'hdeep_256to128': 'hdeep', 'hdeep_512to256': 'hdeep', 'ci266': 'igemm64', 'k3s2_b': 'igemm64',
+}
+# variant digits of the hdeep family (imm_hdeep_variant): persistent 10000, row at a time 20000, 8x8 maps 40000
+CONV_VARIANT = {'hdeep_persistent_bn64': 510648, 'hdeep_persistent_ragged': 600001, 'hdeep_bn128_one_slice': 600000,
+                'hdeep_map8': 560644}
+
+
+def check_family(ops, desc, dt, tag):
+    fam, key = ops.conv2d_variant(desc, dt)
+    assert fam == CONV_FAMILY.get(tag, 'igemm'), (tag, fam, key)
+    if tag in CONV_VARIANT:
+        assert key == CONV_VARIANT[tag], (tag, key)
 
 
 def run_conv(ops, x16, w, bias, k, stride, co, ci_pad, out_f32, extra_flags=0, mask=None, ldy=None):
@@ -127,6 +152,7 @@ def test_conv_forward(ops, case, dt):
     w = rnd((k, k, ci_real, co), 2, 0.05, dt)
     b = rnd((co,), 3, 0.5, torch.float32)
     y, _, desc = run_conv(ops, x, w, b, k, stride, co, ci_pad, out_f32)
+    check_family(ops, desc, dt, tag)
     ref = O.conv2d_same(x.float(), w.float(), b, stride)
     # f32 out: accumulation-order error only; 16-bit out: one rounding (2^-8 bf16, 2^-11 f16)
     rt = 2e-3 if out_f32 else (1e-2 if dt == torch.bfloat16 else 2e-3)
@@ -156,8 +182,13 @@ def test_conv_relu_stats_mask(ops, B, H, ci, co, dt):
     y, stats, desc = run_conv(ops, x, w, b, 3, 1, co, ci, False, extra_flags=L.CONV_STATS)
     ref = O.conv2d_same(x.float(), w.float(), b, 1)
     close(y, ref, 1e-2, 2e-3, 'conv+stats/y')
-    y1, _, _ = run_conv(ops, x, w, b, 3, 1, co, ci, False)
-    assert torch.equal(y1, y), 'the stats flag must not change the output'
+    y1, _, desc1 = run_conv(ops, x, w, b, 3, 1, co, ci, False)
+    if ops.conv2d_variant(desc1, dt) == ops.conv2d_variant(desc, dt):
+        assert torch.equal(y1, y), 'the stats flag must not change the output'
+    else:
+        # the 16x16x128 tile without partial sums runs conv_hdeep6.hip (32-channel K slices: another accumulation order)
+        assert ops.conv2d_variant(desc1, dt)[0] == 'hdeep6' and ops.conv2d_variant(desc, dt)[0] == 'hdeep'
+        close(y1, y, 1e-2 if dt == torch.bfloat16 else 2e-3, 1e-3, 'conv+stats vs conv (other kernel)')
     s = stats.sum(dim=0).cpu()
     close(s[0], ref.sum(dim=(0, 1, 2)), 1e-3, 1e-3, 'conv+stats/sum')      # f32 sums of f32 accumulators
     close(s[1], (ref ** 2).sum(dim=(0, 1, 2)), 1e-3, 1e-3, 'conv+stats/sumsq')
@@ -206,6 +237,7 @@ def test_conv_dgrad(ops, case, dt):
     dy = rnd(tuple(yref.shape), 12, 1.0, dt)
     (gx,) = torch.autograd.grad(yref, xr, dy.float())
     desc = ops.dgrad_desc(B, H, H, ci_real, ci_pad, co_pad, co_pad, k, stride, 0)
+    check_family(ops, desc, dt, tag)
     rows = ops.round_up(ci_real, 128)
     wt = torch.zeros(rows, desc.kpad, dtype=dt, device=DEV)
     ops.pack_weights(w.float().to(DEV).contiguous(), wt, 1, k, k, ci_real, co, co_pad, rows, desc.kpad)
