@@ -3,10 +3,13 @@
     python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: re-executes itself under
                                                             torch.distributed.run, one rank per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+    python bench.py --config {1,3,4} [--gpus N]            the other BASELINE.json configurations, same one-line contract
 
 One process per GPU; batch 32 per GPU (BASELINE.json configs[1]; N>1 = configs[2] weak scaling); synthetic
 inputs resident in HBM; a step = forward (both encoders, landmark bottleneck, renderer, VGG16 perceptual
 loss) + backward + RCCL gradient all-reduce + per-tensor clip + Adam.  Rank 0 prints ONE JSON line.
+--config 3 = configs[3] (K=30 at 256x256, bf16, batch 16 per GPU), --config 4 = configs[4] (K=50 at 128x128, f16 storage with
+the device-resident dynamic loss scale, batch 32 per GPU; --gpus 8 is the configuration as BASELINE.json states it).
 
 Timing protocol: the step is first spun for a fixed wall time (default 1 s, untimed) so that the clocks have
 settled, then W untimed warm-up steps, then `--windows` (default 3) windows of EXACTLY K steps, each bracketed by
@@ -30,10 +33,32 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
+PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 / f16 MFMA peak (MI355X_MICROARCH.md)
+# BASELINE.json configurations this file can run (configs[0] is the CPU-only plumbing case, configs[2] = --config 1 --gpus 8)
+WORKLOADS = {
+    1: dict(batch=32, size=128, n_maps=10, dtype='bf16', name='BASELINE configs[1] (N>1: configs[2])',
+            what='CelebA-shape 128x128 K=10 IMM training step'),
+    3: dict(batch=16, size=256, n_maps=30, dtype='bf16', name='BASELINE configs[3]',
+            what='K=30 at 256x256 IMM training step (align-corners resize path, wider bottleneck)'),
+    4: dict(batch=32, size=128, n_maps=50, dtype='f16', name='BASELINE configs[4] (as stated at --gpus 8)',
+            what='AFLW-finetune shape 128x128 K=50 IMM training step, f16 storage + dynamic loss scale'),
+}
+WL = dict(WORKLOADS[1])        # the selected workload (set by --config before anything runs)
 BATCH_PER_GPU = 32
 IMAGE_SIZE = 128
 N_MAPS = 10
+
+
+def select_workload(idx):
+    global BATCH_PER_GPU, IMAGE_SIZE, N_MAPS
+    WL.clear(); WL.update(WORKLOADS[idx]); WL['index'] = idx
+    BATCH_PER_GPU, IMAGE_SIZE, N_MAPS = WL['batch'], WL['size'], WL['n_maps']
+
+
+def torch_dtype(name=None):
+    return torch.float16 if (name or WL['dtype']) == 'f16' else torch.bfloat16
+
+
 IGEMM_TAGS = ('conv_fwd', 'vgg_fwd', 'conv_dgrad', 'vgg_dgrad')    # forward + data-gradient convolution launches
 CONV_FAMILY = ('conv_igemm', 'conv_halo', 'conv_hdeep')            # kernel-name prefixes of those launches (not wgrad)
 
@@ -97,7 +122,7 @@ def pmc_traffic_live(timeout_s=240):
         for ctr in ('FETCH_SIZE', 'WRITE_SIZE'):
             d = os.path.join(tmp, ctr)
             cmd = [exe, '--kernel-trace', '--output-format', 'csv', '--pmc', ctr, '-d', d, '--', sys.executable,
-                   os.path.abspath(__file__), '--pmc-pass', '--steps', str(steps)]
+                   os.path.abspath(__file__), '--pmc-pass', '--steps', str(steps), '--config', str(WL.get('index', 1))]
             r = subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s)
             if r.returncode != 0:
                 sys.stderr.write('bench: rocprofv3 %s pass failed (rc %d): %s\n' % (ctr, r.returncode, r.stderr.decode()[-400:]))
@@ -144,7 +169,7 @@ def pmc_pass(steps):
     from imm_amd.models.imm_model import IMMModel
     from imm_amd.train.cnn_train_multi import TrainStep
     torch.cuda.set_device(0)
-    model = IMMModel(model_config(N_MAPS), dtype=torch.bfloat16, device='cuda:0')
+    model = IMMModel(model_config(N_MAPS), dtype=torch_dtype(), device='cuda:0')
     ts = TrainStep(model, BATCH_PER_GPU, IMAGE_SIZE, world_size=1, use_graph=False)
     inputs = synthetic_batch(BATCH_PER_GPU, IMAGE_SIZE, seed=0, device='cuda:0')
     ts.engine.set_inputs(inputs['image'], inputs['future_image'], inputs['mask'])
@@ -200,7 +225,7 @@ def cpu_baseline(budget_s=12.0):
         inp32 = O.synthetic_inputs(BATCH_PER_GPU, IMAGE_SIZE)
         opt = O.new_adam_state(P)
         O.train_step(P, S, O.new_adam_state(P), [inp4], cfg)            # untimed warm-up of the backward / optimizer code paths
-        tB = timed(lambda: O.train_step(P, S, opt, [inp32], cfg), 3 if full else 0, 10 if full else 3)
+        tB = timed(lambda: O.train_step(P, S, opt, [inp32], cfg), 3 if full else 0, 10 if full else (3 if IMAGE_SIZE <= 128 else 2))
         legs['train_step_b32'] = {'images_per_s': round(BATCH_PER_GPU / median(tB), 3), 'timed': len(tB), 'threads': best,
                                   'step_s': [round(x, 2) for x in tB]}
         if full and best != n_all:
@@ -210,38 +235,50 @@ def cpu_baseline(budget_s=12.0):
     finally:
         torch.set_num_threads(n_all)
     return {'value': legs['train_step_b32']['images_per_s'], 'unit': 'images/s', 'cores': cores, 'threads': best, 'kind': 'port',
-            'sample': '%d timed fp32 training steps (median) of batch 32 at 128x128 K=10 on %d of %d host threads — the thread count '
+            'sample': '%d timed fp32 training steps (median) of batch %d at %dx%d K=%d on %d of %d host threads — the thread count '
                       'at which the batch-4 forward+loss leg ran fastest in a sweep over %s (torch-CPU restatement of the TF1 graph, '
-                      'oracle/imm_oracle.py; TF 1.10 itself is not installable here)' % (len(tB), best, n_all, counts),
+                      'oracle/imm_oracle.py; TF 1.10 itself is not installable here)' % (len(tB), BATCH_PER_GPU, IMAGE_SIZE, IMAGE_SIZE,
+                                                                                          N_MAPS, best, n_all, counts),
             'legs': legs}
 
 
 def parity_vs_oracle(dev, batch=2):
     """The second half of BASELINE.json's metric ("landmark MSE vs TF1 ref"): one training-mode forward pass of the HIP path on a
-    seeded batch of `batch` 128x128 images at K=10 against the CPU restatement of the TF1 graph (oracle/imm_oracle.py — TF 1.10
-    itself cannot run here) on the same inputs and the same seeded initial weights.  Part of the cpu_baseline leg
-    (the oracle is the checker, never the thing measured); ~1 s of CPU work."""
+    seeded batch of `batch` images of the workload's size and K against the CPU restatement of the TF1 graph (oracle/imm_oracle.py —
+    TF 1.10 itself cannot run here) on the same inputs and the same seeded initial weights, for BOTH storage types:
+    bf16 (the headline engine) and f16 (8x finer storage rounding: the tight witness — bounds recon 0.02, six terms 2e-3).  Part of
+    the cpu_baseline leg (the oracle is the checker, never the thing measured); ~1 s of CPU work at 128x128."""
     from oracle import imm_oracle as O
     from imm_amd.models.imm_model import IMMModel
     from imm_amd.utils.box import Box
     cfg = O.default_model_config(N_MAPS)
     inputs = O.synthetic_inputs(batch, IMAGE_SIZE, seed=0)
-    model = IMMModel(Box(dict(cfg)), dtype=torch.bfloat16, device=dev)
-    _, loss, _, tensors = model.build(inputs, True, output_tensors=True)
-    torch.cuda.synchronize()
     P, S = O.init_params(cfg, IMAGE_SIZE)
     with torch.no_grad():
         ref = O.forward(P, S, inputs, cfg, training=True)
-    mu = tensors['gauss_yx'].detach().float().cpu()
-    d = mu - ref['gauss_yx']
-    pred = tensors['future_im_pred'].detach().float().cpu()
     rp = ref['future_im_pred']
-    return {'reference': 'oracle/imm_oracle.py (fp32 torch-CPU restatement of the TF1 graph; parity unpinned against TF itself)',
-            'batch': batch, 'dtype': 'bf16 storage vs fp32',
-            'landmark_mse': float((d * d).mean()), 'mu_max_abs': float(d.abs().max()),
-            'loss_rel': abs(float(loss) - float(ref['loss'])) / abs(float(ref['loss'])),
-            'recon_rel_l2': float((pred - rp).norm() / rp.norm()),
-            'bounds': {'mu_max_abs': 1e-3, 'loss_rel': 1e-3, 'recon_rel_l2': 0.12}}
+    rt = torch.as_tensor([float(t) for t in ref['loss_terms']], dtype=torch.float64)
+
+    def one(dt):
+        model = IMMModel(Box(dict(cfg)), dtype=dt, device=dev)
+        _, loss, _, tensors = model.build(inputs, True, output_tensors=True)
+        torch.cuda.synchronize()
+        d = tensors['gauss_yx'].detach().float().cpu() - ref['gauss_yx']
+        pred = tensors['future_im_pred'].detach().float().cpu()
+        terms = torch.as_tensor([float(t) for t in model.engine.loss_terms], dtype=torch.float64)
+        return {'landmark_mse': float((d * d).mean()), 'mu_max_abs': float(d.abs().max()),
+                'loss_rel': abs(float(loss) - float(ref['loss'])) / abs(float(ref['loss'])),
+                'terms_max_rel': float(((terms - rt).abs() / rt.abs()).max()),
+                'recon_rel_l2': float((pred - rp).norm() / rp.norm())}
+    out = {'reference': 'oracle/imm_oracle.py (fp32 torch-CPU restatement of the TF1 graph; parity unpinned against TF itself)',
+           'batch': batch, 'image_size': IMAGE_SIZE, 'n_maps': N_MAPS, 'dtype': 'bf16 storage vs fp32'}
+    out.update(one(torch.bfloat16))
+    out['bounds'] = {'mu_max_abs': 1e-3, 'loss_rel': 1e-3, 'terms_max_rel': 1e-2, 'recon_rel_l2': 0.12}
+    out['f16'] = dict(one(torch.float16), dtype='f16 storage vs fp32',
+                      bounds={'mu_max_abs': 1e-3, 'loss_rel': 1e-3, 'terms_max_rel': 2e-3, 'recon_rel_l2': 0.02})
+    out['within_bounds'] = all(out[k] <= v for k, v in out['bounds'].items()) and \
+        all(out['f16'][k] <= v for k, v in out['f16']['bounds'].items())
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -271,6 +308,9 @@ def self_spawn(args, argv):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--config', type=int, choices=sorted(WORKLOADS), default=1,
+                    help='BASELINE.json configuration: 1 = configs[1] (the headline metric; --gpus 8 = configs[2]), 3 = configs[3] '
+                         '(K=30 at 256x256), 4 = configs[4] (K=50, f16 + loss scale; --gpus 8 as stated)')
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--windows', type=int, default=3, help='timed windows of --steps steps each; the median is reported')
@@ -290,6 +330,7 @@ def main():
                     help='all-reduce buckets (2: the renderer bucket travels while the encoders\' backward runs); default IMM_DP_BUCKETS or 1')
     ap.add_argument('--pmc-pass', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args()
+    select_workload(args.config)
 
     if args.pmc_pass:
         pmc_pass(args.steps)
@@ -328,7 +369,7 @@ def main():
     from imm_amd.models.imm_model import IMMModel
     from imm_amd.train.cnn_train_multi import TrainStep
 
-    model = IMMModel(model_config(N_MAPS), dtype=torch.bfloat16, device=dev, world_size=world, dp_buckets=args.buckets)
+    model = IMMModel(model_config(N_MAPS), dtype=torch_dtype(), device=dev, world_size=world, dp_buckets=args.buckets)
     ts = TrainStep(model, BATCH_PER_GPU, IMAGE_SIZE, world_size=world, use_graph=not args.no_graph, split_graphs=args.force_dist,
                    collective=args.collective)
     eng = ts.engine
@@ -426,12 +467,15 @@ def main():
         step_flops = eng.step_flops()
         ms_per_step = elapsed / args.steps * 1e3
         out = {
-            'metric': 'training images/sec at 128x128 K=10', 'value': round(world * BATCH_PER_GPU * args.steps / elapsed, 2),
+            'metric': 'training images/sec at %dx%d K=%d' % (IMAGE_SIZE, IMAGE_SIZE, N_MAPS),
+            'value': round(world * BATCH_PER_GPU * args.steps / elapsed, 2),
             'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'bf16', 'data': 'synthetic',
-            'config': {'workload': 'CelebA-shape 128x128 K=10 IMM training step (fwd + VGG16 perceptual loss + bwd + '
-                                   'clip + Adam), batch %d per GPU' % BATCH_PER_GPU,
+            'dtype': WL['dtype'], 'data': 'synthetic',
+            'config': {'workload': '%s: %s (fwd + VGG16 perceptual loss + bwd + clip + Adam), batch %d per GPU'
+                                   % (WL['name'], WL['what'], BATCH_PER_GPU),
+                       'baseline_config': WL.get('index', 1),
+                       'loss_scale': (None if eng.loss_scale_state is None else [float(v) for v in eng.loss_scale_state.tolist()]),
                        'global_batch': world * BATCH_PER_GPU, 'image_size': IMAGE_SIZE, 'n_maps': N_MAPS,
                        'parallelism': 'dp%d' % world, 'hip_graph': not args.no_graph,
                        'collective': ({'backend': dist.get_backend(), 'world_size': dist.get_world_size(),
@@ -452,7 +496,10 @@ def main():
         }
         if (not args.no_cpu_baseline and world == 1) or args.cpu_baseline_full:
             out['cpu_baseline'] = cpu_baseline(0.0 if args.cpu_baseline_full else 12.0)
-            out['parity'] = parity_vs_oracle(dev)
+            try:        # the checker must never lose the measurement
+                out['parity'] = parity_vs_oracle(dev)
+            except Exception as e:
+                out['parity'] = {'error': '%s: %s' % (type(e).__name__, e)}
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + '\n').encode())
     if dist.is_initialized():

@@ -1,0 +1,7 @@
+"""Import-path alias: `imm.eval.eval_imm` IS `imm_amd.eval.eval_imm` (the same module object), so that code written against the reference's
+package layout (/root/reference/scripts/train.py:13-19, scripts/test.py, imm/eval/eval_imm.py:14-15) runs unchanged."""
+import sys
+
+import imm_amd.eval.eval_imm as _real
+
+sys.modules[__name__] = _real

@@ -39,6 +39,29 @@ VGG_LAYERS = [('conv1_1', 1, 64), ('conv1_2', 64, 64), ('conv2_1', 64, 128), ('c
               ('conv5_1', 512, 512), ('conv5_2', 512, 512)]
 VGG_POOL_AFTER = ('conv1_2', 'conv2_2', 'conv3_3', 'conv4_3')
 WGRAD_MULTI_MAX_JOBS, WGRAD_MULTI_MAX_VARIANTS = 64, 16     # WGM_MAX_JOBS / WGM_MAX_LAUNCH of csrc/conv_wgrad.hip
+
+
+def plan_wgrad_chunks(groups, max_jobs, max_slots):
+    """Split {(variant key, per-CU residency): [jobs]} into chunks that one imm_conv2d_wgrad_multi table can hold: at most
+    `max_jobs` jobs and `max_slots` LAUNCH SLOTS, counted the way imm_conv2d_wgrad_multi_plan counts them — a group of the generic
+    kernel (key // 100000 == 0) takes one slot PER JOB, every other group one slot (ADVICE r4: with the specialised kernels
+    disabled, or on odd shapes, more than 16 generic jobs in one chunk still failed with "more than 16 kernel variants").
+    Deeper configurations are issued as several launches instead of failing at engine build.  Pure host logic (CPU-tested)."""
+    chunks, cur, cur_jobs, cur_slots = [], [], 0, 0
+    for gk, members in groups.items():
+        generic = gk[0] // 100000 == 0
+        members = list(members)
+        while members:
+            room_jobs, room_slots = max_jobs - cur_jobs, max_slots - cur_slots
+            take = min(len(members), room_jobs, room_slots) if generic else (min(len(members), room_jobs) if room_slots >= 1 else 0)
+            if take <= 0:
+                chunks.append(cur); cur, cur_jobs, cur_slots = [], 0, 0
+                continue
+            part, members = members[:take], members[take:]
+            cur.append((gk, part)); cur_jobs += len(part); cur_slots += len(part) if generic else 1
+    if cur:
+        chunks.append(cur)
+    return chunks
 VGG_TAPS = {'conv1_2': 1, 'conv2_2': 2, 'conv3_2': 3, 'conv4_2': 4, 'conv5_2': 5}
 
 
@@ -385,9 +408,14 @@ class IMMEngine:
             mv.fill_(1.0)
             self.state[scope + '/moving_mean'], self.state[scope + '/moving_variance'] = mm, mv
             gamma, beta = self.pview[scope + '/gamma'], self.pview[scope + '/beta']
-            if out is None and not defer_apply:
+            # an up-sampled block taken by the fused finalize + apply + up-sample pass never stores its own normalised tensor (nobody
+            # reads it): it is not allocated either (a zero-filled `out` that looks valid).  lay.nol marks "normalise on
+            # load" (the consumers read y); lay.out is None alone no longer means that.
+            fused_up = bool(up2x) and not defer_apply and nblk <= 256 and co % 32 == 0
+            if out is None and not defer_apply and not fused_up:
                 out, ldo = self._act(B, fd.ho, fd.wo, co), co
-            lay.out, lay.ldo = out, ldo
+            lay.out, lay.ldo = out, (ldo if out is not None else None)
+            lay.nol = bool(defer_apply)
 
             def f_conv():
                 if first_src is not None:
@@ -420,10 +448,10 @@ class IMMEngine:
                 # an up-sampled block's own normalised tensor has no reader (the next convolution and its filter gradient read the
                 # up-sampled one, the batch-norm backward reads y): only `up` is written
                 x_w = None if lay.up is not None else out
-                lay.out_stale = x_w is None          # (lay.out stays allocated but is never written)
+                assert (x_w is None) == fused_up
                 self._add(self.prog_fwd, lambda: ops.bn_apply_fused(lay.stats, nblk, co, npix, gamma, beta, BN_EPS, BN_MOMENTUM,
                                                                     self._training, mm, mv, lay.scale, lay.shift, lay.mean, lay.rstd,
-                                                                    lay.y, ldy, relu, x_w, ldo, lay.up, co, fd.ho, fd.wo),
+                                                                    lay.y, ldy, relu, x_w, (ldo if x_w is not None else co), lay.up, co, fd.ho, fd.wo),
                           'bn_apply', 0.0, npix * co * (4.0 + (8.0 if lay.up is not None else 0.0)))
             elif co % 32 == 0:
                 # many partial rows: 32-row groups are summed by rows/32 workgroups in parallel, the fused apply pass finishes
@@ -591,17 +619,7 @@ class IMMEngine:
         for lay, dy, lddy, flops in jobs:
             key, wps, units, pcu = ops.conv2d_wgrad_variant(lay.fd, lddy, self.dt)
             groups.setdefault((key, pcu), []).append((lay, dy, lddy, wps, units, flops))
-        # a multi-problem launch takes at most WGRAD_MULTI_MAX_JOBS jobs of WGRAD_MULTI_MAX_VARIANTS kernel variants (the library's
-        # table caps): deeper configurations are issued as several such launches instead of failing at engine build
-        chunks, cur, cur_jobs = [], [], 0
-        for gk, members in groups.items():
-            if cur and (cur_jobs + len(members) > WGRAD_MULTI_MAX_JOBS or len(cur) + 1 > WGRAD_MULTI_MAX_VARIANTS):
-                chunks.append(cur); cur, cur_jobs = [], 0
-            while len(members) > WGRAD_MULTI_MAX_JOBS:           # one variant with more members than a table holds
-                chunks.append([(gk, members[:WGRAD_MULTI_MAX_JOBS])]); members = members[WGRAD_MULTI_MAX_JOBS:]
-            cur.append((gk, members)); cur_jobs += len(members)
-        if cur:
-            chunks.append(cur)
+        chunks = plan_wgrad_chunks(groups, WGRAD_MULTI_MAX_JOBS, WGRAD_MULTI_MAX_VARIANTS)
         for ci_, chunk in enumerate(chunks):
             self._issue_wgrad_chunk(chunk, name if len(chunks) == 1 else '%s [%d/%d]' % (name, ci_ + 1, len(chunks)))
 
@@ -698,13 +716,13 @@ class IMMEngine:
                 out, ldo = (None, None)
                 if last and scope == 'model/image_encoder' and He == 16:
                     out, ldo = self.joint, Cj       # conv_8 writes straight into the concat buffer
-                nol_src = prev if (prev is not None and prev.out is None) else None
+                nol_src = prev if (prev is not None and getattr(prev, 'nol', False)) else None
                 lay = self._conv_block('%s/encoder/conv_%d' % (scope, i + 1), x, H, H, ci_real, ci_pad, ldx, co, k,
                                        stride, True, True, needs_dgrad=(i > 0), out=out, ldo=ldo, kw=(1 if i == 0 else None),
                                        nol_src=nol_src, defer_apply=defer[i], first_src=(src if (i == 0 and direct) else None))
                 layers.append(lay)
                 prev = lay
-                if lay.out is None:
+                if lay.nol:
                     x, H, ci_real, ci_pad, ldx = lay.y, lay.Ho, co, co, lay.ldy
                 else:
                     x, H, ci_real, ci_pad, ldx = lay.out, lay.Ho, co, co, lay.ldo
@@ -771,12 +789,12 @@ class IMMEngine:
             if bn and not up and i + 1 < len(rspec) and co % 8 == 0:
                 k2, _ci2, co2, bn2, _up2 = rspec[i + 1]
                 defer = self._nol_consumer_ok(H, H, co, co, co2, k2, 1, bn2, not bn2)
-            nol_src = prev if (prev is not None and prev.bn and prev.out is None) else None
+            nol_src = prev if (prev is not None and prev.bn and getattr(prev, 'nol', False)) else None
             lay = self._conv_block('model/renderer/conv_%d' % (i + 1), x, H, H, ci_real, ci_pad, ldx, co, k, 1, bn, bn,
                                    needs_dgrad=True, out_f32=not bn, up2x=bool(up and bn), nol_src=nol_src, defer_apply=defer)
             self.ren.append(lay)
             prev = lay
-            if lay.bn and lay.out is None:
+            if lay.bn and lay.nol:
                 x, ci_real, ci_pad, ldx = lay.y, co, co, lay.ldy
             else:
                 x, ci_real, ci_pad, ldx = lay.out, co, co, lay.ldo
@@ -785,6 +803,8 @@ class IMMEngine:
                 if ub is None:       # not taken by the fused finalize + apply + up-sample pass
                     ub = self._act(B, 2 * H, 2 * H, co)
                     src = lay.out
+                    assert src is not None, 'up-sampling pass without a stored normalised tensor'
+
                     self._add(self.prog_fwd, (lambda src=src, ub=ub, H=H, co=co: ops.upsample2x_fwd(src, ub, B, H, H, co, co, co)),
                               'upsample', 0.0, B * H * H * co * 10.0)
                 self.ren_up.append((len(self.ren) - 1, ub, H, co))

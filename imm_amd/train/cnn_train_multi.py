@@ -360,6 +360,7 @@ def train_loop(opts, train_step, data_iter, num_steps, log_every=10, checkpoint_
     n_ckpt = int(opts.get('n_checkpoint') or 0)
     scaled = getattr(eng, 'loss_scale_state', None) is not None
     step = start_step
+    last_event_step = None          # (loss scaling) the step whose events were evaluated last: a skipped update repeats its index
     while step < num_steps:
         t0 = time.time()
         loss = train_step.step(next(data_iter))
@@ -367,6 +368,20 @@ def train_loop(opts, train_step, data_iter, num_steps, log_every=10, checkpoint_
         do_log = (step - start_step) % log_every == 0
         do_sum = bool(n_summary) and step % n_summary == 0      # the same on every rank: the loss mean is a collective
         synced = False
+        if scaled and (do_log or do_sum or (n_test and step % n_test == 0) or (n_ckpt and step % n_ckpt == 0)):
+            # f16 storage with a dynamic loss scale: an update whose gradients overflowed is SKIPPED on the device, so between two
+            # synchronisations the host's count can run AHEAD of global_step (never behind).  Whenever the host's count says an
+            # event may fire, look at the device first and follow it (a summary / checkpoint named after a drifted count,
+            # or fired twice / not at all).  `global_step - 1` = the index of the update this iteration applied; when this very
+            # iteration was skipped it is the previous index, whose events are not repeated (no multiple of n there or already done).
+            train_step.synchronize(); synced = True
+            true_pre = int(eng.step_count) - 1
+            if true_pre != step:
+                step = true_pre
+                do_sum = bool(n_summary) and step >= 0 and step % n_summary == 0 and step != last_event_step
+            if step == last_event_step or step < 0:
+                do_sum = False
+        fire = not scaled or (step >= 0 and step != last_event_step)
         if do_log or do_sum:
             train_step.synchronize(); synced = True
             loss_value = mean_tower_loss(loss, train_step.world_size, train_step.group)   # every rank takes part
@@ -381,16 +396,18 @@ def train_loop(opts, train_step, data_iter, num_steps, log_every=10, checkpoint_
                                             'loss_terms': [float(v) for v in eng.loss_terms],
                                             'examples_per_sec': opts['batch_size'] / dt}, step, images=images)
                 summary_writer.flush()
-        if test_dataset is not None and model is not None and n_test and step % n_test == 0:
+        if fire and test_dataset is not None and model is not None and n_test and step % n_test == 0:
             train_step.synchronize(); synced = True
             if rank == 0:
                 run_test_pass(model, test_dataset, step, summary_writer)
             if train_step.world_size > 1:
                 torch.distributed.barrier(group=train_step.group)
-        if checkpoint_fn is not None and n_ckpt and step % n_ckpt == 0:
+        if fire and checkpoint_fn is not None and n_ckpt and step % n_ckpt == 0:
             train_step.synchronize(); synced = True
             if rank == 0:
                 checkpoint_fn(step)
+        if synced:
+            last_event_step = step
         step += 1
         if scaled and (synced or step >= num_steps):
             # f16 storage with a dynamic loss scale: an update whose gradients overflowed is SKIPPED on the device (weights,

@@ -102,7 +102,7 @@ def test_layerwise_forward_diagnostics(fwd2):
         for lays in (eng.enc_im, eng.enc_pose, eng.ren):
             for lay in lays:
                 ref = acts[lay.scope]
-                if lay.bn and (lay.out is None or getattr(lay, 'out_stale', False)):
+                if lay.bn and lay.out is None:
                     # the block's normalised output is never stored (normalise on load: its consumers rebuild it in LDS; an
                     # up-sampled renderer block: only the up-sampled tensor has readers); materialise it here with the
                     # stand-alone apply pass from the same scale / shift
@@ -511,7 +511,7 @@ def test_gradient_parity_on_a_trained_model(dt):
     Pe, Se = emul_params(P1, St1)
     _oe, g_e = O.loss_and_grads(Pe, Se, inputs, cfg, act_round=bf)
     assert abs(float(eng.loss) - float(out_f['loss'])) / abs(float(out_f['loss'])) < 2e-3
-    bad, rels, worst = [], [], (0.0, 1.0)
+    bad, rels, worst, waivers = [], [], (0.0, 1.0), []
     # f16 storage rounds 8x finer than bf16: measured worst 0.035, median 0.008, cosine 0.9994 (round 3) — held to half the
     # bf16 bounds (which stay where the chaotic 60-step trajectory needs them, see above)
     lim_rel, lim_cos, lim_med = (0.30, 0.97, 0.10) if dt == torch.bfloat16 else (0.15, 0.99, 0.05)
@@ -537,12 +537,21 @@ def test_gradient_parity_on_a_trained_model(dt):
         #     the first pose-encoder layer of some states is ill conditioned: round 4 met beta at 0.378 with the emulation at
         #     0.387): then the engine must be at least as close to the fp32 oracle as the emulation is
         tight = e <= 1.25 * e_emul + 0.03
-        absolute = (e <= lim_rel and cos >= lim_cos) or (e <= e_emul and cos >= cos_emul - 1e-3)
+        waived = not (e <= lim_rel and cos >= lim_cos) and (e <= e_emul and cos >= cos_emul - 1e-3)
+        absolute = (e <= lim_rel and cos >= lim_cos) or waived
+        # (iii) ADVICE r4: the waiver has a hard outer cap of its own (a mis-scaled gradient in an ill-conditioned tensor must not
+        #     pass just because the emulation is bad there too) and at most ONE tensor of a trained state may use it
+        if waived:
+            waivers.append((k, e, cos))
+            absolute = e <= 0.45 and cos >= 0.90
         if not (tight and absolute):
             bad.append((k, e, cos, e_emul, cos_emul))
     med = float(np.median(np.array(rels)))
     print('TRAINED_GRAD worst rel %.4f, worst cos %.5f, median rel %.4f' % (worst + (med,)))
     assert not bad, bad
+    assert len(waivers) <= 1, waivers
+    if waivers:
+        print('TRAINED_GRAD waiver used by', waivers)
     assert med <= lim_med, med
 
 
