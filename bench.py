@@ -281,6 +281,52 @@ def parity_vs_oracle(dev, batch=2):
     return out
 
 
+def collective_selfcheck(dev, world, inputs, buckets):
+    """N > 1 default by construction: the candidate — the whole step as ONE HIP graph whose nodes include the
+    all-reduce of `buckets` gradient buckets (the renderer's travelling on a forked stream while the encoders' backward nodes run) —
+    is compared at start-up with the simplest correct sequence there is: eager, one stream, fwd, bwd, ONE torch.distributed
+    all-reduce of the whole flat buffer, clip + Adam.  Same seeds, same inputs, two steps; the two paths use different
+    communicators (the summation order over > 2 ranks may differ), so the UPDATES are compared to 1e-3 relative (a mis-ordered
+    exchange — stale, partial or un-reduced gradients — moves an Adam update by O(1)); the candidate's replicas must be
+    bit-identical across ranks.  Every rank must pass.  Returns (TrainStep of the candidate restored to its initial state, or None,
+    record for the bench line)."""
+    from imm_amd.models.imm_model import IMMModel
+    from imm_amd.train.cnn_train_multi import TrainStep
+    rec = {'candidate': 'graph, %d bucket(s)' % buckets, 'reference': 'eager one-stream step, one torch.distributed all-reduce',
+           'steps': 2, 'bound_update_rel': 1e-3}
+    try:
+        mc = IMMModel(model_config(N_MAPS), dtype=torch_dtype(), device=dev, world_size=world, dp_buckets=buckets)
+        tc = TrainStep(mc, BATCH_PER_GPU, IMAGE_SIZE, world_size=world, use_graph=True, split_graphs=True, collective='graph')
+        mr = IMMModel(model_config(N_MAPS), dtype=torch_dtype(), device=dev, world_size=world, dp_buckets=buckets)
+        tr = TrainStep(mr, BATCH_PER_GPU, IMAGE_SIZE, world_size=world, use_graph=False, split_graphs=True, collective='pg')
+        snap = tc.engine.snapshot()
+        p0 = tc.engine.params.clone()
+        for t in (tc, tr):
+            t.step(inputs); t.step(None); t.synchronize()
+        uc, ur = tc.engine.params - p0, tr.engine.params - p0
+        rel = float((uc - ur).norm() / ur.norm().clamp_min(1e-30))
+        bits = tc.engine.params.view(torch.int32).to(torch.int64)
+        chk = torch.stack([bits.sum(), (bits * (torch.arange(bits.numel(), device=bits.device) % 8191 + 1)).sum()])
+        got = [torch.zeros_like(chk) for _ in range(dist.get_world_size())]
+        dist.all_gather(got, chk)
+        same = all(bool(torch.equal(g, got[0])) for g in got)
+        ok = bool(torch.isfinite(uc).all()) and rel < 1e-3 and same
+        flag = torch.tensor([1 if ok else 0], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        rec.update(update_rel_diff=rel, replicas_identical=same, passed=bool(int(flag)))
+        tc.engine.restore(snap)
+        torch.cuda.synchronize()
+        del tr, mr
+        torch.cuda.empty_cache()
+        if rec['passed']:
+            return tc, rec
+        tc.native_comm.destroy()
+        return None, rec
+    except Exception as e:          # a candidate that cannot even be built falls back like one that fails
+        rec.update(passed=False, error='%s: %s' % (type(e).__name__, e))
+        return None, rec
+
+
 # ---------------------------------------------------------------------------------------------------------
 def free_port():
     s = socket.socket()
@@ -322,12 +368,15 @@ def main():
     ap.add_argument('--force-dist', action='store_true', help='initialise the process group and run the split-graph + all-reduce path even at 1 GPU')
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend: 'nccl' (= RCCL on ROCm) or 'gloo' (tests)")
     ap.add_argument('--share-gpu', action='store_true', help='tests: let several ranks share one device (needs --backend gloo)')
-    ap.add_argument('--collective', choices=('pg', 'native', 'graph'), default=None,
-                    help="gradient exchange at N > 1: 'pg' torch.distributed all-reduce between two graphs (default), 'native' "
-                         "imm_rccl_allreduce on its own stream, 'graph' imm_rccl_allreduce captured into the step's single HIP graph "
-                         "(RCCL only); default: IMM_RCCL_GRAPH / IMM_RCCL_NATIVE, else pg")
+    ap.add_argument('--collective', choices=('auto', 'pg', 'native', 'graph'), default=None,
+                    help="gradient exchange at N > 1: 'auto' (default over RCCL) = the step as ONE HIP graph with two overlapped "
+                         "all-reduce buckets as its nodes IF a start-up self-check against the eager one-stream step passes on every "
+                         "rank, else 'pg'/1 bucket — the line records which (config.collective.selfcheck); 'pg' torch.distributed "
+                         "all-reduce between two graphs (default with gloo), 'native' imm_rccl_allreduce on its own stream, 'graph' "
+                         "imm_rccl_allreduce captured into the step's single graph (RCCL only)")
     ap.add_argument('--buckets', type=int, choices=(1, 2), default=None,
-                    help='all-reduce buckets (2: the renderer bucket travels while the encoders\' backward runs); default IMM_DP_BUCKETS or 1')
+                    help='all-reduce buckets (2: the renderer bucket travels while the encoders\' backward runs); default: 2 with '
+                         "'auto', else IMM_DP_BUCKETS or 1")
     ap.add_argument('--pmc-pass', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args()
     select_workload(args.config)
@@ -369,11 +418,21 @@ def main():
     from imm_amd.models.imm_model import IMMModel
     from imm_amd.train.cnn_train_multi import TrainStep
 
-    model = IMMModel(model_config(N_MAPS), dtype=torch_dtype(), device=dev, world_size=world, dp_buckets=args.buckets)
-    ts = TrainStep(model, BATCH_PER_GPU, IMAGE_SIZE, world_size=world, use_graph=not args.no_graph, split_graphs=args.force_dist,
-                   collective=args.collective)
-    eng = ts.engine
     inputs = synthetic_batch(BATCH_PER_GPU, IMAGE_SIZE, seed=rank, device=dev)
+    collective = args.collective
+    if collective is None and use_dist and not any(os.environ.get(v, '0') != '0' for v in ('IMM_RCCL_GRAPH', 'IMM_RCCL_NATIVE')):
+        collective = 'auto' if (args.backend == 'nccl' and not args.no_graph) else 'pg'
+    selfcheck = None
+    ts = None
+    if collective == 'auto':
+        ts, selfcheck = collective_selfcheck(dev, world, inputs, args.buckets or 2)
+        collective = 'graph' if ts is not None else 'pg'
+    if ts is None:
+        model = IMMModel(model_config(N_MAPS), dtype=torch_dtype(), device=dev, world_size=world,
+                         dp_buckets=(1 if selfcheck is not None else args.buckets))
+        ts = TrainStep(model, BATCH_PER_GPU, IMAGE_SIZE, world_size=world, use_graph=not args.no_graph, split_graphs=args.force_dist,
+                       collective=collective)
+    eng = ts.engine
     eng.set_inputs(inputs['image'], inputs['future_image'], inputs['mask'])     # resident in HBM from here on
     torch.cuda.synchronize()
 
@@ -480,7 +539,8 @@ def main():
                        'parallelism': 'dp%d' % world, 'hip_graph': not args.no_graph,
                        'collective': ({'backend': dist.get_backend(), 'world_size': dist.get_world_size(),
                                        'mode': ts.collective, 'buckets': ts.buckets, 'graph_resident': bool(ts.graph_resident),
-                                       'native_rccl': ts.native_comm is not None} if dist.is_initialized() else None),
+                                       'native_rccl': ts.native_comm is not None, 'selfcheck': selfcheck}
+                                      if dist.is_initialized() else None),
                        'weights': 'seeded random init; synthetic VGG16 (vgg16.caffemodel.h5 unavailable offline)'},
             'roofline': roof,
             'step': {'windows_ms': [round(w / args.steps * 1e3, 4) for w in windows],

@@ -796,8 +796,8 @@ class IMMEngine:
             prev = lay
             if lay.bn and lay.nol:
                 x, ci_real, ci_pad, ldx = lay.y, co, co, lay.ldy
-            else:
-                x, ci_real, ci_pad, ldx = lay.out, co, co, lay.ldo
+            else:       # (an up-sampled block without a stored `out`: x becomes the up-sampled tensor below, pixel stride co)
+                x, ci_real, ci_pad, ldx = lay.out, co, co, (lay.ldo if lay.out is not None else co)
             if up:
                 ub = getattr(lay, 'up', None)
                 if ub is None:       # not taken by the fused finalize + apply + up-sample pass

@@ -84,7 +84,7 @@ class TrainStep:
     COLLECTIVES = ('pg', 'native', 'graph')
 
     def __init__(self, model, batch_per_rank, image_size, world_size=1, use_graph=True, group=None, split_graphs=False,
-                 collective=None):
+                 collective=None, debug_poison=None):
         """collective (how the gradient exchange of a multi-rank step is issued; identical sums):
              'pg'      torch.distributed.all_reduce on the process group's stream between the two graphs (default)
              'native'  imm_rccl_allreduce of the C-ABI on a stream of this object, ordered by events (the process group then
@@ -93,7 +93,17 @@ class TrainStep:
                        step at N > 1 is ONE graph launch, like at N = 1 (needs use_graph)
            None = IMM_RCCL_GRAPH=1 -> 'graph', IMM_RCCL_NATIVE=1 -> 'native', else 'pg' (the environment only supplies the
            default of this argument).  The bucket count is the one the ENGINE was built for (IMMModel(dp_buckets=...) /
-           IMM_DP_BUCKETS at engine construction): it fixes the layout of the backward program and is read back from it."""
+           IMM_DP_BUCKETS at engine construction): it fixes the layout of the backward program and is read back from it.
+           With 'graph' and two buckets the renderer bucket's all-reduce is captured on a FORKED stream of the same graph
+           (concurrent with the encoders' backward nodes) and joined in front of the optimizer nodes.
+           debug_poison (None = IMM_DEBUG_POISON_GRADS): after the optimizer has been enqueued the flat gradient buffer is
+           filled with NaN on the step's stream.  Every element of it is rewritten by the next backward pass, so a correctly
+           ordered step never sees the poison; an exchange that is NOT ordered between "backward finished" and "optimizer
+           started" (a missing event / stream wait) reads or leaves NaNs and shows up as a NaN update.  So that this also works
+           with a ONE-rank communicator on a single-GPU box (where RCCL's in-place all-reduce touches nothing), every exchange is
+           followed — on the stream the collective itself was issued on — by `flat *= 2` (exact in f32): an optimizer that starts
+           before the exchange has finished sees unscaled gradients, an exchange that starts before the backward has finished
+           doubles NaNs; tests compare with the eager one-stream sequence fwd, bwd, grads *= 2, clip + Adam."""
         self.model = model
         self.world_size = world_size
         # two graphs with the all-reduce in between (always for world_size > 1; selectable at 1 to test that path)
@@ -118,9 +128,13 @@ class TrainStep:
             raise ValueError('collective must be one of %r, got %r' % (self.COLLECTIVES, collective))
         if collective == 'graph' and not use_graph:
             raise ValueError("collective 'graph' needs use_graph=True")
-        if collective == 'graph' and self.buckets >= 2:
-            raise ValueError("collective 'graph' is the one-bucket, one-graph form: build the engine with dp_buckets=1")
         self.collective = collective if self.split else None
+        if debug_poison is None:
+            debug_poison = os.environ.get('IMM_DEBUG_POISON_GRADS', '0') != '0'
+        self.debug_poison = bool(debug_poison)
+        self._poison_mask = None
+        self.after_backward = None                # test hook: f(engine) on the step's stream after the backward graph(s) of a
+                                                  # split step, before the exchange (fault injection: an overflow on ONE rank)
         # 'graph' has been validated with a one-rank communicator on the single-GPU test box only; multi-GPU timing has to come
         # from a node
         self.graph_resident = self.split and use_graph and collective == 'graph'
@@ -134,10 +148,32 @@ class TrainStep:
         self._graphs = None
         torch.cuda.synchronize(self.engine.dev)   # engine construction ran on the default stream
 
+    def _probe(self, flat):
+        """debug_poison: the marker every exchange leaves behind on the stream it was issued on (see __init__)."""
+        if self.debug_poison:
+            flat.mul_(2.0)
+
+    def _poison(self):
+        """debug_poison: NaN into every element of the flat gradient buffer that a backward pass rewrites (found once by running a
+        backward pass over a NaN-filled buffer: the analytically-zero bias gradients in front of a batch norm are written at
+        engine construction only and keep their zeros)."""
+        eng = self.engine
+        if self._poison_mask is None:
+            snap = eng.snapshot()
+            eng.grads.fill_(float('nan'))
+            eng.forward(True); eng.backward()
+            torch.cuda.current_stream(eng.dev).synchronize()
+            self._poison_mask = ~torch.isnan(eng.grads)
+            eng.restore(snap)
+            torch.cuda.current_stream(eng.dev).synchronize()
+        eng.grads.masked_fill_(self._poison_mask, float('nan'))
+
     # -- graph capture --------------------------------------------------------------------------------
     def _capture(self):
         eng = self.engine
         with torch.cuda.stream(self.stream):
+            if self.debug_poison and self._poison_mask is None:
+                snap0 = eng.snapshot(); self._poison(); eng.restore(snap0)      # builds the mask outside capture
             # warm every kernel up once outside capture (code-object loading, LDS attribute calls),
             # then roll the state back so the warm-up leaves no trace
             snap = eng.snapshot()
@@ -152,9 +188,30 @@ class TrainStep:
                 self.stream.synchronize()
                 g = ops.Graph()
                 g.capture_begin()
-                eng.run(eng.prog_fwd); eng.run(eng.prog_bwd)
-                self.native_comm.all_reduce_sum(eng.grads)
+                if self.buckets < 2:
+                    eng.run(eng.prog_fwd); eng.run(eng.prog_bwd)
+                    self.native_comm.all_reduce_sum(eng.grads); self._probe(eng.grads)
+                else:
+                    # fork: the renderer bucket (the tail of the flat buffer) is all-reduced on comm_stream — captured into the
+                    # same graph through the event — while the encoders' backward nodes run; the encoder bucket follows on the
+                    # same stream (one communicator: its collectives are issued in one order on every rank); join before the
+                    # optimizer nodes
+                    n0, off = eng.n_bwd_bucket0, eng.bucket0_offset
+                    eng.run(eng.prog_fwd); eng.run(eng.prog_bwd[:n0])
+                    fork = torch.cuda.Event(); fork.record(self.stream)
+                    self.comm_stream.wait_event(fork)
+                    with torch.cuda.stream(self.comm_stream):
+                        self.native_comm.all_reduce_sum(eng.grads[off:]); self._probe(eng.grads[off:])
+                    eng.run(eng.prog_bwd[n0:])
+                    tail = torch.cuda.Event(); tail.record(self.stream)
+                    self.comm_stream.wait_event(tail)
+                    with torch.cuda.stream(self.comm_stream):
+                        self.native_comm.all_reduce_sum(eng.grads[:off]); self._probe(eng.grads[:off])
+                    join = torch.cuda.Event(); join.record(self.comm_stream)
+                    self.stream.wait_event(join)
                 eng.run(eng.prog_opt)
+                if self.debug_poison:
+                    self._poison()
                 g.capture_end()
                 self._graphs = (g,)
             elif not self.split:
@@ -205,25 +262,37 @@ class TrainStep:
                 if self._graphs is None:
                     self._capture()
                 self._graphs[0].launch()
+                hook = self.after_backward
                 if self.graph_resident:
                     pass                              # the collective and the optimizer are nodes of that graph
                 elif self.split and self.native_comm is not None:
+                    if hook is not None and self.buckets < 2:
+                        hook(eng)
                     self._native_exchange(eng)
                 elif self.split and self.buckets < 2:
-                    average_gradients(eng.grads, self.world_size, self.group, force=True)
+                    if hook is not None:
+                        hook(eng)
+                    average_gradients(eng.grads, self.world_size, self.group, force=True); self._probe(eng.grads)
                     self._graphs[1].launch()
                 elif self.split:
                     off = eng.bucket0_offset
                     w0 = average_gradients(eng.grads[off:], self.world_size, self.group, force=True, async_op=True)
                     self._graphs[1].launch()          # encoder backward overlaps the first bucket's all-reduce
+                    if hook is not None:
+                        hook(eng)                     # (the encoder bucket: the renderer's is already travelling)
                     w1 = average_gradients(eng.grads[:off], self.world_size, self.group, force=True, async_op=True)
                     for w in (w0, w1):
                         if w is not None:
                             w.wait()                  # stream-level wait (RCCL stream -> this stream), not a host sync
+                    self._probe(eng.grads)            # (the process group's own stream is not ours to enqueue on)
                     self._graphs[2].launch()
+                if self.debug_poison and not self.graph_resident and self.split:
+                    self._poison()                    # after the optimizer graph: see __init__
             else:
                 eng.forward(True)
                 eng.backward()
+                if self.after_backward is not None:
+                    self.after_backward(eng)
                 average_gradients(eng.grads, self.world_size, self.group)
                 eng.optimizer_step()
         # the returned loss (a view of the engine's result buffer) is consumed on the CALLER's stream: order that stream after
@@ -239,7 +308,7 @@ class TrainStep:
             ev = torch.cuda.Event(); ev.record(self.stream)
             self.comm_stream.wait_event(ev)
             with torch.cuda.stream(self.comm_stream):
-                self.native_comm.all_reduce_sum(flat)
+                self.native_comm.all_reduce_sum(flat); self._probe(flat)
         if self.buckets < 2:
             on_comm(eng.grads)
         else:

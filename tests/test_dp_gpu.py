@@ -164,6 +164,57 @@ def test_two_ranks_on_one_gpu_run_the_split_graph_path_bitwise(emu, buckets):
     assert torch.equal(r0['agg'], A.loss_agg.cpu()) and torch.equal(r1['agg'], Bn.loss_agg.cpu())
 
 
+def _rank_main_f16(rank, world, port, ret):
+    """BASELINE configs[4] per-rank shape (K=50, f16 storage, dynamic loss scale) at world 2; the gradient of ONE rank overflows in
+    the second step (an inf planted after its backward pass, before the exchange)."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0')
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from imm_amd.models.imm_model import IMMModel
+    from imm_amd.train.cnn_train_multi import TrainStep, split_inputs
+    from imm_amd.utils.box import Box
+    full = O.synthetic_inputs(B_GLOBAL, S_IMG, seed=11)
+    mine = split_inputs(full, world, rank)
+    model = IMMModel(Box(dict(O.default_model_config(50))), dtype=torch.float16, device=DEV, world_size=world)
+    ts = TrainStep(model, B_GLOBAL // world, S_IMG, world_size=world, use_graph=True)
+    eng = ts.engine
+    assert eng.loss_scale_state is not None and float(eng.loss_scale_state[0]) == 4096.0
+    sums, scales, steps = [], [], []
+    for it in range(4):
+        ts.after_backward = (lambda e: e.gview['model/renderer/conv_3/w'].view(-1)[17:18].fill_(float('inf'))) if (it == 1 and rank == 1) else None
+        ts.step(mine if it == 0 else None)
+        ts.synchronize()
+        bits = eng.params.view(torch.int32).to(torch.int64)
+        sums.append(int(bits.sum()))
+        scales.append(float(eng.loss_scale_state[0])); steps.append((int(eng.step_count), int(eng.adam_t)))
+    ret[rank] = {'params': eng.params.cpu(), 'sums': sums, 'scales': scales, 'steps': steps, 'finite': bool(torch.isfinite(eng.params).all())}
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_two_ranks_f16_loss_scale_overflow_on_one_rank_skips_the_step_everywhere():
+    """VERDICT r4 item 4c / BASELINE configs[4] (f16 + loss scaling at world > 1, never run together before): the skip decision is
+    taken on the device from the norms of the ALL-REDUCED gradient (imm_clip_adam_step), so an overflow on one rank must make every
+    rank skip the same update (weights, Adam slots, global_step, Adam's t untouched), halve the scale on every rank, and leave the
+    replicas bit-identical (reference: cnn_train_multi.py:66-106 averages, then clips, then applies ONE update)."""
+    import torch.multiprocessing as mp
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    port = 29950 + (os.getpid() % 40)
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_rank_main_f16, args=(2, port, ret), nprocs=2, join=True)
+        r0, r1 = dict(ret[0]), dict(ret[1])
+    assert r0['finite'] and r1['finite']
+    assert torch.equal(r0['params'], r1['params']) and r0['sums'] == r1['sums']          # replicas identical after every step
+    assert r0['steps'] == r1['steps'] == [(1, 1), (1, 1), (2, 2), (3, 3)]                # step 2 of 4 skipped on BOTH ranks
+    assert r0['scales'] == r1['scales'] == [4096.0, 2048.0, 2048.0, 2048.0]              # ... and the scale halved on both
+    assert r0['sums'][1] == r0['sums'][0] and r0['sums'][2] != r0['sums'][1]             # the skipped step moved nothing
+
+
 @pytest.mark.timeout(900)
 def test_bench_self_spawns_two_ranks(tmp_path):
     """`python bench.py --gpus 2` with no launcher in front of it: bench.py re-executes itself under torch.distributed.run
@@ -209,3 +260,28 @@ def test_bench_self_spawns_eight_ranks(tmp_path):
     assert c['world_size'] == 8 and c['buckets'] == 1 and c['mode'] == 'pg' and c['backend'] == 'gloo'
     assert d['value'] > 0 and d['scaling'] == 'weak' and np.isfinite(d['step']['loss'])
     assert d['step']['replicas_identical'] is True
+
+
+@pytest.mark.timeout(1500)
+def test_bench_config4_eight_ranks_f16_loss_scale(tmp_path):
+    """`bench.py --config 4 --gpus 8` — BASELINE configs[4] as stated (K=50, f16 storage + dynamic loss scale, 8 ranks), with gloo
+    standing in for RCCL and the ranks sharing the one GPU: the f16 engine, its loss scale and the multi-rank path run TOGETHER,
+    the line names the configuration, and the replicas end bit-identical."""
+    import json
+    import subprocess
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    if torch.cuda.mem_get_info(0)[0] < 40 * 2 ** 30:
+        pytest.skip('needs ~30 GB of free HBM for eight co-resident engines')
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--config', '4', '--gpus', '8', '--steps', '3', '--warmup', '1',
+                          '--windows', '1', '--spin-seconds', '0', '--backend', 'gloo', '--share-gpu', '--no-cpu-baseline', '--no-pmc',
+                          '--collective', 'pg'], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1400)
+    assert out.returncode == 0, out.stderr.decode()[-3000:]
+    lines = [l for l in out.stdout.decode().splitlines() if l.strip().startswith('{')]
+    assert len(lines) == 1, out.stdout.decode()[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 8 and d['dtype'] == 'f16' and d['config']['n_maps'] == 50 and d['config']['baseline_config'] == 4
+    assert d['config']['global_batch'] == 256 and 'configs[4]' in d['config']['workload'] and 'K=50' in d['metric']
+    assert d['config']['loss_scale'] is not None and d['config']['loss_scale'][0] >= 1.0
+    assert d['step']['replicas_identical'] is True and np.isfinite(d['step']['loss'])

@@ -447,6 +447,18 @@ def test_bench_rccl_path_single_rank():
     d = json.loads(lines[0])
     assert d['n_gpus'] == 1 and d['steps'] == 3 and d['value'] > 0 and d['scaling'] == 'weak'
     assert d['roofline']['frac'] > 0
+    # round 5: over RCCL the default is chosen by a start-up self-check — the one-graph step with two overlapped buckets against the
+    # eager one-stream step — and recorded in the line
+    c = d['config']['collective']
+    assert c['selfcheck']['passed'] is True and c['selfcheck']['update_rel_diff'] < 1e-3 and c['selfcheck']['replicas_identical'] is True
+    assert c['mode'] == 'graph' and c['buckets'] == 2 and c['graph_resident'] is True
+    # an explicit choice skips the self-check
+    out = subprocess.run([sys.executable, os.path.join(repo, 'bench.py'), '--force-dist', '--steps', '2', '--warmup', '1', '--windows', '1',
+                          '--spin-seconds', '0', '--no-cpu-baseline', '--no-pmc', '--collective', 'pg'], env=env, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, timeout=600)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    c = json.loads([l for l in out.stdout.decode().splitlines() if l.strip()][0])['config']['collective']
+    assert c['mode'] == 'pg' and c['buckets'] == 1 and c['selfcheck'] is None
 
 
 def _smooth_batch(B, S, seed=3):
@@ -668,6 +680,66 @@ def test_native_rccl_exchange_single_rank(monkeypatch):
     assert abs(res[(False, 1, False, False)][0] - res[(False, 2, False, False)][0]) <= 1e-5 * abs(res[(False, 1, False, False)][0])
 
 
+def test_exchange_ordering_is_enforced_poisoned_gradients_and_delayed_collective(monkeypatch):
+    """the hand-offs between the step's stream, the communication stream and the optimizer have only ever met a
+    ONE-rank communicator, where a mis-ordered all-reduce changes no value.  TrainStep(debug_poison=True) makes ordering visible on
+    one GPU: the gradient buffer is NaN between steps (every element a backward pass rewrites) and every exchange leaves `*= 2`
+    behind on the stream it was issued on.  Expected result = the eager ONE-stream sequence fwd, bwd, grads *= 2, clip + Adam.
+      * all modes (C-ABI collective on its own stream / as nodes of the step's graph, one bucket / two overlapped buckets), with
+        the collective DELAYED by a 3 ms spin on its stream: bit-identical to the expected result — events, not luck, order them;
+      * negative control: the same delayed exchange with the join in front of the optimizer removed is caught (wrong or NaN)."""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    from imm_amd.train.cnn_train_multi import TrainStep
+    for v in ('IMM_RCCL_NATIVE', 'IMM_DP_BUCKETS', 'IMM_RCCL_GRAPH', 'IMM_DEBUG_POISON_GRADS'):
+        monkeypatch.delenv(v, raising=False)
+
+    def delayed(comm):
+        real = comm.all_reduce_sum
+
+        def f(flat):
+            torch.cuda._sleep(6_000_000)              # ~3 ms on the collective's stream, in front of the collective
+            real(flat)
+        comm.all_reduce_sum = f
+    for buckets in (1, 2):
+        cfg, model, eng, inputs, P, St = make(4, dp_buckets=buckets)
+        ref = TrainStep(model, 4, 128, world_size=1, use_graph=False)
+        ref.after_backward = lambda e: e.grads.mul_(2.0)
+        for it in range(3):
+            loss = ref.step(inputs)
+        ref.synchronize()
+        want_loss, want = float(loss), eng.params.clone()
+        assert bool(torch.isfinite(want).all())
+        for mode in ('native', 'graph'):
+            cfg, model, eng, inputs, P, St = make(4, dp_buckets=buckets)
+            ts = TrainStep(model, 4, 128, world_size=1, use_graph=True, split_graphs=True, collective=mode, debug_poison=True)
+            delayed(ts.native_comm)
+            for it in range(3):
+                loss = ts.step(inputs)
+            ts.synchronize()
+            assert float(loss) == want_loss and torch.equal(eng.params, want), (mode, buckets)
+            assert bool(torch.isnan(eng.grads).any())                 # the poison really sits there between steps
+            assert ts.graph_resident == (mode == 'graph') and ts.buckets == buckets
+            ts.native_comm.destroy()
+    # negative control: one bucket, the exchange on its own stream, delayed, and NOT joined in front of the optimizer
+    cfg, model, eng, inputs, P, St = make(4, dp_buckets=1)
+    ts = TrainStep(model, 4, 128, world_size=1, use_graph=True, split_graphs=True, collective='native', debug_poison=True)
+    delayed(ts.native_comm)
+
+    def broken_exchange(e):
+        ev = torch.cuda.Event(); ev.record(ts.stream)
+        ts.comm_stream.wait_event(ev)
+        with torch.cuda.stream(ts.comm_stream):
+            ts.native_comm.all_reduce_sum(e.grads); ts._probe(e.grads)
+        ts._graphs[-1].launch()                                      # <- no wait for the communication stream
+    ts._native_exchange = broken_exchange
+    for it in range(3):
+        ts.step(inputs)
+    ts.synchronize(); torch.cuda.synchronize()
+    assert not torch.equal(eng.params, want) or not bool(torch.isfinite(eng.params).all())
+    ts.native_comm.destroy()
+
+
 def test_train_loop_follows_the_device_step_when_updates_are_skipped(capsys):
     """f16 storage with a loss scale that starts far too high: the first updates overflow and are SKIPPED on the device (weights,
     slots and global_step untouched).  train_loop's host count follows the device's global_step, so the run ends with global_step ==
@@ -725,7 +797,7 @@ def test_filter_gradient_launches_are_chunked_by_the_table_caps(monkeypatch):
 
 
 def test_train_step_argument_checks():
-    """TrainStep(collective=...): unknown names, 'graph' without graph capture, 'graph' with two buckets are refused at construction."""
+    """TrainStep(collective=...): unknown names and 'graph' without graph capture are refused at construction."""
     if not torch.cuda.is_available():
         pytest.skip('no GPU')
     from imm_amd.train.cnn_train_multi import TrainStep
@@ -735,7 +807,8 @@ def test_train_step_argument_checks():
     with pytest.raises(ValueError):
         TrainStep(model, 2, 128, use_graph=False, collective='graph')
     cfg2, model2, eng2, _i, _P, _S = make(2, dp_buckets=2)
-    with pytest.raises(ValueError):
-        TrainStep(model2, 2, 128, split_graphs=True, collective='graph')
+    tg = TrainStep(model2, 2, 128, split_graphs=True, collective='graph')      # round 5: two overlapped buckets inside the one graph
+    assert tg.graph_resident and tg.buckets == 2
+    tg.native_comm.destroy()
     ts = TrainStep(model, 2, 128)                       # single rank, no split: no collective at all
     assert ts.collective is None and ts.buckets == 1 and ts.native_comm is None
