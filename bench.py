@@ -273,7 +273,8 @@ def parity_vs_oracle(dev, batch=2):
     out = {'reference': 'oracle/imm_oracle.py (fp32 torch-CPU restatement of the TF1 graph; parity unpinned against TF itself)',
            'batch': batch, 'image_size': IMAGE_SIZE, 'n_maps': N_MAPS, 'dtype': 'bf16 storage vs fp32'}
     out.update(one(torch.bfloat16))
-    out['bounds'] = {'mu_max_abs': 1e-3, 'loss_rel': 1e-3, 'terms_max_rel': 1e-2, 'recon_rel_l2': 0.12}
+    # reconstruction: bf16 storage drift through 16 conv + BN blocks (18 at 256x256): measured 0.080 / 0.106
+    out['bounds'] = {'mu_max_abs': 1e-3, 'loss_rel': 1e-3, 'terms_max_rel': 1e-2, 'recon_rel_l2': 0.10 if IMAGE_SIZE <= 128 else 0.13}
     out['f16'] = dict(one(torch.float16), dtype='f16 storage vs fp32',
                       bounds={'mu_max_abs': 1e-3, 'loss_rel': 1e-3, 'terms_max_rel': 2e-3, 'recon_rel_l2': 0.02})
     out['within_bounds'] = all(out[k] <= v for k, v in out['bounds'].items()) and \

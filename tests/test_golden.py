@@ -34,36 +34,52 @@ def test_oracle_matches_golden(K, B):
         assert list(G['param_names']) == names
 
 
+# Bounds per storage type (round 5: the f16 engine is a first-class parity row — 8x finer storage rounding makes it the tight
+# witness; measured on MI355X against these vectors, bf16 | f16: landmarks 1.8e-4 | 2.6e-5, loss 1.3e-6 | 2.3e-7, six terms
+# 3.8e-3 | 1.0e-3, reconstruction sample 0.080 | 0.011, normalisers 5e-7 | 9e-8, gradient norms of the well-conditioned tensors
+# 1.5e-3 .. 7.8e-3 | 4e-6 .. 1.5e-3).
+ENGINE_BOUNDS = {
+    'bf16': dict(mu=5e-4, loss=1e-4, terms=8e-3, recon=0.10, agg=1e-4,
+                 gn=(('model/renderer/conv_8/w', 5e-3), ('model/renderer/conv_8/b', 1e-3), ('model/renderer/conv_7/gamma', 1e-2),
+                     ('model/renderer/conv_7/w', 2e-2), ('model/renderer/conv_1/w', 1e-2), ('model/image_encoder/encoder/conv_8/w', 2e-2))),
+    'f16': dict(mu=1e-4, loss=1e-5, terms=2e-3, recon=0.02, agg=1e-5,
+                gn=(('model/renderer/conv_8/w', 1e-3), ('model/renderer/conv_8/b', 1e-4), ('model/renderer/conv_7/gamma', 1e-3),
+                    ('model/renderer/conv_7/w', 1e-3), ('model/renderer/conv_1/w', 5e-3), ('model/image_encoder/encoder/conv_8/w', 5e-3))),
+}
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('K,B', [(10, 2), (30, 1)])
-def test_engine_matches_golden(K, B):
+@pytest.mark.parametrize('dtn', ['bf16', 'f16'])
+def test_engine_matches_golden(K, B, dtn):
     """The HIP path against the SAME committed vectors (not against a fresh run of the oracle's code): landmarks, loss, its
     six terms, the weight-decay term, a sample of the reconstruction, the loss normalisers after one training forward and
-    the gradient norms of the well-conditioned tensors."""
+    the gradient norms of the well-conditioned tensors — with bf16 AND with f16 storage (f16: loss scale divided out)."""
     if not torch.cuda.is_available():
         pytest.skip('no GPU')
     from imm_amd.models.imm_model import IMMModel
     from imm_amd.utils.box import Box
+    lim = ENGINE_BOUNDS[dtn]
     cfg = O.default_model_config(K)
-    model = IMMModel(Box(dict(cfg)), dtype=torch.bfloat16, device='cuda:0')
+    model = IMMModel(Box(dict(cfg)), dtype=torch.bfloat16 if dtn == 'bf16' else torch.float16, device='cuda:0')
     inp = O.synthetic_inputs(B, 128, seed=0)
     _, loss, _, tens = model.build(inp, True, output_tensors=True)
     eng = model.engine
     eng.backward()
     torch.cuda.synchronize()
     t = 'k%d_b%d' % (K, B)
-    np.testing.assert_allclose(tens['gauss_yx'].cpu().numpy(), G[t + '/gauss_yx'], atol=1e-3)      # BASELINE.json tolerance
-    np.testing.assert_allclose(float(loss), float(G[t + '/loss']), rtol=1e-3)
+    np.testing.assert_allclose(tens['gauss_yx'].cpu().numpy(), G[t + '/gauss_yx'], atol=lim['mu'])   # BASELINE.json asks for 1e-3
+    np.testing.assert_allclose(float(loss), float(G[t + '/loss']), rtol=lim['loss'])
     np.testing.assert_allclose(float(eng.wd_loss), float(G[t + '/weights_loss']), rtol=1e-5)
-    np.testing.assert_allclose(eng.loss_terms.cpu().numpy(), G[t + '/loss_terms'], rtol=1e-2)
+    np.testing.assert_allclose(eng.loss_terms.cpu().numpy(), G[t + '/loss_terms'], rtol=lim['terms'])
     got = tens['future_im_pred'].float().cpu().numpy()[:, ::16, ::16, :]
     ref = G[t + '/pred_sample']
-    assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < 0.12          # bf16 storage drift (DESIGN.md numerics)
-    np.testing.assert_allclose(eng.loss_agg.cpu().numpy(), G[t + '/agg_after_step'], rtol=1e-2)
+    assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < lim['recon']   # storage drift through 16 conv + BN blocks (DESIGN.md §5)
+    np.testing.assert_allclose(eng.loss_agg.cpu().numpy(), G[t + '/agg_after_step'], rtol=lim['agg'])
     names = [n for n, _s, _w in eng.spec]
     if K == 10:
         assert names == list(G['param_names'])
         gn = G[t + '/grad_norms']
-        for k, tol in (('model/renderer/conv_8/w', 2e-2), ('model/renderer/conv_8/b', 1e-2), ('model/renderer/conv_7/gamma', 5e-2),
-                       ('model/renderer/conv_7/w', 8e-2)):
-            np.testing.assert_allclose(float(eng.gview[k].double().norm()), gn[names.index(k)], rtol=tol, err_msg=k)
+        gv = eng.named_gradients()
+        for k, tol in lim['gn']:
+            np.testing.assert_allclose(float(gv[k].double().norm()), gn[names.index(k)], rtol=tol, err_msg=k)

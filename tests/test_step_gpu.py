@@ -196,7 +196,7 @@ def test_one_step_matches_oracle(fwd2):
     opt = O.new_adam_state(Pe)
     newP, newS, info = O.train_step(Pe, Se, opt, [inputs], cfg, clip=1.0, lr=O.learning_rate(0), act_round=bf)
     got = eng.named_parameters()
-    bad = []
+    bad, coss = [], []
     for k, v in newP.items():
         if k.endswith('/b'):
             continue   # gradient is cancellation noise in the oracle (see test_gradient_parity)
@@ -205,14 +205,17 @@ def test_one_step_matches_oracle(fwd2):
         du_ref = (v - Pe[k]).detach().flatten().double()
         du_got = (got[k].cpu() - fwd2['P'][k]).flatten().double()
         cos = float((du_ref * du_got).sum() / (du_ref.norm() * du_got.norm() + 1e-30))
-        lim = 0.97 if k in ('model/renderer/conv_8/w', 'model/renderer/conv_7/gamma', 'model/renderer/conv_7/beta') else 0.5
+        # round 5: the floor for the ill-conditioned tensors raised from 0.5 (measured bf16 minimum 0.60 against the fp32 oracle)
+        lim = 0.97 if k in ('model/renderer/conv_8/w', 'model/renderer/conv_7/gamma', 'model/renderer/conv_7/beta') else 0.55
         print('STEP_PARITY %-48s cos(update) %.4f' % (k, cos))
+        coss.append(cos)
         if cos < lim:
             bad.append((k, cos))
         mag = float(du_got.abs().max())
         if not (mag <= 1.05e-3):
             bad.append((k, 'update magnitude', mag))      # |lr_t * m/(sqrt(v)+eps)| <= lr at t=1
     assert not bad, bad
+    assert float(np.median(np.array(coss))) >= 0.75, float(np.median(np.array(coss)))
     st = eng.named_state()
     for k, v in newS.items():
         if k.startswith('vgg16/'):
@@ -220,6 +223,43 @@ def test_one_step_matches_oracle(fwd2):
         tol = 2e-2 if 'moving' in k else 5e-3
         assert rel(st[k], v) < tol, (k, rel(st[k], v))
     assert int(eng.step_count) == 1
+
+
+def test_one_step_of_the_f16_engine_matches_the_fp32_oracle():
+    """The tight witness of the update direction (VERDICT r4 item 5 ii): the f16 engine (loss scale 4096) against the PLAIN fp32
+    oracle — no storage emulation in between.  The first Adam step moves every element by lr * sign(g), so cos(update) is the
+    fraction of elements whose gradient sign agrees: measured 0.82 (pose-encoder conv_4 gamma, the worst-conditioned tensor at
+    the 0.01-std initialisation) .. 1.0, median 0.94 — bounds 0.75 / 0.97 for the three well-conditioned tensors / median 0.9
+    (bf16 reaches 0.60 / median 0.80 on the same comparison)."""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    from imm_amd.models.imm_model import IMMModel
+    from imm_amd.utils.box import Box
+    cfg = O.default_model_config(10)
+    inputs = O.synthetic_inputs(2, 128)
+    P, St = O.init_params(cfg, 128)
+    newP, _newS, _info = O.train_step(P, St, O.new_adam_state(P), [inputs], cfg, clip=1.0, lr=O.learning_rate(0))
+    model = IMMModel(Box(dict(cfg)), dtype=torch.float16, device=DEV)
+    model.build(inputs, True)
+    eng = model.engine
+    eng.backward(); eng.optimizer_step()
+    torch.cuda.synchronize()
+    assert int(eng.step_count) == 1 and float(eng.loss_scale_state[0]) == 4096.0      # no overflow, update applied
+    got = eng.named_parameters()
+    bad, coss = [], []
+    for k, v in newP.items():
+        if k.endswith('/b'):
+            continue
+        du_ref = (v - P[k]).detach().flatten().double()
+        du_got = (got[k].cpu() - P[k]).flatten().double()
+        cos = float((du_ref * du_got).sum() / (du_ref.norm() * du_got.norm() + 1e-30))
+        coss.append(cos)
+        lim = 0.97 if k in ('model/renderer/conv_8/w', 'model/renderer/conv_7/gamma', 'model/renderer/conv_7/beta') else 0.75
+        if cos < lim:
+            bad.append((k, cos))
+        assert float(du_got.abs().max()) <= 1.05e-3, k
+    assert not bad, bad
+    assert float(np.median(np.array(coss))) >= 0.9, float(np.median(np.array(coss)))
 
 
 def test_eval_mode_and_model_only(fwd2):
