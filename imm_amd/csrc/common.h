@@ -127,5 +127,6 @@ static inline int imm_div_up(int64_t a, int64_t b) { return (int)((a + b - 1) / 
 
 // IMM_CONV_DISABLE=<comma list>: take a specialised convolution kernel out of the dispatch so that the layer falls back to
 // the next more general one (A/B timing and the fallback paths' tests): halo, halo2, hdeep, deepk, group, group32, wgrad_tr,
-// wgrad_halo, s2d / s2d_halo (one-launch stride-2 data gradient, deep-K / whole-filter form -> the four class launches), nol (imm_conv2d_nol_supported -> 0).  The ONLY dispatch switch the kernels read; every tuning constant is compiled in.
+// wgrad_halo, s2d / s2d_halo (one-launch stride-2 data gradient, deep-K / whole-filter form -> the four class launches), nol (imm_conv2d_nol_supported -> 0),
+// hdeep6 (six-k-steps-per-barrier 16x16x128 tile -> conv_hdeep's tap-at-a-time form), s2f (stride-2 forward LDS-halo kernel -> im2col).  The ONLY dispatch switch the kernels read; every tuning constant is compiled in.
 bool imm_conv_disabled(const char* name);

@@ -27,6 +27,10 @@ void imm_conv_halo_nol_launch(int dtype, const imm_conv_desc* d, const ConvArgs&
                               hipStream_t s);
 bool imm_halo_s2d_applicable(const imm_conv_desc* d);
 void imm_conv_halo_s2d_launch(int dtype, const imm_conv_desc* d, const ConvArgs& a, hipStream_t s);
+bool imm_s2f_applicable(const imm_conv_desc* d);                                   // conv_s2f.hip
+int imm_s2f_stats_blocks(const imm_conv_desc* d);
+int imm_s2f_variant(const imm_conv_desc* d);
+void imm_conv_s2f_launch(int dtype, const imm_conv_desc* d, const ConvArgs& a, hipStream_t s);
 bool imm_hdeep_s2d_applicable(const imm_conv_desc* d);
 void imm_conv_hdeep_s2d_launch(int dtype, const imm_conv_desc* d, const ConvArgs& a, hipStream_t s);
 bool imm_halo2_applicable(const imm_conv_desc* d);                                 // conv_halo2.hip
@@ -286,6 +290,7 @@ extern "C" int imm_conv_stats_blocks(const imm_conv_desc* d) {
   if (imm_halo2_applicable(d)) return imm_halo2_grid(d);
   if (imm_halo_applicable(d)) return imm_halo_grid(d);
   if (imm_hdeep_applicable(d)) return imm_hdeep_stats_blocks(d);
+  if (imm_s2f_applicable(d)) return imm_s2f_stats_blocks(d);
   const int64_t M = (int64_t)d->batch * d->ho * d->wo;
   const TileCfg t = pick_tile(M, d->co);
   return (int)((M + t.bm - 1) / t.bm);
@@ -336,6 +341,11 @@ static int conv_launch(const imm_conv_desc* d, const void* x, const void* wt, co
     IMM_CHECK_LAUNCH("imm_conv2d(hdeep)");
     return 0;
   }
+  if (imm_s2f_applicable(d)) {
+    imm_conv_s2f_launch(ET::kEnum, d, a, s);
+    IMM_CHECK_LAUNCH("imm_conv2d(s2f)");
+    return 0;
+  }
   const TileCfg t = pick_tile(a.M, a.co);
   a.n_nblk = (a.co + t.bn - 1) / t.bn;
   const int64_t xb = (int64_t)d->batch * d->hi * d->wi * d->ldx * 2, wb = (int64_t)d->co * d->kpad * 2;
@@ -355,13 +365,15 @@ static int conv_launch(const imm_conv_desc* d, const void* x, const void* wt, co
 
 // Which kernel imm_conv2d runs for a descriptor (the twin of imm_conv2d_wgrad_variant): family * 100000 + tile variant, following
 // conv_launch's order exactly.  Families: 1 conv_igemm (BK = 32, register-staged), 2 conv_igemm64 (BK = 64, LDS-DMA ring),
-// 3 conv_halo (filter in LDS), 4 conv_halo2 (filter in registers), 5 conv_hdeep (LDS halo, tap / row at a time), 6 conv_hdeep6.
+// 3 conv_halo (filter in LDS), 4 conv_halo2 (filter in registers), 5 conv_hdeep (LDS halo, tap / row at a time), 6 conv_hdeep6,
+// 7 conv_s2f (stride-2 forward through a parity-de-interleaved LDS halo).
 extern "C" int imm_conv2d_variant(const imm_conv_desc* d, int dtype) {
   if (validate_desc(d)) return IMM_E_INVALID;
   IMM_REQUIRE(dtype == IMM_BF16 || dtype == IMM_F16, "unknown dtype %d", dtype);
   if (imm_halo2_applicable(d)) return 400000 + (d->kw == 1 ? 10000 : 0) + d->ci * 100 + (d->co > 32 ? 64 : 32);
   if (imm_halo_applicable(d)) return 300000 + (d->stride == 2 ? 10000 : 0) + d->ci * 100 + (d->co > 32 ? 64 : d->co > 16 ? 32 : 16);
   if (imm_hdeep_applicable(d)) return imm_hdeep_variant(d);
+  if (imm_s2f_applicable(d)) return imm_s2f_variant(d);
   const TileCfg t = pick_tile((int64_t)d->batch * d->ho * d->wo, d->co);
   const int64_t xb = (int64_t)d->batch * d->hi * d->wi * d->ldx * 2, wb = (int64_t)d->co * d->kpad * 2;
   const bool fast = (d->ci % 32 == 0) && xb < (1LL << 31) && wb < (1LL << 31);

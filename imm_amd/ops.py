@@ -183,7 +183,7 @@ def conv2d_wgrad(desc, x, dy, lddy, slab, nsplit):
     call('imm_conv2d_wgrad', C.byref(desc), dtype_enum(x.dtype), _p(x), _p(dy), lddy, _p(slab), nsplit, _s())
 
 
-CONV_FAMILIES = {1: 'igemm', 2: 'igemm64', 3: 'halo', 4: 'halo2', 5: 'hdeep', 6: 'hdeep6'}
+CONV_FAMILIES = {1: 'igemm', 2: 'igemm64', 3: 'halo', 4: 'halo2', 5: 'hdeep', 6: 'hdeep6', 7: 's2f'}
 
 
 def conv2d_variant(desc, dtype):

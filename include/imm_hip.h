@@ -150,7 +150,8 @@ int imm_conv_stats_blocks(const imm_conv_desc* desc_host);
 /* Which kernel imm_conv2d dispatches `desc` to: family * 100000 + tile variant (>= 100000; negative = invalid descriptor).
  * Families: 1 conv_igemm (im2col, BK = 32), 2 conv_igemm64 (im2col, BK = 64, LDS-DMA ring), 3 conv_halo (LDS halo, filter in LDS),
  * 4 conv_halo2 (LDS halo, filter in registers), 5 conv_hdeep (LDS halo of a 64-channel slice, filter taps streamed), 6 conv_hdeep6
- * (the 16x16x128 tile on 32-channel slices, six k-steps per barrier).  The twin of imm_conv2d_wgrad_variant: tests assert that the
+ * (the 16x16x128 tile on 32-channel slices, six k-steps per barrier), 7 conv_s2f (3x3 stride-2 forward, parity-de-interleaved LDS
+ * halo).  The twin of imm_conv2d_wgrad_variant: tests assert that the
  * kernel a case is named after is the one that ran; tools/layer_table.py prints it per layer.  Host-only, no launch. */
 int imm_conv2d_variant(const imm_conv_desc* desc_host, int dtype);
 /* imm_conv2d of a data gradient (no bias / ReLU / statistics) that ENTERS a tapped activation of the frozen VGG16 (conv3_2, conv4_2 of

@@ -218,6 +218,44 @@ def test_conv_stride2_halo_bias_and_bn_sums(ops, dt):
     close(st[1], (ref ** 2).sum(dim=(0, 1, 2)), 1e-3, 1e-3, 'halo_s2/sumsq')
 
 
+S2F_CASES = [
+    # B, H, ci, co, expected channel block, tag        (3x3 stride 2, ci % 64 == 0, co % 64 == 0: conv_s2f.hip)
+    (32, 64, 64, 128, 128, 'enc_conv5_64to128'),      # 256 patches x one 128-channel block: 8 waves
+    (32, 32, 128, 256, 64, 'enc_conv7_128to256'),     # 64 patches: 128-wide blocks would leave half the chip idle -> 64 (4 waves)
+    (3, 32, 64, 64, 64, 'one_nblk_two_slices'),
+    (2, 32, 192, 192, 64, 'six_slices_three_nblk'),     # two patches per image (32x32 -> 16x16 outputs), 192 = six 32-channel slices
+    (5, 48, 64, 128, 64, 'ragged_rows_h48'),           # 24x24 outputs: wo % 16 != 0 -> NOT served (falls to the im2col kernel)
+]
+
+
+@pytest.mark.parametrize('case', S2F_CASES, ids=[c[-1] for c in S2F_CASES])
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16], ids=['bf16', 'f16'])
+def test_conv_stride2_forward_lds_halo(ops, case, dt):
+    """Encoder conv_5 / conv_7 (imm_model.py:204,211): the stride-2 forward convolution through the parity-de-interleaved LDS
+    halo (conv_s2f.hip) against the oracle — bias + batch-norm partial sums as the encoder uses it, the zero padding of S1 (0 top /
+    left, 1 bottom / right: the last output row / column reads one row / column of zeros), several slices and channel blocks."""
+    from imm_amd import _lib as L
+    B, H, ci, co, bn, tag = case
+    x = rnd((B, H, H, ci), 191, 1.0, dt)
+    w = rnd((3, 3, ci, co), 192, 0.05, dt)
+    b = rnd((co,), 193, 0.5, torch.float32)
+    y, stats, desc = run_conv(ops, x, w, b, 3, 2, co, ci, False, extra_flags=L.CONV_STATS)
+    fam, key = ops.conv2d_variant(desc, dt)
+    if tag.startswith('ragged'):
+        assert fam == 'igemm64', (fam, key)
+    else:
+        assert (fam, key) == ('s2f', 700000 + bn), (fam, key)
+        assert stats.shape[0] == B * (H // 16) * (H // 32)
+    assert (desc.ho, desc.pad_t, desc.pad_l) == (H // 2, 0, 0)
+    ref = O.conv2d_same(x.float(), w.float(), b, 2)
+    close(y, ref, 1e-2 if dt == torch.bfloat16 else 2e-3, 2e-3, 's2f/' + tag)
+    st = stats.sum(dim=0).cpu()
+    close(st[0], ref.sum(dim=(0, 1, 2)), 1e-3, 1e-3, 's2f/sum')
+    close(st[1], (ref ** 2).sum(dim=(0, 1, 2)), 1e-3, 1e-3, 's2f/sumsq')
+    y1, _, _ = run_conv(ops, x, w, None, 3, 2, co, ci, False)               # no bias, no sums
+    close(y1, O.conv2d_same(x.float(), w.float(), None, 2), 1e-2 if dt == torch.bfloat16 else 2e-3, 2e-3, 's2f/nobias/' + tag)
+
+
 # ----------------------------------------------------------------------------------------------
 # data gradient
 # ----------------------------------------------------------------------------------------------

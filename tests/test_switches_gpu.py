@@ -41,7 +41,8 @@ def same(a, b, rel):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize('names', ['halo,halo2,hdeep,deepk', 'group,group32', 'wgrad_tr,wgrad_halo', 's2d', 's2d,s2d_halo,group,group32'])
+@pytest.mark.parametrize('names', ['halo,halo2,hdeep,deepk', 'group,group32', 'wgrad_tr,wgrad_halo', 's2d', 's2d,s2d_halo,group,group32',
+                                   'hdeep6', 's2f', 'hdeep6,s2f'])
 def test_conv_disable_falls_back_to_the_general_kernels(base, names):
     """IMM_CONV_DISABLE: with the specialised kernels out of the dispatch every layer runs on the im2col / generic kernels —
     the same step to accumulation order (loss 1e-4, parameters after two updates 1e-4 of their abs-sum)."""

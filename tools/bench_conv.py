@@ -48,6 +48,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--ablate', action='store_true')
     ap.add_argument('--wgrad', action='store_true')
+    ap.add_argument('--bn', action='store_true', help='flags of a conv + BN block: bias + batch-norm partial sums, no ReLU')
     ap.add_argument('--layers', default='', help="probe shapes instead of the table: 'images,H,ci,co[,k[,stride]];...'")
     args = ap.parse_args()
     global LAYERS
@@ -74,14 +75,15 @@ def main():
             if use_mask:
                 desc = ops.fwd_desc(n, H, H, ci, ci, co, co, k, stride, L.CONV_MASK | vflag, ldmask=co)
             else:
-                desc = ops.fwd_desc(n, H, H, ci, ci, co, co, k, stride, L.CONV_BIAS | L.CONV_RELU | vflag)
+                desc = ops.fwd_desc(n, H, H, ci, ci, co, co, k, stride, (L.CONV_BIAS | L.CONV_STATS if args.bn else L.CONV_BIAS | L.CONV_RELU) | vflag)
             wt = torch.zeros(ops.round_up(co, 128), desc.kpad, dtype=dt, device=DEV)
             ops.pack_weights(w, wt, 0, k, k, ci, co, ci, wt.shape[0], desc.kpad)
             y = torch.empty(n, desc.ho, desc.wo, co, dtype=dt, device=DEV)
-            us = time_launch(lambda: ops.conv2d(desc, x, wt, None if use_mask else b, y, None, mref))
+            st = torch.empty(ops.conv_stats_blocks(desc), 2, co, device=DEV) if args.bn else None
+            us = time_launch(lambda: ops.conv2d(desc, x, wt, None if use_mask else b, y, st, mref))
             flops = 2.0 * n * desc.ho * desc.wo * k * k * ci * co
             nbytes = x.numel() * 2 + y.numel() * 2 + wt.numel() * 2 + (mref.numel() * 2 if use_mask else 0)
-            print('%-30s %-13s %10.1f %9.1f %9.0f' % (tag, vname, us, flops / us / 1e6, nbytes / us / 1e3))
+            print('%-30s %-13s %10.1f %9.1f %9.0f  %s' % (tag, vname, us, flops / us / 1e6, nbytes / us / 1e3, ops.conv2d_variant(desc, dt)[0]))
         if args.wgrad:
             desc = ops.fwd_desc(n, H, H, ci, ci, co, co, k, stride, 0)
             dy = (torch.randn(n, desc.ho, desc.wo, co, device=DEV)).to(dt)
