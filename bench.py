@@ -289,8 +289,9 @@ def collective_selfcheck(dev, world, inputs, buckets):
     all-reduce of the whole flat buffer, clip + Adam.  Same seeds, same inputs, two steps; the two paths use different
     communicators (the summation order over > 2 ranks may differ), so the UPDATES are compared to 1e-3 relative (a mis-ordered
     exchange — stale, partial or un-reduced gradients — moves an Adam update by O(1)); the candidate's replicas must be
-    bit-identical across ranks.  Every rank must pass.  Returns (TrainStep of the candidate restored to its initial state, or None,
-    record for the bench line)."""
+    bit-identical across ranks.  Every rank must pass.  Runs in a CHILD process per rank (selfcheck_in_children): the candidate
+    has only ever met a one-rank communicator on the build boxes, and a hang there must not take the measurement with it.
+    Returns the record for the bench line."""
     from imm_amd.models.imm_model import IMMModel
     from imm_amd.train.cnn_train_multi import TrainStep
     rec = {'candidate': 'graph, %d bucket(s)' % buckets, 'reference': 'eager one-stream step, one torch.distributed all-reduce',
@@ -300,7 +301,6 @@ def collective_selfcheck(dev, world, inputs, buckets):
         tc = TrainStep(mc, BATCH_PER_GPU, IMAGE_SIZE, world_size=world, use_graph=True, split_graphs=True, collective='graph')
         mr = IMMModel(model_config(N_MAPS), dtype=torch_dtype(), device=dev, world_size=world, dp_buckets=buckets)
         tr = TrainStep(mr, BATCH_PER_GPU, IMAGE_SIZE, world_size=world, use_graph=False, split_graphs=True, collective='pg')
-        snap = tc.engine.snapshot()
         p0 = tc.engine.params.clone()
         for t in (tc, tr):
             t.step(inputs); t.step(None); t.synchronize()
@@ -315,17 +315,49 @@ def collective_selfcheck(dev, world, inputs, buckets):
         flag = torch.tensor([1 if ok else 0], device=dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         rec.update(update_rel_diff=rel, replicas_identical=same, passed=bool(int(flag)))
-        tc.engine.restore(snap)
-        torch.cuda.synchronize()
-        del tr, mr
-        torch.cuda.empty_cache()
-        if rec['passed']:
-            return tc, rec
-        tc.native_comm.destroy()
-        return None, rec
     except Exception as e:          # a candidate that cannot even be built falls back like one that fails
         rec.update(passed=False, error='%s: %s' % (type(e).__name__, e))
-        return None, rec
+    return rec
+
+
+def selfcheck_child(args):
+    """`bench.py --selfcheck-child`: one rank of the self-check's own process group (MASTER_PORT of the run + 7)."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local_rank)
+    dev = 'cuda:%d' % local_rank
+    dist.init_process_group('nccl', device_id=torch.device(dev))
+    rec = collective_selfcheck(dev, world, synthetic_batch(BATCH_PER_GPU, IMAGE_SIZE, seed=rank, device=dev), args.buckets or 2)
+    sys.stdout.write('SELFCHECK ' + json.dumps(rec) + '\n'); sys.stdout.flush()
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0 if rec.get('passed') else 3
+
+
+def selfcheck_in_children(args, dev, world, ctrl, timeout_s=300.0):
+    """Every rank runs the self-check in a child process (same GPU, a process group of the children's own) and waits for it with a
+    time limit; a child that hangs, crashes or fails makes EVERY rank fall back (MIN over ranks on the parents' group)."""
+    env = dict(os.environ)
+    env['MASTER_PORT'] = str(int(os.environ.get('MASTER_PORT', '29511')) + 7)
+    cmd = [sys.executable, os.path.abspath(__file__), '--selfcheck-child', '--config', str(WL.get('index', 1)), '--gpus', str(world),
+           '--buckets', str(args.buckets or 2)]
+    rec = {'candidate': 'graph, %d bucket(s)' % (args.buckets or 2), 'passed': False, 'isolated': 'child process per rank, %.0f s limit' % timeout_s}
+    t0 = time.time()
+    try:
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s)
+        for line in r.stdout.decode().splitlines():
+            if line.startswith('SELFCHECK '):
+                rec.update(json.loads(line[10:]))
+        if r.returncode not in (0, 3):
+            rec.update(passed=False, error='child exit code %d: %s' % (r.returncode, r.stderr.decode()[-300:]))
+    except subprocess.TimeoutExpired:
+        rec.update(passed=False, error='child timed out after %.0f s' % timeout_s)
+    rec['seconds'] = round(time.time() - t0, 1)
+    flag = torch.tensor([1 if rec.get('passed') else 0], dtype=torch.int64, device=ctrl)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    rec['passed'] = bool(int(flag))
+    return rec
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -379,12 +411,15 @@ def main():
                     help='all-reduce buckets (2: the renderer bucket travels while the encoders\' backward runs); default: 2 with '
                          "'auto', else IMM_DP_BUCKETS or 1")
     ap.add_argument('--pmc-pass', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--selfcheck-child', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args()
     select_workload(args.config)
 
     if args.pmc_pass:
         pmc_pass(args.steps)
         return 0
+    if args.selfcheck_child:
+        return selfcheck_child(args)
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         return self_spawn(args, sys.argv[1:])
 
@@ -424,15 +459,13 @@ def main():
     if collective is None and use_dist and not any(os.environ.get(v, '0') != '0' for v in ('IMM_RCCL_GRAPH', 'IMM_RCCL_NATIVE')):
         collective = 'auto' if (args.backend == 'nccl' and not args.no_graph) else 'pg'
     selfcheck = None
-    ts = None
+    buckets = args.buckets
     if collective == 'auto':
-        ts, selfcheck = collective_selfcheck(dev, world, inputs, args.buckets or 2)
-        collective = 'graph' if ts is not None else 'pg'
-    if ts is None:
-        model = IMMModel(model_config(N_MAPS), dtype=torch_dtype(), device=dev, world_size=world,
-                         dp_buckets=(1 if selfcheck is not None else args.buckets))
-        ts = TrainStep(model, BATCH_PER_GPU, IMAGE_SIZE, world_size=world, use_graph=not args.no_graph, split_graphs=args.force_dist,
-                       collective=collective)
+        selfcheck = selfcheck_in_children(args, dev, world, dev if args.backend == 'nccl' else 'cpu')
+        collective, buckets = ('graph', args.buckets or 2) if selfcheck['passed'] else ('pg', 1)
+    model = IMMModel(model_config(N_MAPS), dtype=torch_dtype(), device=dev, world_size=world, dp_buckets=buckets)
+    ts = TrainStep(model, BATCH_PER_GPU, IMAGE_SIZE, world_size=world, use_graph=not args.no_graph,
+                   split_graphs=args.force_dist or collective == 'graph', collective=collective)
     eng = ts.engine
     eng.set_inputs(inputs['image'], inputs['future_image'], inputs['mask'])     # resident in HBM from here on
     torch.cuda.synchronize()

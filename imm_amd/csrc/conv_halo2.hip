@@ -44,7 +44,12 @@ __device__ __forceinline__ void h2_dma16(u32x4_t rsrc, uint32_t lds_addr, uint32
                :: "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
 }
 __device__ __forceinline__ void h2_store16(u32x4_t rsrc, u32x4_t data, uint32_t voff, uint32_t soff) {
-  asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen" :: "v"(data), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+  // The trailing s_nop 1 is REQUIRED (round 5): a VMEM store of more than 64 bits reads its data registers over the cycles after
+  // issue, and hipcc — which does not know what is inside an asm statement — pads no wait states behind it; without them its next
+  // VALU instruction may overwrite v[data] before the store has read it (cdna_hip_programming.md §5.7 "Stores").  Seen as a
+  // 0.3 % rate of corrupted 16-byte outputs of the ci = 64 instantiations (358 registers, the data registers are reused at once)
+  // whenever a second process shared the GPU — the flaky two-rank test of rounds 3-5 (tools/det_graph.py reproduces it).
+  asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" :: "v"(data), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
 }
 
 // same chunk swizzle as conv_halo.hip: a ds_read_b128 of 16 consecutive halo pixels (any start) is conflict-free

@@ -148,10 +148,10 @@ def synthetic_vgg_weights(seed=2):
 
 
 class _Launch:
-    __slots__ = ('fn', 'tag', 'flops', 'bytes', 'name', 'lane')
+    __slots__ = ('fn', 'tag', 'flops', 'bytes', 'name', 'lane', 'variant')
 
-    def __init__(self, fn, tag, flops=0.0, nbytes=0.0, name='', lane=0):
-        self.fn, self.tag, self.flops, self.bytes, self.name, self.lane = fn, tag, flops, nbytes, name, lane
+    def __init__(self, fn, tag, flops=0.0, nbytes=0.0, name='', lane=0, variant=''):
+        self.fn, self.tag, self.flops, self.bytes, self.name, self.lane, self.variant = fn, tag, flops, nbytes, name, lane, variant
 
 
 class _ConvLayer:
@@ -336,8 +336,12 @@ class IMMEngine:
     # ------------------------------------------------------------------------------------------
     # network construction
     # ------------------------------------------------------------------------------------------
-    def _add(self, prog, fn, tag, flops=0.0, nbytes=0.0, name=''):
-        prog.append(_Launch(fn, tag, flops, nbytes, name or getattr(self, '_cur_scope', ''), getattr(self, '_cur_lane', 0)))
+    def _add(self, prog, fn, tag, flops=0.0, nbytes=0.0, name='', desc=None, variant=''):
+        """desc: the imm_conv_desc of a convolution launch — its kernel variant (imm_conv2d_variant) is recorded with the launch
+        (tools/layer_table.py: layer -> kernel -> time -> floor)."""
+        if desc is not None:
+            variant = '%s:%d' % ops.conv2d_variant(desc, self.dt)
+        prog.append(_Launch(fn, tag, flops, nbytes, name or getattr(self, '_cur_scope', ''), getattr(self, '_cur_lane', 0), variant))
 
     def _signal(self, prog, key, lane=None):
         """Record an event on `lane` (default: the current lane) that other lanes can wait for."""
@@ -431,7 +435,8 @@ class IMMEngine:
                 ops.bn_finalize(lay.stats, nblk, co, npix, gamma, beta, BN_EPS, BN_MOMENTUM, self._training, mm, mv,
                                 lay.scale, lay.shift, lay.mean, lay.rstd)
             cbytes = 2.0 * (B * H * W * ci_pad + npix * co + fd.kpad * co)
-            self._add(self.prog_fwd, f_conv, 'conv_fwd', flops, cbytes)
+            self._add(self.prog_fwd, f_conv, 'conv_fwd', flops, cbytes, desc=(fd if (first_src is None and nol_src is None) else None),
+                      variant=('first' if first_src is not None else 'halo:nol' if nol_src is not None else ''))
             lay.up = None
             if defer_apply:
                 # normalise on load: the consumers rebuild relu(scale * y + shift) in LDS, so the apply pass (read y, write out:
@@ -480,7 +485,7 @@ class IMMEngine:
                           'conv_fwd', flops, 2.0 * (B * H * W * ci_pad + fd.kpad * co) + npix * co * (4.0 if out_f32 else 2.0))
             elif fwd_launch:      # (the pose head's convolution is part of the fused imm_pose_head_fwd launch instead)
                 self._add(self.prog_fwd, lambda: ops.conv2d(fd_eval, x, lay.wt, b, lay.y), 'conv_fwd', flops,
-                          2.0 * (B * H * W * ci_pad + fd.kpad * co) + npix * co * (4.0 if out_f32 else 2.0))
+                          2.0 * (B * H * W * ci_pad + fd.kpad * co) + npix * co * (4.0 if out_f32 else 2.0), desc=fd_eval)
 
         # ---- backward resources -------------------------------------------------------------------
         lay.needs_dgrad = needs_dgrad
@@ -586,7 +591,7 @@ class IMMEngine:
         if lay.needs_dgrad and dx is not None and getattr(lay, 's2_fused', False):
             assert lddx % 8 == 0 and lddx >= lay.ci_real, (lddx, lay.ci_real)
             self._add(self.prog_bwd, lambda: ops.conv2d_dgrad_s2(dy, lddy, lay.wt_d, dx, lddx, lay.ci_real, B, lay.Ho, lay.Wo),
-                      'conv_dgrad', flops, 2.0 * (npix * lddy + 4 * npix * lay.ci_real + 9 * lddy * lay.ci_real))
+                      'conv_dgrad', flops, 2.0 * (npix * lddy + 4 * npix * lay.ci_real + 9 * lddy * lay.ci_real), variant='s2d')
         elif lay.needs_dgrad and dx is not None and getattr(lay, 's2', None) is not None:
             # stride 2: the four input-pixel parity classes as one grouped launch (falls back to four launches inside the
             # library when the members do not take a grouped tile)
@@ -595,7 +600,7 @@ class IMMEngine:
             ntaps = sum(dd0.kh * dd0.kw for dd0, _m in classes)
             self._add(self.prog_bwd, (lambda grp=grp: ops.conv2d_group(grp, dy, dx, None, None)), 'conv_dgrad',
                       2.0 * npix * ntaps * lay.ci_real * co,
-                      2.0 * (4 * npix * lddy + 4 * npix * lay.ci_real + sum(dd0.kpad for dd0, _m in classes) * lay.ci_real))
+                      2.0 * (4 * npix * lddy + 4 * npix * lay.ci_real + sum(dd0.kpad for dd0, _m in classes) * lay.ci_real), variant='group')
         elif lay.needs_dgrad and dx is not None:
             # output channels: the padded count when that makes whole 64-channel blocks (the concat layer: 266 -> 320, its
             # packed filter rows beyond ci_real are zeros) — the deep-K kernels need co % 64 == 0
@@ -604,7 +609,7 @@ class IMMEngine:
             dd = ops.dgrad_desc(B, lay.H, lay.W, co_dx, lddx, lddy, lddy, k, lay.stride, 0)
             assert dd.kpad == lay.wt_d.shape[1], (dd.kpad, lay.wt_d.shape)
             self._add(self.prog_bwd, lambda: ops.conv2d(dd, dy, lay.wt_d, None, dx), 'conv_dgrad', flops,
-                      2.0 * (npix * lddy + B * lay.H * lay.W * lay.ci_real + dd.kpad * lay.ci_real))
+                      2.0 * (npix * lddy + B * lay.H * lay.W * lay.ci_real + dd.kpad * lay.ci_real), desc=dd)
 
     def _flush_wgrads(self, name):
         """Issue the collected filter-gradient jobs as ONE multi-problem launch per kernel variant (imm_conv2d_wgrad_multi) and
@@ -847,7 +852,7 @@ class IMMEngine:
             bias = self.vgg_w['vgg16/%s/biases' % name]
             self._add(self.prog_fwd, (lambda fd=fd, x=x, wt=wt, bias=bias, y=y: ops.conv2d(fd, x, wt, bias, y)),
                       'vgg_fwd', 2.0 * nimg * H * H * 9 * cin * cout, 2.0 * (nimg * H * H * (cin + cout) + 9 * cin * cout),
-                      name='vgg16/' + name)
+                      name='vgg16/' + name, desc=fd)
             self.vgg_act[name] = (y, H)
             x = y
             if name in VGG_POOL_AFTER and li < len(self.vgg_layers) - 1:      # the deepest layer is not pooled: nobody reads it
@@ -971,13 +976,14 @@ class IMMEngine:
                     ya = acts[tap_of][0]
                     self._add(self.prog_bwd, lambda: ops.conv2d_tap(dt0, src, wtd, dst, ya[B:], ya[:B], cin, mask, S, self.coef,
                                                                     taps[tap_of], l1), 'vgg_dgrad', flops,
-                              2.0 * (B * H * H * (3 * cin + cout) + 9 * cin * cout), name='vgg16/%s+tap(%s)' % (name, tap_of))
+                              2.0 * (B * H * H * (3 * cin + cout) + 9 * cin * cout), name='vgg16/%s+tap(%s)' % (name, tap_of), desc=dt0)
                     fused_taps.add(tap_of)
                     return
             flags = L.CONV_MASK if mask_ref is not None else 0
             dd = ops.dgrad_desc(B, H, H, cin, cin, cout, cout, 3, 1, flags, ldmask=cin)
             self._add(self.prog_bwd, lambda: ops.conv2d(dd, src, wtd, None, dst, None, mask_ref), 'vgg_dgrad', flops,
-                      2.0 * (B * H * H * (cin + cout + (cin if mask_ref is not None else 0)) + 9 * cin * cout), name='vgg16/' + name)
+                      2.0 * (B * H * H * (cin + cout + (cin if mask_ref is not None else 0)) + 9 * cin * cout), name='vgg16/' + name,
+                      desc=dd)
 
         def unpool(src_name, dy, relu_mask):
             y, H = acts[src_name]
@@ -1228,6 +1234,7 @@ class IMMEngine:
             e1.record()
             evs.append((l, e0, e1))
         torch.cuda.synchronize()
+        self.last_variants = [l.variant for l, _e0, _e1 in evs]
         return [(l.tag, e0.elapsed_time(e1), l.flops, l.bytes, l.name) for l, e0, e1 in evs]
 
     def set_inputs(self, image, future_image, mask=None):

@@ -1,0 +1,55 @@
+"""Determinism of a graph-replayed forward + backward pass while ANOTHER process shares the GPU (round 5: how the missing wait
+states behind conv_halo2.hip's inline-asm 16-byte stores were found — bit-identical alone, 0.3 % of the replays corrupted when
+two processes ran side by side).  Run two copies at once on one GPU:
+
+    python tools/det_graph.py A & python tools/det_graph.py B; wait
+
+Each replays the step's first graph from the same state for DET_SECONDS (default 25) and compares every activation, the loss
+and every gradient tensor bitwise with its own first replay: `mismatching 0` is the expected output."""
+import os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import imm_oracle as O
+from imm_amd.models.imm_model import IMMModel
+from imm_amd.train.cnn_train_multi import TrainStep
+from imm_amd.utils.box import Box
+torch.cuda.set_device(0)
+tag = sys.argv[1] if len(sys.argv) > 1 else 'p'
+B = 2
+model = IMMModel(Box(dict(O.default_model_config(10))), dtype=torch.bfloat16, device='cuda:0')
+ts = TrainStep(model, B, 128, world_size=1, use_graph=True, split_graphs=True, collective='pg')
+eng = ts.engine
+inp = O.synthetic_inputs(B, 128, seed=7)
+ts.step(inp); ts.synchronize()
+snap = eng.snapshot()
+names = [n for n, _s, _w in eng.spec]
+ref = None; bad = 0; diff = {}; adiff = {}
+t_end = time.time() + float(os.environ.get('DET_SECONDS', '25'))
+n = 0
+while time.time() < t_end:
+    with torch.cuda.stream(ts.stream):
+        eng.restore(snap)
+        ts._graphs[0].launch()
+    ts.synchronize(); n += 1
+    g = eng.grads.clone(); l = eng.loss_out.clone()
+    acts = {}
+    for nm, lays in (('enc_im', eng.enc_im), ('enc_pose', eng.enc_pose), ('ren', eng.ren)):
+        for i, ly in enumerate(lays):
+            acts['%s%d.y' % (nm, i + 1)] = ly.y
+            if getattr(ly, 'stats', None) is not None: acts['%s%d.stats' % (nm, i + 1)] = ly.stats
+            if getattr(ly, 'out', None) is not None: acts['%s%d.out' % (nm, i + 1)] = ly.out
+            if getattr(ly, 'scale', None) is not None: acts['%s%d.scale' % (nm, i + 1)] = ly.scale
+    acts['joint'] = eng.joint; acts['mu'] = eng.mu; acts['heat'] = eng.heat; acts['wd'] = eng.wd_loss
+    for k_, (y_, _h) in eng.vgg_act.items(): acts['vgg.' + k_] = y_
+    if ref is None:
+        ref = (g, l); aref = {k: v.clone() for k, v in acts.items()}
+    elif not (torch.equal(g, ref[0]) and torch.equal(l, ref[1])):
+        bad += 1
+        for i, nm in enumerate(names):
+            if not torch.equal(g[eng.tab.offsets[i]:eng.tab.offsets[i + 1]], ref[0][eng.tab.offsets[i]:eng.tab.offsets[i + 1]]):
+                diff[nm] = diff.get(nm, 0) + 1
+        if not torch.equal(l, ref[1]): diff['LOSS'] = diff.get('LOSS', 0) + 1
+        for k, v in acts.items():
+            a_, b_ = (v, aref[k]) if v.dtype == torch.float32 else (v.view(torch.int16), aref[k].view(torch.int16))
+            if not torch.equal(a_, b_): adiff[k] = adiff.get(k, 0) + 1
+print('DETACTS', tag, adiff)
+print('DETGRAPH', tag, 'runs', n, 'mismatching', bad, 'tensors', dict(sorted(diff.items(), key=lambda kv: -kv[1])[:12]), 'n_tensors_diff', len(diff))
