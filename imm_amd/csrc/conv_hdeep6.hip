@@ -47,7 +47,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 #define H6_LDS (H6_RING + 2 * H6_GROUP)       // 141 312
 #define H6_ROWB (H6_HW * 64)                  // bytes per halo row (1 152)
 #define H6_OOB 0x80000000u
-// -DIMM_H6_ABLATE=<bits> (diagnosis builds only, tools/h6_ablate.sh; results are wrong, only the time is read):
+// -DIMM_H6_ABLATE=<bits> (diagnosis builds only, tools/ablate_build.sh; results are wrong, only the time is read):
 //   1 no DMA inside the loop, 2 no fragment reads inside the loop, 4 no barrier / vmcnt wait inside the loop, 8 no MFMAs,
 //   16 no output stores
 #ifndef IMM_H6_ABLATE

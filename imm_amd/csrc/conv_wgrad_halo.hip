@@ -27,6 +27,12 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
 
+// -DIMM_WH_ABLATE=<bits> (diagnosis builds only, tools/ablate_build.sh; results are wrong, only the time is read):
+//   1 no DMA after the prologue, 2 no X^T transpose reads inside the loop, 4 no dY^T transpose reads inside the loop, 8 no MFMAs,
+//   16 no barrier / vmcnt wait inside the loop, 32 no slab stores
+#ifndef IMM_WH_ABLATE
+#define IMM_WH_ABLATE 0
+#endif
 #define WH_PH 8
 #define WH_PW 16
 // halo of an 8x16-pixel patch under a KH x KW stride-1 SAME filter: (8+KH-1) x (16+KW-1) pixels, padded to whole rounds of DMA
@@ -195,6 +201,7 @@ __device__ __forceinline__ void conv_wgrad_halo_body(const WgradHaloArgs& a, con
     for (int h = 0; h < 2; ++h)
       yb[j][h] = (uint32_t)(X_BYTES + (ly * YC8 + (((((wn * TNT + j) * 16) + ch4) >> 3) ^ wh_swzx<YC8>(k_x + 4 * h))) * 16 + (ch4 & 4) * 2);
 
+  uint4 af_keep = make_uint4(0, 0, 0, 0);
   const int n_mine = (bx < a.n_patches) ? (a.n_patches - bx + G - 1) / G : 0;
 #pragma unroll
   for (int t = 0; t < NS - 1; ++t)
@@ -202,11 +209,14 @@ __device__ __forceinline__ void conv_wgrad_halo_body(const WgradHaloArgs& a, con
   int stage = 0;
   for (int it = 0; it < n_mine; ++it) {
     // patches it .. min(it+NS-2, n_mine-1) are in flight; patch `it` must have landed (this wave's share, then everyone's)
-    if (it + NS - 2 < n_mine) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * LPP) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (nol) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (first patch: the coefficient table)
-    __builtin_amdgcn_s_barrier();
-    if (it + NS - 1 < n_mine) {      // into the stage patch it-1 occupied: every wave is past its reads (the barrier above)
+    constexpr int ABL = IMM_WH_ABLATE;
+    if (!(ABL & 16) || it == 0) {
+      if (it + NS - 2 < n_mine) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * LPP) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (nol) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (first patch: the coefficient table)
+      __builtin_amdgcn_s_barrier();
+    }
+    if (it + NS - 1 < n_mine && !(ABL & 1)) {      // into the stage patch it-1 occupied: every wave is past its reads (the barrier above)
       int ns = stage + NS - 1; if (ns >= NS) ns -= NS;
       issue(bx + (it + NS - 1) * G, ns);
     }
@@ -243,6 +253,7 @@ __device__ __forceinline__ void conv_wgrad_halo_body(const WgradHaloArgs& a, con
 
     // dY^T fragments of this wave's co tiles for the 4 k-steps of the patch: reused by all nine taps
     uint4 bfr[4][TNT];
+    if (!(ABL & 4) || it == 0)
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -262,10 +273,15 @@ __device__ __forceinline__ void conv_wgrad_halo_body(const WgradHaloArgs& a, con
         const int e = ST == 2 ? (kx >> 1) : kx;
         const int cp = ST == 2 ? ((ky & 1) * 2 + (kx & 1)) * WH_S2_PP + (ks * 2 + (ky >> 1)) * WH_S2_PW + (kx >> 1)
                                : (ks * 2 + ky) * WH_HW + kx;
-        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(Xl + xb[e][0] + cp * XC8 * 16));
-        const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(Xl + xb[e][1] + (cp + 4) * XC8 * 16));
-        const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
-        const uint4 af = make_uint4(l2.x, l2.y, h2.x, h2.y);
+        uint4 af;
+        if (!(ABL & 2) || (it == 0 && tap == 0 && ks == 0)) {
+          const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(Xl + xb[e][0] + cp * XC8 * 16));
+          const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(Xl + xb[e][1] + (cp + 4) * XC8 * 16));
+          const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+          af = make_uint4(l2.x, l2.y, h2.x, h2.y);
+          af_keep = af;
+        } else af = af_keep;
+        if (!(ABL & 8))
 #pragma unroll
         for (int j = 0; j < TNT; ++j) acc[tap][j] = ET::mfma(bfr[ks][j], af, acc[tap][j]);   // D[n][c]
       }
@@ -282,7 +298,9 @@ __device__ __forceinline__ void conv_wgrad_halo_body(const WgradHaloArgs& a, con
     for (int j = 0; j < TNT; ++j) {
       const int n = co0 + (wn * TNT + j) * 16 + 4 * (lane >> 4);
       float* op = out + (int64_t)kk * a.co + n;
-      if (n + 3 < a.co && (a.co & 3) == 0) {
+      if (IMM_WH_ABLATE & 32) {
+        if (acc[tap][j][0] == 123456.789f) op[0] = acc[tap][j][1] + acc[tap][j][2] + acc[tap][j][3];
+      } else if (n + 3 < a.co && (a.co & 3) == 0) {
         *(float4*)op = make_float4(acc[tap][j][0], acc[tap][j][1], acc[tap][j][2], acc[tap][j][3]);
       } else {
 #pragma unroll
