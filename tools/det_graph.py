@@ -8,17 +8,16 @@ Each replays the step's first graph from the same state for DET_SECONDS (default
 and every gradient tensor bitwise with its own first replay: `mismatching 0` is the expected output."""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from oracle import imm_oracle as O
+import bench
 from imm_amd.models.imm_model import IMMModel
 from imm_amd.train.cnn_train_multi import TrainStep
-from imm_amd.utils.box import Box
 torch.cuda.set_device(0)
 tag = sys.argv[1] if len(sys.argv) > 1 else 'p'
 B = 2
-model = IMMModel(Box(dict(O.default_model_config(10))), dtype=torch.bfloat16, device='cuda:0')
+model = IMMModel(bench.model_config(10), dtype=torch.bfloat16, device='cuda:0')
 ts = TrainStep(model, B, 128, world_size=1, use_graph=True, split_graphs=True, collective='pg')
 eng = ts.engine
-inp = O.synthetic_inputs(B, 128, seed=7)
+inp = bench.synthetic_batch(B, 128, seed=7, device='cuda:0')
 ts.step(inp); ts.synchronize()
 snap = eng.snapshot()
 names = [n for n, _s, _w in eng.spec]
