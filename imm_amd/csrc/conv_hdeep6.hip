@@ -54,6 +54,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 #define IMM_H6_ABLATE 0
 #endif
 
+
 struct H6Args {
   ConvArgs c;
   int n_patches, patches_x, patches_y, n_wg;
