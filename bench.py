@@ -335,10 +335,11 @@ def selfcheck_child(args):
     return 0 if rec.get('passed') else 3
 
 
-def selfcheck_in_children(args, dev, world, ctrl, timeout_s=300.0):
+def selfcheck_in_children(args, dev, world, ctrl, timeout_s=240.0):
     """Every rank runs the self-check in a child process (same GPU, a process group of the children's own) and waits for it with a
     time limit; a child that hangs, crashes or fails makes EVERY rank fall back (MIN over ranks on the parents' group)."""
-    env = dict(os.environ)
+    # the children rendezvous among themselves: their own TCP store on MASTER_PORT + 7, not the launcher's agent store
+    env = {k: v for k, v in os.environ.items() if not k.startswith('TORCHELASTIC_')}
     env['MASTER_PORT'] = str(int(os.environ.get('MASTER_PORT', '29511')) + 7)
     cmd = [sys.executable, os.path.abspath(__file__), '--selfcheck-child', '--config', str(WL.get('index', 1)), '--gpus', str(world),
            '--buckets', str(args.buckets or 2)]
