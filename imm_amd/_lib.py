@@ -20,7 +20,7 @@ CONV_BIAS, CONV_RELU, CONV_STATS, CONV_MASK, CONV_OUT_F32 = 1, 2, 4, 8, 16
 SSE_BLOCKS = 512
 OPTIMIZERS = {'adam': 0, 'adadelta': 1, 'adagrad': 2}      # IMM_OPT_* (scripts/train.py:97-104)
 GAUSS_MODES = {'rot': 0, 'flat': 1, 'ankush': 2}     # IMM_GAUSS_* (config key gauss_mode, imm_model.py:48-72)
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 
 class ImmHipError(RuntimeError):
@@ -124,6 +124,8 @@ _SIGS = {
     'imm_masked_sse': [_P, _P, _I, _I, _I, _I, _P, _I, _I, _P, _P],
     'imm_masked_sse_f32': [_P, _I, _P, _I, _I, _I, _I, _P, _I, _P, _P],
     'imm_perceptual_finalize': [_P, _I, _P, _P, _I, _P, _I, _I, _P, _P, _P],
+    'imm_cost_ema': [_P, _P, _F, _P],
+    'imm_rms16': [_P, _L, _I, _P, _I, _P, _P],
     'imm_tap_grad': [_P, _I, _P, _P, _I, _I, _I, _I, _P, _I, _P, _I, _I, _I, _P],
     'imm_weight_decay_loss': [_P, _P, _P, _P, _I, _P, _P, _P, _P],
     'imm_clip_adam_step': [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, C.POINTER(OptHParams), _P, _P],

@@ -514,6 +514,63 @@ extern "C" int imm_weight_decay_loss(const float* params, const int32_t* blk_seg
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// summaries (round 5): the reference's cost moving averages and per-VGG-layer activation scale
+// ---------------------------------------------------------------------------------------------
+// BaseModel._add_cost_summary (base_model.py:52-60): tf.train.ExponentialMovingAverage(0.99).apply([cost]) for reconstruction_loss,
+// weights_loss and loss_total, run with every training step (avg_ops, cnn_train_multi.py:61-62).  For a TENSOR the shadow value
+// starts at 0 and is zero-debiased: biased <- decay * biased + (1 - decay) * cost, local_step <- local_step + 1, and the value
+// summarised is biased / (1 - decay^local_step) (the host divides).  state = {biased[3], local_step}.
+__global__ void cost_ema_kernel(const float* __restrict__ cost3, float* __restrict__ state, float decay) {
+  if (threadIdx.x < 3) state[threadIdx.x] = decay * state[threadIdx.x] + (1.f - decay) * cost3[threadIdx.x];
+  if (threadIdx.x == 3) state[3] += 1.f;
+}
+
+extern "C" int imm_cost_ema(const float* cost3, float* state4, float decay, void* stream) {
+  IMM_REQUIRE(cost3 && state4 && decay >= 0.f && decay < 1.f, "cost_ema: args");
+  hipLaunchKernelGGL(cost_ema_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, cost3, state4, decay);
+  IMM_CHECK_LAUNCH("imm_cost_ema");
+  return 0;
+}
+
+// selfsup/vgg16.py:232-234: tf.summary.scalar('activation/<layer>', sqrt(reduce_mean(z^2))) of every VGG layer's output.
+template <typename ET>
+__global__ __launch_bounds__(LO_THREADS) void sumsq16_kernel(const uint16_t* __restrict__ x, int64_t n8, float* __restrict__ partial) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * LO_THREADS + threadIdx.x; i < n8; i += (int64_t)gridDim.x * LO_THREADS) {
+    float f[8];
+    unpack8<ET>(*(const uint4*)(x + i * 8), f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc = fmaf(f[e], f[e], acc);
+  }
+  acc = block_sum_256(acc, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = acc;
+}
+
+__global__ __launch_bounds__(LO_THREADS) void rms_finish_kernel(const float* __restrict__ partial, int n, double count, float* out) {
+  __shared__ double dred[LO_THREADS];
+  double v = 0.0;
+  for (int i = threadIdx.x; i < n; i += LO_THREADS) v += (double)partial[i];
+  dred[threadIdx.x] = v;
+  __syncthreads();
+  for (int o = LO_THREADS / 2; o > 0; o >>= 1) {
+    if (threadIdx.x < o) dred[threadIdx.x] += dred[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = (float)sqrt(dred[0] / count);
+}
+
+extern "C" int imm_rms16(const void* x, int64_t n, int dtype, float* partial, int nblk, float* out, void* stream) {
+  IMM_REQUIRE(x && partial && out && n > 0 && n % 8 == 0 && nblk > 0 && nblk <= 4096, "rms16: args (n must be a multiple of 8)");
+  IMM_REQUIRE(((uintptr_t)x % 16) == 0, "rms16: 16-byte alignment");
+  IMM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((sumsq16_kernel<ET>), dim3(nblk), dim3(LO_THREADS), 0, (hipStream_t)stream,
+                                              (const uint16_t*)x, n / 8, partial));
+  hipLaunchKernelGGL(rms_finish_kernel, dim3(1), dim3(LO_THREADS), 0, (hipStream_t)stream, partial, nblk, (double)n, out);
+  IMM_CHECK_LAUNCH("imm_rms16");
+  return 0;
+}
+
 // The optimizer step is TWO launches (round 3; three before, with a one-workgroup "tick" between them whose threads walked their
 // tensor's chunk sums serially: 12 us of latency chain on the strictly serial tail of the step):
 //   grad_prepare: g <- g * grad_scale / S + wd * w and the chunk sums of g^2; one extra workgroup computes the step's learning

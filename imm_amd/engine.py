@@ -883,6 +883,10 @@ class IMMEngine:
                 nel.append(float(B * H * H * y.shape[-1]))
         self.nel = torch.tensor(nel, dtype=torch.float32, device=self.dev)
         self.loss_out = self._zeros(3 * nfeat + 3)
+        # BaseModel._add_cost_summary (base_model.py:52-60): moving averages of reconstruction_loss / weights_loss / loss_total,
+        # {biased[3], local_step}, advanced by every TRAINING step (imm_cost_ema, at the head of the image-encoder lane's backward
+        # pass: off the critical path); cost_summaries() zero-debiases them like tf.train.ExponentialMovingAverage does for a tensor
+        self.cost_ema = self._zeros(4)
         mask = self.in_mask
         l1 = self.l1
         self._cur_scope = 'loss'
@@ -1113,6 +1117,8 @@ class IMMEngine:
 
         # ---- image encoder backward ----------------------------------------------------------------------------
         self._cur_lane = 1
+        self._cur_scope = 'loss'
+        self._add(self.prog_bwd, lambda: ops.cost_ema(self.loss_out[3 * self.nfeat:], self.cost_ema, 0.99), 'cost_ema')
         if He == 16:
             self._encoder_backward(self.enc_im, self.d_joint, Cj)
         else:
@@ -1260,13 +1266,13 @@ class IMMEngine:
     def snapshot(self):
         """Everything a step mutates (used to warm kernels up before graph capture without side effects)."""
         return {'params': self.params.clone(), 'm': self.adam_m.clone(), 'v': self.adam_v.clone(),
-                'step': self.step_count.clone(), 'adam_t': self.adam_t.clone(), 'agg': self.loss_agg.clone(), 'grads': self.grads.clone(),
+                'step': self.step_count.clone(), 'adam_t': self.adam_t.clone(), 'agg': self.loss_agg.clone(), 'grads': self.grads.clone(), 'cost_ema': self.cost_ema.clone(),
                 'state': {k: v.clone() for k, v in self.state.items()},
                 'loss_scale': None if self.loss_scale_state is None else self.loss_scale_state.clone()}
 
     def restore(self, snap):
         self.params.copy_(snap['params']); self.adam_m.copy_(snap['m']); self.adam_v.copy_(snap['v'])
-        self.step_count.copy_(snap['step']); self.adam_t.copy_(snap['adam_t']); self.loss_agg.copy_(snap['agg']); self.grads.copy_(snap['grads'])
+        self.step_count.copy_(snap['step']); self.adam_t.copy_(snap['adam_t']); self.loss_agg.copy_(snap['agg']); self.grads.copy_(snap['grads']); self.cost_ema.copy_(snap['cost_ema'])
         for k, v in snap['state'].items():
             self.state[k].copy_(v)
         if self.loss_scale_state is not None:
@@ -1290,6 +1296,32 @@ class IMMEngine:
         """Current loss scale S (1.0 when loss scaling is off): `grads` / `gview` hold S x the gradient between backward()
         and optimizer_step().  Reads the device scalar (synchronises)."""
         return 1.0 if self.loss_scale_state is None else float(self.loss_scale_state[0])
+
+    def cost_summaries(self):
+        """The reference's cost summaries (base_model.py:52-60, family 'train'): `<name>_raw` = this step's value, `<name>_avg` =
+        the zero-debiased moving average (decay 0.99) over the training steps so far.  Reads device scalars (synchronises)."""
+        raw = [float(v) for v in self.loss_out[3 * self.nfeat:3 * self.nfeat + 3]]
+        ema = [float(v) for v in self.cost_ema]
+        t = ema[3]
+        out = {}
+        for i, name in enumerate(('reconstruction_loss', 'weights_loss', 'loss_total')):
+            out[name + '_raw'] = raw[i]
+            out[name + '_avg'] = ema[i] / (1.0 - 0.99 ** t) if t > 0 else 0.0
+        return out
+
+    def vgg_activation_rms(self):
+        """selfsup/vgg16.py:232-234: {'activation/<layer>': sqrt(mean(z^2))} of every VGG16 layer output of the last forward pass
+        (both halves of the concat([gt, pred]) batch, like the reference's graph).  Summary steps only: one small reduction per layer."""
+        if not getattr(self, 'vgg_act', None):
+            return {}
+        if getattr(self, '_rms_scratch', None) is None:
+            self._rms_scratch = (self._zeros(1024), self._zeros(1))
+        part, out = self._rms_scratch
+        res = {}
+        for name, (y, _h) in self.vgg_act.items():
+            ops.rms16(y, part, out)
+            res['activation/' + name] = float(out)
+        return res
 
     def named_gradients(self):
         """{tf variable name: gradient of the loss (weight decay excluded), loss scale divided out} after backward()."""

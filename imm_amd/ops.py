@@ -442,6 +442,17 @@ def tap_grad(da, has_in, a_pred, a_gt, batch, s, c, mask, S, coef, idx, relu, l1
          _p(coef), idx, int(relu), int(l1), _s())
 
 
+def cost_ema(cost3, state4, decay=0.99):
+    """BaseModel._add_cost_summary's moving averages (base_model.py:52-60): state4 = {biased[3], local_step}."""
+    call('imm_cost_ema', _p(cost3), _p(state4), float(decay), _s())
+
+
+def rms16(x, partial, out):
+    """sqrt(mean(x^2)) of a contiguous 16-bit tensor (selfsup/vgg16.py:232-234 'activation/<layer>'); partial: f32 scratch."""
+    assert x.is_contiguous() and x.numel() % 8 == 0
+    call('imm_rms16', _p(x), x.numel(), dtype_enum(x.dtype), _p(partial), min(int(partial.numel()), 4096), _p(out), _s())
+
+
 # ---- optimizer --------------------------------------------------------------------------------
 def weight_decay_loss(params, tab, blk_partial, out):
     call('imm_weight_decay_loss', _p(params), _p(tab.blk_seg), _p(tab.blk_begin), _p(tab.blk_end), tab.nblk, _p(tab.seg_wd),

@@ -461,9 +461,13 @@ def train_loop(opts, train_step, data_iter, num_steps, log_every=10, checkpoint_
                                                                                     opts['batch_size'] / dt, dt))
             if rank == 0 and do_sum and summary_writer is not None:
                 images = image_summaries(eng) if n_image and step % n_image == 0 else None
-                summary_writer.add_summary({'tag': 'train', 'loss': loss_value, 'lr': float(eng.lr_state[1]),
-                                            'loss_terms': [float(v) for v in eng.loss_terms],
-                                            'examples_per_sec': opts['batch_size'] / dt}, step, images=images)
+                rec = {'tag': 'train', 'loss': loss_value, 'lr': float(eng.lr_state[1]),
+                       'loss_terms': [float(v) for v in eng.loss_terms], 'examples_per_sec': opts['batch_size'] / dt}
+                # the reference's own scalar summaries: cost moving averages (base_model.py:52-60) and the activation scale of
+                # every VGG16 layer (selfsup/vgg16.py:232-234)
+                rec.update(eng.cost_summaries())
+                rec.update(eng.vgg_activation_rms())
+                summary_writer.add_summary(rec, step, images=images)
                 summary_writer.flush()
         if fire and test_dataset is not None and model is not None and n_test and step % n_test == 0:
             train_step.synchronize(); synced = True

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define IMM_ABI_VERSION 16   /* 16: imm_conv2d_variant.  15: imm_conv2d_dgrad_s2, imm_conv2d_nol, imm_conv_first, imm_wgrad_job.x_scale/x_shift/x_relu; entry points removed
+#define IMM_ABI_VERSION 17   /* 17: imm_cost_ema, imm_rms16 (summaries).  16: imm_conv2d_variant.  15: imm_conv2d_dgrad_s2, imm_conv2d_nol, imm_conv_first, imm_wgrad_job.x_scale/x_shift/x_relu; entry points removed
                                   since 14 (imm_bn_bwd_reduce_finalize, imm_conv2d_stats_workspace_bytes) finally counted */
 
 enum imm_dtype { IMM_BF16 = 0, IMM_F16 = 1 };
@@ -380,6 +380,15 @@ int imm_masked_sse_f32(const float* a, int lda, const float* b, int ldb, int bat
  * in fp32 (imm_model.py:97) and needs none; imm_clip_adam_step divides the scale out again. */
 int imm_perceptual_finalize(const float* partial, int nfeat, const float* nel, float* agg, int training,
                             const float* wd_loss, int l1, int mode, const float* loss_scale, float* out, void* stream);
+/* Summaries of the reference's train loop that live on the device (round 5):
+ * imm_cost_ema — BaseModel._add_cost_summary (base_model.py:52-60; tf.train.ExponentialMovingAverage(0.99) of reconstruction_loss,
+ *   weights_loss, loss_total, applied with every training step through avg_ops): cost3 = the three f32 scalars in that order (the
+ *   tail out[3 nfeat .. 3 nfeat + 3) of imm_perceptual_finalize), state4 = {biased[3], local_step}, zero at start; the summarised
+ *   value is biased[i] / (1 - decay^local_step) (TF zero-debiases the average of a tensor).  One tiny launch, capturable.
+ * imm_rms16 — selfsup/vgg16.py:232-234 'activation/<layer>' = sqrt(mean(z^2)) of a 16-bit tensor of n elements (n % 8 == 0, 16-byte
+ *   aligned); partial: nblk f32 of scratch (nblk <= 4096 workgroups); out[0] = the scalar.  Called on summary steps only. */
+int imm_cost_ema(const float* cost3, float* state4, float decay, void* stream);
+int imm_rms16(const void* x, int64_t n, int dtype, float* partial, int nblk, float* out, void* stream);
 /* imm_maxpool2_bwd (no ReLU mask) followed by imm_tap_grad (has_in, relu) in one pass, for tapped layers that are pooled
  * next (conv1_2, conv2_2); dpool [batch, s/2, s/2, c] is the gradient of the pooled tensor.  Bitwise equal to the sequence. */
 int imm_unpool_tap_grad(void* da, const void* dpool, const void* a_pred, const void* a_gt, int dtype, int batch, int s, int c,

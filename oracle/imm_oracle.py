@@ -445,6 +445,16 @@ def perceptual_loss(ctx, gt, pred, mask, cfg):
     return 1000.0 * sum(terms), terms, ms
 
 
+def cost_ema_update(state, costs, decay=0.99):
+    """BaseModel._add_cost_summary (base_model.py:52-60): tf.train.ExponentialMovingAverage(decay).apply([cost]) on a TENSOR — the
+    shadow value starts at 0 and TF zero-debiases it: biased <- decay * biased + (1 - decay) * cost, local_step += 1,
+    average = biased / (1 - decay^local_step).  state = [biased_0, .., biased_{n-1}, local_step] (python floats); returns
+    (new state, averages)."""
+    n = len(costs)
+    new = [decay * state[i] + (1.0 - decay) * float(costs[i]) for i in range(n)] + [state[n] + 1.0]
+    return new, [new[i] / (1.0 - decay ** new[n]) for i in range(n)]
+
+
 def weight_decay_loss(P):
     """base_model.py:33-37 + nn_utils.py:44-46 (S6): conv kernels only."""
     return sum(WEIGHT_DECAY * 0.5 * (v ** 2).sum() for k, v in P.items() if k.endswith('/w'))

@@ -1703,3 +1703,28 @@ def test_conv_group_equals_sequential(ops, H, ci, co):
     torch.cuda.synchronize()
     assert not bool(torch.isnan(got.float()).any())
     assert torch.equal(got, ref)
+
+
+def test_cost_ema_and_activation_rms(ops):
+    """Round 5: the reference's device-side summaries.  imm_cost_ema against oracle.cost_ema_update (base_model.py:52-60, zero-debiased
+    moving averages of three costs over several steps); imm_rms16 against sqrt(mean(z^2)) (selfsup/vgg16.py:232-234), bf16 and f16."""
+    st = torch.zeros(4, device=DEV)
+    ref = [0.0, 0.0, 0.0, 0.0]
+    g = torch.Generator().manual_seed(3)
+    for it in range(6):
+        c = torch.rand(3, generator=g) * 1000.0
+        ops.cost_ema(c.to(DEV), st, 0.99)
+        ref, avg = O.cost_ema_update(ref, [float(v) for v in c])
+    torch.cuda.synchronize()
+    got = st.cpu()
+    assert float(got[3]) == 6.0
+    np.testing.assert_allclose(got[:3].numpy(), ref[:3], rtol=1e-5)
+    np.testing.assert_allclose((got[:3] / (1 - 0.99 ** 6)).numpy(), avg, rtol=1e-5)
+    part, out = torch.zeros(1024, device=DEV), torch.zeros(1, device=DEV)
+    for dt in (torch.bfloat16, torch.float16):
+        for shape in ((2, 16, 16, 64), (64, 128, 128, 64), (3, 5, 7, 8)):
+            x = rnd(shape, 11, 2.0, dt).to(DEV)
+            ops.rms16(x, part, out)
+            torch.cuda.synchronize()
+            want = float(x.float().pow(2).mean().sqrt())
+            assert abs(float(out) - want) <= 1e-5 * want, (shape, float(out), want)
