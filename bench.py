@@ -512,7 +512,7 @@ def main():
         dist.all_reduce(lt)
         loss = float(lt) / world
 
-    replicas_identical = None
+    replicas_identical, replicas_diff = None, None
     if world > 1:
         # data-parallel invariant: after the same number of updates from all-reduced gradients every rank holds the SAME bits
         bits = eng.params.view(torch.int32).to(torch.int64)
@@ -520,6 +520,18 @@ def main():
         got = [torch.zeros_like(chk) for _ in range(world)]
         dist.all_gather(got, chk)
         replicas_identical = all(bool(torch.equal(g, got[0])) for g in got)
+        if not replicas_identical:
+            # which tensors differ, and on which ranks (diagnosis: goes into the line as step.replicas_diff)
+            names = [n for n, _s, _w in eng.spec]
+            per = torch.stack([bits[eng.tab.offsets[i]:eng.tab.offsets[i + 1]].sum() for i in range(len(names))]).to(ctrl)
+            allp = [torch.zeros_like(per) for _ in range(world)]
+            dist.all_gather(allp, per)
+            replicas_diff = {}
+            for i, n in enumerate(names):
+                odd = [r for r in range(world) if int(allp[r][i]) != int(allp[0][i])]
+                if odd:
+                    replicas_diff[n] = odd
+            sys.stderr.write('bench: replicas differ in %d tensors: %r\n' % (len(replicas_diff), dict(list(replicas_diff.items())[:12])))
 
     if rank == 0:
         # per-kernel timing with HIP events on the launch stream (eager pass; graph replay hides launches)
@@ -586,7 +598,8 @@ def main():
                      'frac_of_peak': round(step_flops / (ms_per_step * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
                      'trainable_conv_tflops': round(sum(d[2] for d in tr) / (sum(d[1] for d in tr) * 1e-3) / 1e12, 1) if tr else None,
                      'sum_kernel_ms_eager': round(total_ms, 3), 'hbm_gb_per_step': hbm_gb_step, 'loss': round(loss, 3),
-                     'hbm_bytes_allocated': eng.memory_bytes(), 'replicas_identical': replicas_identical},
+                     'hbm_bytes_allocated': eng.memory_bytes(), 'replicas_identical': replicas_identical,
+                     'replicas_diff': (None if not replicas_diff else {k: v for k, v in list(replicas_diff.items())[:12]})},
             'kernels': breakdown,
         }
         if (not args.no_cpu_baseline and world == 1) or args.cpu_baseline_full:
