@@ -265,14 +265,16 @@ __global__ __launch_bounds__(HEAD ? PH_BWD_THREADS : BT_THREADS) void softargmax
       v = drow[yy * K + k] / (float)w + dcol[xx * K + k] / (float)h;
     }
     const uint16_t q = ET::from_f32(v);
-    dheat[(int64_t)b * h * w * lddh + i] = q;
+    // HEAD: gridDim.y workgroups per sample share the data gradient's output channels (round 5); each rebuilds the (tiny) heat-map
+    // gradient for itself, the first one stores it and the bias partial row
+    if (!HEAD || blockIdx.y == 0) dheat[(int64_t)b * h * w * lddh + i] = q;
     if constexpr (HEAD) sdh[i] = q;
   }
   if constexpr (HEAD) {
     __syncthreads();
     const int hw = h * w;
     // bias gradient partial of this sample: column sums of the STORED (16-bit) gradient, like imm_colsum; thread = (part, k)
-    {
+    if (blockIdx.y == 0) {
       const int parts = NTHR / lddh;                // lddh in {32, 64}
       const int k = tid % lddh, part = tid / lddh;
       float acc = 0.f;
@@ -286,8 +288,12 @@ __global__ __launch_bounds__(HEAD ? PH_BWD_THREADS : BT_THREADS) void softargmax
       }
     }
     // data gradient: 16-pixel tiles x 16-channel tiles, contraction over the lddh landmark channels (zeros beyond K)
-    const int lm = lane & 15, lk = (lane >> 4) * 8, KS = lddh >> 5, NTc = C >> 4;
-    for (int n0 = 0; n0 < NTc; n0 += 16) {                // 256 output channels at a time: their filter rows live in registers
+    const int lm = lane & 15, lk = (lane >> 4) * 8, KS = lddh >> 5;
+    // this workgroup's share of the C / 16 output-channel tiles (gridDim.y equal shares: 32 workgroups of one sample each were a
+    // 31 us latency chain on the pose lane of the backward pass with 12 % of the CUs busy)
+    const int nt_all = C >> 4, per = (nt_all + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int nt_lo = (int)blockIdx.y * per, NTc = min(nt_all, nt_lo + per);
+    for (int n0 = nt_lo; n0 < NTc; n0 += 16) {            // <= 256 output channels at a time: their filter rows live in registers
       uint4 bfr[2][16];
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
@@ -412,7 +418,9 @@ extern "C" int imm_pose_head_bwd(const void* dgauss, int ldg, int dtype, int bat
   if (lds > kMaxDynLds) return imm_fail(IMM_E_UNSUPPORTED, "pose_head_bwd: %dx%dx%d needs %zu B LDS", h, w, lddh, lds);
   IMM_DISPATCH_DTYPE(dtype, {
     if (set_dyn_lds(softargmax_gauss_bwd_kernel<ET, true>, lds)) return IMM_E_HIP;
-    hipLaunchKernelGGL((softargmax_gauss_bwd_kernel<ET, true>), dim3(batch), dim3(PH_BWD_THREADS), lds, (hipStream_t)stream,
+    // four workgroups per sample where that still leaves each at least two 16-channel tiles
+    const int ysplit = (c >= 128 && batch <= 512) ? 4 : 1;
+    hipLaunchKernelGGL((softargmax_gauss_bwd_kernel<ET, true>), dim3(batch, ysplit), dim3(PH_BWD_THREADS), lds, (hipStream_t)stream,
                        (const uint16_t*)dgauss, ldg, h, w, k, inv_std, s, mu, py, px, (uint16_t*)dheat, lddh, gauss_mode,
                        (const uint16_t*)wt_dgrad, kpad_d, c, (uint16_t*)dfeat, lddf, bias_partial);
   });
