@@ -115,6 +115,33 @@ struct Crc32cTables {
 };
 }  // namespace
 
+// A copy done by a KERNEL (loads and stores go through the L2 like every other kernel's), for hand-overs between the host-bounced
+// gradient exchange of the gloo test path and the step's kernels: src / dst may be device memory or pinned host memory (device
+// accessible under HIP's unified addressing).  Round 5: after `hipMemcpyAsync` host -> device into the gradient buffer, a replayed
+// optimizer graph read — on one rank in ~1 of 50 eight-rank runs sharing one GPU — the PREVIOUS (local, un-reduced) gradient of
+// the tensor the backward pass had written last: lines still valid in an L2 that the copy engine's writes to memory do not update.
+__global__ __launch_bounds__(256) void copy_f32_kernel(float* __restrict__ dst, const float* __restrict__ src, int64_t n, int vec) {
+  if (vec) {
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256)
+      ((float4*)dst)[i] = ((const float4*)src)[i];
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) dst[(n4 << 2) + threadIdx.x] = src[(n4 << 2) + threadIdx.x];
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i] = src[i];
+  }
+}
+
+extern "C" int imm_copy_f32(float* dst, const float* src, int64_t n, void* stream) {
+  IMM_REQUIRE(dst && src && n > 0 && ((uintptr_t)dst % 4 == 0) && ((uintptr_t)src % 4 == 0), "copy_f32: args");
+  const int vec = ((uintptr_t)dst % 16 == 0) && ((uintptr_t)src % 16 == 0);        // (a bucket of the flat buffer may start anywhere)
+  int64_t blocks = ((vec ? n / 4 : n) + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(copy_f32_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, dst, src, n, vec);
+  IMM_CHECK_LAUNCH("imm_copy_f32");
+  return 0;
+}
+
 extern "C" int imm_crc32c(const void* data, uint64_t n, uint32_t* crc_inout) {
   IMM_REQUIRE(crc_inout && (data || n == 0), "crc32c: null pointer");
   static const Crc32cTables tab;

@@ -442,6 +442,13 @@ def tap_grad(da, has_in, a_pred, a_gt, batch, s, c, mask, S, coef, idx, relu, l1
          _p(coef), idx, int(relu), int(l1), _s())
 
 
+def copy_f32(dst, src):
+    """dst <- src (f32, same numel) by a KERNEL on torch's current stream; either may be a pinned host tensor."""
+    assert dst.dtype == torch.float32 and src.dtype == torch.float32 and dst.numel() == src.numel()
+    assert dst.is_contiguous() and src.is_contiguous() and (dst.is_cuda or dst.is_pinned()) and (src.is_cuda or src.is_pinned())
+    call('imm_copy_f32', _p(dst), _p(src), dst.numel(), _s())
+
+
 def cost_ema(cost3, state4, decay=0.99):
     """BaseModel._add_cost_summary's moving averages (base_model.py:52-60): state4 = {biased[3], local_step}."""
     call('imm_cost_ema', _p(cost3), _p(state4), float(decay), _s())

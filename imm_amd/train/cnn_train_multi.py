@@ -44,12 +44,16 @@ def average_gradients(flat_grads, world_size, group=None, force=False, async_op=
         if flat_grads.is_cuda and dist.get_backend(group) == 'gloo':
             # pinned staging buffer + explicit stream synchronisation on both legs: a pageable bounce buffer that is freed
             # right after an asynchronous 16 MB host-to-device copy was the one non-deterministic piece of the two-rank test
+            # Both legs are KERNEL copies (imm_copy_f32 reads / writes the pinned buffer directly): with hipMemcpyAsync the copy
+            # engine wrote the reduced gradients to memory while lines of the local ones — the tensors the backward pass had written
+            # last — were still valid in the L2, and a replayed optimizer graph read those on one of eight ranks in ~1 of 50 runs
+            # (round 5; the replicas then differ in exactly that tensor).  A kernel's stores go through the L2.
             host = _pinned_like(flat_grads)
             stream = torch.cuda.current_stream(flat_grads.device)
-            host.copy_(flat_grads.detach(), non_blocking=True)
+            ops.copy_f32(host, flat_grads.detach())
             stream.synchronize()                      # the producing graph and the copy have finished
             dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
-            flat_grads.copy_(host, non_blocking=True)
+            ops.copy_f32(flat_grads, host)
             stream.synchronize()                      # the staging buffer may be reused
             return None
         return dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM, group=group, async_op=async_op)

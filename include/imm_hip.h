@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define IMM_ABI_VERSION 17   /* 17: imm_cost_ema, imm_rms16 (summaries).  16: imm_conv2d_variant.  15: imm_conv2d_dgrad_s2, imm_conv2d_nol, imm_conv_first, imm_wgrad_job.x_scale/x_shift/x_relu; entry points removed
+#define IMM_ABI_VERSION 18   /* 18: imm_copy_f32.  17: imm_cost_ema, imm_rms16 (summaries).  16: imm_conv2d_variant.  15: imm_conv2d_dgrad_s2, imm_conv2d_nol, imm_conv_first, imm_wgrad_job.x_scale/x_shift/x_relu; entry points removed
                                   since 14 (imm_bn_bwd_reduce_finalize, imm_conv2d_stats_workspace_bytes) finally counted */
 
 enum imm_dtype { IMM_BF16 = 0, IMM_F16 = 1 };
@@ -74,6 +74,11 @@ int imm_device_info(int32_t* out2_host);
  * `stream`.  Placed between the launches of a captured program it gives a profiler-free timeline of a HIP-graph replay
  * (IMM_DEBUG_STAMPS=1 in imm_amd/engine.py). */
 int imm_debug_stamp(uint64_t* slots, int index, void* stream);
+/* dst[0..n) = src[0..n) by a kernel on `stream`; either side may be device memory or PINNED host memory (4-byte aligned; 16-byte
+ * aligned pairs are copied 16 bytes at a time).  Used by
+ * the host-bounced gradient exchange of the multi-rank TESTS (torch.distributed backend "gloo": several ranks on one GPU) instead of
+ * hipMemcpyAsync, whose copy-engine writes are not seen by lines still valid in the L2 (imm_amd/train/cnn_train_multi.py). */
+int imm_copy_f32(float* dst, const float* src, int64_t n, void* stream);
 /* HIP-graph capture of a launch sequence on `stream` (replaces TF's session.run of a static graph,
  * imm/train/cnn_train_multi.py:459). */
 int imm_graph_begin(void* stream);
