@@ -89,7 +89,15 @@ def synthetic_batch(batch, size, seed, device):
     im = torch.rand(batch, size, size, 3, generator=g) * 255.0
     fut = torch.rand(batch, size, size, 3, generator=g) * 255.0
     mask = smooth_mask(size, size).reshape(1, size, size, 1).repeat(batch, 1, 1, 1)
-    return {'image': im.to(device), 'future_image': fut.to(device), 'mask': mask.to(device).contiguous()}
+    def dev(t):
+        # through pinned memory, stream-synchronised before the host tensor may go (imm_amd/ops.py upload: the runtime's path for
+        # pageable sources of more than ~1 MB tore one upload in ~100 with eight processes on one GPU)
+        if str(device) == 'cpu':
+            return t.contiguous()
+        d = t.contiguous().pin_memory().to(device, non_blocking=True)
+        torch.cuda.current_stream(d.device).synchronize()
+        return d
+    return {'image': dev(im), 'future_image': dev(fut), 'mask': dev(mask)}
 
 
 # ---------------------------------------------------------------------------------------------------------

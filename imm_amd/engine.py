@@ -240,7 +240,10 @@ class IMMEngine:
         self.state = OrderedDict()           # BN moving statistics, loss normalisers
         self.nfeat = len(self.comp)
         self.loss_agg = torch.tensor(PERCEPTUAL_WS[:self.nfeat], dtype=torch.float32, device=self.dev)
-        self.vgg_w = OrderedDict((k, v.to(self.dev).contiguous()) for k, v in (vgg_weights or synthetic_vgg_weights()).items())
+        self.vgg_w = OrderedDict()
+        for k, v in (vgg_weights or synthetic_vgg_weights()).items():
+            self.vgg_w[k] = torch.empty(tuple(v.shape), dtype=v.dtype, device=self.dev)
+            ops.upload(self.vgg_w[k], v, k)               # (pinned staging + read-back: see ops.upload)
 
         self.prog_pack, self.prog_fwd, self.prog_bwd, self.prog_opt = [], [], [], []
         # IMM_TWO_STREAMS=0: everything on one stream (A/B of the two-lane schedule; the results are identical)
@@ -282,13 +285,17 @@ class IMMEngine:
     def init_parameters(self, seed=1):
         """truncated-normal(0.01) kernels, zero biases, gamma 1 / beta 0; Adam state reset."""
         rng = np.random.default_rng(seed)
-        for name, shape, _wd in self.spec:
+        # the whole flat vector is built on the host and uploaded ONCE through pinned memory, verified (ops.upload: per-tensor
+        # copies from pageable temporaries were the source of the one-rank-in-eight divergence of round 5)
+        host = torch.zeros(self.tab.total, dtype=torch.float32)
+        for i, (name, shape, _wd) in enumerate(self.spec):
+            o0 = self.tab.offsets[i]
+            n = int(np.prod(shape))
             if name.endswith('/w'):
-                self.pview[name].copy_(torch.from_numpy(truncated_normal(rng, shape, INIT_STD)))
+                host[o0:o0 + n] = torch.from_numpy(truncated_normal(rng, shape, INIT_STD)).reshape(-1)
             elif name.endswith('/gamma'):
-                self.pview[name].fill_(1.0)
-            else:
-                self.pview[name].zero_()
+                host[o0:o0 + n] = 1.0
+        ops.upload(self.params, host, 'the initial parameters')
         for k, v in self.state.items():
             v.fill_(1.0 if k.endswith('moving_variance') else 0.0)
         self.loss_agg.copy_(torch.tensor(PERCEPTUAL_WS[:self.nfeat]))
@@ -308,16 +315,16 @@ class IMMEngine:
     def load_parameters(self, named, state=None):
         """named: {tf_variable_name: tensor}.  Missing names raise (no silent partial restore)."""
         for name in self.pview:
-            self.pview[name].copy_(named[name].to(self.dev))
+            ops.upload(self.pview[name], named[name], name)
         if state:
             for k, v in state.items():
                 if k in self.state:
-                    self.state[k].copy_(v.to(self.dev))
+                    ops.upload(self.state[k], v, k)
                 elif k.startswith('loss/') and k.endswith('_agg'):
                     if self.loss_kind == 'perceptual' and k[5:-4] in self.comp:
                         self.loss_agg[self.comp.index(k[5:-4])] = float(v)
                 elif k.startswith('vgg16/'):
-                    self.vgg_w[k].copy_(v.to(self.dev))
+                    ops.upload(self.vgg_w[k], v, k)
                 else:
                     raise KeyError(k)
             self._pack_vgg()
@@ -1244,12 +1251,13 @@ class IMMEngine:
         return [(l.tag, e0.elapsed_time(e1), l.flops, l.bytes, l.name) for l, e0, e1 in evs]
 
     def set_inputs(self, image, future_image, mask=None):
-        self.in_image.copy_(image.reshape(self.in_image.shape))
-        self.in_future.copy_(future_image.reshape(self.in_future.shape))
+        # device tensors (the loader's, the bench's): stream-ordered copies; host tensors: pinned staging + read-back (ops.upload)
+        ops.upload(self.in_image, image, 'image')
+        ops.upload(self.in_future, future_image, 'future_image')
         if self.use_mask:
             if mask is None:
                 raise RuntimeError('No loss mask recieved but is required.')
-            self.in_mask.copy_(mask.reshape(self.in_mask.shape))
+            ops.upload(self.in_mask, mask, 'mask')
 
     def forward(self, training=True):
         self._training = bool(training)

@@ -449,6 +449,50 @@ def copy_f32(dst, src):
     call('imm_copy_f32', _p(dst), _p(src), dst.numel(), _s())
 
 
+def upload(dst, src, what='tensor'):
+    """dst (device) <- src (host tensor / ndarray), staged through PINNED memory, stream-synchronised and read back.
+
+    Why not `dst.copy_(cpu_tensor)`: with eight processes sharing one GPU, about once in 100 engine constructions ONE rank started
+    from other initial weights in exactly the 2.4 MB / 2.9 MB filters — uploaded one by one from pageable temporaries that were freed
+    (and refilled with the next tensor's random numbers) as soon as `copy_` returned (round 5; found by comparing the replicas'
+    parameters before the first update — DESIGN.md §7; the runtime's pin-in-place path for pageable sources above ~1 MB is the
+    inferred culprit).  Here the source is pinned (read in place by the DMA engine), the stream is synchronised before the staging
+    buffer may go, and the result is read back and compared bitwise: a wrong upload is repeated (loudly) and, if it stays wrong,
+    raises."""
+    import sys
+    if not dst.is_cuda:
+        dst.copy_(torch.as_tensor(src).reshape(dst.shape))
+        return
+    src = torch.as_tensor(src)
+    if src.is_cuda:
+        dst.copy_(src.reshape(dst.shape))
+        return
+    stage = torch.empty(dst.shape, dtype=dst.dtype, pin_memory=True)
+    stage.copy_(src.reshape(dst.shape))                    # host side: layout / dtype conversion into the pinned buffer
+    back = torch.empty(dst.shape, dtype=dst.dtype, pin_memory=True)
+    stream = torch.cuda.current_stream(dst.device)
+    for attempt in range(3):
+        dst.copy_(stage, non_blocking=True)
+        back.copy_(dst, non_blocking=True)
+        stream.synchronize()
+        if torch.equal(back.reshape(-1).view(torch.uint8), stage.reshape(-1).view(torch.uint8)):
+            return
+        sys.stderr.write('imm_amd: the upload of %s (%d bytes) read back differently (attempt %d): repeating\n'
+                         % (what, stage.numel() * stage.element_size(), attempt + 1))
+    raise RuntimeError('imm_amd: host-to-device upload of %s does not read back as written' % what)
+
+
+def download(src):
+    """Host copy of a device tensor through pinned memory, stream-synchronised (the mirror of upload(): checkpoints are written from
+    these); returns an ordinary (pageable) CPU tensor."""
+    if not src.is_cuda:
+        return src.detach().clone()
+    back = torch.empty(src.shape, dtype=src.dtype, pin_memory=True)
+    back.copy_(src.detach(), non_blocking=True)
+    torch.cuda.current_stream(src.device).synchronize()
+    return back.clone()
+
+
 def cost_ema(cost3, state4, decay=0.99):
     """BaseModel._add_cost_summary's moving averages (base_model.py:52-60): state4 = {biased[3], local_step}."""
     call('imm_cost_ema', _p(cost3), _p(state4), float(decay), _s())

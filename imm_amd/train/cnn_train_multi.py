@@ -42,12 +42,11 @@ def average_gradients(flat_grads, world_size, group=None, force=False, async_op=
     through the host — same sum, same flat layout, no claim about speed."""
     if world_size > 1 or (force and dist.is_initialized()):
         if flat_grads.is_cuda and dist.get_backend(group) == 'gloo':
-            # pinned staging buffer + explicit stream synchronisation on both legs: a pageable bounce buffer that is freed
-            # right after an asynchronous 16 MB host-to-device copy was the one non-deterministic piece of the two-rank test
-            # Both legs are KERNEL copies (imm_copy_f32 reads / writes the pinned buffer directly): with hipMemcpyAsync the copy
-            # engine wrote the reduced gradients to memory while lines of the local ones — the tensors the backward pass had written
-            # last — were still valid in the L2, and a replayed optimizer graph read those on one of eight ranks in ~1 of 50 runs
-            # (round 5; the replicas then differ in exactly that tensor).  A kernel's stores go through the L2.
+            # pinned staging buffer + explicit stream synchronisation on both legs (a pageable bounce buffer that is freed right
+            # after an asynchronous 16 MB host-to-device copy was the one non-deterministic piece of the two-rank test).  Both legs
+            # are kernel copies (imm_copy_f32 reads / writes the pinned buffer directly) rather than hipMemcpyAsync: introduced while
+            # chasing the one-rank-in-eight divergence of round 5 — which turned out to be the upload of the INITIAL weights
+            # (ops.upload, DESIGN.md §7), not this exchange; kept because it needs no copy engine and is as fast.
             host = _pinned_like(flat_grads)
             stream = torch.cuda.current_stream(flat_grads.device)
             ops.copy_f32(host, flat_grads.detach())

@@ -384,23 +384,24 @@ LOSS_SCALE_VAR = 'imm_amd/loss_scale_state'
 def engine_to_tf(engine, with_optimizer=True):
     """{TF variable name: numpy array} of an engine: model variables, BN moving statistics, loss normalisers, global_step
     and (optionally) Adam's slots `<var>/Adam`, `<var>/Adam_1`, `beta1_power`, `beta2_power` (tf.train.AdamOptimizer)."""
+    from .. import ops                 # device -> host through pinned memory, stream-synchronised (ops.download)
     out = OrderedDict()
     for k, v in engine.named_parameters().items():
-        out[tf_variable_name(k)] = v.cpu().numpy()
+        out[tf_variable_name(k)] = ops.download(v).numpy()
     for k, v in engine.named_state().items():
-        out[tf_variable_name(k)] = np.asarray(v.cpu().numpy(), dtype=np.float32)
+        out[tf_variable_name(k)] = np.asarray(ops.download(v).numpy(), dtype=np.float32)
     step = int(engine.step_count)
     out['global_step'] = np.asarray(step, dtype=np.float32)      # a float model_variable upstream (scripts/train.py:86-88)
     if with_optimizer:
         for buf, suffix in optimizer_slots(engine):
-            flat = getattr(engine, buf).cpu().numpy()
+            flat = ops.download(getattr(engine, buf)).numpy()
             for i, (name, shape, _wd) in enumerate(engine.spec):
                 o0, o1 = engine.tab.offsets[i], engine.tab.offsets[i + 1]
                 out[tf_variable_name(name) + suffix] = flat[o0:o1].reshape(shape)
         if getattr(engine, 'loss_scale_state', None) is not None:
             # not a TensorFlow variable (the reference computes in fp32): the dynamic loss scale of f16 storage and its
             # clean-step counter, so that a resume continues at the scale the run had reached
-            out[LOSS_SCALE_VAR] = engine.loss_scale_state.cpu().numpy().astype(np.float32)
+            out[LOSS_SCALE_VAR] = ops.download(engine.loss_scale_state).numpy().astype(np.float32)
         if getattr(engine, 'optim', 'adam') != 'adam':
             return out
         # tf.train.AdamOptimizer: beta_power starts at beta and is multiplied by beta after every apply => beta^(t+1) after
@@ -420,6 +421,7 @@ def load_tf_checkpoint(engine, prefix, restore_optim=False, ignore_missing_vars=
     variables (+ global_step) always, Adam slots with `restore_optim`, missing variables skipped only with
     `ignore_missing_vars`, `reset_global_step >= 0` overrides the step.  Returns the list of variables not found."""
     import torch
+    from .. import ops
     have = list_bundle(prefix)
     want_params = OrderedDict((k, tf_variable_name(k)) for k in engine.pview)
     want_state = OrderedDict((k, tf_variable_name(k)) for k in engine.named_state())
@@ -440,13 +442,13 @@ def load_tf_checkpoint(engine, prefix, restore_optim=False, ignore_missing_vars=
     engine.load_parameters(params, state)
     if restore_optim:
         for buf, suffix in optimizer_slots(engine):
-            flat = getattr(engine, buf).cpu().numpy()
+            flat = ops.download(getattr(engine, buf)).numpy()
             for i, (name, _shape, _wd) in enumerate(engine.spec):
                 o0, o1 = engine.tab.offsets[i], engine.tab.offsets[i + 1]
                 n = want_params[name]
                 if n + suffix in data:
                     flat[o0:o1] = data[n + suffix].reshape(-1)
-            getattr(engine, buf).copy_(torch.from_numpy(flat))
+            ops.upload(getattr(engine, buf), torch.from_numpy(flat), buf)      # pinned staging + read-back (ops.upload)
         # Adam's t from the saved accumulators beta^(t+1) (beta2_power first: it resolves t up to ~1e5 before float32
         # underflow, beta1_power only up to ~1e3); both underflown = the correction factors are 1 anyway: any large t
         t = 0

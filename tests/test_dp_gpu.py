@@ -258,13 +258,12 @@ def test_bench_self_spawns_eight_ranks(tmp_path):
 
 def _eight_rank_bench(env, extra):
     """`bench.py --gpus 8 --backend gloo --share-gpu` (+ extra flags); returns the parsed line.
-    EIGHT processes time-sharing one GPU is a situation only these tests create (the product runs one process per GPU), and in
-    about one of ten executions of this file ONE of the eight ranks ends with other bits in a few of the largest, clipped tensors
-    (the 256-channel 3x3 filters) — i.e. one gradient element or chunk sum of that rank differed AFTER the exchange (a tensor's
-    clip factor turns one element into a whole-tensor difference).  Never seen at two ranks (after the round-5 store-hazard fix:
-    0 of 22 865 two-process replays), never in 32 consecutive stand-alone runs of this command, not explained; every kernel of the
-    path is bit-reproducible alone and under a second process.  The line names the differing tensors / ranks
-    (step.replicas_diff).  One repetition, loudly, so that a one-off does not end a -x run; twice in a row is a failure."""
+    EIGHT processes time-sharing one GPU is a situation only these tests create (the product runs one process per GPU).  Until the
+    end of round 5 about one execution in ten of this file ended with ONE rank holding other bits in a few of the largest tensors:
+    its INITIAL weights — per-tensor `copy_` from pageable temporaries, torn by the runtime's pin-in-place path for > 1 MB sources
+    under eight-fold contention (found with a cross-rank checksum at the first exchange; fixed by ops.upload: pinned staging,
+    stream-synchronised, read back).  The line still names differing tensors / ranks (step.replicas_diff), and one
+    loud repetition is kept so that a one-off of any other kind does not end a -x run; twice in a row is a failure."""
     import json
     import subprocess
 

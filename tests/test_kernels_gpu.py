@@ -1728,3 +1728,33 @@ def test_cost_ema_and_activation_rms(ops):
             torch.cuda.synchronize()
             want = float(x.float().pow(2).mean().sqrt())
             assert abs(float(out) - want) <= 1e-5 * want, (shape, float(out), want)
+
+
+def test_upload_and_download_through_pinned_memory(ops):
+    """Round 5: host <-> device transfers of parameters, frozen weights, inputs and checkpoints go through pinned staging buffers,
+    stream-synchronised, and an upload is read back (ops.upload / ops.download; DESIGN.md §7: a pageable 2.4 / 2.9 MB source freed
+    right after `copy_` was what made one of eight co-resident ranks start from other weights about once in 100 constructions)."""
+    x = np.random.default_rng(0).standard_normal((3, 3, 320, 256)).astype(np.float32)      # 2.9 MB: the size class that was torn
+    d = torch.full(x.shape, float('nan'), device=DEV)
+    ops.upload(d, x, 'x')
+    del x
+    ref = np.random.default_rng(0).standard_normal((3, 3, 320, 256)).astype(np.float32)
+    back = ops.download(d)
+    assert not back.is_cuda and not back.is_pinned() and torch.equal(back, torch.from_numpy(ref))
+    # layout and dtype conversion happen on the host side of the staging buffer
+    src = torch.arange(35.).reshape(7, 5).t()                                               # non-contiguous
+    d16 = torch.empty(5, 7, dtype=torch.bfloat16, device=DEV)
+    ops.upload(d16, src)
+    assert torch.equal(d16.float().cpu(), src.contiguous())
+    # a flat destination takes any source of the same size; a device source is a plain stream-ordered copy
+    flat = torch.empty(35, device=DEV)
+    ops.upload(flat, src)
+    assert torch.equal(flat.cpu(), src.reshape(-1))
+    ops.upload(flat, (flat * 2).reshape(5, 7))
+    assert torch.equal(flat.cpu(), 2 * src.reshape(-1))
+    with pytest.raises(RuntimeError):
+        ops.upload(flat, torch.zeros(36))
+    # host destination (CPU tools): a plain copy
+    h = torch.empty(35)
+    ops.upload(h, src)
+    assert torch.equal(h, src.reshape(-1)) and torch.equal(ops.download(h), h)
