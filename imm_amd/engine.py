@@ -1272,7 +1272,10 @@ class IMMEngine:
         self.run(self.prog_bwd)
 
     def snapshot(self):
-        """Everything a step mutates (used to warm kernels up before graph capture without side effects)."""
+        """Everything a step mutates (used to warm kernels up before graph capture without side effects).  The clones run on torch's
+        CURRENT stream: take the snapshot on the stream the steps run on (TrainStep._capture does), or synchronise before the next
+        step is launched on another one — a snapshot taken on the default stream and restored on the step's stream is a race that
+        only shows when the device is shared (tools/det_graph.py had it, round 5)."""
         return {'params': self.params.clone(), 'm': self.adam_m.clone(), 'v': self.adam_v.clone(),
                 'step': self.step_count.clone(), 'adam_t': self.adam_t.clone(), 'agg': self.loss_agg.clone(), 'grads': self.grads.clone(), 'cost_ema': self.cost_ema.clone(),
                 'state': {k: v.clone() for k, v in self.state.items()},
