@@ -221,3 +221,20 @@ def test_wgrad_chunk_planner_counts_launch_slots_like_the_library():
     assert len(plan_wgrad_chunks(g2, 64, 16)) == 1
     # forced caps (tests/test_step_gpu.py): 5 jobs / 2 variants
     assert all(len(c) <= 2 and sum(len(m) for _k, m in c) <= 5 for c in plan_wgrad_chunks(g2, 5, 2))
+
+
+def test_upload_and_download_host_side():
+    """ops.upload / ops.download (pinned staging + read-back on a GPU: tests/test_kernels_gpu.py) with host destinations: plain copies
+    with the same reshape / dtype rules, and a size mismatch raises instead of broadcasting."""
+    import numpy as np
+    from imm_amd import ops
+    src = torch.arange(35.).reshape(7, 5).t()                  # non-contiguous
+    dst = torch.empty(35, dtype=torch.float64)
+    ops.upload(dst, src, 'x')
+    assert torch.equal(dst, src.reshape(-1).double())
+    ops.upload(dst, np.arange(35, dtype=np.int32).reshape(5, 7))
+    assert torch.equal(dst, torch.arange(35.).double())
+    back = ops.download(dst)
+    assert torch.equal(back, dst) and back.data_ptr() != dst.data_ptr()
+    with pytest.raises(RuntimeError):
+        ops.upload(dst, torch.zeros(36))
