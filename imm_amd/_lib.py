@@ -20,7 +20,7 @@ CONV_BIAS, CONV_RELU, CONV_STATS, CONV_MASK, CONV_OUT_F32 = 1, 2, 4, 8, 16
 SSE_BLOCKS = 512
 OPTIMIZERS = {'adam': 0, 'adadelta': 1, 'adagrad': 2}      # IMM_OPT_* (scripts/train.py:97-104)
 GAUSS_MODES = {'rot': 0, 'flat': 1, 'ankush': 2}     # IMM_GAUSS_* (config key gauss_mode, imm_model.py:48-72)
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 
 class ImmHipError(RuntimeError):
@@ -50,6 +50,8 @@ _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 _SIGS = {
     'imm_abi_version': [],
     'imm_device_info': [_P],
+    'imm_set_cu_limit': [_I],
+    'imm_get_cu_limit': [],
     'imm_graph_begin': [_P],
     'imm_graph_end': [_P, C.POINTER(C.c_void_p)],
     'imm_graph_launch': [_P, _P],

@@ -130,3 +130,7 @@ static inline int imm_div_up(int64_t a, int64_t b) { return (int)((a + b - 1) / 
 // wgrad_halo, s2d / s2d_halo (one-launch stride-2 data gradient, deep-K / whole-filter form -> the four class launches), nol (imm_conv2d_nol_supported -> 0),
 // hdeep6 (six-k-steps-per-barrier 16x16x128 tile -> conv_hdeep's tap-at-a-time form), s2f (stride-2 forward LDS-halo kernel -> im2col).  The ONLY dispatch switch the kernels read; every tuning constant is compiled in.
 bool imm_conv_disabled(const char* name);
+// The CU count a persistent / chip-sized launch of THIS THREAD sizes its grid for: the device's, or the caller's smaller
+// imm_set_cu_limit() value (runtime.hip) — a launch confined to a share of the chip leaves the other CUs to the kernels of a
+// concurrent stream (the frozen VGG's ground-truth half beside the encoder chains, imm_amd/engine.py).
+int imm_limit_cus(int device_cus);

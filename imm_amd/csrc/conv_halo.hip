@@ -387,7 +387,7 @@ static int halo_num_cu() {
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) g_halo_cu = p.multiProcessorCount;
     if (g_halo_cu <= 0) g_halo_cu = 256;
   }
-  return g_halo_cu;
+  return imm_limit_cus(g_halo_cu);
 }
 
 static bool halo_is_s2(const imm_conv_desc* d) {

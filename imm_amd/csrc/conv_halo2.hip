@@ -425,7 +425,7 @@ static int h2_num_cu() {
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) cu = p.multiProcessorCount;
     if (cu <= 0) cu = 256;
   }
-  return cu;
+  return imm_limit_cus(cu);
 }
 
 bool imm_halo2_applicable(const imm_conv_desc* d) {

@@ -616,7 +616,7 @@ static int hd_num_cu() {
     else (void)hipGetLastError();
     if (cu <= 0) cu = 256;
   }
-  return cu;
+  return imm_limit_cus(cu);
 }
 
 // Tile plan of a layer: patch height (16 = 8-wave kernel, 8 = 4-wave kernel) and channel-block width.

@@ -130,7 +130,7 @@ __global__ __launch_bounds__(LO_THREADS) void masked_sse_pool_kernel(const uint1
         acc += mk * sq;
       }
     const int64_t po = ((bi * so + Y) * so + X) * c + cg * 8;
-    *(uint4*)(pool_a + po) = pack8<ET>(ma);
+    if (pool_a) *(uint4*)(pool_a + po) = pack8<ET>(ma);
     *(uint4*)(pool_b + po) = pack8<ET>(mb);
   }
   acc = block_sum_256(acc, red);
@@ -207,7 +207,7 @@ extern "C" int imm_masked_sse_multi(int n, const void* const* a, const void* con
 
 extern "C" int imm_masked_sse_pool(const void* a, const void* b, int dtype, int batch, int s, int c, const float* mask, int S,
                                    float* partial, void* pool_a, void* pool_b, void* stream) {
-  IMM_REQUIRE(a && b && partial && pool_a && pool_b && batch > 0 && s > 0 && s % 2 == 0 && c > 0 && c % 8 == 0, "masked_sse_pool: args");
+  IMM_REQUIRE(a && b && partial && pool_b && batch > 0 && s > 0 && s % 2 == 0 && c > 0 && c % 8 == 0, "masked_sse_pool: args");
   IMM_REQUIRE(mask == nullptr || (S >= s && S % s == 0), "masked_sse_pool: mask side %d not a multiple of feature side %d", S, s);
   IMM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((masked_sse_pool_kernel<ET>), dim3(IMM_SSE_BLOCKS), dim3(LO_THREADS), 0,
                                                (hipStream_t)stream, (const uint16_t*)a, (const uint16_t*)b, batch, s, c / 8,

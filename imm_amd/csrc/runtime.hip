@@ -30,6 +30,15 @@ bool imm_conv_disabled(const char* name) {
   return false;
 }
 extern "C" const char* imm_last_error(void) { return imm_err_buf; }
+
+static thread_local int imm_cu_limit_tl = 0;
+int imm_limit_cus(int device_cus) { return (imm_cu_limit_tl > 0 && imm_cu_limit_tl < device_cus) ? imm_cu_limit_tl : device_cus; }
+extern "C" int imm_set_cu_limit(int cus) {
+  IMM_REQUIRE(cus >= 0 && cus % 8 == 0, "set_cu_limit: %d is not 0 or a multiple of 8 (one share per XCD)", cus);
+  imm_cu_limit_tl = cus;
+  return 0;
+}
+extern "C" int imm_get_cu_limit(void) { return imm_cu_limit_tl; }
 #ifndef IMM_SOURCE_DIGEST
 #define IMM_SOURCE_DIGEST "unknown"
 #endif

@@ -148,10 +148,13 @@ def synthetic_vgg_weights(seed=2):
 
 
 class _Launch:
-    __slots__ = ('fn', 'tag', 'flops', 'bytes', 'name', 'lane', 'variant')
+    __slots__ = ('fn', 'tag', 'flops', 'bytes', 'name', 'lane', 'variant', 'cus', 'group')
 
-    def __init__(self, fn, tag, flops=0.0, nbytes=0.0, name='', lane=0, variant=''):
+    def __init__(self, fn, tag, flops=0.0, nbytes=0.0, name='', lane=0, variant='', cus=0, group=''):
         self.fn, self.tag, self.flops, self.bytes, self.name, self.lane, self.variant = fn, tag, flops, nbytes, name, lane, variant
+        # cus: the launch is issued under imm_set_cu_limit(cus) (0 = whole device); group: 'gt' = the frozen VGG's ground-truth
+        # lane (launches AND its fork / join / event marks): needed by the loss only (forward_model_only drops it)
+        self.cus, self.group = cus, group
 
 
 class _ConvLayer:
@@ -346,22 +349,32 @@ class IMMEngine:
     def _add(self, prog, fn, tag, flops=0.0, nbytes=0.0, name='', desc=None, variant=''):
         """desc: the imm_conv_desc of a convolution launch — its kernel variant (imm_conv2d_variant) is recorded with the launch
         (tools/layer_table.py: layer -> kernel -> time -> floor)."""
+        cus = int(getattr(self, '_cur_cus', 0))
         if desc is not None:
-            variant = '%s:%d' % ops.conv2d_variant(desc, self.dt)
-        prog.append(_Launch(fn, tag, flops, nbytes, name or getattr(self, '_cur_scope', ''), getattr(self, '_cur_lane', 0), variant))
+            if cus:
+                ops.set_cu_limit(cus)            # the variant the launch will take under its CU limit
+            try:
+                variant = '%s:%d' % ops.conv2d_variant(desc, self.dt)
+            finally:
+                if cus:
+                    ops.set_cu_limit(0)
+        prog.append(_Launch(fn, tag, flops, nbytes, name or getattr(self, '_cur_scope', ''), getattr(self, '_cur_lane', 0), variant,
+                            cus, getattr(self, '_cur_group', '')))
 
     def _signal(self, prog, key, lane=None):
         """Record an event on `lane` (default: the current lane) that other lanes can wait for."""
-        prog.append(_Launch(None, 'record:' + key, lane=self._cur_lane if lane is None else lane))
+        prog.append(_Launch(None, 'record:' + key, lane=self._cur_lane if lane is None else lane, group=getattr(self, '_cur_group', '')))
 
     def _wait(self, prog, key, lane):
         prog.append(_Launch(None, 'wait:' + key, lane=lane))
 
-    def _mark(self, prog, what):
-        """'fork': the side stream may start once everything issued so far has finished; 'join': the main stream waits
-        for the side stream.  Launches registered with lane 1 in between run on the side stream: the two encoders
-        (and their backward passes) are independent chains of small kernels that do not fill 256 CUs on their own."""
-        prog.append(_Launch(None, what))
+    def _mark(self, prog, what, lane=1):
+        """'fork': side stream `lane` may start once everything issued so far on the main stream has finished; 'join': the main
+        stream waits for side stream `lane`.  Launches registered with that lane in between run on the side stream: the two
+        encoders (and their backward passes) are independent chains of small kernels that do not fill 256 CUs on their own
+        (lane 1); lane 2 carries chip-filling work CONFINED to a share of the CUs (_Launch.cus) beside those chains: the
+        ground-truth half of the frozen VGG16 forward, the renderer's filter gradients."""
+        prog.append(_Launch(None, what, lane=lane, group=getattr(self, '_cur_group', '')))
 
     def _nol_consumer_ok(self, H, W, ci, ldx, co, k, stride, bn, out_f32):
         """Can a convolution of this geometry take the RAW output of the conv + BN + ReLU block in front of it (normalise on
@@ -618,8 +631,9 @@ class IMMEngine:
             self._add(self.prog_bwd, lambda: ops.conv2d(dd, dy, lay.wt_d, None, dx), 'conv_dgrad', flops,
                       2.0 * (npix * lddy + B * lay.H * lay.W * lay.ci_real + dd.kpad * lay.ci_real), desc=dd)
 
-    def _flush_wgrads(self, name):
-        """Issue the collected filter-gradient jobs as ONE multi-problem launch per kernel variant (imm_conv2d_wgrad_multi) and
+    def _flush_wgrads(self, name, cus=0):
+        """cus: size the members' splits for that many compute units instead of the whole chip (a confined lane).
+        Issue the collected filter-gradient jobs as ONE multi-problem launch per kernel variant (imm_conv2d_wgrad_multi) and
         register their slab reductions.  Jobs that share a launch share the chip, so a layer no longer needs enough pixel
         splits to fill 256 CUs on its own: the splits of a group are sized to a common length per workgroup with about
         one round of resident workgroups in total (the library reports how many of a variant's workgroups fit a CU) — slab
@@ -633,13 +647,13 @@ class IMMEngine:
             groups.setdefault((key, pcu), []).append((lay, dy, lddy, wps, units, flops))
         chunks = plan_wgrad_chunks(groups, WGRAD_MULTI_MAX_JOBS, WGRAD_MULTI_MAX_VARIANTS)
         for ci_, chunk in enumerate(chunks):
-            self._issue_wgrad_chunk(chunk, name if len(chunks) == 1 else '%s [%d/%d]' % (name, ci_ + 1, len(chunks)))
+            self._issue_wgrad_chunk(chunk, name if len(chunks) == 1 else '%s [%d/%d]' % (name, ci_ + 1, len(chunks)), cus)
 
-    def _issue_wgrad_chunk(self, chunk, name):
+    def _issue_wgrad_chunk(self, chunk, name, cus=0):
         multi_jobs, flops_total = [], 0.0
         for (key, pcu), members in chunk:
             kind = key // 100000                    # 0 generic kernel (one launch per job), 1 transpose-read, 2 LDS-halo
-            target = pcu * self.n_cu
+            target = pcu * (cus or self.n_cu)
             # shortest useful workgroup: 16 steps of 32 pixels / 2 (sliced) or 4 (whole-filter) patches of 128 pixels
             floor_units = [16 if kind != 2 else (2 if wps > 1 else 4) for _l, _d, _ld, wps, _u, _f in members]
 
@@ -843,40 +857,87 @@ class IMMEngine:
         nimg = 2 * B
         fuse_ok = not self.l1                    # the fused SSE+pool / unpool+tap passes exist for the squared error only
         fused_sse = set()
-        if self.vgg_layers:
-            self.w11 = self._zeros(9, 64); self.b11 = self._zeros(64)
-            a = self._act(2 * B, S, S, 64)
-            self.vgg_act['conv1_1'] = (a, S)
-            self._add(self.prog_fwd, lambda: ops.vgg_conv1_1_fwd(self.in_future, self.pred, self.ldp, B, S, self.w11, self.b11, a),
-                      'vgg_conv1_1', 2.0 * 2 * B * S * S * 9 * 64, 2 * B * S * S * 128.0, name='vgg16/conv1_1')
+        # Round 6, built and MEASURED WITHOUT GAIN, off by default (IMM_VGG_SPLIT=1 turns it on): the
+        # ground-truth half of concat([gt, pred]) (imm_model.py:126) depends on the input batch only.  With the split it runs on a
+        # lane of its own (lane 2) that forks at the START of the forward program, every persistent convolution CONFINED to
+        # `gt_cus` compute units (imm_set_cu_limit; IMM_GT_CUS, 0 = no limit); the prediction half follows the renderer on the
+        # main lane with the whole chip and waits for the ground-truth activation of a tapped layer right in front of that
+        # layer's error sum.  Same box, ms/step: one launch per layer 3.193 / 3.206 | split with 128 / 96 / 64 / all CUs 3.199 /
+        # 3.238 / 3.256 / 3.261 (profiles/r06_lanes_ab.txt).  The per-lane stamps (profiles/r06_lanes_timeline_split.txt) say why:
+        # the lane's 0.29 ms of chip time take 0.80 ms beside the chains, the encoder lanes finish at 0.58 ms instead of 0.40, and
+        # the half-batch launches of the deep layers (conv4_x / conv5_x: 128 tiles) under-fill the chip the prediction half then
+        # has to itself (0.37 ms for what the 2B-image launches do in 0.25).  The chains' "latency-bound" launches are not idle
+        # CUs: every one of them puts a 119 KB-LDS workgroup on each of the 256 CUs and runs it at a third of the CU's matrix
+        # rate, and neither LDS nor registers leave room for a second kernel's workgroup on the same CU — so a CU given to the
+        # lane is a CU taken from the chains.
+        split = bool(self.vgg_layers) and os.environ.get('IMM_VGG_SPLIT', '0') != '0'
+        self.vgg_split = split
+        self.gt_cus = int(os.environ.get('IMM_GT_CUS', '128')) if split else 0
+        halves = ([('gt', slice(0, B), 2, self.gt_cus), ('pred', slice(B, 2 * B), 0, 0)] if split else
+                  [('', slice(0, 2 * B), 0, 0)])
+        gt_prog = []
+        for hname, hs, lane, cus in halves:
+            if not self.vgg_layers:
+                break
+            prog = gt_prog if hname == 'gt' else self.prog_fwd
+            self._cur_lane, self._cur_cus, self._cur_group = lane, cus, ('gt' if hname == 'gt' else '')
+            sfx = ' [%s]' % hname if hname else ''
+            nb = hs.stop - hs.start
+            if hname != 'pred':
+                self.w11 = self._zeros(9, 64); self.b11 = self._zeros(64)
+                a = self._act(2 * B, S, S, 64)
+                self.vgg_act['conv1_1'] = (a, S)
+            a = self.vgg_act['conv1_1'][0]
+            hv = {'': 3, 'gt': 1, 'pred': 2}[hname]
+            self._add(prog, (lambda a=a, hv=hv: ops.vgg_conv1_1_fwd(self.in_future, self.pred, self.ldp, B, S, self.w11, self.b11, a, hv)),
+                      'vgg_conv1_1', 2.0 * nb * S * S * 9 * 64, nb * S * S * 128.0, name='vgg16/conv1_1' + sfx)
             x, H = a, S
-        for li, (name, cin, cout) in enumerate(self.vgg_layers[1:], start=1):
-            fd = ops.fwd_desc(nimg, H, H, cin, cin, cout, cout, 3, 1, L.CONV_BIAS | L.CONV_RELU)
-            wt = self._zeros(ops.round_up(cout, 128), fd.kpad, dtype=dt)
-            wtd = self._zeros(ops.round_up(cin, 128), ops.round_up(9 * cout, 32), dtype=dt)
-            y = self._act(2 * B, H, H, cout)
-            self.vgg_wt[name], self.vgg_wtd[name], self.vgg_desc[name] = wt, wtd, fd
-            bias = self.vgg_w['vgg16/%s/biases' % name]
-            self._add(self.prog_fwd, (lambda fd=fd, x=x, wt=wt, bias=bias, y=y: ops.conv2d(fd, x, wt, bias, y)),
-                      'vgg_fwd', 2.0 * nimg * H * H * 9 * cin * cout, 2.0 * (nimg * H * H * (cin + cout) + 9 * cin * cout),
-                      name='vgg16/' + name, desc=fd)
-            self.vgg_act[name] = (y, H)
-            x = y
-            if name in VGG_POOL_AFTER and li < len(self.vgg_layers) - 1:      # the deepest layer is not pooled: nobody reads it
-                p = self._act(2 * B, H // 2, H // 2, cout)
-                if name in taps and fuse_ok:
-                    # the loss taps this layer AND it is pooled next: one pass computes the masked SSE of the two halves
-                    # and both pooled halves (the feature map is read once instead of twice)
-                    idx = self.tap_idx[name]
-                    fused_sse.add(name)
-                    self._add(self.prog_fwd, (lambda x=x, p=p, H=H, cout=cout, idx=idx: ops.masked_sse_pool(
-                        x[:B], x[B:], B, H, cout, self.in_mask, S, self.sse_partial[idx], p[:B], p[B:])), 'sse',
-                              0.0, 2 * B * H * H * cout * 2.5, name='vgg16/%s+pool' % name)
-                else:
-                    self._add(self.prog_fwd, (lambda x=x, p=p, H=H, cout=cout: ops.maxpool2_fwd(x, p, nimg, H, H, cout)),
-                              'maxpool', 0.0, nimg * H * H * cout * 2.5, name='vgg16/pool_' + name)
-                self.vgg_pool[name] = p
-                x, H = p, H // 2
+            for li, (name, cin, cout) in enumerate(self.vgg_layers[1:], start=1):
+                fd = ops.fwd_desc(nb, H, H, cin, cin, cout, cout, 3, 1, L.CONV_BIAS | L.CONV_RELU)
+                if hname != 'pred':
+                    wt = self._zeros(ops.round_up(cout, 128), fd.kpad, dtype=dt)
+                    wtd = self._zeros(ops.round_up(cin, 128), ops.round_up(9 * cout, 32), dtype=dt)
+                    y = self._act(2 * B, H, H, cout)
+                    self.vgg_wt[name], self.vgg_wtd[name], self.vgg_desc[name] = wt, wtd, fd
+                    self.vgg_act[name] = (y, H)
+                wt, y = self.vgg_wt[name], self.vgg_act[name][0]
+                bias = self.vgg_w['vgg16/%s/biases' % name]
+                self._add(prog, (lambda fd=fd, x=x, wt=wt, bias=bias, y=y, hs=hs: ops.conv2d(fd, x[hs], wt, bias, y[hs])),
+                          'vgg_fwd', 2.0 * nb * H * H * 9 * cin * cout, 2.0 * (nb * H * H * (cin + cout) + 9 * cin * cout),
+                          name='vgg16/' + name + sfx, desc=fd)
+                if hname == 'gt' and name in taps:
+                    self._signal(prog, 'gt:' + name)
+                x = y
+                if name in VGG_POOL_AFTER and li < len(self.vgg_layers) - 1:      # the deepest layer is not pooled: nobody reads it
+                    if hname != 'pred':
+                        self.vgg_pool[name] = self._act(2 * B, H // 2, H // 2, cout)
+                    p = self.vgg_pool[name]
+                    if name in taps and fuse_ok and hname != 'gt':
+                        # the loss taps this layer AND it is pooled next: one pass computes the masked SSE of the two halves
+                        # and both pooled halves (the feature map is read once instead of twice); with the ground-truth lane the
+                        # pooled ground-truth half is that lane's (imm_maxpool2_fwd below) and this pass writes the prediction's
+                        idx = self.tap_idx[name]
+                        fused_sse.add(name)
+                        if hname == 'pred':
+                            self._wait(prog, 'gt:' + name, lane=0)
+                        pa = None if hname == 'pred' else p[:B]
+                        self._add(prog, (lambda x=x, p=p, pa=pa, H=H, cout=cout, idx=idx: ops.masked_sse_pool(
+                            x[:B], x[B:], B, H, cout, self.in_mask, S, self.sse_partial[idx], pa, p[B:])), 'sse',
+                                  0.0, 2 * B * H * H * cout * 2.5, name='vgg16/%s+pool' % name)
+                    else:
+                        self._add(prog, (lambda x=x, p=p, H=H, cout=cout, hs=hs, nb=nb: ops.maxpool2_fwd(x[hs], p[hs], nb, H, H, cout)),
+                                  'maxpool', 0.0, nb * H * H * cout * 2.5, name='vgg16/pool_' + name + sfx)
+                    x, H = p, H // 2
+        self._cur_lane, self._cur_cus, self._cur_group = 0, 0, ''
+        if gt_prog:
+            # the ground-truth lane forks in front of everything else (list order = host issue order; the lane's stream is
+            # released by an event at the head of the main stream); it is joined in front of the loss below
+            self._cur_group = 'gt'
+            head = []
+            self._mark(head, 'fork', lane=2)
+            self._cur_group = ''
+            self.prog_fwd[0:0] = head + gt_prog
+            self.n_fwd_model += len(head) + len(gt_prog)
         if self.vgg_layers:
             self._pack_vgg()
 
@@ -902,6 +963,12 @@ class IMMEngine:
             self._add(self.prog_fwd, lambda: ops.masked_sse_f32(self.in_future, 3, self.pred, self.ldp, B, S, 3, mask,
                                                                 self.sse_partial[idx0], l1), 'sse')
         tail = [name for name in taps if name not in fused_sse]
+        if self.vgg_split:
+            # the last launch of the ground-truth lane produced the deepest tapped activation: the lane is joined here (every tap
+            # that is not pooled next — conv3_2, conv4_2, conv5_2 — is read by the error sums below)
+            self._cur_group = 'gt'
+            self._mark(self.prog_fwd, 'join', lane=2)
+            self._cur_group = ''
         if len(tail) > 1:
             # the deep tapped layers' error sums in one launch (they sit back to back in front of the loss)
             feats = []
@@ -1092,6 +1159,20 @@ class IMMEngine:
             self._add(self.prog_bwd, lambda: ops.wgrad_reduce_multi(self.reduce_tab_ren), 'wgrad_reduce', name='renderer')
             self._reduce_jobs = []
             self.n_bwd_bucket0 = len(self.prog_bwd)
+        # Round 6, built and measured, off by default (IMM_WG_CUS=<CUs> turns it on): the renderer's filter
+        # gradients (46 % of the trainable filter-gradient FLOPs, ready here) as a CONFINED launch group on lane 2 — splits sized
+        # for `wg_cus` compute units — beside the encoders' backward chains.  Same box: off 3.193 / 3.206 ms | 96 CUs 3.172 | 128
+        # CUs 3.257 | 64 CUs 3.373.  At 96 CUs the final filter-gradient phase shrinks by 113 us and the encoders' backward grows
+        # by 110 (profiles/r06_lanes_timeline_split.txt): zero-sum for the reason given at IMM_VGG_SPLIT above.
+        self.wg_cus = int(os.environ.get('IMM_WG_CUS', '0')) if self.dp_buckets < 2 else 0
+        if self.wg_cus:
+            self._mark(self.prog_bwd, 'fork', lane=2)
+            self._cur_lane = 2
+            self._flush_wgrads('renderer', cus=self.wg_cus)
+            self.reduce_tab_ren = ops.reduce_table([j for j, _n in self._reduce_jobs], [n for _j, n in self._reduce_jobs], self.dev)
+            self._add(self.prog_bwd, lambda: ops.wgrad_reduce_multi(self.reduce_tab_ren), 'wgrad_reduce', name='renderer')
+            self._reduce_jobs = []
+            self._cur_lane = 0
         self.bucket0_offset = self.tab.offsets[[n for n, _s, _w in self.spec].index('model/renderer/conv_1/w')]
         # ---- bottleneck + pose encoder backward (main stream) || image encoder backward (side stream) --------------
         self._mark(self.prog_bwd, 'fork')       # d_joint is complete here
@@ -1141,12 +1222,14 @@ class IMMEngine:
         self._colsum_pending = []
         self._cur_lane = 0
         self._mark(self.prog_bwd, 'join')
-        self._flush_wgrads('encoders' if self.n_bwd_bucket0 is not None else 'all layers')
+        if self.wg_cus:
+            self._mark(self.prog_bwd, 'join', lane=2)
+        self._flush_wgrads('encoders' if (self.n_bwd_bucket0 is not None or self.wg_cus) else 'all layers')
         # one table-driven launch sums every layer's split-K slabs into the flat gradient buffer
         if self._reduce_jobs:
             self.reduce_tab = ops.reduce_table([j for j, _n in self._reduce_jobs], [n for _j, n in self._reduce_jobs], self.dev)
             self._add(self.prog_bwd, lambda: ops.wgrad_reduce_multi(self.reduce_tab), 'wgrad_reduce',
-                      name='encoders' if self.n_bwd_bucket0 is not None else 'all layers')
+                      name='encoders' if (self.n_bwd_bucket0 is not None or self.wg_cus) else 'all layers')
 
     def _encoder_backward(self, layers, d_out, ldd):
         B = self.B
@@ -1170,7 +1253,7 @@ class IMMEngine:
         if not self.two_streams:
             for l in prog:
                 if l.fn is not None:
-                    l.fn()
+                    self._issue(l)
             return
         main = torch.cuda.current_stream(self.dev)
         streams = {0: main}
@@ -1197,21 +1280,21 @@ class IMMEngine:
                 continue
             if l.fn is not None:
                 if l.lane == 0:
-                    l.fn()
+                    self._issue(l)
                 else:
                     with torch.cuda.stream(lane_stream(l.lane)):
-                        l.fn()
+                        self._issue(l)
                 if self._stamp_mode == 'all':
                     stamp(l.lane, '%s %s' % (l.tag, l.name))
             elif l.tag == 'fork':
-                stamp(0, 'fork')
-                ev = torch.cuda.Event(); ev.record(main); lane_stream(1).wait_event(ev)
-                stamp(1, 'fork: lane 1 released')
+                stamp(0, 'fork' if l.lane == 1 else 'fork%d' % l.lane)
+                ev = torch.cuda.Event(); ev.record(main); lane_stream(l.lane).wait_event(ev)
+                stamp(l.lane, 'fork: lane %d released' % l.lane)
             elif l.tag == 'join':
-                stamp(1, 'join: lane 1 done')
-                stamp(0, 'join: lane 0 arrives')
-                ev = torch.cuda.Event(); ev.record(lane_stream(1)); main.wait_event(ev)
-                stamp(0, 'join: lane 0 resumes')
+                stamp(l.lane, 'join: lane %d done' % l.lane)
+                stamp(0, 'join: lane 0 arrives' if l.lane == 1 else 'join%d: lane 0 arrives' % l.lane)
+                ev = torch.cuda.Event(); ev.record(lane_stream(l.lane)); main.wait_event(ev)
+                stamp(0, 'join: lane 0 resumes' if l.lane == 1 else 'join%d: lane 0 resumes' % l.lane)
             elif l.tag.startswith('record:'):
                 stamp(l.lane, l.tag)
                 ev = torch.cuda.Event(); ev.record(lane_stream(l.lane)); events[l.tag[7:]] = ev
@@ -1220,6 +1303,19 @@ class IMMEngine:
                 lane_stream(l.lane).wait_event(events[l.tag[5:]])
                 stamp(l.lane, l.tag + ' resumes')
         stamp(0, 'end')
+
+    @staticmethod
+    def _issue(l):
+        """One launch, under its CU limit (imm_set_cu_limit is thread-local host state read by the launch code: the confined
+        grid is baked into the launch, also when it is captured into a graph)."""
+        if l.cus:
+            ops.set_cu_limit(l.cus)
+            try:
+                l.fn()
+            finally:
+                ops.set_cu_limit(0)
+        else:
+            l.fn()
 
     def stamp_report(self):
         """[(microseconds since the first probe of the step, lane, label)] of the last step issued with IMM_DEBUG_STAMPS set."""
@@ -1243,7 +1339,7 @@ class IMMEngine:
                 continue
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            l.fn()
+            self._issue(l)
             e1.record()
             evs.append((l, e0, e1))
         torch.cuda.synchronize()
@@ -1266,7 +1362,7 @@ class IMMEngine:
     def forward_model_only(self, training=False):
         """IMMModel.build(build_loss=False): encoders, bottleneck, renderer (no VGG, no loss)."""
         self._training = bool(training)
-        self.run([l for l in self.prog_fwd[:self.n_fwd_model] if not l.name.endswith('[gt]')])   # VGG gt half: loss only
+        self.run([l for l in self.prog_fwd[:self.n_fwd_model] if l.group != 'gt'])   # the VGG ground-truth lane: loss only
 
     def backward(self):
         self.run(self.prog_bwd)

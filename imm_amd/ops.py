@@ -83,6 +83,12 @@ def device_info():
     return int(out[0]), int(out[1])
 
 
+def set_cu_limit(cus):
+    """Size the persistent convolution launches this thread issues from now on for `cus` compute units (0 = the whole device):
+    include/imm_hip.h imm_set_cu_limit."""
+    call('imm_set_cu_limit', int(cus))
+
+
 # ---- graph capture ---------------------------------------------------------------------------
 class Graph:
     """A captured launch sequence (HIP graph) on torch's current stream."""

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define IMM_ABI_VERSION 18   /* 18: imm_copy_f32.  17: imm_cost_ema, imm_rms16 (summaries).  16: imm_conv2d_variant.  15: imm_conv2d_dgrad_s2, imm_conv2d_nol, imm_conv_first, imm_wgrad_job.x_scale/x_shift/x_relu; entry points removed
+#define IMM_ABI_VERSION 19   /* 19: imm_set_cu_limit / imm_get_cu_limit, imm_masked_sse_pool with pool_a == NULL.  18: imm_copy_f32.  17: imm_cost_ema, imm_rms16 (summaries).  16: imm_conv2d_variant.  15: imm_conv2d_dgrad_s2, imm_conv2d_nol, imm_conv_first, imm_wgrad_job.x_scale/x_shift/x_relu; entry points removed
                                   since 14 (imm_bn_bwd_reduce_finalize, imm_conv2d_stats_workspace_bytes) finally counted */
 
 enum imm_dtype { IMM_BF16 = 0, IMM_F16 = 1 };
@@ -70,6 +70,16 @@ const char* imm_last_error(void);
 const char* imm_source_digest(void);
 /* device properties the host needs to size launches: [0]=CU count, [1]=gfx arch number (950) */
 int imm_device_info(int32_t* out2_host);
+/* Confine the launches THIS THREAD issues from now on to a share of the chip: the persistent / chip-sized convolution kernels
+ * (conv_halo, conv_halo2, conv_hdeep, conv_hdeep6) size their grids — and choose their tiles — as if the device had `cus` compute
+ * units (a multiple of 8: one share per XCD; 0 = the whole device, the default).  The other CUs stay free for the kernels of a
+ * concurrent stream: the weight-independent ground-truth half of the frozen VGG16 forward (concat([gt, pred]),
+ * imm/models/imm_model.py:126) runs beside the latency-bound encoder chains this way (imm_amd/engine.py).  Results do not depend
+ * on the limit except through the tile choice (accumulation order).  Row-count queries (imm_conv_stats_blocks ...) follow the
+ * limit in force when they are called: query and launch under the same one (launches with IMM_CONV_STATS are never confined by
+ * the engine).  Thread-local, like imm_last_error. */
+int imm_set_cu_limit(int cus);
+int imm_get_cu_limit(void);
 /* timeline probe: slots[index] = the device's constant-rate wall clock (100 MHz ticks) when this one-thread kernel runs on
  * `stream`.  Placed between the launches of a captured program it gives a profiler-free timeline of a HIP-graph replay
  * (IMM_DEBUG_STAMPS=1 in imm_amd/engine.py). */
@@ -366,7 +376,8 @@ int imm_masked_sse_multi(int n, const void* const* a, const void* const* b, cons
 int imm_masked_sse(const void* a, const void* b, int dtype, int batch, int s, int c, const float* mask, int S, int l1,
                    float* partial, void* stream);
 /* imm_masked_sse fused with the 2x2/2 max-pool that follows the tapped VGG layer (conv1_2, conv2_2): reads the two feature
- * halves once, writes the SSE partials and both pooled halves [batch, s/2, s/2, c]. */
+ * halves once, writes the SSE partials and both pooled halves [batch, s/2, s/2, c].  pool_a == NULL: the ground-truth half is
+ * pooled elsewhere (its own lane pools it with imm_maxpool2_fwd, imm_amd/engine.py), only pool_b is written. */
 int imm_masked_sse_pool(const void* a, const void* b, int dtype, int batch, int s, int c, const float* mask, int S,
                         float* partial, void* pool_a, void* pool_b, void* stream);
 int imm_masked_sse_f32(const float* a, int lda, const float* b, int ldb, int batch, int s, int c, const float* mask,
