@@ -100,6 +100,29 @@ def synthetic_batch(batch, size, seed, device):
     return {'image': dev(im), 'future_image': dev(fut), 'mask': dev(mask)}
 
 
+def forward_only_rates(dev, batches, steps=20):
+    """images/s of TrainStep.forward_only (forward + perceptual loss as one graph replay; the reference's `fwd_only`,
+    cnn_train_multi.py:447-449) at the given per-GPU batches: {'b<batch>': {'ms': .., 'images_per_s': ..}}."""
+    from imm_amd.models.imm_model import IMMModel
+    from imm_amd.train.cnn_train_multi import TrainStep
+    out = {}
+    for b in batches:
+        model = IMMModel(model_config(N_MAPS), dtype=torch_dtype(), device=dev)      # (its own model: the timed one is not touched)
+        ts_f = TrainStep(model, b, IMAGE_SIZE, world_size=1, use_graph=True)
+        inp = synthetic_batch(b, IMAGE_SIZE, seed=0, device=dev)
+        ts_f.engine.set_inputs(inp['image'], inp['future_image'], inp['mask'])
+        for _ in range(5):
+            ts_f.forward_only(None)
+        ts_f.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ts_f.forward_only(None)
+        ts_f.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        out['b%d' % b] = {'ms': round(dt * 1e3, 4), 'images_per_s': round(b / dt, 1)}
+    return out
+
+
 # ---------------------------------------------------------------------------------------------------------
 # HBM traffic of the dominant kernel family (rocprofv3 PMC, separate passes for FETCH_SIZE and WRITE_SIZE)
 # ---------------------------------------------------------------------------------------------------------
@@ -541,6 +564,25 @@ def main():
                     replicas_diff[n] = odd
             sys.stderr.write('bench: replicas differ in %d tensors: %r\n' % (len(replicas_diff), dict(list(replicas_diff.items())[:12])))
 
+    # device-clock phases of the replayed step (every rank runs the probed steps: they contain the collectives)
+    phases = None
+    if not args.no_graph:
+        try:
+            phases = ts.measure_phases(5)
+        except Exception as e:       # the probes must never lose the measurement
+            phases = {'error': '%s: %s' % (type(e).__name__, e)}
+        barrier()
+    fwd_only = None
+    if rank == 0 and not args.no_graph:
+        # the reference's `fwd_only` timing switch (cnn_train_multi.py:378,447-449) on BASELINE.json configs[0]'s shape (batch 4:
+        # forward + perceptual loss, no backward / update) and on this workload's batch
+        try:
+            fwd_only = forward_only_rates(dev, [4, BATCH_PER_GPU])
+        except Exception as e:
+            fwd_only = {'error': '%s: %s' % (type(e).__name__, e)}
+    if world > 1:
+        dist.barrier()
+
     if rank == 0:
         # per-kernel timing with HIP events on the launch stream (eager pass; graph replay hides launches)
         with torch.cuda.stream(ts.stream):
@@ -594,7 +636,12 @@ def main():
                        'parallelism': 'dp%d' % world, 'hip_graph': not args.no_graph,
                        'collective': ({'backend': dist.get_backend(), 'world_size': dist.get_world_size(),
                                        'mode': ts.collective, 'buckets': ts.buckets, 'graph_resident': bool(ts.graph_resident),
-                                       'native_rccl': ts.native_comm is not None, 'selfcheck': selfcheck}
+                                       'native_rccl': ts.native_comm is not None, 'selfcheck': selfcheck,
+                                       'payload_mb': round(eng.tab.total * 4 / 1e6, 2),
+                                       # one ring over ONE xGMI link direction (~153 GB/s) moves 2 (N-1)/N of the payload per GPU:
+                                       # the per-link bound of a ring all-reduce; with all 7 links in rings it is 1/7 of that
+                                       'expected_ring_ms': round(2.0 * (world - 1) / max(world, 1) * eng.tab.total * 4 / 153e9 * 1e3, 4),
+                                       'expected_ring_ms_7_links': round(2.0 * (world - 1) / max(world, 1) * eng.tab.total * 4 / (7 * 153e9) * 1e3, 4)}
                                       if dist.is_initialized() else None),
                        'weights': 'seeded random init; synthetic VGG16 (vgg16.caffemodel.h5 unavailable offline)'},
             'roofline': roof,
@@ -606,6 +653,7 @@ def main():
                      'frac_of_peak': round(step_flops / (ms_per_step * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
                      'trainable_conv_tflops': round(sum(d[2] for d in tr) / (sum(d[1] for d in tr) * 1e-3) / 1e12, 1) if tr else None,
                      'sum_kernel_ms_eager': round(total_ms, 3), 'hbm_gb_per_step': hbm_gb_step, 'loss': round(loss, 3),
+                     'phases_ms': phases, 'fwd_only': fwd_only,
                      'hbm_bytes_allocated': eng.memory_bytes(), 'replicas_identical': replicas_identical,
                      'replicas_diff': (None if not replicas_diff else {k: v for k, v in list(replicas_diff.items())[:12]})},
             'kernels': breakdown,

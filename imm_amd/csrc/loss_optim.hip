@@ -519,8 +519,8 @@ extern "C" int imm_weight_decay_loss(const float* params, const int32_t* blk_seg
 // ---------------------------------------------------------------------------------------------
 // BaseModel._add_cost_summary (base_model.py:52-60): tf.train.ExponentialMovingAverage(0.99).apply([cost]) for reconstruction_loss,
 // weights_loss and loss_total, run with every training step (avg_ops, cnn_train_multi.py:61-62).  For a TENSOR the shadow value
-// starts at 0 and is zero-debiased: biased <- decay * biased + (1 - decay) * cost, local_step <- local_step + 1, and the value
-// summarised is biased / (1 - decay^local_step) (the host divides).  state = {biased[3], local_step}.
+// starts at 0: shadow <- decay * shadow + (1 - decay) * cost, and — tensorflow 1.10, zero_debias=False — the value summarised is
+// the shadow itself.  state = {shadow[3], local_step} (the step count is bookkeeping only).
 __global__ void cost_ema_kernel(const float* __restrict__ cost3, float* __restrict__ state, float decay) {
   if (threadIdx.x < 3) state[threadIdx.x] = decay * state[threadIdx.x] + (1.f - decay) * cost3[threadIdx.x];
   if (threadIdx.x == 3) state[3] += 1.f;

@@ -97,8 +97,8 @@ class TPSRandomSampler(object):
         self.params = TPSParamCache(self.vertical_points, self.horizontal_points, rotsd, scalesd, transsd, self.warpsd,
                                     self.cache_size, self.cache_evict_prob, rng)
         self.m3 = self.vertical_points * self.horizontal_points + 3
-        self.basis_t = torch.from_numpy(tps_basis_t(self.height, self.width, self.vertical_points,
-                                                    self.horizontal_points)).to(self.device)
+        self.basis_t = ops.to_device_pinned(tps_basis_t(self.height, self.width, self.vertical_points, self.horizontal_points),
+                                            self.device)
 
     def sample_params_host(self, batch_size):
         """[B, M+3, 2] float32 numpy.  Cache policy of the reference (tps_sampler.py:60-74): a random slot per sample,
@@ -107,7 +107,7 @@ class TPSRandomSampler(object):
 
     def sample_params(self, batch_size):
         """The same on the device."""
-        return torch.from_numpy(self.sample_params_host(batch_size)).to(self.device)
+        return ops.to_device_pinned(self.sample_params_host(batch_size), self.device)
 
     def warp(self, x, w_tps, dst=None, dst_c0=None, dst_rest=None):
         """x [B,H,W,C] float32 NHWC on the device, w_tps [B, M+3, 2].  Writes any of: dst (all channels), dst_c0

@@ -236,7 +236,7 @@ class TPSDataset(ImagePairDataset):
 
             src, offs_d, hw_d = blob[:total], view('offsets'), view('sizes')
             if key not in self._mask_dev:
-                self._mask_dev[key] = torch.from_numpy(self._get_smooth_mask(height, width, 10, 20)).to(dev)
+                self._mask_dev[key] = ops.to_device_pinned(self._get_smooth_mask(height, width, 10, 20), dev)
                 if self._tps:
                     self._aug[key] = TPSPairAugmenter((width, height), device=dev, **self._tps_args)
             mask = self._mask_dev[key]

@@ -62,6 +62,7 @@ def plan_wgrad_chunks(groups, max_jobs, max_slots):
     if cur:
         chunks.append(cur)
     return chunks
+COST_EMA_STATE = 'summaries/cost_movavg'      # {reconstruction_loss, weights_loss, loss_total shadows, update count}
 VGG_TAPS = {'conv1_2': 1, 'conv2_2': 2, 'conv3_2': 3, 'conv4_2': 4, 'conv5_2': 5}
 
 
@@ -328,6 +329,8 @@ class IMMEngine:
                         self.loss_agg[self.comp.index(k[5:-4])] = float(v)
                 elif k.startswith('vgg16/'):
                     ops.upload(self.vgg_w[k], v, k)
+                elif k == COST_EMA_STATE:
+                    ops.upload(self.cost_ema, torch.as_tensor(v, dtype=torch.float32).reshape(4), k)
                 else:
                     raise KeyError(k)
             self._pack_vgg()
@@ -341,6 +344,9 @@ class IMMEngine:
         if self.loss_kind == 'perceptual':
             for i, name in enumerate(self.comp):
                 out['loss/%s_agg' % name] = self.loss_agg[i].detach().clone()
+        # the shadow variables of the cost moving averages (base_model.py:52-60: tf.train.Saver stores them, so a resumed run's
+        # `_avg` curves continue) + the update count
+        out[COST_EMA_STATE] = self.cost_ema.detach().clone()
         return out
 
     # ------------------------------------------------------------------------------------------
@@ -952,8 +958,9 @@ class IMMEngine:
         self.nel = torch.tensor(nel, dtype=torch.float32, device=self.dev)
         self.loss_out = self._zeros(3 * nfeat + 3)
         # BaseModel._add_cost_summary (base_model.py:52-60): moving averages of reconstruction_loss / weights_loss / loss_total,
-        # {biased[3], local_step}, advanced by every TRAINING step (imm_cost_ema, at the head of the image-encoder lane's backward
-        # pass: off the critical path); cost_summaries() zero-debiases them like tf.train.ExponentialMovingAverage does for a tensor
+        # {shadow[3], local_step}, advanced by every TRAINING step (imm_cost_ema, at the head of the image-encoder lane's backward
+        # pass: off the critical path); cost_summaries() reports the shadow as it is: TF 1.10's ExponentialMovingAverage does not
+        # zero-debias (zero_debias=False), the `_avg` curves start at 0 like the reference's
         self.cost_ema = self._zeros(4)
         mask = self.in_mask
         l1 = self.l1
@@ -1264,7 +1271,10 @@ class IMMEngine:
             if i not in streams:
                 streams[i] = self._side_stream(i)
             return streams[i]
-        pname = 'fwd' if prog is self.prog_fwd else 'bwd' if prog is self.prog_bwd else 'opt'
+        # (TrainStep runs the backward program in two slices when the gradient exchange has two buckets)
+        pname = ('fwd' if prog is self.prog_fwd else 'opt' if (prog is self.prog_opt or not prog) else
+                 'bwd' if (prog is self.prog_bwd or prog[0] is self.prog_bwd[0]) else
+                 'bwd2' if prog[-1] is self.prog_bwd[-1] else 'opt')
         if self._stamp_mode and prog is self.prog_fwd:
             self._stamp_names = []
 
@@ -1347,13 +1357,17 @@ class IMMEngine:
         return [(l.tag, e0.elapsed_time(e1), l.flops, l.bytes, l.name) for l, e0, e1 in evs]
 
     def set_inputs(self, image, future_image, mask=None):
-        # device tensors (the loader's, the bench's): stream-ordered copies; host tensors: pinned staging + read-back (ops.upload)
-        ops.upload(self.in_image, image, 'image')
-        ops.upload(self.in_future, future_image, 'future_image')
+        # device tensors (the loader's, the bench's): stream-ordered copies; host tensors: persistent double-buffered pinned
+        # staging, asynchronous, no read-back and no stream synchronisation (ops.PinnedStager; round 5 verified every step's inputs
+        # like a one-time upload and serialised a host-fed loop with the device)
+        if getattr(self, '_stager', None) is None:
+            self._stager = ops.PinnedStager()
+        self._stager.copy(self.in_image, image, 'image')
+        self._stager.copy(self.in_future, future_image, 'future_image')
         if self.use_mask:
             if mask is None:
                 raise RuntimeError('No loss mask recieved but is required.')
-            ops.upload(self.in_mask, mask, 'mask')
+            self._stager.copy(self.in_mask, mask, 'mask')
 
     def forward(self, training=True):
         self._training = bool(training)
@@ -1406,14 +1420,14 @@ class IMMEngine:
 
     def cost_summaries(self):
         """The reference's cost summaries (base_model.py:52-60, family 'train'): `<name>_raw` = this step's value, `<name>_avg` =
-        the zero-debiased moving average (decay 0.99) over the training steps so far.  Reads device scalars (synchronises)."""
+        the moving-average shadow (decay 0.99, started at 0, NOT zero-debiased: tensorflow 1.10's ExponentialMovingAverage default)
+        over the training steps so far.  Reads device scalars (synchronises)."""
         raw = [float(v) for v in self.loss_out[3 * self.nfeat:3 * self.nfeat + 3]]
         ema = [float(v) for v in self.cost_ema]
-        t = ema[3]
         out = {}
         for i, name in enumerate(('reconstruction_loss', 'weights_loss', 'loss_total')):
             out[name + '_raw'] = raw[i]
-            out[name + '_avg'] = ema[i] / (1.0 - 0.99 ** t) if t > 0 else 0.0
+            out[name + '_avg'] = ema[i]
         return out
 
     def vgg_activation_rms(self):

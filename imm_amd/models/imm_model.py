@@ -127,8 +127,11 @@ class IMMModel(BaseModel):
         eng = self._get_engine(im.shape[0], future_im_size[0])
         if mask is None and eng.use_mask:
             mask = torch.ones(im.shape[0], future_im_size[0], future_im_size[0], 1)
-        eng.set_inputs(im.to(eng.dev, torch.float32), future_im.to(eng.dev, torch.float32),
-                       None if mask is None else mask.to(eng.dev, torch.float32))
+        # host tensors go to set_inputs as they are (f32): it stages them through its persistent pinned buffers (ops.PinnedStager)
+        # — never a raw `.to(device)` of a pageable tensor
+        def f32(t):
+            return t.to(eng.dev, torch.float32) if t.is_cuda else t.to(torch.float32)
+        eng.set_inputs(f32(im), f32(future_im), None if mask is None else f32(mask))
         training = bool(training_pl)
         if build_loss:
             eng.forward(training)

@@ -323,6 +323,79 @@ class TrainStep:
         self.stream.wait_event(done)
         self._graphs[-1].launch()
 
+    def forward_only(self, inputs=None):
+        """The reference's `fwd_only` iteration (cnn_train_multi.py:447-449: session.run of the loss alone, "useful for timing"):
+        forward + perceptual loss in training mode as ONE graph replay (captured on first use) — no backward pass, no gradient
+        exchange, no update; returns the (device) scalar loss.  Forward-side state advances as in a training step (BN moving
+        statistics, loss normalisers)."""
+        eng = self.engine
+        self.stream.wait_stream(torch.cuda.current_stream(eng.dev))
+        with torch.cuda.stream(self.stream):
+            if inputs is not None:
+                eng.set_inputs(inputs['image'], inputs['future_image'], inputs.get('mask'))
+                for v in (inputs['image'], inputs['future_image'], inputs.get('mask')):
+                    if torch.is_tensor(v) and v.is_cuda:
+                        v.record_stream(self.stream)
+            if self.use_graph:
+                if getattr(self, '_fwd_graph', None) is None:
+                    snap = eng.snapshot()
+                    eng.forward(True)                     # warm-up outside capture, rolled back
+                    self.stream.synchronize()
+                    eng.restore(snap)
+                    self.stream.synchronize()
+                    g = ops.Graph()
+                    g.capture_begin()
+                    eng._training = True
+                    eng.run(eng.prog_fwd)
+                    g.capture_end()
+                    self._fwd_graph = g
+                eng._training = True
+                self._fwd_graph.launch()
+            else:
+                eng.forward(True)
+        torch.cuda.current_stream(eng.dev).wait_stream(self.stream)
+        return eng.loss
+
+    def measure_phases(self, steps=5):
+        """Device-clock phases of a replayed step (makes a first multi-GPU run self-explaining): the step is
+        re-captured with one-thread wall-clock probes at the program boundaries (IMM_DEBUG_STAMPS='marks' machinery), `steps`
+        steps run — EVERY rank must call this (the steps contain the collectives) —, and the medians are returned in ms:
+          forward, backward (first backward launch .. last one, incl. the filter gradients),
+          exchange_exposed = optimizer start - backward end: the part of the gradient exchange (and of the host's hand-off
+                             between the two graphs in 'pg' mode) that nothing hides,
+          optimizer (clip + Adam + re-pack).
+        The probes cost a few microseconds per step; the timed windows of bench.py run without them (the graphs captured here are
+        dropped again)."""
+        eng = self.engine
+        old_mode, old_buf = eng._stamp_mode, eng._stamp_buf
+        eng._stamp_mode = 'marks'
+        if eng._stamp_buf is None:
+            eng._stamp_buf = torch.zeros(8192, dtype=torch.int64, device=eng.dev)
+        self._graphs = None
+        rows = []
+        try:
+            for _ in range(max(1, steps)):
+                self.step(None)
+                self.synchronize()
+                rep = eng.stamp_report()
+                t = {}
+                for us, _lane, label in rep:
+                    t[label] = us                         # (a label repeats only across slices: the last occurrence counts)
+                bwd_end = t.get('bwd2:end', t.get('bwd:end'))
+                if None in (t.get('fwd:start'), t.get('fwd:end'), t.get('bwd:start'), bwd_end, t.get('opt:start'), t.get('opt:end')):
+                    continue
+                rows.append(((t['fwd:end'] - t['fwd:start']) / 1e3, (bwd_end - t['bwd:start']) / 1e3,
+                             (t['opt:start'] - bwd_end) / 1e3, (t['opt:end'] - t['opt:start']) / 1e3))
+        finally:
+            eng._stamp_mode, eng._stamp_buf = old_mode, old_buf
+            self._graphs = None
+            self.synchronize()
+        if not rows:
+            return None
+        med = [sorted(r[i] for r in rows)[len(rows) // 2] for i in range(4)]
+        return {'forward': round(med[0], 4), 'backward': round(med[1], 4), 'exchange_exposed': round(med[2], 4),
+                'optimizer': round(med[3], 4), 'steps': len(rows)}
+
     def synchronize(self):
         self.stream.synchronize()
 
@@ -416,8 +489,11 @@ def run_test_pass(model, test_dataset, step, writer=None, verbose=True):
 
 
 def train_loop(opts, train_step, data_iter, num_steps, log_every=10, checkpoint_fn=None, test_dataset=None, model=None,
-               summary_writer=None):
-    """cnn_train_multi.py:371-516 (session loop).  Steps run from the restored global step to num_steps (:441-444);
+               summary_writer=None, fwd_only=False):
+    """cnn_train_multi.py:371-516 (session loop).  fwd_only (:378,447-449, "useful for timing"): every iteration evaluates the loss
+    only — TrainStep.forward_only: forward + perceptual loss as one graph replay, no backward, no update, global_step does not
+    move — for `num_steps - start` iterations, with the same examples/sec lines; no summaries, test passes or checkpoints.
+    Steps run from the restored global step to num_steps (:441-444);
     NaN assert (:463); examples/sec (:466-469); every opts['n_summary'] steps a scalar summary (:447-452); every
     opts['n_test'] steps a pass over `test_dataset` in inference mode (:471-508); every opts['n_checkpoint'] steps
     `checkpoint_fn(step)` (:511-513, `step % n == 0` like the reference, so also at the first step).  Unlike the
@@ -433,6 +509,18 @@ def train_loop(opts, train_step, data_iter, num_steps, log_every=10, checkpoint_
     scaled = getattr(eng, 'loss_scale_state', None) is not None
     step = start_step
     last_event_step = None          # (loss scaling) the step whose events were evaluated last: a skipped update repeats its index
+    while fwd_only and step < num_steps:
+        t0 = time.time()
+        loss = train_step.forward_only(next(data_iter))
+        n_seen += opts['batch_size']
+        if (step - start_step) % log_every == 0:
+            train_step.synchronize()
+            loss_value = mean_tower_loss(loss, train_step.world_size, train_step.group)
+            assert loss_value == loss_value, 'Model diverged with loss = NaN'
+            dt = time.time() - t0
+            if rank == 0:
+                print('step %d, loss = %.4f (%.1f examples/sec; %.3f sec/batch) [fwd_only]' % (step, loss_value, opts['batch_size'] / dt, dt))
+        step += 1
     while step < num_steps:
         t0 = time.time()
         loss = train_step.step(next(data_iter))
@@ -449,10 +537,13 @@ def train_loop(opts, train_step, data_iter, num_steps, log_every=10, checkpoint_
             train_step.synchronize(); synced = True
             true_pre = int(eng.step_count) - 1
             if true_pre != step:
+                # the host's count had run ahead: BOTH cadences are re-evaluated at the device's index (the log line
+                # printed the rewound index on an off-cadence step, could repeat an index, and the collective ran for it)
                 step = true_pre
-                do_sum = bool(n_summary) and step >= 0 and step % n_summary == 0 and step != last_event_step
+                do_log = step >= 0 and (step - start_step) % log_every == 0
+                do_sum = bool(n_summary) and step >= 0 and step % n_summary == 0
             if step == last_event_step or step < 0:
-                do_sum = False
+                do_log = do_sum = False       # this index's events have been evaluated (a skipped update repeats its index)
         fire = not scaled or (step >= 0 and step != last_event_step)
         if do_log or do_sum:
             train_step.synchronize(); synced = True

@@ -358,6 +358,8 @@ def tf_variable_name(engine_name):
     `SelfSupReconstructionLoss`."""
     if engine_name.startswith('loss/') and engine_name.endswith('_agg'):
         return 'SelfSupReconstructionLoss/' + engine_name[5:]
+    if engine_name == COST_EMA_VAR_ENGINE:
+        return COST_EMA_VAR
     scope, leaf = engine_name.rsplit('/', 1)
     if leaf in ('w', 'b'):
         return '%s/%s/%s' % (scope, scope.rsplit('/', 1)[-1], leaf)
@@ -379,6 +381,11 @@ def optimizer_slots(engine):
 
 
 LOSS_SCALE_VAR = 'imm_amd/loss_scale_state'
+# The shadow variables of BaseModel._add_cost_summary's moving averages (base_model.py:52-60).  tf.train.Saver stores them under
+# names derived from the graph's auto-generated op names (`<cost op name>/<name>_movavg`), which cannot be restated without the
+# graph: they travel as ONE 4-vector {reconstruction_loss, weights_loss, loss_total shadows, update count} under a name of this
+# build, optional on restore (a bundle written by TensorFlow does not have it: the averages then restart at 0, like a fresh run).
+COST_EMA_VAR_ENGINE, COST_EMA_VAR = 'summaries/cost_movavg', 'imm_amd/cost_movavg'
 
 
 def engine_to_tf(engine, with_optimizer=True):
@@ -425,13 +432,13 @@ def load_tf_checkpoint(engine, prefix, restore_optim=False, ignore_missing_vars=
     have = list_bundle(prefix)
     want_params = OrderedDict((k, tf_variable_name(k)) for k in engine.pview)
     want_state = OrderedDict((k, tf_variable_name(k)) for k in engine.named_state())
-    needed = list(want_params.values()) + list(want_state.values())
+    needed = list(want_params.values()) + [n for n in want_state.values() if n != COST_EMA_VAR]      # (optional: see COST_EMA_VAR)
     if restore_optim:
         needed += [n + s for n in want_params.values() for _b, s in optimizer_slots(engine)]
     missing = [n for n in needed if n not in have]
     if missing and not ignore_missing_vars:
         raise KeyError('%s lacks %d variables (e.g. %s); pass ignore_missing_vars to skip them' % (prefix, len(missing), missing[0]))
-    data = read_bundle(prefix, names=set(needed) | {'global_step', 'beta1_power', 'beta2_power', LOSS_SCALE_VAR})
+    data = read_bundle(prefix, names=set(needed) | {'global_step', 'beta1_power', 'beta2_power', LOSS_SCALE_VAR, COST_EMA_VAR})
     params = engine.named_parameters()
     for k, n in want_params.items():
         if n in data:

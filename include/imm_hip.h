@@ -399,8 +399,8 @@ int imm_perceptual_finalize(const float* partial, int nfeat, const float* nel, f
 /* Summaries of the reference's train loop that live on the device (round 5):
  * imm_cost_ema — BaseModel._add_cost_summary (base_model.py:52-60; tf.train.ExponentialMovingAverage(0.99) of reconstruction_loss,
  *   weights_loss, loss_total, applied with every training step through avg_ops): cost3 = the three f32 scalars in that order (the
- *   tail out[3 nfeat .. 3 nfeat + 3) of imm_perceptual_finalize), state4 = {biased[3], local_step}, zero at start; the summarised
- *   value is biased[i] / (1 - decay^local_step) (TF zero-debiases the average of a tensor).  One tiny launch, capturable.
+ *   tail out[3 nfeat .. 3 nfeat + 3) of imm_perceptual_finalize), state4 = {shadow[3], local_step}, zero at start; the summarised
+ *   value is shadow[i] itself (tensorflow 1.10: ExponentialMovingAverage(zero_debias=False)).  One tiny launch, capturable.
  * imm_rms16 — selfsup/vgg16.py:232-234 'activation/<layer>' = sqrt(mean(z^2)) of a 16-bit tensor of n elements (n % 8 == 0, 16-byte
  *   aligned); partial: nblk f32 of scratch (nblk <= 4096 workgroups); out[0] = the scalar.  Called on summary steps only. */
 int imm_cost_ema(const float* cost3, float* state4, float decay, void* stream);

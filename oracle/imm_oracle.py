@@ -446,13 +446,17 @@ def perceptual_loss(ctx, gt, pred, mask, cfg):
 
 
 def cost_ema_update(state, costs, decay=0.99):
-    """BaseModel._add_cost_summary (base_model.py:52-60): tf.train.ExponentialMovingAverage(decay).apply([cost]) on a TENSOR — the
-    shadow value starts at 0 and TF zero-debiases it: biased <- decay * biased + (1 - decay) * cost, local_step += 1,
-    average = biased / (1 - decay^local_step).  state = [biased_0, .., biased_{n-1}, local_step] (python floats); returns
+    """BaseModel._add_cost_summary (base_model.py:52-60): tf.train.ExponentialMovingAverage(decay).apply([cost]) on a TENSOR.  The
+    reference pins tensorflow-gpu==1.10.0 (requirements.txt:1), whose ExponentialMovingAverage.__init__ has zero_debias=False: the
+    shadow of a tensor starts at 0 (create_zeros_slot) and `average(cost)` is the RAW biased value
+        shadow <- decay * shadow + (1 - decay) * cost
+    (biased towards 0 by the factor 1 - decay^t for the first few hundred steps — that is what the reference's `<cost>_avg` summary
+    shows; ADVICE r5: round 5 had assumed the zero-debiased form of moving_averages.assign_moving_average's default).
+    state = [shadow_0, .., shadow_{n-1}, local_step] (python floats; the step count is kept for bookkeeping only); returns
     (new state, averages)."""
     n = len(costs)
     new = [decay * state[i] + (1.0 - decay) * float(costs[i]) for i in range(n)] + [state[n] + 1.0]
-    return new, [new[i] / (1.0 - decay ** new[n]) for i in range(n)]
+    return new, [new[i] for i in range(n)]
 
 
 def weight_decay_loss(P):

@@ -14,6 +14,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, osp.dirname(osp.dirname(osp.abspath(__file__))))
+from imm_amd import ops                               # noqa: E402
 from imm_amd.eval import eval_imm                     # noqa: E402
 from imm_amd.models.imm_model import IMMModel        # noqa: E402
 from imm_amd.utils.config import load_configs        # noqa: E402
@@ -25,8 +26,8 @@ def npz_batches(path, batch_size, device):
     n = d['image'].shape[0]
     for i in range(0, n, batch_size):
         sl = slice(i, min(i + batch_size, n))
-        yield {'image': torch.from_numpy(d['image'][sl]).float().to(device),
-               'future_image': torch.from_numpy(d['future_image'][sl]).float().to(device),
+        yield {'image': ops.to_device_pinned(d['image'][sl], device, torch.float32),
+               'future_image': ops.to_device_pinned(d['future_image'][sl], device, torch.float32),
                'future_landmarks': d['future_landmarks'][sl]}
 
 

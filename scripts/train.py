@@ -19,6 +19,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, osp.dirname(osp.dirname(osp.abspath(__file__))))
+from imm_amd import ops                                 # noqa: E402
 from imm_amd.models.imm_model import IMMModel          # noqa: E402
 from imm_amd.train import cnn_train_multi as tru        # noqa: E402
 from imm_amd.utils.config import load_configs           # noqa: E402
@@ -66,11 +67,13 @@ def dataset_loaders(train_config, batch_per_rank, size, device, rank, world):
 
 
 def synthetic_iter(batch, size, device, seed):
+    """Random batches, put on the device through pinned staging (ops.to_device_pinned — never a raw host-to-device `.to` of a pageable
+    temporary: ADVICE r5); host tensors handed to TrainStep.step would be staged by IMMEngine.set_inputs (ops.PinnedStager)."""
     g = torch.Generator().manual_seed(seed)
-    mask = smooth_mask(size, size).reshape(1, size, size, 1).repeat(batch, 1, 1, 1).to(device)
+    mask = ops.to_device_pinned(smooth_mask(size, size).reshape(1, size, size, 1).repeat(batch, 1, 1, 1), device)
     while True:
-        yield {'image': (torch.rand(batch, size, size, 3, generator=g) * 255).to(device),
-               'future_image': (torch.rand(batch, size, size, 3, generator=g) * 255).to(device), 'mask': mask}
+        yield {'image': ops.to_device_pinned(torch.rand(batch, size, size, 3, generator=g) * 255, device),
+               'future_image': ops.to_device_pinned(torch.rand(batch, size, size, 3, generator=g) * 255, device), 'mask': mask}
 
 
 def npz_iter(path, batch, device, rank, world):
@@ -79,7 +82,7 @@ def npz_iter(path, batch, device, rank, world):
     i = rank * batch
     while True:
         idx = [(i + j) % n for j in range(batch)]
-        yield {k: torch.from_numpy(d[k][idx]).float().to(device) for k in ('image', 'future_image', 'mask')}
+        yield {k: ops.to_device_pinned(d[k][idx], device, torch.float32) for k in ('image', 'future_image', 'mask')}
         i += batch * world
 
 
@@ -93,7 +96,7 @@ def tps_pair_iter(source, size, device, cfg_dataset):
         if cfg_dataset is not None and k in cfg_dataset:
             kw[k] = cfg_dataset[k]
     aug = TPSPairAugmenter((size, size), device=device, **kw)
-    base_mask = smooth_mask(size, size).reshape(1, size, size, 1).to(device)
+    base_mask = ops.to_device_pinned(smooth_mask(size, size).reshape(1, size, size, 1), device)
     for batch in source:
         img = batch['image']
         yield aug(img, base_mask.expand(img.shape[0], -1, -1, -1))

@@ -207,12 +207,12 @@ def test_train_and_test_scripts_on_dataset_tree(celeba, tmp_path, capsys):
     assert [r['step'] for r in recs if r['tag'] == 'train'] == [0]
     assert [r['step'] for r in recs if r['tag'] == 'test'] == [0, 2] and all(r['n_samples'] == 6 for r in recs if r['tag'] == 'test')
     assert abs(recs[0]['lr'] - 1e-3) < 1e-9 and len(recs[0]['loss_terms']) == 6
-    # the reference's own scalar summaries (round 5): cost moving averages — zero-debiased, so after the first training step the
-    # average IS the value (base_model.py:52-60) — and the activation scale of every VGG16 layer (selfsup/vgg16.py:232-234)
+    # the reference's own scalar summaries (round 5): cost moving averages — TF 1.10's biased shadow that starts at 0, so after
+    # the first training step the average is 0.01 x the value (base_model.py:52-60) — and the activation scale of every VGG16 layer (selfsup/vgg16.py:232-234)
     r0 = recs[0]
     assert abs(r0['loss_total_raw'] - r0['loss']) <= 1e-5 * abs(r0['loss'])
     for name in ('reconstruction_loss', 'weights_loss', 'loss_total'):
-        assert abs(r0[name + '_avg'] - r0[name + '_raw']) <= 1e-4 * abs(r0[name + '_raw']), name
+        assert abs(r0[name + '_avg'] - 0.01 * r0[name + '_raw']) <= 1e-4 * abs(0.01 * r0[name + '_raw']), name
     assert abs(r0['reconstruction_loss_raw'] + r0['weights_loss_raw'] - r0['loss_total_raw']) <= 1e-5 * r0['loss_total_raw']
     acts = [k for k in r0 if k.startswith('activation/')]
     assert 'activation/conv1_2' in acts and 'activation/conv5_2' in acts and len(acts) == 12 and all(r0[k] > 0 for k in acts)

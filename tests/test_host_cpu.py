@@ -174,7 +174,7 @@ def test_every_entry_point_named_in_the_documents_exists():
                 continue
             bad.append((doc, name))
     assert not bad, bad
-    assert len(exported) == 92 and ('%d entry points' % len(exported)) in open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    assert len(exported) == 94 and ('%d entry points' % len(exported)) in open(os.path.join(ROOT, 'INTEGRATION.md')).read()
 
 
 def test_reference_import_paths_resolve_to_the_product_modules():
@@ -238,3 +238,38 @@ def test_upload_and_download_host_side():
     assert torch.equal(back, dst) and back.data_ptr() != dst.data_ptr()
     with pytest.raises(RuntimeError):
         ops.upload(dst, torch.zeros(36))
+
+
+def test_no_raw_pageable_uploads_in_scripts_and_datasets():
+    """`torch.from_numpy(x).to(device)` / `(expr).to(device)` of a host temporary is the pattern behind round 5's torn
+    upload (a pageable source above ~1 MB freed right after the asynchronous copy).  Scripts, datasets and the data path put host
+    arrays on the device through ops.to_device_pinned / ops.upload / ops.PinnedStager or their own pinned staging ring; this test
+    greps for the raw form.  (A `.to(dev, non_blocking=True)` FROM a pinned buffer guarded by an event is the staging ring itself.)"""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pat = re.compile(r'\.(to\((dev|device|self\.device|d)\b|cuda\(\))')
+    allowed = re.compile(r'_staging\[i\]\[:need\]\.to\(dev, non_blocking=True\)')
+    bad = []
+    for sub in ('scripts', os.path.join('imm_amd', 'datasets'), os.path.join('imm_amd', 'data'), os.path.join('imm_amd', 'eval'),
+                os.path.join('imm_amd', 'train')):
+        for dirpath, _dirs, files in os.walk(os.path.join(root, sub)):
+            for fn in files:
+                if not fn.endswith('.py'):
+                    continue
+                for no, line in enumerate(open(os.path.join(dirpath, fn)), 1):
+                    code = line.split('#', 1)[0]
+                    if pat.search(code) and not allowed.search(code):
+                        bad.append('%s:%d: %s' % (os.path.relpath(os.path.join(dirpath, fn), root), no, line.strip()))
+    assert not bad, 'raw host-to-device uploads (use ops.to_device_pinned):\n' + '\n'.join(bad)
+
+
+def test_pinned_stager_host_side():
+    """ops.PinnedStager / ops.to_device_pinned with host destinations: plain copies (the CPU tools and this suite)."""
+    import numpy as np
+    from imm_amd import ops
+    st = ops.PinnedStager()
+    dst = torch.empty(5, 7)
+    st.copy(dst, torch.arange(35.).reshape(7, 5).t(), 'x')
+    assert torch.equal(dst, torch.arange(35.).reshape(7, 5).t())
+    t = ops.to_device_pinned(np.arange(6, dtype=np.float64), 'cpu', torch.float32)
+    assert t.dtype == torch.float32 and torch.equal(t, torch.arange(6.))

@@ -343,14 +343,15 @@ def test_conv7_same_padding_on_odd_and_even_sides():
     np.testing.assert_array_equal(y3, [[7 * (4 - 2 * a) + (4 - 2 * b) for b in range(3)] for a in range(3)])
 
 
-def test_cost_moving_average_is_zero_debiased():
-    """base_model.py:52-60: the moving average of a cost TENSOR starts at 0 and is zero-debiased — after one step it equals the
-    cost itself, after two steps (0.99 * 0.01 x1 + 0.01 x2) / (1 - 0.99^2); a constant cost has a constant average."""
+def test_cost_moving_average_is_the_biased_tf110_shadow():
+    """base_model.py:52-60 under the pinned TF 1.10 (ExponentialMovingAverage(zero_debias=False)): the shadow of a cost TENSOR starts
+    at 0 and is NOT debiased — after one step it is 0.01 x1, after two 0.99 * 0.01 x1 + 0.01 x2; a constant cost c reads
+    c (1 - 0.99^t) after t steps."""
     st, avg = O.cost_ema_update([0.0, 0.0], [5.0])
-    assert abs(avg[0] - 5.0) < 1e-12 and st[1] == 1.0
+    assert abs(avg[0] - 0.05) < 1e-12 and st[1] == 1.0
     st, avg = O.cost_ema_update(st, [7.0])
-    assert abs(avg[0] - (0.99 * 0.01 * 5.0 + 0.01 * 7.0) / (1 - 0.99 ** 2)) < 1e-12
+    assert abs(avg[0] - (0.99 * 0.01 * 5.0 + 0.01 * 7.0)) < 1e-12
     st = [0.0, 0.0]
     for _ in range(50):
         st, avg = O.cost_ema_update(st, [3.25])
-    assert abs(avg[0] - 3.25) < 1e-9
+    assert abs(avg[0] - 3.25 * (1 - 0.99 ** 50)) < 1e-9

@@ -514,7 +514,7 @@ def _smooth_batch(B, S, seed=3):
 def test_gradient_parity_on_a_trained_model(dt):
     """Chain-level gradient parity where the problem is WELL CONDITIONED.  At the 0.01-std initialisation the gradient is
     ill conditioned (test_gradient_parity); after 60 Adam steps on a smooth batch the fp32 oracle agrees with an fp64 run of
-    itself to 1.3e-4 on every tensor (tests/diag_grad_conditioning.py), so a mis-scaled or mis-wired gradient anywhere in
+    itself to 1.3e-4 on every tensor (tools/diag/diag_grad_conditioning.py), so a mis-scaled or mis-wired gradient anywhere in
     the backward chain would show.  Bound for the bf16 engine against the fp32 oracle at the SAME trained parameters and
     state: EVERY trainable tensor no further from the fp32 oracle than 1.25 x the oracle's own bf16-storage emulation + 0.03 (the
     emulation rounds weights and forward activations; the engine also stores every gradient tensor in bf16) AND within 0.30
@@ -613,7 +613,7 @@ def test_backward_is_the_derivative_of_the_forward():
         [L(theta + eps d) - L(theta - eps d)] / (2 eps)  ==  <g_engine, d>,     d = g_engine restricted / its norm.
     A mis-scaled gradient entering an encoder, a wrong wgrad/dgrad pairing or a wrong BN-backward coefficient changes the
     right-hand side only.  f16 storage (8x less rounding noise than bf16 in the forward), eps = 3e-4 |theta_d|: the step-size
-    table of tests/diag_fd_check.py shows the central difference within 0.2 % of the analytic value there for single tensors
+    table of tools/diag/diag_fd_check.py shows the central difference within 0.2 % of the analytic value there for single tensors
     (the loss is strongly curved along the gradient: measured ratios 0.97 .. 1.00 at 3e-4, bound 5 %).  Sub-networks whose gradient is too small for the
     f32 resolution of the loss at that step (the pose encoder at initialisation: |g| ~ 1, loss ~ 5e4) are checked as one
     group with a looser bound."""
@@ -778,6 +778,85 @@ def test_exchange_ordering_is_enforced_poisoned_gradients_and_delayed_collective
     ts.synchronize(); torch.cuda.synchronize()
     assert not torch.equal(eng.params, want) or not bool(torch.isfinite(eng.params).all())
     ts.native_comm.destroy()
+
+
+def test_step_phases_show_an_exposed_exchange_and_hide_an_overlapped_one(monkeypatch):
+    """TrainStep.measure_phases (bench.py: step.phases_ms) reads forward / backward / exchange-exposed / optimizer
+    off device-clock probes of a replayed step.  Verified where it can be on one GPU: the C-ABI collective on its own stream DELAYED
+    by a ~3 ms spin shows up as ~3 ms of `exchange_exposed` with ONE bucket (nothing beside it) and with TWO buckets the spin in
+    front of the renderer bucket hides behind the encoders' backward (only the second bucket's spin stays exposed); without the
+    delay the exposed time is a few tens of microseconds.  The probed graphs are dropped again: the next step re-captures."""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    from imm_amd.train.cnn_train_multi import TrainStep
+    for v in ('IMM_RCCL_NATIVE', 'IMM_DP_BUCKETS', 'IMM_RCCL_GRAPH', 'IMM_DEBUG_POISON_GRADS'):
+        monkeypatch.delenv(v, raising=False)
+    spins = []
+
+    def delayed(comm):
+        real = comm.all_reduce_sum
+
+        def f(flat):
+            if spins and spins[0]:
+                torch.cuda._sleep(6_000_000)          # ~3 ms in front of the collective, on the collective's stream
+            real(flat)
+        comm.all_reduce_sum = f
+    got = {}
+    for buckets in (1, 2):
+        cfg, model, eng, inputs, P, St = make(4, dp_buckets=buckets)
+        ts = TrainStep(model, 4, 128, world_size=1, use_graph=True, split_graphs=True, collective='native')
+        delayed(ts.native_comm)
+        ts.step(inputs); ts.synchronize()
+        spins[:] = [False]
+        ts._graphs = None
+        quiet = ts.measure_phases(3)
+        spins[:] = [True]
+        slow = ts.measure_phases(3)
+        spins[:] = [False]
+        got[buckets] = (quiet, slow)
+        for ph in (quiet, slow):
+            assert ph['steps'] == 3 and all(ph[k] >= 0.0 for k in ('forward', 'backward', 'exchange_exposed', 'optimizer')), ph
+            assert 0.05 < ph['forward'] < 20.0 and 0.05 < ph['backward'] < 20.0 and ph['optimizer'] < 5.0, ph
+        assert ts._graphs is None                       # the probed capture is gone
+        loss = ts.step(inputs); ts.synchronize()
+        assert np.isfinite(float(loss))
+        ts.native_comm.destroy()
+    q1, s1 = got[1]
+    q2, s2 = got[2]
+    spin_ms = s1['exchange_exposed'] - q1['exchange_exposed']
+    assert q1['exchange_exposed'] < 0.5 and 1.0 < spin_ms < 12.0, (q1, s1)           # one bucket: the whole delay is exposed
+    # two buckets: two spins are issued (one per bucket); the first one runs beside the encoders' backward, so less than the
+    # two spins' total is exposed — at least the part the encoders' backward covers
+    assert s2['exchange_exposed'] - q2['exchange_exposed'] < 2.0 * spin_ms - 0.2, (q2, s2, spin_ms)
+
+
+def test_forward_only_iterations(capsys):
+    """The reference's fwd_only switch (cnn_train_multi.py:378,447-449): TrainStep.forward_only = forward + perceptual loss as one
+    graph replay — the loss of a training step's forward pass, no update, global_step untouched; train_loop(fwd_only=True)."""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    from imm_amd.train import cnn_train_multi as tru
+    cfg, model, eng, inputs, P, St = make(2)
+    ts = tru.TrainStep(model, 2, 128, world_size=1, use_graph=True)
+    p0 = eng.params.clone()
+    l_f = float(ts.forward_only(inputs)); ts.synchronize()
+    assert int(eng.step_count) == 0 and torch.equal(eng.params, p0)
+    out = O.forward(P, St, inputs, cfg, training=True)
+    assert abs(l_f - float(out['loss'])) <= 1e-3 * abs(float(out['loss']))
+    # eager form, on a fresh model (the loss normalisers of the first one have moved with its forward pass): the same loss
+    cfg2, model2, eng2, _i, _P, _S = make(2)
+    l_e = float(tru.TrainStep(model2, 2, 128, world_size=1, use_graph=False).forward_only(inputs))
+    assert l_e == l_f and int(eng2.step_count) == 0
+
+    def batches():
+        while True:
+            yield inputs
+    tru.train_loop({'batch_size': 2}, ts, batches(), 4, log_every=2, fwd_only=True)
+    txt = capsys.readouterr().out
+    assert txt.count('[fwd_only]') == 2 and 'Avg. samples per second' in txt
+    assert int(eng.step_count) == 0 and torch.equal(eng.params, p0)
+    ts.step(inputs); ts.synchronize()                   # the training graph is a separate capture
+    assert int(eng.step_count) == 1 and not torch.equal(eng.params, p0)
 
 
 def test_train_loop_follows_the_device_step_when_updates_are_skipped(capsys):

@@ -29,10 +29,11 @@ def test_engine_round_trip_through_a_tf_bundle(tmp_path):
     prefix = str(tmp_path / 'model.ckpt-3')
     T.save_tf_checkpoint(eng, prefix)
     listing = T.list_bundle(prefix)
-    # trainable + BN moving statistics (23 layers x 2) + 6 loss normalisers + global_step + 2 Adam slots each + 2 beta powers
+    # trainable + BN moving statistics (23 layers x 2) + 6 loss normalisers + the cost moving-average shadows (one 4-vector, round 6)
+    # + global_step + 2 Adam slots each + 2 beta powers
     n_train = len(eng.pview)
     assert n_train == 96 and len(eng.state) == 46
-    assert len(listing) == n_train + 46 + 6 + 1 + 2 * n_train + 2
+    assert len(listing) == n_train + 46 + 6 + 1 + 1 + 2 * n_train + 2 and listing[T.COST_EMA_VAR][1] == (4,)
     assert listing['model/image_encoder/encoder/conv_1/conv_1/w'][1] == (7, 7, 3, 32)
     assert listing['model/renderer/conv_8/conv_8/b/Adam_1'][1] == tuple(eng.pview['model/renderer/conv_8/b'].shape)
     assert 'SelfSupReconstructionLoss/input_agg' in listing and listing['global_step'][1] == ()
@@ -45,6 +46,8 @@ def test_engine_round_trip_through_a_tf_bundle(tmp_path):
     assert missing == []
     assert torch.equal(fresh.params, eng.params) and torch.equal(fresh.adam_m, eng.adam_m) and torch.equal(fresh.adam_v, eng.adam_v)
     assert int(fresh.step_count) == 3 and torch.equal(fresh.loss_agg, eng.loss_agg)
+    # the `_avg` summaries continue after a resume (tf.train.Saver stores the shadow variables): three updates so far
+    assert torch.equal(fresh.cost_ema, eng.cost_ema) and float(eng.cost_ema[3]) == 3.0 and float(eng.cost_ema[2]) > 0.0
     for k, v in eng.state.items():
         assert torch.equal(fresh.state[k], v), k
     # the restored engine continues exactly like the original (same forward loss on the same batch)

@@ -6,7 +6,7 @@ import sys
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from imm_amd import engine as E, ops          # noqa: E402
 from imm_amd.utils.box import Box             # noqa: E402
 from oracle import imm_oracle as O            # noqa: E402

@@ -4,13 +4,13 @@
 
 for directions d = the oracle's gradient restricted to one tensor group and normalised.  Prints a table over step sizes
 and storage types; tests/test_step_gpu.py::test_backward_is_the_derivative_of_the_forward holds the engine to it with the
-step sizes this table shows to be in the linear, noise-free range.   python tests/diag_fd_check.py [batch]"""
+step sizes this table shows to be in the linear, noise-free range.   python tools/diag/diag_fd_check.py [batch]"""
 import os
 import sys
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import imm_oracle as O   # noqa: E402  (test infrastructure: lives under tests/, the oracle only supplies the directions)
 

@@ -2,13 +2,13 @@
 trainable tensor, relative L2 error and cosine of the engine's gradient (bf16 and f16 storage) against the fp32 oracle
  (a) at the seeded initialisation and (b) after N training steps on a smooth batch (weights off the 0.01-std start, BN
 statistics away from their degenerate initial state).  The bounds of tests/test_step_gpu.py::
-test_gradient_parity_on_a_trained_model come from this table.      python tests/diag_grad_conditioning.py [steps] [batch]"""
+test_gradient_parity_on_a_trained_model come from this table.      python tools/diag/diag_grad_conditioning.py [steps] [batch]"""
 import os
 import sys
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import imm_oracle as O   # noqa: E402  (test infrastructure: lives under tests/)
 
