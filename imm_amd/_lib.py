@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # IMM_HIP_LIB: another build of the same ABI (A/B timing of kernel changes on one box); default = the in-tree library
 LIB_PATH = os.environ.get('IMM_HIP_LIB') or os.path.join(_HERE, 'libimm_hip.so')
 
-IMM_BF16, IMM_F16 = 0, 1
+IMM_BF16, IMM_F16, IMM_F32 = 0, 1, 2      # IMM_F32: f32 storage, the exact-arithmetic witness engine (test instrument)
 CONV_BIAS, CONV_RELU, CONV_STATS, CONV_MASK, CONV_OUT_F32 = 1, 2, 4, 8, 16
 SSE_BLOCKS = 512
 OPTIMIZERS = {'adam': 0, 'adadelta': 1, 'adagrad': 2}      # IMM_OPT_* (scripts/train.py:97-104)

@@ -50,7 +50,7 @@ __device__ __forceinline__ void gauss_grad(int mode, float dy, float dx, float i
 template <typename ET, int NTHR>
 __device__ __forceinline__ void bt_softargmax_tail(float* sm, int b, int tid, int h, int w, int K, float inv_std, int s,
                                                    float* __restrict__ mu, float* __restrict__ py, float* __restrict__ px,
-                                                   uint16_t* __restrict__ gauss, int ldg, int mode) {
+                                                   typename ET::T* __restrict__ gauss, int ldg, int mode) {
   float* sheat = sm;                      // [h*w][K]
   float* rmean = sheat + h * w * K;       // [h][K] row means -> probabilities
   float* cmean = rmean + h * K;           // [w][K]
@@ -105,7 +105,7 @@ __device__ __forceinline__ void bt_softargmax_tail(float* sm, int b, int tid, in
 template <typename ET>
 __global__ __launch_bounds__(BT_THREADS) void softargmax_gauss_fwd_kernel(
     const float* __restrict__ heat, int ldh, int h, int w, int K, float inv_std, int s, float* __restrict__ mu,
-    float* __restrict__ py, float* __restrict__ px, uint16_t* __restrict__ gauss, int ldg, int mode) {
+    float* __restrict__ py, float* __restrict__ px, typename ET::T* __restrict__ gauss, int ldg, int mode) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int b = blockIdx.x, tid = threadIdx.x;
   const float* hb = heat + (int64_t)b * h * w * ldh;
@@ -182,9 +182,9 @@ __global__ __launch_bounds__(PH_THREADS) void pose_head_fwd_kernel(
 // reduction: one launch instead of bottleneck backward + column sum + 1x1 data gradient.
 template <typename ET, bool HEAD>
 __global__ __launch_bounds__(HEAD ? PH_BWD_THREADS : BT_THREADS) void softargmax_gauss_bwd_kernel(
-    const uint16_t* __restrict__ dgauss, int ldg, int h, int w, int K, float inv_std, int s,
+    const typename ET::T* __restrict__ dgauss, int ldg, int h, int w, int K, float inv_std, int s,
     const float* __restrict__ mu, const float* __restrict__ py, const float* __restrict__ px,
-    uint16_t* __restrict__ dheat, int lddh, int mode, const uint16_t* __restrict__ wtd, int kpad_d, int C,
+    typename ET::T* __restrict__ dheat, int lddh, int mode, const uint16_t* __restrict__ wtd, int kpad_d, int C,
     uint16_t* __restrict__ dfeat, int lddf, float* __restrict__ bias_partial) {
   constexpr int NTHR = HEAD ? PH_BWD_THREADS : BT_THREADS;
   extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(HEAD ? PH_BWD_THREADS : BT_THREADS) void softargmax
     for (int p = tid; p < s * s; p += NTHR) {
       const int yy = p / s, xx = p - yy * s;
       const float ly = lin_pm1(yy, s), lx = lin_pm1(xx, s);
-      const uint16_t* dgp = dgauss + ((int64_t)b * s * s + p) * ldg + k0;
+      const typename ET::T* dgp = dgauss + ((int64_t)b * s * s + p) * ldg + k0;
 #pragma unroll
       for (int c = 0; c < KC; ++c) {
         if (k0 + c < K) {
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(HEAD ? PH_BWD_THREADS : BT_THREADS) void softargmax
       const int yy = p / w, xx = p - yy * w;
       v = drow[yy * K + k] / (float)w + dcol[xx * K + k] / (float)h;
     }
-    const uint16_t q = ET::from_f32(v);
+    const typename ET::T q = ET::from_f32(v);
     // HEAD: gridDim.y workgroups per sample share the data gradient's output channels (round 5); each rebuilds the (tiny) heat-map
     // gradient for itself, the first one stores it and the bias partial row
     if (!HEAD || blockIdx.y == 0) dheat[(int64_t)b * h * w * lddh + i] = q;
@@ -354,10 +354,10 @@ extern "C" int imm_softargmax_gauss_fwd(const float* heat, int ldh, int batch, i
   IMM_REQUIRE(gauss_out == nullptr || ldg >= k, "softargmax_fwd: ldg");
   const size_t lds = sizeof(float) * ((size_t)h * w * k + (size_t)(h + w) * k + 2 * (size_t)k);
   if (lds > kMaxDynLds) return imm_fail(IMM_E_UNSUPPORTED, "softargmax_fwd: heat-map %dx%dx%d needs %zu B LDS", h, w, k, lds);
-  IMM_DISPATCH_DTYPE(dtype, {
+  IMM_DISPATCH_DTYPE_F32(dtype, {
     if (set_dyn_lds(softargmax_gauss_fwd_kernel<ET>, lds)) return IMM_E_HIP;
     hipLaunchKernelGGL((softargmax_gauss_fwd_kernel<ET>), dim3(batch), dim3(BT_THREADS), lds, (hipStream_t)stream, heat,
-                       ldh, h, w, k, inv_std, s, mu, py, px, (uint16_t*)gauss_out, ldg, gauss_mode);
+                       ldh, h, w, k, inv_std, s, mu, py, px, (typename ET::T*)gauss_out, ldg, gauss_mode);
   });
   IMM_CHECK_LAUNCH("imm_softargmax_gauss_fwd");
   return 0;
@@ -370,10 +370,10 @@ extern "C" int imm_softargmax_gauss_bwd(const void* dgauss, int ldg, int dtype, 
   IMM_REQUIRE(gauss_mode >= IMM_GAUSS_ROT && gauss_mode <= IMM_GAUSS_ANKUSH, "softargmax_bwd: gauss_mode %d", gauss_mode);
   IMM_REQUIRE(batch > 0 && h > 0 && w > 0 && k > 0 && ldg >= k && lddh >= k && s > 0, "softargmax_bwd: dims");
   const size_t lds = sizeof(float) * (2 * (size_t)k + (size_t)(h + w) * k);
-  IMM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((softargmax_gauss_bwd_kernel<ET, false>), dim3(batch), dim3(BT_THREADS), lds,
-                                               (hipStream_t)stream, (const uint16_t*)dgauss, ldg, h, w, k, inv_std, s, mu,
-                                               py, px, (uint16_t*)dheat, lddh, gauss_mode, (const uint16_t*)nullptr, 0, 0,
-                                               (uint16_t*)nullptr, 0, (float*)nullptr));
+  IMM_DISPATCH_DTYPE_F32(dtype, hipLaunchKernelGGL((softargmax_gauss_bwd_kernel<ET, false>), dim3(batch), dim3(BT_THREADS), lds,
+                                                   (hipStream_t)stream, (const typename ET::T*)dgauss, ldg, h, w, k, inv_std, s, mu,
+                                                   py, px, (typename ET::T*)dheat, lddh, gauss_mode, (const uint16_t*)nullptr, 0, 0,
+                                                   (uint16_t*)nullptr, 0, (float*)nullptr));
   IMM_CHECK_LAUNCH("imm_softargmax_gauss_bwd");
   return 0;
 }

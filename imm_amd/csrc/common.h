@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <type_traits>
 
 #include "../../include/imm_hip.h"
 
@@ -44,6 +45,9 @@ typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
 
 struct BF16 {
   static constexpr int kEnum = IMM_BF16;
+  using T = uint16_t;     // storage element
+  using V8 = uint4;       // eight stored elements (one 16-byte access)
+  __device__ static __forceinline__ V8 zero8() { return make_uint4(0, 0, 0, 0); }
   __device__ static __forceinline__ float to_f32(uint16_t u) { return __uint_as_float(((uint32_t)u) << 16); }
   // round to nearest even in hardware (v_cvt_pk_bf16_f32 on gfx950)
   __device__ static __forceinline__ uint16_t from_f32(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
@@ -63,6 +67,9 @@ struct BF16 {
 
 struct F16 {
   static constexpr int kEnum = IMM_F16;
+  using T = uint16_t;
+  using V8 = uint4;
+  __device__ static __forceinline__ V8 zero8() { return make_uint4(0, 0, 0, 0); }
   __device__ static __forceinline__ float to_f32(uint16_t u) { return (float)__builtin_bit_cast(_Float16, u); }
   __device__ static __forceinline__ uint16_t from_f32(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
   __device__ static __forceinline__ uint32_t pack2(float lo, float hi) {
@@ -78,6 +85,33 @@ struct F16 {
   }
 };
 
+// f32 STORAGE (IMM_F32): the exact-arithmetic witness of the wiring (round 6; the reference computes in fp32, imm_model.py:97).
+// Only the HBM-bound passes (elementwise.hip, loss_optim.hip, bottleneck.hip's soft-argmax) are instantiated on it — eight
+// elements are two 16-byte accesses; the convolutions of the f32 engine are the plain kernels of conv_f32.hip (no MFMA
+// instantiation exists for it: mfma / dot2 / pack2 are deliberately absent).
+struct F32 {
+  static constexpr int kEnum = IMM_F32;
+  using T = float;
+  struct V8 { float4 a, b; };
+  __device__ static __forceinline__ V8 zero8() { V8 v; v.a = make_float4(0.f, 0.f, 0.f, 0.f); v.b = v.a; return v; }
+  __device__ static __forceinline__ float to_f32(float u) { return u; }
+  __device__ static __forceinline__ float from_f32(float f) { return f; }
+};
+
+// eight stored elements <-> registers
+template <typename ET>
+__device__ __forceinline__ typename ET::V8 ld8(const typename ET::T* p) { return *(const uint4*)p; }
+template <>
+__device__ __forceinline__ F32::V8 ld8<F32>(const float* p) { F32::V8 v; v.a = *(const float4*)p; v.b = *(const float4*)(p + 4); return v; }
+template <typename ET>
+__device__ __forceinline__ void st8(typename ET::T* p, const typename ET::V8& v) { *(uint4*)p = v; }
+template <>
+__device__ __forceinline__ void st8<F32>(float* p, const F32::V8& v) { *(float4*)p = v.a; *(float4*)(p + 4) = v.b; }
+
+__device__ __forceinline__ void unpack8_f32(const F32::V8& v, float (&f)[8]) {
+  f[0] = v.a.x; f[1] = v.a.y; f[2] = v.a.z; f[3] = v.a.w; f[4] = v.b.x; f[5] = v.b.y; f[6] = v.b.z; f[7] = v.b.w;
+}
+
 // unpack / pack 8 16-bit values held in a uint4
 template <typename ET>
 __device__ __forceinline__ void unpack8(const uint4& v, float (&f)[8]) {
@@ -89,18 +123,35 @@ __device__ __forceinline__ void unpack8(const uint4& v, float (&f)[8]) {
   }
 }
 template <typename ET>
+__device__ __forceinline__ void unpack8(const F32::V8& v, float (&f)[8]) { unpack8_f32(v, f); }
+template <typename ET, typename std::enable_if<!std::is_same<ET, F32>::value, int>::type = 0>
 __device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
   uint32_t w[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) w[i] = ET::pack2(f[2 * i], f[2 * i + 1]);
   return make_uint4(w[0], w[1], w[2], w[3]);
 }
+template <typename ET, typename std::enable_if<std::is_same<ET, F32>::value, int>::type = 0>
+__device__ __forceinline__ F32::V8 pack8(const float (&f)[8]) {
+  F32::V8 v;
+  v.a = make_float4(f[0], f[1], f[2], f[3]); v.b = make_float4(f[4], f[5], f[6], f[7]);
+  return v;
+}
 
-// dispatch on the runtime dtype enum
+// dispatch on the runtime dtype enum (16-bit storage: every kernel; IMM_DISPATCH_DTYPE_F32 below adds f32 storage for the
+// HBM-bound passes that are instantiated on it)
 #define IMM_DISPATCH_DTYPE(dtype, ...)                                          \
   do {                                                                          \
     if ((dtype) == IMM_BF16) { using ET = BF16; __VA_ARGS__; }                  \
     else if ((dtype) == IMM_F16) { using ET = F16; __VA_ARGS__; }               \
+    else return imm_fail(IMM_E_INVALID, "unknown dtype %d", (int)(dtype));      \
+  } while (0)
+
+#define IMM_DISPATCH_DTYPE_F32(dtype, ...)                                      \
+  do {                                                                          \
+    if ((dtype) == IMM_BF16) { using ET = BF16; __VA_ARGS__; }                  \
+    else if ((dtype) == IMM_F16) { using ET = F16; __VA_ARGS__; }               \
+    else if ((dtype) == IMM_F32) { using ET = F32; __VA_ARGS__; }               \
     else return imm_fail(IMM_E_INVALID, "unknown dtype %d", (int)(dtype));      \
   } while (0)
 

@@ -369,6 +369,7 @@ static int conv_launch(const imm_conv_desc* d, const void* x, const void* wt, co
 // 7 conv_s2f (stride-2 forward through a parity-de-interleaved LDS halo).
 extern "C" int imm_conv2d_variant(const imm_conv_desc* d, int dtype) {
   if (validate_desc(d)) return IMM_E_INVALID;
+  if (dtype == IMM_F32) return 800000;                 // family 8: the plain f32 kernels of the witness engine (conv_f32.hip)
   IMM_REQUIRE(dtype == IMM_BF16 || dtype == IMM_F16, "unknown dtype %d", dtype);
   if (imm_halo2_applicable(d)) return 400000 + (d->kw == 1 ? 10000 : 0) + d->ci * 100 + (d->co > 32 ? 64 : 32);
   if (imm_halo_applicable(d)) return 300000 + (d->stride == 2 ? 10000 : 0) + d->ci * 100 + (d->co > 32 ? 64 : d->co > 16 ? 32 : 16);
@@ -381,6 +382,9 @@ extern "C" int imm_conv2d_variant(const imm_conv_desc* d, int dtype) {
   return (deep ? 200000 : 100000) + (fast ? 10000 : 0) + (t.bm / 16) * 100 + t.bn / 16;
 }
 
+int imm_conv_f32(const imm_conv_desc* d, const void* x, const void* wt, const float* bias, void* y, float* stats_partial,
+                 const void* mask_ref, hipStream_t s);                                  // conv_f32.hip
+
 extern "C" int imm_conv2d(const imm_conv_desc* d, int dtype, const void* x, const void* wt, const float* bias,
                           void* y, float* stats_partial, const void* mask_ref, void* stream) {
   if (validate_desc(d)) return IMM_E_INVALID;
@@ -389,6 +393,7 @@ extern "C" int imm_conv2d(const imm_conv_desc* d, int dtype, const void* x, cons
   IMM_REQUIRE(!(d->flags & IMM_CONV_STATS) || stats_partial, "conv: stats flag without buffer");
   IMM_REQUIRE(!(d->flags & IMM_CONV_MASK) || (mask_ref && d->ldmask >= d->co), "conv: mask flag without mask/ldmask");
   IMM_REQUIRE(((uintptr_t)x % 16 == 0) && ((uintptr_t)wt % 16 == 0) && ((uintptr_t)y % 16 == 0), "conv: 16-byte alignment");
+  if (dtype == IMM_F32) return imm_conv_f32(d, x, wt, bias, y, stats_partial, mask_ref, (hipStream_t)stream);   // the f32 witness (conv_f32.hip)
   IMM_DISPATCH_DTYPE(dtype, return conv_launch<ET>(d, x, wt, bias, y, stats_partial, mask_ref, (hipStream_t)stream));
   return 0;
 }
@@ -534,9 +539,10 @@ extern "C" int imm_conv2d_group_stats_blocks(const imm_conv_desc* descs, int n) 
 extern "C" int imm_conv2d_group(const imm_conv_desc* descs, int n, int dtype, const void* x, const void* const* wts, void* y,
                                 float* stats_partial, const void* mask_ref, void* stream) {
   IMM_REQUIRE(descs && wts && x && y && n >= 1 && n <= 4, "conv_group: 1..4 members");
-  IMM_REQUIRE(dtype == IMM_BF16 || dtype == IMM_F16, "unknown dtype %d", dtype);
+  IMM_REQUIRE(dtype == IMM_BF16 || dtype == IMM_F16 || dtype == IMM_F32, "unknown dtype %d", dtype);
   GroupPlan gp;
   if (group_plan(descs, n, &gp)) return IMM_E_INVALID;
+  if (dtype == IMM_F32) gp.grouped = gp.grouped32 = false;       // f32 witness: the members one after the other (imm_conv2d)
   ConvArgs args[4];
   int row0 = 0;
   for (int i = 0; i < n; ++i) {
@@ -585,7 +591,7 @@ extern "C" int imm_conv2d_group(const imm_conv_desc* descs, int n, int dtype, co
 // weight packing: f32 HWIO master -> 16-bit Wt[rows][kpad]
 // ---------------------------------------------------------------------------------------------
 template <typename ET>
-__global__ void pack_weights_kernel(const float* __restrict__ w, uint16_t* __restrict__ wt, int mode, int kh, int kw,
+__global__ void pack_weights_kernel(const float* __restrict__ w, typename ET::T* __restrict__ wt, int mode, int kh, int kw,
                                     int ci_real, int co_real, int c_pad, int rows, int kpad) {
   const int64_t total = (int64_t)rows * kpad;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -627,9 +633,9 @@ extern "C" int imm_pack_weights(const float* w, void* wt, int dtype, int mode, i
   IMM_REQUIRE(rows >= (mode == 0 ? co_real : ci_real), "pack_weights: rows too small");
   const int64_t total = (int64_t)rows * kpad;
   const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-  IMM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((pack_weights_kernel<ET>), dim3(blocks), dim3(256), 0,
-                                               (hipStream_t)stream, w, (uint16_t*)wt, mode, kh, kw, ci_real,
-                                               co_real, c_pad, rows, kpad));
+  IMM_DISPATCH_DTYPE_F32(dtype, hipLaunchKernelGGL((pack_weights_kernel<ET>), dim3(blocks), dim3(256), 0,
+                                                   (hipStream_t)stream, w, (typename ET::T*)wt, mode, kh, kw, ci_real,
+                                                   co_real, c_pad, rows, kpad));
   IMM_CHECK_LAUNCH("imm_pack_weights");
   return 0;
 }

@@ -303,6 +303,8 @@ int imm_wgrad_halo_splits(const imm_conv_desc* d, int lddy);
 void imm_wgrad_halo_launch(int dtype, const imm_conv_desc* d, const void* x, const void* dy, int lddy, float* slab,
                            int nsplit, hipStream_t s, const float* nol_scale, const float* nol_shift, int nol_relu);
 
+int imm_conv_f32_wgrad(const imm_conv_desc* d, const void* x, const void* dy, int lddy, float* slab, int nsplit, hipStream_t s);   // conv_f32.hip
+
 extern "C" int imm_conv2d_wgrad_splits(const imm_conv_desc* d, int lddy) {
   if (!d) return IMM_E_INVALID;
   return imm_wgrad_halo_applicable(d, lddy) ? imm_wgrad_halo_splits(d, lddy) : 0;
@@ -318,6 +320,7 @@ extern "C" int imm_conv2d_wgrad(const imm_conv_desc* d, int dtype, const void* x
   IMM_REQUIRE(nsplit >= 1, "wgrad: nsplit");
   IMM_REQUIRE(d->wo % 2 == 0, "wgrad: output width must be even (pixel pairs)");
   IMM_REQUIRE(((uintptr_t)x % 16 == 0) && ((uintptr_t)dy % 16 == 0) && ((uintptr_t)slab % 16 == 0), "wgrad: alignment");
+  if (dtype == IMM_F32) return imm_conv_f32_wgrad(d, x, dy, lddy, slab, nsplit, (hipStream_t)stream);     // the f32 witness (conv_f32.hip)
   if (imm_wgrad_halo_applicable(d, lddy) && nsplit == imm_wgrad_halo_splits(d, lddy) && (dtype == IMM_BF16 || dtype == IMM_F16)) {
     imm_wgrad_halo_launch(dtype, d, x, dy, lddy, slab, nsplit, (hipStream_t)stream, nullptr, nullptr, 0);
     IMM_CHECK_LAUNCH("imm_conv2d_wgrad(halo)");

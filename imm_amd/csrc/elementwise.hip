@@ -45,7 +45,7 @@ extern "C" int imm_pack_image(const float* src, void* dst, int dtype, int64_t np
 // dst[b,y,x, kx*3+ch] = src[b,y,x+kx-pad_l,ch] (zero outside, channels kw*3..ld-1 zero), so the
 // layer becomes a (kh x 1) convolution over ld=32 channels whose K tile is one vertical tap.
 template <typename ET>
-__global__ void pack_image_taps_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, int batch, int h, int w,
+__global__ void pack_image_taps_kernel(const float* __restrict__ src, typename ET::T* __restrict__ dst, int batch, int h, int w,
                                        int kw, int pad_l, int ld) {
   const int c8n = ld / 8;
   const int64_t total = (int64_t)batch * h * w * c8n;
@@ -63,7 +63,7 @@ __global__ void pack_image_taps_kernel(const float* __restrict__ src, uint16_t* 
       const int xx = x + kx - pad_l;
       f[e] = (kx < kw && xx >= 0 && xx < w) ? src[(row + xx) * 3 + ch] : 0.f;
     }
-    *(uint4*)(dst + p * ld + cg * 8) = pack8<ET>(f);
+    st8<ET>(dst + p * ld + cg * 8, pack8<ET>(f));
   }
 }
 
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void pack_image_taps_rows_kernel(const float* 
 extern "C" int imm_pack_image_taps(const float* src, void* dst, int dtype, int batch, int h, int w, int kw, int pad_l,
                                    int ld, void* stream) {
   IMM_REQUIRE(src && dst && batch > 0 && h > 0 && w > 0 && kw > 0 && ld % 8 == 0 && ld >= 3 * kw, "pack_image_taps: args");
-  if (ld == 32 && pad_l >= 0 && pad_l < kw && (w + kw - 1) * 3 * PIT_ROWS * 2 <= 48 * 1024) {
+  if (dtype != IMM_F32 && ld == 32 && pad_l >= 0 && pad_l < kw && (w + kw - 1) * 3 * PIT_ROWS * 2 <= 48 * 1024) {
     const int nrows = batch * h;
     const size_t lds = (size_t)PIT_ROWS * (w + kw - 1) * 3 * 2 + 64;      // + slack: the last chunk of a row reads <= 11 values past it
     IMM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((pack_image_taps_rows_kernel<ET>), dim3((nrows + PIT_ROWS - 1) / PIT_ROWS), dim3(256),
@@ -112,8 +112,8 @@ extern "C" int imm_pack_image_taps(const float* src, void* dst, int dtype, int b
     return 0;
   }
   const int64_t total = (int64_t)batch * h * w * (ld / 8);
-  IMM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((pack_image_taps_kernel<ET>), dim3(ew_blocks(total)), dim3(EW_THREADS), 0,
-                                               (hipStream_t)stream, src, (uint16_t*)dst, batch, h, w, kw, pad_l, ld));
+  IMM_DISPATCH_DTYPE_F32(dtype, hipLaunchKernelGGL((pack_image_taps_kernel<ET>), dim3(ew_blocks(total)), dim3(EW_THREADS), 0,
+                                               (hipStream_t)stream, src, (typename ET::T*)dst, batch, h, w, kw, pad_l, ld));
   IMM_CHECK_LAUNCH("imm_pack_image_taps");
   return 0;
 }
@@ -252,16 +252,16 @@ extern "C" int imm_bn_finalize(const float* partial, int nblk, int c, int64_t co
 }
 
 template <typename ET>
-__global__ void bn_apply_kernel(const uint16_t* __restrict__ y, int64_t npix, int c8n, int ldy,
+__global__ void bn_apply_kernel(const typename ET::T* __restrict__ y, int64_t npix, int c8n, int ldy,
                                 const float* __restrict__ scale, const float* __restrict__ shift, int relu,
-                                uint16_t* __restrict__ x, int ldx) {
+                                typename ET::T* __restrict__ x, int ldx) {
   const int64_t total = npix * c8n;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (int64_t)gridDim.x * blockDim.x) {
     const int64_t p = idx / c8n;
     const int cg = (int)(idx - p * c8n);
     float f[8];
-    unpack8<ET>(*(const uint4*)(y + p * ldy + cg * 8), f);
+    unpack8<ET>(ld8<ET>(y + p * ldy + cg * 8), f);
     const float4 sa = *(const float4*)(scale + cg * 8), sb = *(const float4*)(scale + cg * 8 + 4);
     const float4 ha = *(const float4*)(shift + cg * 8), hb = *(const float4*)(shift + cg * 8 + 4);
     const float sc[8] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w};
@@ -271,7 +271,7 @@ __global__ void bn_apply_kernel(const uint16_t* __restrict__ y, int64_t npix, in
       f[i] = f[i] * sc[i] + sh[i];
       if (relu) f[i] = fmaxf(f[i], 0.f);
     }
-    *(uint4*)(x + p * ldx + cg * 8) = pack8<ET>(f);
+    st8<ET>(x + p * ldx + cg * 8, pack8<ET>(f));
   }
 }
 
@@ -280,9 +280,9 @@ extern "C" int imm_bn_apply_relu(const void* y, int dtype, int64_t npix, int c, 
   IMM_REQUIRE(y && scale && shift && x_out && npix > 0, "bn_apply: null");
   EW_REQUIRE_VEC(c, ldy, "bn_apply(y)");
   EW_REQUIRE_VEC(c, ldx, "bn_apply(x)");
-  IMM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_apply_kernel<ET>), dim3(ew_blocks(npix * (c / 8))), dim3(EW_THREADS),
-                                               0, (hipStream_t)stream, (const uint16_t*)y, npix, c / 8, ldy, scale,
-                                               shift, relu, (uint16_t*)x_out, ldx));
+  IMM_DISPATCH_DTYPE_F32(dtype, hipLaunchKernelGGL((bn_apply_kernel<ET>), dim3(ew_blocks(npix * (c / 8))), dim3(EW_THREADS),
+                                               0, (hipStream_t)stream, (const typename ET::T*)y, npix, c / 8, ldy, scale,
+                                               shift, relu, (typename ET::T*)x_out, ldx));
   IMM_CHECK_LAUNCH("imm_bn_apply_relu");
   return 0;
 }
@@ -343,8 +343,8 @@ template <typename ET>
 __global__ __launch_bounds__(EW_THREADS) void bn_apply_fused_kernel(
     const float* __restrict__ partial, int nblk, int c, double count, const float* __restrict__ gamma,
     const float* __restrict__ beta, float eps, float momentum, int training, float* moving_mean, float* moving_var,
-    float* scale, float* shift, float* mean_out, float* rstd_out, const uint16_t* __restrict__ y, int64_t npix, int ldy,
-    int relu, uint16_t* __restrict__ x, int ldx, int px_per_blk, uint16_t* __restrict__ up, int ldu, int h, int w) {
+    float* scale, float* shift, float* mean_out, float* rstd_out, const typename ET::T* __restrict__ y, int64_t npix, int ldy,
+    int relu, typename ET::T* __restrict__ x, int ldx, int px_per_blk, typename ET::T* __restrict__ up, int ldu, int h, int w) {
   __shared__ double sums[64];
   __shared__ float ssc[32], ssh[32];
   const int tid = threadIdx.x, ch0 = blockIdx.y * 32;
@@ -354,9 +354,9 @@ __global__ __launch_bounds__(EW_THREADS) void bn_apply_fused_kernel(
   // this thread's first two pixels are requested before the finalize prologue (its L2 round trips hide their latency)
   const int64_t pf = p0 + (tid >> 2);
   constexpr int PSTEP = EW_THREADS / 4;
-  uint4 raw0 = make_uint4(0, 0, 0, 0), raw1 = raw0;
-  if (up == nullptr && pf < p1) raw0 = *(const uint4*)(y + pf * ldy + ch0 + q * 8);
-  if (up == nullptr && pf + PSTEP < p1) raw1 = *(const uint4*)(y + (pf + PSTEP) * ldy + ch0 + q * 8);
+  typename ET::V8 raw0 = ET::zero8(), raw1 = raw0;
+  if (up == nullptr && pf < p1) raw0 = ld8<ET>(y + pf * ldy + ch0 + q * 8);
+  if (up == nullptr && pf + PSTEP < p1) raw1 = ld8<ET>(y + (pf + PSTEP) * ldy + ch0 + q * 8);
   if (training) slice32_reduce<2>(partial, nblk, c, ch0, sums);
   if (tid < 32) {
     const int ch = ch0 + tid;
@@ -383,7 +383,7 @@ __global__ __launch_bounds__(EW_THREADS) void bn_apply_fused_kernel(
   float sc[8], sh[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) { sc[i] = ssc[q * 8 + i]; sh[i] = ssh[q * 8 + i]; }
-  auto normq = [&](const uint4& rawq, float (&f)[8]) {
+  auto normq = [&](const typename ET::V8& rawq, float (&f)[8]) {
     unpack8<ET>(rawq, f);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -391,20 +391,20 @@ __global__ __launch_bounds__(EW_THREADS) void bn_apply_fused_kernel(
       if (relu) f[i] = fmaxf(f[i], 0.f);
     }
   };
-  auto norm = [&](int64_t pp, float (&f)[8]) { normq(*(const uint4*)(y + pp * ldy + ch0 + q * 8), f); };
+  auto norm = [&](int64_t pp, float (&f)[8]) { normq(ld8<ET>(y + pp * ldy + ch0 + q * 8), f); };
   if (up == nullptr) {
     // plain pass: two pixels per trip, the next trip's loads issued before this trip's stores
     for (int64_t p = pf; p < p1; p += 2 * PSTEP) {
       const bool two = p + PSTEP < p1;
-      uint4 n0 = make_uint4(0, 0, 0, 0), n1 = n0;
-      if (p + 2 * PSTEP < p1) n0 = *(const uint4*)(y + (p + 2 * PSTEP) * ldy + ch0 + q * 8);
-      if (p + 3 * PSTEP < p1) n1 = *(const uint4*)(y + (p + 3 * PSTEP) * ldy + ch0 + q * 8);
+      typename ET::V8 n0 = ET::zero8(), n1 = n0;
+      if (p + 2 * PSTEP < p1) n0 = ld8<ET>(y + (p + 2 * PSTEP) * ldy + ch0 + q * 8);
+      if (p + 3 * PSTEP < p1) n1 = ld8<ET>(y + (p + 3 * PSTEP) * ldy + ch0 + q * 8);
       float f[8];
       normq(raw0, f);
-      *(uint4*)(x + p * ldx + ch0 + q * 8) = pack8<ET>(f);
+      st8<ET>(x + p * ldx + ch0 + q * 8, pack8<ET>(f));
       if (two) {
         normq(raw1, f);
-        *(uint4*)(x + (p + PSTEP) * ldx + ch0 + q * 8) = pack8<ET>(f);
+        st8<ET>(x + (p + PSTEP) * ldx + ch0 + q * 8, pack8<ET>(f));
       }
       raw0 = n0; raw1 = n1;
     }
@@ -413,7 +413,7 @@ __global__ __launch_bounds__(EW_THREADS) void bn_apply_fused_kernel(
   for (int64_t p = pf; p < p1; p += PSTEP) {
     float f[8];
     norm(p, f);
-    if (x != nullptr) *(uint4*)(x + p * ldx + ch0 + q * 8) = pack8<ET>(f);      // (nobody reads the un-sampled tensor of an up-sampled block)
+    if (x != nullptr) st8<ET>(x + p * ldx + ch0 + q * 8, pack8<ET>(f));      // (nobody reads the un-sampled tensor of an up-sampled block)
     {
       // x2 bilinear up-sampling of the normalised activation in the same pass (tf.image.resize_images, legacy
       // align_corners=False, imm_model.py:175: out[2i] = in[i], out[2i+1] = (in[i] + in[min(i+1, n-1)]) / 2), from the
@@ -423,22 +423,22 @@ __global__ __launch_bounds__(EW_THREADS) void bn_apply_fused_kernel(
       const int i = (int)(t % h);
       const int64_t b = t / h;
       float c00[8], c01[8], c10[8], c11[8], g[8];
-      { const uint4 u = pack8<ET>(f); unpack8<ET>(u, c00); }
+      { const typename ET::V8 u = pack8<ET>(f); unpack8<ET>(u, c00); }
       const int64_t pr = p + (j + 1 < w ? 1 : 0), pd = p + (i + 1 < h ? w : 0), pdr = pd + (j + 1 < w ? 1 : 0);
-      norm(pr, g); { const uint4 u = pack8<ET>(g); unpack8<ET>(u, c01); }
-      norm(pd, g); { const uint4 u = pack8<ET>(g); unpack8<ET>(u, c10); }
-      norm(pdr, g); { const uint4 u = pack8<ET>(g); unpack8<ET>(u, c11); }
-      uint16_t* o = up + (((b * 2 * h + 2 * i) * (int64_t)(2 * w)) + 2 * j) * ldu + ch0 + q * 8;
+      norm(pr, g); { const typename ET::V8 u = pack8<ET>(g); unpack8<ET>(u, c01); }
+      norm(pd, g); { const typename ET::V8 u = pack8<ET>(g); unpack8<ET>(u, c10); }
+      norm(pdr, g); { const typename ET::V8 u = pack8<ET>(g); unpack8<ET>(u, c11); }
+      typename ET::T* o = up + (((b * 2 * h + 2 * i) * (int64_t)(2 * w)) + 2 * j) * ldu + ch0 + q * 8;
       float r01[8], r10[8], r11[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float top = c00[e] + (c01[e] - c00[e]) * 0.5f, bot = c10[e] + (c11[e] - c10[e]) * 0.5f;
         r01[e] = top; r10[e] = c00[e] + (c10[e] - c00[e]) * 0.5f; r11[e] = top + (bot - top) * 0.5f;
       }
-      *(uint4*)o = pack8<ET>(c00);
-      *(uint4*)(o + ldu) = pack8<ET>(r01);
-      *(uint4*)(o + (int64_t)2 * w * ldu) = pack8<ET>(r10);
-      *(uint4*)(o + (int64_t)2 * w * ldu + ldu) = pack8<ET>(r11);
+      st8<ET>(o, pack8<ET>(c00));
+      st8<ET>(o + ldu, pack8<ET>(r01));
+      st8<ET>(o + (int64_t)2 * w * ldu, pack8<ET>(r10));
+      st8<ET>(o + (int64_t)2 * w * ldu + ldu, pack8<ET>(r11));
     }
   }
 }
@@ -467,10 +467,10 @@ extern "C" int imm_bn_apply_fused(const float* partial, int nblk, int c, int64_t
   }
   const int ppb = fused_px_per_blk(count, c);
   const dim3 grid((unsigned)((count + ppb - 1) / ppb), (unsigned)(c / 32));
-  IMM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_apply_fused_kernel<ET>), grid, dim3(EW_THREADS), 0, (hipStream_t)stream, partial,
+  IMM_DISPATCH_DTYPE_F32(dtype, hipLaunchKernelGGL((bn_apply_fused_kernel<ET>), grid, dim3(EW_THREADS), 0, (hipStream_t)stream, partial,
                                                nblk, c, (double)count, gamma, beta, eps, momentum, training, moving_mean, moving_var,
-                                               scale, shift, mean, rstd, (const uint16_t*)y, count, ldy, relu, (uint16_t*)x_out, ldx, ppb,
-                                               (uint16_t*)up2x_out, ldu, h, w));
+                                               scale, shift, mean, rstd, (const typename ET::T*)y, count, ldy, relu, (typename ET::T*)x_out, ldx, ppb,
+                                               (typename ET::T*)up2x_out, ldu, h, w));
   IMM_CHECK_LAUNCH("imm_bn_apply_fused");
   return 0;
 }
@@ -562,9 +562,9 @@ __device__ __forceinline__ void col_reduce_tail(float (&acc)[NS][8], int c, int 
 // reads it) and taken as this pass's d_out — the standalone adjoint launch and the re-read of its result are gone.
 template <typename ET, bool UP = false>
 __global__ __launch_bounds__(EW_THREADS) void bn_bwd_reduce_kernel(
-    const uint16_t* __restrict__ dout, int lddo, const uint16_t* __restrict__ y, int ldy, int64_t npix, int c,
+    const typename ET::T* __restrict__ dout, int lddo, const typename ET::T* __restrict__ y, int ldy, int64_t npix, int c,
     const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
-    const float* __restrict__ rstd, int relu, float* __restrict__ partial, uint16_t* __restrict__ dprev = nullptr,
+    const float* __restrict__ rstd, int relu, float* __restrict__ partial, typename ET::T* __restrict__ dprev = nullptr,
     int lddp = 0, int h = 0, int w = 0) {
   const int tpp = c / 8, rows = EW_THREADS / tpp;
   const int r = threadIdx.x / tpp, cg = threadIdx.x - r * tpp;
@@ -579,7 +579,7 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_reduce_kernel(
   float acc[2][8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
-  auto take = [&](const uint4& dq, const uint4& yq) {
+  auto take = [&](const typename ET::V8& dq, const typename ET::V8& yq) {
     float d[8], v[8];
     unpack8<ET>(dq, d);
     unpack8<ET>(yq, v);
@@ -605,14 +605,14 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_reduce_kernel(
       Xs[0] = 2 * j - 1; wx[0] = (j >= 1) ? 0.5f : 0.f;
       Xs[1] = 2 * j;     wx[1] = 1.f;
       Xs[2] = 2 * j + 1; wx[2] = (j == w - 1) ? 1.f : 0.5f;
-      const uint4 yq = *(const uint4*)(y + p * ldy + cg * 8);
-      uint4 q[9];
-      const uint16_t* base = dout + b * H * W * lddo + cg * 8;
+      const typename ET::V8 yq = ld8<ET>(y + p * ldy + cg * 8);
+      typename ET::V8 q[9];
+      const typename ET::T* base = dout + b * H * W * lddo + cg * 8;
 #pragma unroll
       for (int a = 0; a < 3; ++a)
 #pragma unroll
         for (int bb = 0; bb < 3; ++bb)
-          q[a * 3 + bb] = (wy[a] != 0.f && wx[bb] != 0.f) ? *(const uint4*)(base + ((int64_t)Ys[a] * W + Xs[bb]) * lddo) : make_uint4(0, 0, 0, 0);
+          q[a * 3 + bb] = (wy[a] != 0.f && wx[bb] != 0.f) ? ld8<ET>(base + ((int64_t)Ys[a] * W + Xs[bb]) * lddo) : ET::zero8();
       float o[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] = 0.f;
@@ -629,8 +629,8 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_reduce_kernel(
           for (int e = 0; e < 8; ++e) o[e] += wgt * d[e];
         }
       }
-      const uint4 dq = pack8<ET>(o);
-      *(uint4*)(dprev + p * lddp + cg * 8) = dq;
+      const typename ET::V8 dq = pack8<ET>(o);
+      st8<ET>(dprev + p * lddp + cg * 8, dq);
       take(dq, yq);
     }
     col_reduce_tail<2>(acc, c, tpp, rows, partial + (int64_t)blockIdx.x * 2 * c);
@@ -639,16 +639,16 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_reduce_kernel(
   // 4 pixels (8 x 16-byte loads) in flight per thread
   int64_t p = p0 + r;
   for (; p + 3 * (int64_t)rows < p1; p += 4 * (int64_t)rows) {
-    uint4 dq[4], yq[4];
+    typename ET::V8 dq[4], yq[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      dq[u] = *(const uint4*)(dout + (p + u * (int64_t)rows) * lddo + cg * 8);
-      yq[u] = *(const uint4*)(y + (p + u * (int64_t)rows) * ldy + cg * 8);
+      dq[u] = ld8<ET>(dout + (p + u * (int64_t)rows) * lddo + cg * 8);
+      yq[u] = ld8<ET>(y + (p + u * (int64_t)rows) * ldy + cg * 8);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) take(dq[u], yq[u]);
   }
-  for (; p < p1; p += rows) take(*(const uint4*)(dout + p * lddo + cg * 8), *(const uint4*)(y + p * ldy + cg * 8));
+  for (; p < p1; p += rows) take(ld8<ET>(dout + p * lddo + cg * 8), ld8<ET>(y + p * ldy + cg * 8));
   col_reduce_tail<2>(acc, c, tpp, rows, partial + (int64_t)blockIdx.x * 2 * c);
 }
 
@@ -660,8 +660,8 @@ extern "C" int imm_bn_bwd_reduce(const void* dout, int lddo, const void* y, int 
   EW_REQUIRE_VEC(c, ldy, "bn_bwd_reduce(y)");
   const int nblk = imm_bn_bwd_blocks(npix, c);
   if (nblk < 0) return imm_fail(IMM_E_UNSUPPORTED, "bn_bwd_reduce: C=%d unsupported (C/8 must divide 256)", c);
-  IMM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_bwd_reduce_kernel<ET>), dim3(nblk), dim3(EW_THREADS), 0,
-                                               (hipStream_t)stream, (const uint16_t*)dout, lddo, (const uint16_t*)y,
+  IMM_DISPATCH_DTYPE_F32(dtype, hipLaunchKernelGGL((bn_bwd_reduce_kernel<ET>), dim3(nblk), dim3(EW_THREADS), 0,
+                                               (hipStream_t)stream, (const typename ET::T*)dout, lddo, (const typename ET::T*)y,
                                                ldy, npix, c, scale, shift, mean, rstd, relu, partial));
   IMM_CHECK_LAUNCH("imm_bn_bwd_reduce");
   return 0;
@@ -677,9 +677,9 @@ extern "C" int imm_bn_bwd_reduce_up(const void* dy_up, int lddy, void* dprev, in
   const int64_t npix = (int64_t)batch * h * w;
   const int nblk = imm_bn_bwd_blocks(npix, c);
   if (nblk < 0) return imm_fail(IMM_E_UNSUPPORTED, "bn_bwd_reduce_up: C=%d unsupported (C/8 must divide 256)", c);
-  IMM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_bwd_reduce_kernel<ET, true>), dim3(nblk), dim3(EW_THREADS), 0,
-                                               (hipStream_t)stream, (const uint16_t*)dy_up, lddy, (const uint16_t*)y,
-                                               ldy, npix, c, scale, shift, mean, rstd, relu, partial, (uint16_t*)dprev, lddp, h, w));
+  IMM_DISPATCH_DTYPE_F32(dtype, hipLaunchKernelGGL((bn_bwd_reduce_kernel<ET, true>), dim3(nblk), dim3(EW_THREADS), 0,
+                                               (hipStream_t)stream, (const typename ET::T*)dy_up, lddy, (const typename ET::T*)y,
+                                               ldy, npix, c, scale, shift, mean, rstd, relu, partial, (typename ET::T*)dprev, lddp, h, w));
   IMM_CHECK_LAUNCH("imm_bn_bwd_reduce_up");
   return 0;
 }
@@ -726,9 +726,9 @@ extern "C" int imm_bn_bwd_finalize(const float* partial, int nblk, int c, int ld
 // per-channel constants in registers and streams pixels -> 2 loads + 1 store + ~50 VALU per 16 bytes.
 template <typename ET>
 __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(
-    const uint16_t* __restrict__ dout, int lddo, const uint16_t* __restrict__ y, int ldy, int64_t npix, int c8n, int c,
+    const typename ET::T* __restrict__ dout, int lddo, const typename ET::T* __restrict__ y, int ldy, int64_t npix, int c8n, int c,
     const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
-    const float* __restrict__ rstd, int relu, const float* __restrict__ coef, uint16_t* __restrict__ dy, int lddy) {
+    const float* __restrict__ rstd, int relu, const float* __restrict__ coef, typename ET::T* __restrict__ dy, int lddy) {
   const int tpp = c8n, rows = EW_THREADS / tpp;
   const int r = threadIdx.x / tpp, cg = threadIdx.x - r * tpp;
   float sc[8], sh[8], mu[8], rs[8], k0[8], k1[8], k2[8];
@@ -740,8 +740,8 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(
   }
   for (int64_t p = (int64_t)blockIdx.x * rows + r; p < npix; p += (int64_t)gridDim.x * rows) {
     float d[8], v[8], o[8];
-    unpack8<ET>(*(const uint4*)(dout + p * lddo + cg * 8), d);
-    unpack8<ET>(*(const uint4*)(y + p * ldy + cg * 8), v);
+    unpack8<ET>(ld8<ET>(dout + p * lddo + cg * 8), d);
+    unpack8<ET>(ld8<ET>(y + p * ldy + cg * 8), v);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       float dz = d[i];
@@ -749,7 +749,7 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(
       const float xhat = (v[i] - mu[i]) * rs[i];
       o[i] = k0[i] * (dz - k1[i] - xhat * k2[i]);
     }
-    *(uint4*)(dy + p * lddy + cg * 8) = pack8<ET>(o);
+    st8<ET>(dy + p * lddy + cg * 8, pack8<ET>(o));
   }
 }
 
@@ -762,10 +762,10 @@ extern "C" int imm_bn_bwd_apply(const void* dout, int lddo, const void* y, int l
   EW_REQUIRE_VEC(c, lddy, "bn_bwd_apply(dy)");
   if (imm_bn_bwd_blocks(npix, c) < 0) return imm_fail(IMM_E_UNSUPPORTED, "bn_bwd_apply: C=%d unsupported (C/8 must divide 256)", c);
   const int rows_per_blk = EW_THREADS / (c / 8);
-  IMM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<ET>), dim3(ew_blocks((npix + rows_per_blk - 1) / rows_per_blk * EW_THREADS / 4, 4096)),
-                                               dim3(EW_THREADS), 0, (hipStream_t)stream, (const uint16_t*)dout, lddo,
-                                               (const uint16_t*)y, ldy, npix, c / 8, c, scale, shift, mean, rstd, relu,
-                                               coef, (uint16_t*)dy_out, lddy));
+  IMM_DISPATCH_DTYPE_F32(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<ET>), dim3(ew_blocks((npix + rows_per_blk - 1) / rows_per_blk * EW_THREADS / 4, 4096)),
+                                               dim3(EW_THREADS), 0, (hipStream_t)stream, (const typename ET::T*)dout, lddo,
+                                               (const typename ET::T*)y, ldy, npix, c / 8, c, scale, shift, mean, rstd, relu,
+                                               coef, (typename ET::T*)dy_out, lddy));
   IMM_CHECK_LAUNCH("imm_bn_bwd_apply");
   return 0;
 }
@@ -775,9 +775,9 @@ extern "C" int imm_bn_bwd_apply(const void* dout, int lddo, const void* y, int l
 template <typename ET>
 __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_fused_kernel(
     const float* __restrict__ partial, int nblk, int c, double count, const float* __restrict__ gamma,
-    const uint16_t* __restrict__ dout, int lddo, const uint16_t* __restrict__ y, int ldy, int64_t npix,
+    const typename ET::T* __restrict__ dout, int lddo, const typename ET::T* __restrict__ y, int ldy, int64_t npix,
     const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
-    const float* __restrict__ rstd, int relu, float* dgamma, float* dbeta, uint16_t* __restrict__ dy, int lddy, int px_per_blk) {
+    const float* __restrict__ rstd, int relu, float* dgamma, float* dbeta, typename ET::T* __restrict__ dy, int lddy, int px_per_blk) {
   __shared__ double sums[64];
   const int tid = threadIdx.x, ch0 = blockIdx.y * 32;
   const int q = tid & 3;
@@ -787,9 +787,9 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_fused_kernel(
   // trips hide their latency)
   const int64_t pf = p0 + (tid >> 2);
   constexpr int PSTEP = EW_THREADS / 4;
-  uint4 d0 = make_uint4(0, 0, 0, 0), y0 = d0, d1 = d0, y1 = d0;
-  if (pf < p1) { d0 = *(const uint4*)(dout + pf * lddo + ch0 + q * 8); y0 = *(const uint4*)(y + pf * ldy + ch0 + q * 8); }
-  if (pf + PSTEP < p1) { d1 = *(const uint4*)(dout + (pf + PSTEP) * lddo + ch0 + q * 8); y1 = *(const uint4*)(y + (pf + PSTEP) * ldy + ch0 + q * 8); }
+  typename ET::V8 d0 = ET::zero8(), y0 = d0, d1 = d0, y1 = d0;
+  if (pf < p1) { d0 = ld8<ET>(dout + pf * lddo + ch0 + q * 8); y0 = ld8<ET>(y + pf * ldy + ch0 + q * 8); }
+  if (pf + PSTEP < p1) { d1 = ld8<ET>(dout + (pf + PSTEP) * lddo + ch0 + q * 8); y1 = ld8<ET>(y + (pf + PSTEP) * ldy + ch0 + q * 8); }
   float sc[8], sh[8], mu[8], rs[8], k0[8], k1[8], k2[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -804,7 +804,7 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_fused_kernel(
     const int l = q * 8 + i;
     k1[i] = (float)(sums[l] / count); k2[i] = (float)(sums[32 + l] / count);
   }
-  auto one = [&](const uint4& dq, const uint4& yq, int64_t p) {
+  auto one = [&](const typename ET::V8& dq, const typename ET::V8& yq, int64_t p) {
     float d[8], v[8], o[8];
     unpack8<ET>(dq, d);
     unpack8<ET>(yq, v);
@@ -815,14 +815,14 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_fused_kernel(
       const float xhat = (v[i] - mu[i]) * rs[i];
       o[i] = k0[i] * (dz - k1[i] - xhat * k2[i]);
     }
-    *(uint4*)(dy + p * lddy + ch0 + q * 8) = pack8<ET>(o);
+    st8<ET>(dy + p * lddy + ch0 + q * 8, pack8<ET>(o));
   };
   // two pixels per trip, the next trip's loads issued before this trip's stores
   for (int64_t p = pf; p < p1; p += 2 * PSTEP) {
     const bool two = p + PSTEP < p1;
-    uint4 nd0 = make_uint4(0, 0, 0, 0), ny0 = nd0, nd1 = nd0, ny1 = nd0;
-    if (p + 2 * PSTEP < p1) { nd0 = *(const uint4*)(dout + (p + 2 * PSTEP) * lddo + ch0 + q * 8); ny0 = *(const uint4*)(y + (p + 2 * PSTEP) * ldy + ch0 + q * 8); }
-    if (p + 3 * PSTEP < p1) { nd1 = *(const uint4*)(dout + (p + 3 * PSTEP) * lddo + ch0 + q * 8); ny1 = *(const uint4*)(y + (p + 3 * PSTEP) * ldy + ch0 + q * 8); }
+    typename ET::V8 nd0 = ET::zero8(), ny0 = nd0, nd1 = nd0, ny1 = nd0;
+    if (p + 2 * PSTEP < p1) { nd0 = ld8<ET>(dout + (p + 2 * PSTEP) * lddo + ch0 + q * 8); ny0 = ld8<ET>(y + (p + 2 * PSTEP) * ldy + ch0 + q * 8); }
+    if (p + 3 * PSTEP < p1) { nd1 = ld8<ET>(dout + (p + 3 * PSTEP) * lddo + ch0 + q * 8); ny1 = ld8<ET>(y + (p + 3 * PSTEP) * ldy + ch0 + q * 8); }
     one(d0, y0, p);
     if (two) one(d1, y1, p + PSTEP);
     d0 = nd0; y0 = ny0; d1 = nd1; y1 = ny1;
@@ -841,9 +841,9 @@ extern "C" int imm_bn_bwd_apply_fused(const float* partial, int nblk, int c, int
   EW_REQUIRE_VEC(c, lddy, "bn_bwd_apply_fused(dy)");
   const int ppb = fused_px_per_blk(count, c);
   const dim3 grid((unsigned)((count + ppb - 1) / ppb), (unsigned)(c / 32));
-  IMM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_bwd_apply_fused_kernel<ET>), grid, dim3(EW_THREADS), 0, (hipStream_t)stream, partial,
-                                               nblk, c, (double)count, gamma, (const uint16_t*)dout, lddo, (const uint16_t*)y, ldy,
-                                               count, scale, shift, mean, rstd, relu, dgamma, dbeta, (uint16_t*)dy_out, lddy, ppb));
+  IMM_DISPATCH_DTYPE_F32(dtype, hipLaunchKernelGGL((bn_bwd_apply_fused_kernel<ET>), grid, dim3(EW_THREADS), 0, (hipStream_t)stream, partial,
+                                               nblk, c, (double)count, gamma, (const typename ET::T*)dout, lddo, (const typename ET::T*)y, ldy,
+                                               count, scale, shift, mean, rstd, relu, dgamma, dbeta, (typename ET::T*)dy_out, lddy, ppb));
   IMM_CHECK_LAUNCH("imm_bn_bwd_apply_fused");
   return 0;
 }
@@ -852,7 +852,7 @@ extern "C" int imm_bn_bwd_apply_fused(const float* partial, int nblk, int c, int
 // bias gradient: out[n] = sum_p dy[p][n]   (convs without batch norm)
 // ---------------------------------------------------------------------------------------------
 template <typename ET>
-__global__ __launch_bounds__(EW_THREADS) void colsum_kernel(const uint16_t* __restrict__ dy, int ld, int64_t npix,
+__global__ __launch_bounds__(EW_THREADS) void colsum_kernel(const typename ET::T* __restrict__ dy, int ld, int64_t npix,
                                                             int c, float* __restrict__ partial) {
   const int tpp = c / 8, rows = EW_THREADS / tpp;
   const int r = threadIdx.x / tpp, cg = threadIdx.x - r * tpp;
@@ -864,7 +864,7 @@ __global__ __launch_bounds__(EW_THREADS) void colsum_kernel(const uint16_t* __re
   for (int i = 0; i < 8; ++i) acc[0][i] = 0.f;
   for (int64_t p = p0 + r; p < p1; p += rows) {
     float d[8];
-    unpack8<ET>(*(const uint4*)(dy + p * ld + cg * 8), d);
+    unpack8<ET>(ld8<ET>(dy + p * ld + cg * 8), d);
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[0][i] += d[i];
   }
@@ -886,8 +886,8 @@ extern "C" int imm_colsum(const void* dy, int dtype, int64_t npix, int c, int c_
   EW_REQUIRE_VEC(c, ld, "colsum");
   const int nblk = imm_colsum_blocks(npix, c);
   if (nblk < 0) return imm_fail(IMM_E_UNSUPPORTED, "colsum: C=%d unsupported", c);
-  IMM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((colsum_kernel<ET>), dim3(nblk), dim3(EW_THREADS), 0, (hipStream_t)stream,
-                                               (const uint16_t*)dy, ld, npix, c, partial));
+  IMM_DISPATCH_DTYPE_F32(dtype, hipLaunchKernelGGL((colsum_kernel<ET>), dim3(nblk), dim3(EW_THREADS), 0, (hipStream_t)stream,
+                                               (const typename ET::T*)dy, ld, npix, c, partial));
   hipLaunchKernelGGL(colsum_finalize_kernel, dim3((c + 31) / 32), dim3(32, 32), 0, (hipStream_t)stream, partial, nblk, c, c_out, out);
   IMM_CHECK_LAUNCH("imm_colsum");
   return 0;
@@ -897,7 +897,7 @@ extern "C" int imm_colsum(const void* dy, int dtype, int64_t npix, int c, int c_
 // x2 bilinear upsample, TF legacy mapping (src = dst/2): out[2i] = in[i], out[2i+1] = (in[i]+in[min(i+1,n-1)])/2
 // ---------------------------------------------------------------------------------------------
 template <typename ET>
-__global__ void upsample2x_fwd_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y, int batch, int h, int w,
+__global__ void upsample2x_fwd_kernel(const typename ET::T* __restrict__ x, typename ET::T* __restrict__ y, int batch, int h, int w,
                                       int c8n, int ldx, int ldy) {
   const int H = 2 * h, W = 2 * w;
   const int64_t total = (int64_t)batch * H * W * c8n;
@@ -911,25 +911,25 @@ __global__ void upsample2x_fwd_kernel(const uint16_t* __restrict__ x, uint16_t* 
     const int y0 = Y >> 1, x0 = X >> 1;
     const int y1 = min(y0 + 1, h - 1), x1 = min(x0 + 1, w - 1);
     const float ly = (Y & 1) ? 0.5f : 0.f, lx = (X & 1) ? 0.5f : 0.f;
-    const uint16_t* base = x + (int64_t)b * h * w * ldx + cg * 8;
+    const typename ET::T* base = x + (int64_t)b * h * w * ldx + cg * 8;
     float tl[8], tr[8], bl[8], br[8], o[8];
-    unpack8<ET>(*(const uint4*)(base + ((int64_t)y0 * w + x0) * ldx), tl);
-    unpack8<ET>(*(const uint4*)(base + ((int64_t)y0 * w + x1) * ldx), tr);
-    unpack8<ET>(*(const uint4*)(base + ((int64_t)y1 * w + x0) * ldx), bl);
-    unpack8<ET>(*(const uint4*)(base + ((int64_t)y1 * w + x1) * ldx), br);
+    unpack8<ET>(ld8<ET>(base + ((int64_t)y0 * w + x0) * ldx), tl);
+    unpack8<ET>(ld8<ET>(base + ((int64_t)y0 * w + x1) * ldx), tr);
+    unpack8<ET>(ld8<ET>(base + ((int64_t)y1 * w + x0) * ldx), bl);
+    unpack8<ET>(ld8<ET>(base + ((int64_t)y1 * w + x1) * ldx), br);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const float top = tl[i] + (tr[i] - tl[i]) * lx;
       const float bot = bl[i] + (br[i] - bl[i]) * lx;
       o[i] = top + (bot - top) * ly;
     }
-    *(uint4*)(y + (((int64_t)b * H + Y) * W + X) * ldy + cg * 8) = pack8<ET>(o);
+    st8<ET>(y + (((int64_t)b * H + Y) * W + X) * ldy + cg * 8, pack8<ET>(o));
   }
 }
 
 // adjoint as a gather: dx[i][j] = sum_{Y,X} wy(i,Y)*wx(j,X)*dy[Y][X]
 template <typename ET>
-__global__ void upsample2x_bwd_kernel(const uint16_t* __restrict__ dy, uint16_t* __restrict__ dx, int batch, int h,
+__global__ void upsample2x_bwd_kernel(const typename ET::T* __restrict__ dy, typename ET::T* __restrict__ dx, int batch, int h,
                                       int w, int c8n, int lddy, int lddx) {
   const int H = 2 * h, W = 2 * w;
   const int64_t total = (int64_t)batch * h * w * c8n;
@@ -951,7 +951,7 @@ __global__ void upsample2x_bwd_kernel(const uint16_t* __restrict__ dy, uint16_t*
     float o[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = 0.f;
-    const uint16_t* base = dy + (int64_t)b * H * W * lddy + cg * 8;
+    const typename ET::T* base = dy + (int64_t)b * H * W * lddy + cg * 8;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
       if (wy[a] == 0.f) continue;
@@ -959,13 +959,13 @@ __global__ void upsample2x_bwd_kernel(const uint16_t* __restrict__ dy, uint16_t*
       for (int bb = 0; bb < 3; ++bb) {
         if (wx[bb] == 0.f) continue;
         float d[8];
-        unpack8<ET>(*(const uint4*)(base + ((int64_t)Ys[a] * W + Xs[bb]) * lddy), d);
+        unpack8<ET>(ld8<ET>(base + ((int64_t)Ys[a] * W + Xs[bb]) * lddy), d);
         const float wgt = wy[a] * wx[bb];
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] += wgt * d[e];
       }
     }
-    *(uint4*)(dx + (((int64_t)b * h + i) * w + j) * lddx + cg * 8) = pack8<ET>(o);
+    st8<ET>(dx + (((int64_t)b * h + i) * w + j) * lddx + cg * 8, pack8<ET>(o));
   }
 }
 
@@ -975,8 +975,8 @@ extern "C" int imm_upsample2x_fwd(const void* x, void* y, int dtype, int batch, 
   EW_REQUIRE_VEC(c, ldx, "upsample2x_fwd(x)");
   EW_REQUIRE_VEC(c, ldy, "upsample2x_fwd(y)");
   const int64_t total = (int64_t)batch * 4 * h * w * (c / 8);
-  IMM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((upsample2x_fwd_kernel<ET>), dim3(ew_blocks(total)), dim3(EW_THREADS), 0,
-                                               (hipStream_t)stream, (const uint16_t*)x, (uint16_t*)y, batch, h, w, c / 8,
+  IMM_DISPATCH_DTYPE_F32(dtype, hipLaunchKernelGGL((upsample2x_fwd_kernel<ET>), dim3(ew_blocks(total)), dim3(EW_THREADS), 0,
+                                               (hipStream_t)stream, (const typename ET::T*)x, (typename ET::T*)y, batch, h, w, c / 8,
                                                ldx, ldy));
   IMM_CHECK_LAUNCH("imm_upsample2x_fwd");
   return 0;
@@ -988,8 +988,8 @@ extern "C" int imm_upsample2x_bwd(const void* dy, void* dx, int dtype, int batch
   EW_REQUIRE_VEC(c, lddy, "upsample2x_bwd(dy)");
   EW_REQUIRE_VEC(c, lddx, "upsample2x_bwd(dx)");
   const int64_t total = (int64_t)batch * h * w * (c / 8);
-  IMM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((upsample2x_bwd_kernel<ET>), dim3(ew_blocks(total)), dim3(EW_THREADS), 0,
-                                               (hipStream_t)stream, (const uint16_t*)dy, (uint16_t*)dx, batch, h, w,
+  IMM_DISPATCH_DTYPE_F32(dtype, hipLaunchKernelGGL((upsample2x_bwd_kernel<ET>), dim3(ew_blocks(total)), dim3(EW_THREADS), 0,
+                                               (hipStream_t)stream, (const typename ET::T*)dy, (typename ET::T*)dx, batch, h, w,
                                                c / 8, lddy, lddx));
   IMM_CHECK_LAUNCH("imm_upsample2x_bwd");
   return 0;
@@ -1000,8 +1000,8 @@ extern "C" int imm_upsample2x_bwd(const void* dy, void* dx, int dtype, int batch
 // (sum dz, sum dz*out) per channel — the pass imm_bn_bwd_reduce would otherwise make over dx and the conv output.
 template <typename ET>
 __global__ __launch_bounds__(EW_THREADS) void upsample2x_bwd_bn_kernel(
-    const uint16_t* __restrict__ dy, uint16_t* __restrict__ dx, int batch, int h, int w, int c8n, int lddy, int lddx,
-    const uint16_t* __restrict__ out, int ldo, float* __restrict__ partial) {
+    const typename ET::T* __restrict__ dy, typename ET::T* __restrict__ dx, int batch, int h, int w, int c8n, int lddy, int lddx,
+    const typename ET::T* __restrict__ out, int ldo, float* __restrict__ partial) {
   const int H = 2 * h, W = 2 * w;
   const int64_t total = (int64_t)batch * h * w * c8n;
   float acc[2][8];
@@ -1025,7 +1025,7 @@ __global__ __launch_bounds__(EW_THREADS) void upsample2x_bwd_bn_kernel(
     float o[8], m[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = 0.f;
-    const uint16_t* base = dy + (int64_t)b * H * W * lddy + cg * 8;
+    const typename ET::T* base = dy + (int64_t)b * H * W * lddy + cg * 8;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
       if (wy[a] == 0.f) continue;
@@ -1033,21 +1033,21 @@ __global__ __launch_bounds__(EW_THREADS) void upsample2x_bwd_bn_kernel(
       for (int bb = 0; bb < 3; ++bb) {
         if (wx[bb] == 0.f) continue;
         float d[8];
-        unpack8<ET>(*(const uint4*)(base + ((int64_t)Ys[a] * W + Xs[bb]) * lddy), d);
+        unpack8<ET>(ld8<ET>(base + ((int64_t)Ys[a] * W + Xs[bb]) * lddy), d);
         const float wgt = wy[a] * wx[bb];
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] += wgt * d[e];
       }
     }
     const int64_t p = ((int64_t)b * h + i) * w + j;
-    unpack8<ET>(*(const uint4*)(out + p * ldo + cg * 8), m);
+    unpack8<ET>(ld8<ET>(out + p * ldo + cg * 8), m);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       if (!(m[e] > 0.f)) o[e] = 0.f;
       acc[0][e] += o[e];
       acc[1][e] += o[e] * m[e];
     }
-    *(uint4*)(dx + p * lddx + cg * 8) = pack8<ET>(o);
+    st8<ET>(dx + p * lddx + cg * 8, pack8<ET>(o));
   }
   col_reduce_tail<2>(acc, c8n * 8, c8n, EW_THREADS / c8n, partial + (int64_t)blockIdx.x * 2 * c8n * 8);
 }
@@ -1069,9 +1069,9 @@ extern "C" int imm_upsample2x_bwd_bn(const void* dy, void* dx, int dtype, int ba
   EW_REQUIRE_VEC(c, ldo, "upsample2x_bwd_bn(out)");
   const int nblk = imm_upsample2x_bwd_bn_blocks(batch, h, w, c);
   if (nblk < 0) return imm_fail(IMM_E_UNSUPPORTED, "upsample2x_bwd_bn: C=%d unsupported (C/8 must divide 256)", c);
-  IMM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((upsample2x_bwd_bn_kernel<ET>), dim3(nblk), dim3(EW_THREADS), 0,
-                                               (hipStream_t)stream, (const uint16_t*)dy, (uint16_t*)dx, batch, h, w,
-                                               c / 8, lddy, lddx, (const uint16_t*)out, ldo, partial));
+  IMM_DISPATCH_DTYPE_F32(dtype, hipLaunchKernelGGL((upsample2x_bwd_bn_kernel<ET>), dim3(nblk), dim3(EW_THREADS), 0,
+                                               (hipStream_t)stream, (const typename ET::T*)dy, (typename ET::T*)dx, batch, h, w,
+                                               c / 8, lddy, lddx, (const typename ET::T*)out, ldo, partial));
   IMM_CHECK_LAUNCH("imm_upsample2x_bwd_bn");
   return 0;
 }
@@ -1088,7 +1088,7 @@ __device__ __forceinline__ void ac_coord(int o, int n_in, int n_out, int& lo, in
 }
 
 template <typename ET>
-__global__ void resize_ac_fwd_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y, int batch, int hi, int wi,
+__global__ void resize_ac_fwd_kernel(const typename ET::T* __restrict__ x, typename ET::T* __restrict__ y, int batch, int hi, int wi,
                                      int ho, int wo, int c8n, int ldx, int ldy) {
   const int64_t total = (int64_t)batch * ho * wo * c8n;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -1101,25 +1101,25 @@ __global__ void resize_ac_fwd_kernel(const uint16_t* __restrict__ x, uint16_t* _
     int y0, y1, x0, x1; float ly, lx;
     ac_coord(Y, hi, ho, y0, y1, ly);
     ac_coord(X, wi, wo, x0, x1, lx);
-    const uint16_t* base = x + (int64_t)b * hi * wi * ldx + cg * 8;
+    const typename ET::T* base = x + (int64_t)b * hi * wi * ldx + cg * 8;
     float tl[8], tr[8], bl[8], br[8], o[8];
-    unpack8<ET>(*(const uint4*)(base + ((int64_t)y0 * wi + x0) * ldx), tl);
-    unpack8<ET>(*(const uint4*)(base + ((int64_t)y0 * wi + x1) * ldx), tr);
-    unpack8<ET>(*(const uint4*)(base + ((int64_t)y1 * wi + x0) * ldx), bl);
-    unpack8<ET>(*(const uint4*)(base + ((int64_t)y1 * wi + x1) * ldx), br);
+    unpack8<ET>(ld8<ET>(base + ((int64_t)y0 * wi + x0) * ldx), tl);
+    unpack8<ET>(ld8<ET>(base + ((int64_t)y0 * wi + x1) * ldx), tr);
+    unpack8<ET>(ld8<ET>(base + ((int64_t)y1 * wi + x0) * ldx), bl);
+    unpack8<ET>(ld8<ET>(base + ((int64_t)y1 * wi + x1) * ldx), br);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const float top = tl[i] + (tr[i] - tl[i]) * lx;
       const float bot = bl[i] + (br[i] - bl[i]) * lx;
       o[i] = top + (bot - top) * ly;
     }
-    *(uint4*)(y + (((int64_t)b * ho + Y) * wo + X) * ldy + cg * 8) = pack8<ET>(o);
+    st8<ET>(y + (((int64_t)b * ho + Y) * wo + X) * ldy + cg * 8, pack8<ET>(o));
   }
 }
 
 // adjoint by gather: each input pixel scans the (few) output rows/cols whose stencil touches it
 template <typename ET>
-__global__ void resize_ac_bwd_kernel(const uint16_t* __restrict__ dy, uint16_t* __restrict__ dx, int batch, int hi,
+__global__ void resize_ac_bwd_kernel(const typename ET::T* __restrict__ dy, typename ET::T* __restrict__ dx, int batch, int hi,
                                      int wi, int ho, int wo, int c8n, int lddy, int lddx) {
   const int64_t total = (int64_t)batch * hi * wi * c8n;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -1132,7 +1132,7 @@ __global__ void resize_ac_bwd_kernel(const uint16_t* __restrict__ dy, uint16_t* 
     float o[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = 0.f;
-    const uint16_t* base = dy + (int64_t)b * ho * wo * lddy + cg * 8;
+    const typename ET::T* base = dy + (int64_t)b * ho * wo * lddy + cg * 8;
     for (int Y = 0; Y < ho; ++Y) {
       int y0, y1; float ly;
       ac_coord(Y, hi, ho, y0, y1, ly);
@@ -1148,13 +1148,13 @@ __global__ void resize_ac_bwd_kernel(const uint16_t* __restrict__ dy, uint16_t* 
         if (x1 == j) wx += lx;
         if (wx == 0.f) continue;
         float d[8];
-        unpack8<ET>(*(const uint4*)(base + ((int64_t)Y * wo + X) * lddy), d);
+        unpack8<ET>(ld8<ET>(base + ((int64_t)Y * wo + X) * lddy), d);
         const float wgt = wy * wx;
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] += wgt * d[e];
       }
     }
-    *(uint4*)(dx + (((int64_t)b * hi + i) * wi + j) * lddx + cg * 8) = pack8<ET>(o);
+    st8<ET>(dx + (((int64_t)b * hi + i) * wi + j) * lddx + cg * 8, pack8<ET>(o));
   }
 }
 
@@ -1164,8 +1164,8 @@ extern "C" int imm_resize_ac_fwd(const void* x, void* y, int dtype, int batch, i
   EW_REQUIRE_VEC(c, ldx, "resize_ac_fwd(x)");
   EW_REQUIRE_VEC(c, ldy, "resize_ac_fwd(y)");
   const int64_t total = (int64_t)batch * ho * wo * (c / 8);
-  IMM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((resize_ac_fwd_kernel<ET>), dim3(ew_blocks(total)), dim3(EW_THREADS), 0,
-                                               (hipStream_t)stream, (const uint16_t*)x, (uint16_t*)y, batch, hi, wi, ho,
+  IMM_DISPATCH_DTYPE_F32(dtype, hipLaunchKernelGGL((resize_ac_fwd_kernel<ET>), dim3(ew_blocks(total)), dim3(EW_THREADS), 0,
+                                               (hipStream_t)stream, (const typename ET::T*)x, (typename ET::T*)y, batch, hi, wi, ho,
                                                wo, c / 8, ldx, ldy));
   IMM_CHECK_LAUNCH("imm_resize_ac_fwd");
   return 0;
@@ -1177,8 +1177,8 @@ extern "C" int imm_resize_ac_bwd(const void* dy, void* dx, int dtype, int batch,
   EW_REQUIRE_VEC(c, lddy, "resize_ac_bwd(dy)");
   EW_REQUIRE_VEC(c, lddx, "resize_ac_bwd(dx)");
   const int64_t total = (int64_t)batch * hi * wi * (c / 8);
-  IMM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((resize_ac_bwd_kernel<ET>), dim3(ew_blocks(total)), dim3(EW_THREADS), 0,
-                                               (hipStream_t)stream, (const uint16_t*)dy, (uint16_t*)dx, batch, hi, wi, ho,
+  IMM_DISPATCH_DTYPE_F32(dtype, hipLaunchKernelGGL((resize_ac_bwd_kernel<ET>), dim3(ew_blocks(total)), dim3(EW_THREADS), 0,
+                                               (hipStream_t)stream, (const typename ET::T*)dy, (typename ET::T*)dx, batch, hi, wi, ho,
                                                wo, c / 8, lddy, lddx));
   IMM_CHECK_LAUNCH("imm_resize_ac_bwd");
   return 0;
@@ -1188,7 +1188,7 @@ extern "C" int imm_resize_ac_bwd(const void* dy, void* dx, int dtype, int batch,
 // 2x2/2 max pool (dense NHWC, ld == c)
 // ---------------------------------------------------------------------------------------------
 template <typename ET>
-__global__ void maxpool2_fwd_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y, int batch, int h, int w,
+__global__ void maxpool2_fwd_kernel(const typename ET::T* __restrict__ x, typename ET::T* __restrict__ y, int batch, int h, int w,
                                     int c8n) {
   const int ho = h / 2, wo = w / 2, c = c8n * 8;
   const int64_t total = (int64_t)batch * ho * wo * c8n;
@@ -1199,21 +1199,21 @@ __global__ void maxpool2_fwd_kernel(const uint16_t* __restrict__ x, uint16_t* __
     const int X = (int)(t % wo); t /= wo;
     const int Y = (int)(t % ho);
     const int b = (int)(t / ho);
-    const uint16_t* base = x + (((int64_t)b * h + 2 * Y) * w + 2 * X) * c + cg * 8;
+    const typename ET::T* base = x + (((int64_t)b * h + 2 * Y) * w + 2 * X) * c + cg * 8;
     float a0[8], a1[8], a2[8], a3[8], o[8];
-    unpack8<ET>(*(const uint4*)(base), a0);
-    unpack8<ET>(*(const uint4*)(base + c), a1);
-    unpack8<ET>(*(const uint4*)(base + (int64_t)w * c), a2);
-    unpack8<ET>(*(const uint4*)(base + (int64_t)w * c + c), a3);
+    unpack8<ET>(ld8<ET>(base), a0);
+    unpack8<ET>(ld8<ET>(base + c), a1);
+    unpack8<ET>(ld8<ET>(base + (int64_t)w * c), a2);
+    unpack8<ET>(ld8<ET>(base + (int64_t)w * c + c), a3);
 #pragma unroll
     for (int i = 0; i < 8; ++i) o[i] = fmaxf(fmaxf(a0[i], a1[i]), fmaxf(a2[i], a3[i]));
-    *(uint4*)(y + (((int64_t)b * ho + Y) * wo + X) * c + cg * 8) = pack8<ET>(o);
+    st8<ET>(y + (((int64_t)b * ho + Y) * wo + X) * c + cg * 8, pack8<ET>(o));
   }
 }
 
 template <typename ET>
-__global__ void maxpool2_bwd_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy,
-                                    uint16_t* __restrict__ dx, int batch, int h, int w, int c8n, int relu_mask) {
+__global__ void maxpool2_bwd_kernel(const typename ET::T* __restrict__ x, const typename ET::T* __restrict__ dy,
+                                    typename ET::T* __restrict__ dx, int batch, int h, int w, int c8n, int relu_mask) {
   const int ho = h / 2, wo = w / 2, c = c8n * 8;
   const int64_t total = (int64_t)batch * ho * wo * c8n;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -1225,11 +1225,11 @@ __global__ void maxpool2_bwd_kernel(const uint16_t* __restrict__ x, const uint16
     const int b = (int)(t / ho);
     const int64_t off = (((int64_t)b * h + 2 * Y) * w + 2 * X) * c + cg * 8;
     float a[4][8], g[8], o[4][8];
-    unpack8<ET>(*(const uint4*)(x + off), a[0]);
-    unpack8<ET>(*(const uint4*)(x + off + c), a[1]);
-    unpack8<ET>(*(const uint4*)(x + off + (int64_t)w * c), a[2]);
-    unpack8<ET>(*(const uint4*)(x + off + (int64_t)w * c + c), a[3]);
-    unpack8<ET>(*(const uint4*)(dy + (((int64_t)b * ho + Y) * wo + X) * c + cg * 8), g);
+    unpack8<ET>(ld8<ET>(x + off), a[0]);
+    unpack8<ET>(ld8<ET>(x + off + c), a[1]);
+    unpack8<ET>(ld8<ET>(x + off + (int64_t)w * c), a[2]);
+    unpack8<ET>(ld8<ET>(x + off + (int64_t)w * c + c), a[3]);
+    unpack8<ET>(ld8<ET>(dy + (((int64_t)b * ho + Y) * wo + X) * c + cg * 8), g);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       int am = 0; float mv = a[0][i];
@@ -1239,10 +1239,10 @@ __global__ void maxpool2_bwd_kernel(const uint16_t* __restrict__ x, const uint16
 #pragma unroll
       for (int q = 0; q < 4; ++q) o[q][i] = (q == am) ? gv : 0.f;
     }
-    *(uint4*)(dx + off) = pack8<ET>(o[0]);
-    *(uint4*)(dx + off + c) = pack8<ET>(o[1]);
-    *(uint4*)(dx + off + (int64_t)w * c) = pack8<ET>(o[2]);
-    *(uint4*)(dx + off + (int64_t)w * c + c) = pack8<ET>(o[3]);
+    st8<ET>(dx + off, pack8<ET>(o[0]));
+    st8<ET>(dx + off + c, pack8<ET>(o[1]));
+    st8<ET>(dx + off + (int64_t)w * c, pack8<ET>(o[2]));
+    st8<ET>(dx + off + (int64_t)w * c + c, pack8<ET>(o[3]));
   }
 }
 
@@ -1250,8 +1250,8 @@ extern "C" int imm_maxpool2_fwd(const void* x, void* y, int dtype, int batch, in
   IMM_REQUIRE(x && y && batch > 0 && h > 0 && w > 0 && h % 2 == 0 && w % 2 == 0, "maxpool2_fwd: even sides required");
   EW_REQUIRE_VEC(c, c, "maxpool2_fwd");
   const int64_t total = (int64_t)batch * (h / 2) * (w / 2) * (c / 8);
-  IMM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((maxpool2_fwd_kernel<ET>), dim3(ew_blocks(total)), dim3(EW_THREADS), 0,
-                                               (hipStream_t)stream, (const uint16_t*)x, (uint16_t*)y, batch, h, w, c / 8));
+  IMM_DISPATCH_DTYPE_F32(dtype, hipLaunchKernelGGL((maxpool2_fwd_kernel<ET>), dim3(ew_blocks(total)), dim3(EW_THREADS), 0,
+                                               (hipStream_t)stream, (const typename ET::T*)x, (typename ET::T*)y, batch, h, w, c / 8));
   IMM_CHECK_LAUNCH("imm_maxpool2_fwd");
   return 0;
 }
@@ -1261,9 +1261,9 @@ extern "C" int imm_maxpool2_bwd(const void* x, const void* dy, void* dx, int dty
   IMM_REQUIRE(x && dy && dx && batch > 0 && h > 0 && w > 0 && h % 2 == 0 && w % 2 == 0, "maxpool2_bwd: even sides required");
   EW_REQUIRE_VEC(c, c, "maxpool2_bwd");
   const int64_t total = (int64_t)batch * (h / 2) * (w / 2) * (c / 8);
-  IMM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((maxpool2_bwd_kernel<ET>), dim3(ew_blocks(total)), dim3(EW_THREADS), 0,
-                                               (hipStream_t)stream, (const uint16_t*)x, (const uint16_t*)dy,
-                                               (uint16_t*)dx, batch, h, w, c / 8, relu_mask));
+  IMM_DISPATCH_DTYPE_F32(dtype, hipLaunchKernelGGL((maxpool2_bwd_kernel<ET>), dim3(ew_blocks(total)), dim3(EW_THREADS), 0,
+                                               (hipStream_t)stream, (const typename ET::T*)x, (const typename ET::T*)dy,
+                                               (typename ET::T*)dx, batch, h, w, c / 8, relu_mask));
   IMM_CHECK_LAUNCH("imm_maxpool2_bwd");
   return 0;
 }

@@ -17,7 +17,7 @@
 // masked sum of squared differences (per feature; IMM_SSE_BLOCKS deterministic partials)
 // ---------------------------------------------------------------------------------------------
 template <typename ET>
-__global__ __launch_bounds__(LO_THREADS) void masked_sse_kernel(const uint16_t* __restrict__ a, const uint16_t* __restrict__ b,
+__global__ __launch_bounds__(LO_THREADS) void masked_sse_kernel(const typename ET::T* __restrict__ a, const typename ET::T* __restrict__ b,
                                                                 int batch, int s, int c8n, const float* __restrict__ mask,
                                                                 int S, int l1, float* __restrict__ partial) {
   __shared__ float red[4];
@@ -36,8 +36,8 @@ __global__ __launch_bounds__(LO_THREADS) void masked_sse_kernel(const uint16_t* 
       mk = mask[(bi * S + (int64_t)yy * r) * S + (int64_t)xx * r];
     }
     float fa[8], fb[8];
-    unpack8<ET>(*(const uint4*)(a + idx * 8), fa);
-    unpack8<ET>(*(const uint4*)(b + idx * 8), fb);
+    unpack8<ET>(ld8<ET>(a + idx * 8), fa);
+    unpack8<ET>(ld8<ET>(b + idx * 8), fb);
     float sq = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) { const float d = fa[i] - fb[i]; sq += l1 ? fabsf(d) : d * d; }   // perceptual.l2 (imm_model.py:132)
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(LO_THREADS) void masked_sse_kernel(const uint16_t* 
 // Several features in ONE launch (blockIdx.y = feature): the error sums of the deep tapped layers (conv3_2, conv4_2, conv5_2)
 // sit back to back on the one-lane critical path in front of the loss; each is a 5-11 us launch.
 struct SseMultiArgs {
-  const uint16_t* a[8]; const uint16_t* b[8];
+  const void* a[8]; const void* b[8];      // 16-bit or f32 features (the kernel's element type)
   int s[8], c8n[8];
   float* partial[8];
 };
@@ -59,8 +59,8 @@ __global__ __launch_bounds__(LO_THREADS) void masked_sse_multi_kernel(const SseM
                                                                       int S, int l1) {
   __shared__ float red[4];
   const int f = blockIdx.y;
-  const uint16_t* __restrict__ a = g.a[f];
-  const uint16_t* __restrict__ b = g.b[f];
+  const typename ET::T* __restrict__ a = (const typename ET::T*)g.a[f];
+  const typename ET::T* __restrict__ b = (const typename ET::T*)g.b[f];
   const int s = g.s[f], c8n = g.c8n[f];
   const int r = S / s;
   const int64_t total = (int64_t)batch * s * s * c8n;
@@ -77,8 +77,8 @@ __global__ __launch_bounds__(LO_THREADS) void masked_sse_multi_kernel(const SseM
       mk = mask[(bi * S + (int64_t)yy * r) * S + (int64_t)xx * r];
     }
     float fa[8], fb[8];
-    unpack8<ET>(*(const uint4*)(a + idx * 8), fa);
-    unpack8<ET>(*(const uint4*)(b + idx * 8), fb);
+    unpack8<ET>(ld8<ET>(a + idx * 8), fa);
+    unpack8<ET>(ld8<ET>(b + idx * 8), fb);
     float sq = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) { const float d = fa[i] - fb[i]; sq += l1 ? fabsf(d) : d * d; }
@@ -92,10 +92,10 @@ __global__ __launch_bounds__(LO_THREADS) void masked_sse_multi_kernel(const SseM
 // pool1 / pool2 right after the feature the loss reads): one pass over the two feature halves instead of two.
 // a = ground-truth half, b = prediction half [batch,s,s,c]; pool_a / pool_b [batch,s/2,s/2,c].
 template <typename ET>
-__global__ __launch_bounds__(LO_THREADS) void masked_sse_pool_kernel(const uint16_t* __restrict__ a, const uint16_t* __restrict__ b,
+__global__ __launch_bounds__(LO_THREADS) void masked_sse_pool_kernel(const typename ET::T* __restrict__ a, const typename ET::T* __restrict__ b,
                                                                      int batch, int s, int c8n, const float* __restrict__ mask,
                                                                      int S, float* __restrict__ partial,
-                                                                     uint16_t* __restrict__ pool_a, uint16_t* __restrict__ pool_b) {
+                                                                     typename ET::T* __restrict__ pool_a, typename ET::T* __restrict__ pool_b) {
   __shared__ float red[4];
   const int r = S / s, so = s / 2, c = c8n * 8;
   const int64_t total = (int64_t)batch * so * so * c8n;
@@ -117,8 +117,8 @@ __global__ __launch_bounds__(LO_THREADS) void masked_sse_pool_kernel(const uint1
         const int yy = 2 * Y + dy, xx = 2 * X + dx;
         const int64_t off = ((bi * s + yy) * s + xx) * c + cg * 8;
         float fa[8], fb[8];
-        unpack8<ET>(*(const uint4*)(a + off), fa);
-        unpack8<ET>(*(const uint4*)(b + off), fb);
+        unpack8<ET>(ld8<ET>(a + off), fa);
+        unpack8<ET>(ld8<ET>(b + off), fb);
         float sq = 0.f;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -130,8 +130,8 @@ __global__ __launch_bounds__(LO_THREADS) void masked_sse_pool_kernel(const uint1
         acc += mk * sq;
       }
     const int64_t po = ((bi * so + Y) * so + X) * c + cg * 8;
-    if (pool_a) *(uint4*)(pool_a + po) = pack8<ET>(ma);
-    *(uint4*)(pool_b + po) = pack8<ET>(mb);
+    if (pool_a) st8<ET>(pool_a + po, pack8<ET>(ma));
+    st8<ET>(pool_b + po, pack8<ET>(mb));
   }
   acc = block_sum_256(acc, red);
   if (threadIdx.x == 0) partial[blockIdx.x] = acc;
@@ -182,8 +182,8 @@ extern "C" int imm_masked_sse(const void* a, const void* b, int dtype, int batch
                               int l1, float* partial, void* stream) {
   IMM_REQUIRE(a && b && partial && batch > 0 && s > 0 && c > 0 && c % 8 == 0, "masked_sse: args");
   IMM_REQUIRE(mask == nullptr || (S >= s && S % s == 0), "masked_sse: mask side %d not a multiple of feature side %d", S, s);
-  IMM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((masked_sse_kernel<ET>), dim3(IMM_SSE_BLOCKS), dim3(LO_THREADS), 0,
-                                               (hipStream_t)stream, (const uint16_t*)a, (const uint16_t*)b, batch, s, c / 8,
+  IMM_DISPATCH_DTYPE_F32(dtype, hipLaunchKernelGGL((masked_sse_kernel<ET>), dim3(IMM_SSE_BLOCKS), dim3(LO_THREADS), 0,
+                                               (hipStream_t)stream, (const typename ET::T*)a, (const typename ET::T*)b, batch, s, c / 8,
                                                mask, S, l1, partial));
   IMM_CHECK_LAUNCH("imm_masked_sse");
   return 0;
@@ -197,9 +197,9 @@ extern "C" int imm_masked_sse_multi(int n, const void* const* a, const void* con
     const int k = i < n ? i : 0;
     IMM_REQUIRE(a[k] && b[k] && partial[k] && s_host[k] > 0 && c_host[k] > 0 && c_host[k] % 8 == 0, "masked_sse_multi: feature %d", k);
     IMM_REQUIRE(mask == nullptr || (S >= s_host[k] && S % s_host[k] == 0), "masked_sse_multi: mask side %d vs feature side %d", S, s_host[k]);
-    g.a[i] = (const uint16_t*)a[k]; g.b[i] = (const uint16_t*)b[k]; g.s[i] = s_host[k]; g.c8n[i] = c_host[k] / 8; g.partial[i] = partial[k];
+    g.a[i] = a[k]; g.b[i] = b[k]; g.s[i] = s_host[k]; g.c8n[i] = c_host[k] / 8; g.partial[i] = partial[k];
   }
-  IMM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((masked_sse_multi_kernel<ET>), dim3(IMM_SSE_BLOCKS, n), dim3(LO_THREADS), 0,
+  IMM_DISPATCH_DTYPE_F32(dtype, hipLaunchKernelGGL((masked_sse_multi_kernel<ET>), dim3(IMM_SSE_BLOCKS, n), dim3(LO_THREADS), 0,
                                                (hipStream_t)stream, g, batch, mask, S, l1));
   IMM_CHECK_LAUNCH("imm_masked_sse_multi");
   return 0;
@@ -209,9 +209,9 @@ extern "C" int imm_masked_sse_pool(const void* a, const void* b, int dtype, int 
                                    float* partial, void* pool_a, void* pool_b, void* stream) {
   IMM_REQUIRE(a && b && partial && pool_b && batch > 0 && s > 0 && s % 2 == 0 && c > 0 && c % 8 == 0, "masked_sse_pool: args");
   IMM_REQUIRE(mask == nullptr || (S >= s && S % s == 0), "masked_sse_pool: mask side %d not a multiple of feature side %d", S, s);
-  IMM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((masked_sse_pool_kernel<ET>), dim3(IMM_SSE_BLOCKS), dim3(LO_THREADS), 0,
-                                               (hipStream_t)stream, (const uint16_t*)a, (const uint16_t*)b, batch, s, c / 8,
-                                               mask, S, partial, (uint16_t*)pool_a, (uint16_t*)pool_b));
+  IMM_DISPATCH_DTYPE_F32(dtype, hipLaunchKernelGGL((masked_sse_pool_kernel<ET>), dim3(IMM_SSE_BLOCKS), dim3(LO_THREADS), 0,
+                                               (hipStream_t)stream, (const typename ET::T*)a, (const typename ET::T*)b, batch, s, c / 8,
+                                               mask, S, partial, (typename ET::T*)pool_a, (typename ET::T*)pool_b));
   IMM_CHECK_LAUNCH("imm_masked_sse_pool");
   return 0;
 }
@@ -322,8 +322,8 @@ extern "C" int imm_perceptual_finalize(const float* partial, int nfeat, const fl
 // gradient injection at a perceptual tap (+ fused ReLU backward of the tapped activation)
 // ---------------------------------------------------------------------------------------------
 template <typename ET>
-__global__ void tap_grad_kernel(uint16_t* __restrict__ da, int has_in, const uint16_t* __restrict__ ap,
-                                const uint16_t* __restrict__ ag, int batch, int s, int c8n, const float* __restrict__ mask,
+__global__ void tap_grad_kernel(typename ET::T* __restrict__ da, int has_in, const typename ET::T* __restrict__ ap,
+                                const typename ET::T* __restrict__ ag, int batch, int s, int c8n, const float* __restrict__ mask,
                                 int S, const float* __restrict__ coef, int idx_coef, int relu, int l1) {
   const int r = S / s;
   const float ck = coef[idx_coef];
@@ -340,9 +340,9 @@ __global__ void tap_grad_kernel(uint16_t* __restrict__ da, int has_in, const uin
       mk = mask[(bi * S + (int64_t)yy * r) * S + (int64_t)xx * r];
     }
     float fp[8], fg[8], d[8];
-    unpack8<ET>(*(const uint4*)(ap + idx * 8), fp);
-    unpack8<ET>(*(const uint4*)(ag + idx * 8), fg);
-    if (has_in) unpack8<ET>(*(const uint4*)(da + idx * 8), d);
+    unpack8<ET>(ld8<ET>(ap + idx * 8), fp);
+    unpack8<ET>(ld8<ET>(ag + idx * 8), fg);
+    if (has_in) unpack8<ET>(ld8<ET>(da + idx * 8), d);
     const float cm = ck * mk;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -352,7 +352,7 @@ __global__ void tap_grad_kernel(uint16_t* __restrict__ da, int has_in, const uin
       if (relu && !(fp[i] > 0.f)) v = 0.f;
       d[i] = v;
     }
-    *(uint4*)(da + idx * 8) = pack8<ET>(d);
+    st8<ET>(da + idx * 8, pack8<ET>(d));
   }
 }
 
@@ -360,8 +360,8 @@ __global__ void tap_grad_kernel(uint16_t* __restrict__ da, int has_in, const uin
 // da[p] = relu'(ap[p]) * ( [p is the argmax of its 2x2 window] * dpool[window] + c_k * mask[p] * (ap[p] - ag[p]) ).
 // One pass instead of maxpool2_bwd (write da) + tap_grad (read da, ap again); bitwise equal to that sequence.
 template <typename ET>
-__global__ void unpool_tap_grad_kernel(uint16_t* __restrict__ da, const uint16_t* __restrict__ dpool,
-                                       const uint16_t* __restrict__ ap, const uint16_t* __restrict__ ag, int batch, int s,
+__global__ void unpool_tap_grad_kernel(typename ET::T* __restrict__ da, const typename ET::T* __restrict__ dpool,
+                                       const typename ET::T* __restrict__ ap, const typename ET::T* __restrict__ ag, int batch, int s,
                                        int c8n, const float* __restrict__ mask, int S, const float* __restrict__ coef,
                                        int idx_coef) {
   const int r = S / s, so = s / 2, c = c8n * 8;
@@ -379,12 +379,12 @@ __global__ void unpool_tap_grad_kernel(uint16_t* __restrict__ da, const uint16_t
     float fp[4][8], fg[4][8], g[8], o[4][8], cm[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      unpack8<ET>(*(const uint4*)(ap + qoff[q]), fp[q]);
-      unpack8<ET>(*(const uint4*)(ag + qoff[q]), fg[q]);
+      unpack8<ET>(ld8<ET>(ap + qoff[q]), fp[q]);
+      unpack8<ET>(ld8<ET>(ag + qoff[q]), fg[q]);
       const int yy = 2 * Y + (q >> 1), xx = 2 * X + (q & 1);
       cm[q] = ck * (mask ? mask[(bi * S + (int64_t)yy * r) * S + (int64_t)xx * r] : 1.f);
     }
-    unpack8<ET>(*(const uint4*)(dpool + ((bi * so + Y) * so + X) * c + cg * 8), g);
+    unpack8<ET>(ld8<ET>(dpool + ((bi * so + Y) * so + X) * c + cg * 8), g);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       int am = 0; float mv = fp[0][i];
@@ -398,7 +398,7 @@ __global__ void unpool_tap_grad_kernel(uint16_t* __restrict__ da, const uint16_t
       }
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) *(uint4*)(da + qoff[q]) = pack8<ET>(o[q]);
+    for (int q = 0; q < 4; ++q) st8<ET>(da + qoff[q], pack8<ET>(o[q]));
   }
 }
 
@@ -410,9 +410,9 @@ extern "C" int imm_unpool_tap_grad(void* da, const void* dpool, const void* a_pr
   const int64_t total = (int64_t)batch * (s / 2) * (s / 2) * (c / 8);
   int64_t blocks = (total + LO_THREADS - 1) / LO_THREADS;
   if (blocks > 16384) blocks = 16384;
-  IMM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((unpool_tap_grad_kernel<ET>), dim3((int)blocks), dim3(LO_THREADS), 0,
-                                               (hipStream_t)stream, (uint16_t*)da, (const uint16_t*)dpool,
-                                               (const uint16_t*)a_pred, (const uint16_t*)a_gt, batch, s, c / 8, mask, S, coef, idx));
+  IMM_DISPATCH_DTYPE_F32(dtype, hipLaunchKernelGGL((unpool_tap_grad_kernel<ET>), dim3((int)blocks), dim3(LO_THREADS), 0,
+                                               (hipStream_t)stream, (typename ET::T*)da, (const typename ET::T*)dpool,
+                                               (const typename ET::T*)a_pred, (const typename ET::T*)a_gt, batch, s, c / 8, mask, S, coef, idx));
   IMM_CHECK_LAUNCH("imm_unpool_tap_grad");
   return 0;
 }
@@ -424,9 +424,9 @@ extern "C" int imm_tap_grad(void* da, int has_in, const void* a_pred, const void
   const int64_t total = (int64_t)batch * s * s * (c / 8);
   int64_t blocks = (total + LO_THREADS - 1) / LO_THREADS;
   if (blocks > 16384) blocks = 16384;
-  IMM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((tap_grad_kernel<ET>), dim3((int)blocks), dim3(LO_THREADS), 0,
-                                               (hipStream_t)stream, (uint16_t*)da, has_in, (const uint16_t*)a_pred,
-                                               (const uint16_t*)a_gt, batch, s, c / 8, mask, S, coef, idx, relu, l1));
+  IMM_DISPATCH_DTYPE_F32(dtype, hipLaunchKernelGGL((tap_grad_kernel<ET>), dim3((int)blocks), dim3(LO_THREADS), 0,
+                                               (hipStream_t)stream, (typename ET::T*)da, has_in, (const typename ET::T*)a_pred,
+                                               (const typename ET::T*)a_gt, batch, s, c / 8, mask, S, coef, idx, relu, l1));
   IMM_CHECK_LAUNCH("imm_tap_grad");
   return 0;
 }
@@ -437,7 +437,7 @@ extern "C" int imm_tap_grad(void* da, int has_in, const void* a_pred, const void
 template <typename ET>
 __global__ void image_loss_grad_kernel(const float* __restrict__ gt, const float* __restrict__ pred, int ldp, int64_t npix,
                                        const float* __restrict__ mask, const float* __restrict__ coef, int idx, int l1,
-                                       uint16_t* __restrict__ dpred, int lddp) {
+                                       typename ET::T* __restrict__ dpred, int lddp) {
   const int nvec = lddp / 8;
   const float ck = coef[idx];
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix * nvec; i += (int64_t)gridDim.x * blockDim.x) {
@@ -453,7 +453,7 @@ __global__ void image_loss_grad_kernel(const float* __restrict__ gt, const float
         o[ch] = cm * d;
       }
     }
-    *(uint4*)(dpred + p * lddp + cg * 8) = pack8<ET>(o);
+    st8<ET>(dpred + p * lddp + cg * 8, pack8<ET>(o));
   }
 }
 
@@ -464,9 +464,9 @@ extern "C" int imm_image_loss_grad(const float* gt, const float* pred, int ldp, 
   const int64_t npix = (int64_t)batch * s * s;
   int64_t blocks = (npix * (lddp / 8) + LO_THREADS - 1) / LO_THREADS;
   if (blocks > 8192) blocks = 8192;
-  IMM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((image_loss_grad_kernel<ET>), dim3((int)blocks), dim3(LO_THREADS), 0,
+  IMM_DISPATCH_DTYPE_F32(dtype, hipLaunchKernelGGL((image_loss_grad_kernel<ET>), dim3((int)blocks), dim3(LO_THREADS), 0,
                                                (hipStream_t)stream, gt, pred, ldp, npix, mask, coef, idx, l1,
-                                               (uint16_t*)dpred, lddp));
+                                               (typename ET::T*)dpred, lddp));
   IMM_CHECK_LAUNCH("imm_image_loss_grad");
   return 0;
 }
@@ -535,12 +535,12 @@ extern "C" int imm_cost_ema(const float* cost3, float* state4, float decay, void
 
 // selfsup/vgg16.py:232-234: tf.summary.scalar('activation/<layer>', sqrt(reduce_mean(z^2))) of every VGG layer's output.
 template <typename ET>
-__global__ __launch_bounds__(LO_THREADS) void sumsq16_kernel(const uint16_t* __restrict__ x, int64_t n8, float* __restrict__ partial) {
+__global__ __launch_bounds__(LO_THREADS) void sumsq16_kernel(const typename ET::T* __restrict__ x, int64_t n8, float* __restrict__ partial) {
   __shared__ float red[4];
   float acc = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * LO_THREADS + threadIdx.x; i < n8; i += (int64_t)gridDim.x * LO_THREADS) {
     float f[8];
-    unpack8<ET>(*(const uint4*)(x + i * 8), f);
+    unpack8<ET>(ld8<ET>(x + i * 8), f);
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc = fmaf(f[e], f[e], acc);
   }
@@ -564,8 +564,8 @@ __global__ __launch_bounds__(LO_THREADS) void rms_finish_kernel(const float* __r
 extern "C" int imm_rms16(const void* x, int64_t n, int dtype, float* partial, int nblk, float* out, void* stream) {
   IMM_REQUIRE(x && partial && out && n > 0 && n % 8 == 0 && nblk > 0 && nblk <= 4096, "rms16: args (n must be a multiple of 8)");
   IMM_REQUIRE(((uintptr_t)x % 16) == 0, "rms16: 16-byte alignment");
-  IMM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((sumsq16_kernel<ET>), dim3(nblk), dim3(LO_THREADS), 0, (hipStream_t)stream,
-                                              (const uint16_t*)x, n / 8, partial));
+  IMM_DISPATCH_DTYPE_F32(dtype, hipLaunchKernelGGL((sumsq16_kernel<ET>), dim3(nblk), dim3(LO_THREADS), 0, (hipStream_t)stream,
+                                              (const typename ET::T*)x, n / 8, partial));
   hipLaunchKernelGGL(rms_finish_kernel, dim3(1), dim3(LO_THREADS), 0, (hipStream_t)stream, partial, nblk, (double)n, out);
   IMM_CHECK_LAUNCH("imm_rms16");
   return 0;

@@ -22,7 +22,7 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const int64_t* 
   const int j = find_job(blk_first, n_jobs, blockIdx.x);
   const int64_t* jb = jobs + (int64_t)j * MULTI_FIELDS;
   const float* __restrict__ w = (const float*)jb[0];
-  uint16_t* __restrict__ wt = (uint16_t*)jb[1];
+  typename ET::T* __restrict__ wt = (typename ET::T*)jb[1];
   const int mode = (int)jb[2], kh = (int)jb[3], kw = (int)jb[4], ci_real = (int)jb[5], co_real = (int)jb[6];
   const int c_pad = (int)jb[7], rows = (int)jb[8], kpad = (int)jb[9];
   if (mode == 0) {
@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const int64_t* 
       float f[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) f[e] = tile[kq + e][rn];
-      *(uint4*)(wt + (int64_t)(n0 + rn) * kpad + k0 + kq) = pack8<ET>(f);
+      st8<ET>(wt + (int64_t)(n0 + rn) * kpad + k0 + kq, pack8<ET>(f));
     }
     return;
   }
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const int64_t* 
     }
     f[e] = v;
   }
-  *(uint4*)(wt + base) = pack8<ET>(f);
+  st8<ET>(wt + base, pack8<ET>(f));
 }
 
 // workgroups of one job of imm_pack_weights_multi (the caller's blk_first prefix sums are built from these)
@@ -94,7 +94,7 @@ extern "C" int imm_pack_weights_multi_blocks(int mode, int rows, int kpad) {
 extern "C" int imm_pack_weights_multi(const int64_t* jobs, const int32_t* blk_first, int n_jobs, int n_blocks, int dtype,
                                       void* stream) {
   IMM_REQUIRE(jobs && blk_first && n_jobs > 0 && n_blocks > 0, "pack_weights_multi: args");
-  IMM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((pack_weights_multi_kernel<ET>), dim3(n_blocks), dim3(256), 0,
+  IMM_DISPATCH_DTYPE_F32(dtype, hipLaunchKernelGGL((pack_weights_multi_kernel<ET>), dim3(n_blocks), dim3(256), 0,
                                                (hipStream_t)stream, jobs, blk_first, n_jobs));
   IMM_CHECK_LAUNCH("imm_pack_weights_multi");
   return 0;

@@ -17,7 +17,7 @@
 template <typename ET>
 __global__ __launch_bounds__(256) void vgg_conv1_1_fwd_kernel(const float* __restrict__ gt, const float* __restrict__ pred,
                                                               int ldp, int batch, int s, const float* __restrict__ w,
-                                                              const float* __restrict__ bias, uint16_t* __restrict__ out,
+                                                              const float* __restrict__ bias, typename ET::T* __restrict__ out,
                                                               int img0) {
   __shared__ float gray[(VF_TILE + 2) * (VF_TILE + 2)];
   const int tid = threadIdx.x;
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void vgg_conv1_1_fwd_kernel(const float* __res
       o[2 * e] = fmaxf(acc[0], 0.f);
       o[2 * e + 1] = fmaxf(acc[1], 0.f);
     }
-    *(uint4*)(out + (((int64_t)img * s + yy) * s + xx) * 64 + cg * 8) = pack8<ET>(o);
+    st8<ET>(out + (((int64_t)img * s + yy) * s + xx) * 64 + cg * 8, pack8<ET>(o));
   }
 }
 
@@ -160,14 +160,53 @@ __global__ __launch_bounds__(256) void vgg_conv1_1_bwd_kernel(const uint16_t* __
   }
 }
 
+// f32 storage (the witness engine, IMM_F32): the same gradient in plain f32 arithmetic, one thread per pixel — dgray[p] =
+// sum_t sum_c dz[p - (ky-1, kx-1)][c] w[t][c] (zero outside the image), dpred[p][ch < 3] = dgray / (3 * 255) + c0 * mask * (pred -
+// gt) (sign with l1), channels 3 .. lddp - 1 zero.
+__global__ __launch_bounds__(256) void vgg_conv1_1_bwd_f32_kernel(const float* __restrict__ dz, int batch, int s,
+                                                                  const float* __restrict__ w, const float* __restrict__ gt,
+                                                                  const float* __restrict__ pred, int ldp,
+                                                                  const float* __restrict__ mask, const float* __restrict__ coef,
+                                                                  int input_idx, int l1, float* __restrict__ dpred, int lddp) {
+  __shared__ float sw[9 * 64];
+  for (int i = threadIdx.x; i < 9 * 64; i += 256) sw[i] = w[i];
+  __syncthreads();
+  const int64_t npix = (int64_t)batch * s * s;
+  const float c0 = input_idx >= 0 ? coef[input_idx] : 0.f;
+  for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < npix; p += (int64_t)gridDim.x * 256) {
+    const int xx = (int)(p % s);
+    const int64_t t0 = p / s;
+    const int yy = (int)(t0 % s);
+    const int64_t img = t0 / s;
+    float part = 0.f;
+    for (int t = 0; t < 9; ++t) {
+      const int qy = yy - (t / 3 - 1), qx = xx - (t % 3 - 1);
+      if (qy < 0 || qy >= s || qx < 0 || qx >= s) continue;
+      const float* d = dz + ((img * s + qy) * s + qx) * 64;
+      for (int c = 0; c < 64; ++c) part = fmaf(d[c], sw[t * 64 + c], part);
+    }
+    const float dg = part / (3.0f * 255.0f);
+    const float cm = c0 * (mask ? mask[p] : 1.f);
+    for (int ch = 0; ch < lddp; ++ch) {
+      float o = 0.f;
+      if (ch < 3) {
+        float d = pred[p * ldp + ch] - gt[p * 3 + ch];
+        if (l1) d = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+        o = dg + cm * d;
+      }
+      dpred[p * lddp + ch] = o;
+    }
+  }
+}
+
 extern "C" int imm_vgg_conv1_1_fwd(const float* gt, const float* pred, int ldp, int batch, int s, const float* w9x64,
                                    const float* b64, void* out, int dtype, int halves, void* stream) {
   IMM_REQUIRE(gt && pred && w9x64 && b64 && out, "vgg_conv1_1_fwd: null");
   IMM_REQUIRE(batch > 0 && s > 0 && ldp >= 3, "vgg_conv1_1_fwd: dims");
   IMM_REQUIRE(halves >= 1 && halves <= 3, "vgg_conv1_1_fwd: halves must be 1 (gt), 2 (pred) or 3 (both)");
   const dim3 grid((s + VF_TILE - 1) / VF_TILE, (s + VF_TILE - 1) / VF_TILE, halves == 3 ? 2 * batch : batch);
-  IMM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((vgg_conv1_1_fwd_kernel<ET>), grid, dim3(256), 0, (hipStream_t)stream, gt,
-                                               pred, ldp, batch, s, w9x64, b64, (uint16_t*)out, halves == 2 ? batch : 0));
+  IMM_DISPATCH_DTYPE_F32(dtype, hipLaunchKernelGGL((vgg_conv1_1_fwd_kernel<ET>), grid, dim3(256), 0, (hipStream_t)stream, gt,
+                                                   pred, ldp, batch, s, w9x64, b64, (typename ET::T*)out, halves == 2 ? batch : 0));
   IMM_CHECK_LAUNCH("imm_vgg_conv1_1_fwd");
   return 0;
 }
@@ -177,6 +216,13 @@ extern "C" int imm_vgg_conv1_1_bwd(const void* dz, int dtype, int batch, int s, 
                                    void* dpred, int lddp, void* stream) {
   IMM_REQUIRE(dz && w9x64 && gt && pred && coef && dpred, "vgg_conv1_1_bwd: null");
   IMM_REQUIRE(batch > 0 && s > 0 && ldp >= 3 && lddp >= 8 && lddp % 8 == 0 && lddp <= 64, "vgg_conv1_1_bwd: dims");
+  if (dtype == IMM_F32) {
+    const int64_t npix = (int64_t)batch * s * s;
+    hipLaunchKernelGGL(vgg_conv1_1_bwd_f32_kernel, dim3((unsigned)((npix + 255) / 256 > 8192 ? 8192 : (npix + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, (const float*)dz, batch, s, w9x64, gt, pred, ldp, mask, coef, input_idx, l1, (float*)dpred, lddp);
+    IMM_CHECK_LAUNCH("imm_vgg_conv1_1_bwd(f32)");
+    return 0;
+  }
   const dim3 grid((s + VF_TILE - 1) / VF_TILE, (s + VF_TILE - 1) / VF_TILE, batch);
   IMM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((vgg_conv1_1_bwd_kernel<ET>), grid, dim3(256), 0, (hipStream_t)stream,
                                                (const uint16_t*)dz, batch, s, w9x64, gt, pred, ldp, mask, coef, input_idx, l1,

@@ -185,6 +185,11 @@ class IMMEngine:
             raise ValueError('image side must be a multiple of 16 and >= 64')
         L.load()   # fail loudly, now, if the HIP library is missing
         self.cfg, self.B, self.S, self.dev, self.dt = cfg, int(batch), int(image_size), torch.device(device), act_dtype
+        # act_dtype torch.float32 = the WITNESS engine (round 6): the same launch program with f32 activation storage and plain f32
+        # convolution kernels (csrc/conv_f32.hip) — a test instrument (~100x slower), not a product path: the reference computes in
+        # fp32 (imm_model.py:97) and only an exact-arithmetic run can tell storage noise from a wiring error.  The fused MFMA-only
+        # launches (pose head, one-launch stride-2 data gradient, tap-in-epilogue) fall back to their unfused sequences.
+        self.f32 = act_dtype == torch.float32
         self.K = int(cfg.n_maps)
         self.world_size = world_size
         # gradient-exchange buckets the backward program is laid out for (1 = one all-reduce after the backward pass; 2 = the
@@ -257,7 +262,7 @@ class IMMEngine:
         # conv_5 / conv_7.  Built, parity-tested, and MEASURED SLOWER on the step (3.137 -> 3.216 ms, same box, DESIGN.md item 47:
         # the affine + ReLU costs ~3.5 VALU instructions per element at one wave per SIMD with nothing to hide them behind —
         # forward convolutions +5..8 us for 11..15 us of apply pass saved, filter gradients +100 us), so it is off by default.
-        self.nol = os.environ.get('IMM_NOL', '0') != '0'
+        self.nol = os.environ.get('IMM_NOL', '0') != '0' and not self.f32
         # IMM_DEBUG_SKIP_TAGS=tag,tag: timing experiment only (results become wrong): drop every launch whose tag is listed, to
         # measure how much of the step's critical path a kernel class occupies under graph replay / stream concurrency
         self._skip_tags = set(t for t in os.environ.get('IMM_DEBUG_SKIP_TAGS', '').split(',') if t)
@@ -526,7 +531,7 @@ class IMMEngine:
             lay.s2 = ops.dgrad_s2_class_descs(B, H, W, ci_real, 0, lddy, lddy, k) if stride == 2 else None
             # stride 2, 3x3: the four parity classes as ONE launch over one dy halo (imm_conv2d_dgrad_s2: LDS-halo deep-K kernel,
             # four accumulator sets) where the shape is served; its filter image is the ordinary flipped one (mode 1)
-            lay.s2_fused = (lay.s2 is not None and k == 3 and lddy % 64 == 0 and ci_real % 8 == 0 and
+            lay.s2_fused = (lay.s2 is not None and k == 3 and lddy % 64 == 0 and ci_real % 8 == 0 and not self.f32 and
                             ops.conv2d_dgrad_s2_supported(B, fd.ho, fd.wo, lddy, ci_real, ci_real))
             if lay.s2 is not None and not lay.s2_fused:
                 # parity-class decomposition: 4 sub-filters (2x2, 2x1, 1x2, 1x1 taps) instead of a 4x-redundant
@@ -725,7 +730,7 @@ class IMMEngine:
             co1 = encoder_spec(nf)[0][2]
             # (IMM_CONV_FIRST=1: built, bit-compatible, measured NEUTRAL on the step — 26.7 us against 12 + 20 us for the two launches it
             # takes off the chain, whose packing pass still runs at the lane's tail; DESIGN.md item 49 — so the default stays the 7x1 form)
-            direct = (os.environ.get('IMM_CONV_FIRST', '0') != '0' and k1 == 7 and ld1 == 32 and
+            direct = (os.environ.get('IMM_CONV_FIRST', '0') != '0' and not self.f32 and k1 == 7 and ld1 == 32 and
                       ops.conv_first_supported(B, S, co1, ops.round_up(co1, 8)))
             if direct:
                 self._deferred_packs.append(f_pack)
@@ -778,7 +783,7 @@ class IMMEngine:
         # the pose head (1x1 convolution -> soft-argmax -> Gaussian maps, imm_model.py:247-264) as ONE launch each way where the
         # shapes allow (every shipped configuration): -1 launch forward, -2 backward on the pose lane, the longer one
         lddy_h = ops.round_up(K, 32)
-        self.fused_head = ((8 * nf) % 32 == 0 and K <= 64 and (He * He) % 16 == 0 and lddy_h in (32, 64) and
+        self.fused_head = (not self.f32 and (8 * nf) % 32 == 0 and K <= 64 and (He * He) % 16 == 0 and lddy_h in (32, 64) and
                            4 * (He * He * K + 2 * He * K + 2 * K) <= 158 * 1024 and
                            4 * ((2 + 2 * He) * K + 516) + He * He * lddy_h * 2 <= 158 * 1024)
         self.pose_head = self._conv_block('model/pose_encoder/conv_1', pe.out, He, He, 8 * nf, 8 * nf, pe.ldo, K, 1, 1,
@@ -1057,7 +1062,7 @@ class IMMEngine:
             flops = 2.0 * B * H * H * 9 * cin * cout
             if tap_of is not None:
                 dt0 = ops.dgrad_desc(B, H, H, cin, cin, cout, cout, 3, 1, 0)
-                if ops.conv2d_tap_supported(dt0):
+                if not self.f32 and ops.conv2d_tap_supported(dt0):
                     ya = acts[tap_of][0]
                     self._add(self.prog_bwd, lambda: ops.conv2d_tap(dt0, src, wtd, dst, ya[B:], ya[:B], cin, mask, S, self.coef,
                                                                     taps[tap_of], l1), 'vgg_dgrad', flops,

@@ -24,7 +24,9 @@ def dtype_enum(dt):
         return L.IMM_BF16
     if dt == torch.float16:
         return L.IMM_F16
-    raise ValueError('activation dtype must be torch.bfloat16 or torch.float16, got %r' % (dt,))
+    if dt == torch.float32:
+        return L.IMM_F32          # the f32 witness engine (plain f32 kernels; imm_amd/csrc/conv_f32.hip)
+    raise ValueError('activation dtype must be torch.bfloat16 / torch.float16 (or torch.float32: the witness engine), got %r' % (dt,))
 
 
 def round_up(x, m):
@@ -189,7 +191,7 @@ def conv2d_wgrad(desc, x, dy, lddy, slab, nsplit):
     call('imm_conv2d_wgrad', C.byref(desc), dtype_enum(x.dtype), _p(x), _p(dy), lddy, _p(slab), nsplit, _s())
 
 
-CONV_FAMILIES = {1: 'igemm', 2: 'igemm64', 3: 'halo', 4: 'halo2', 5: 'hdeep', 6: 'hdeep6', 7: 's2f'}
+CONV_FAMILIES = {1: 'igemm', 2: 'igemm64', 3: 'halo', 4: 'halo2', 5: 'hdeep', 6: 'hdeep6', 7: 's2f', 8: 'f32'}
 
 
 def conv2d_variant(desc, dtype):

@@ -26,7 +26,10 @@ extern "C" {
 #define IMM_ABI_VERSION 19   /* 19: imm_set_cu_limit / imm_get_cu_limit, imm_masked_sse_pool with pool_a == NULL.  18: imm_copy_f32.  17: imm_cost_ema, imm_rms16 (summaries).  16: imm_conv2d_variant.  15: imm_conv2d_dgrad_s2, imm_conv2d_nol, imm_conv_first, imm_wgrad_job.x_scale/x_shift/x_relu; entry points removed
                                   since 14 (imm_bn_bwd_reduce_finalize, imm_conv2d_stats_workspace_bytes) finally counted */
 
-enum imm_dtype { IMM_BF16 = 0, IMM_F16 = 1 };
+/* IMM_F32 (round 6): f32 activation storage — the exact-arithmetic WITNESS of the wiring, a test instrument (the reference computes
+ * in fp32, imm_model.py:97): accepted by the entry points that say so below; convolutions then run plain f32 FMA kernels
+ * (csrc/conv_f32.hip: no tuning, ~100x slower than the 16-bit MFMA kernels). */
+enum imm_dtype { IMM_BF16 = 0, IMM_F16 = 1, IMM_F32 = 2 };
 
 enum imm_error {
   IMM_OK = 0,
