@@ -308,8 +308,13 @@ def parity_vs_oracle(dev, batch=2):
     out['bounds'] = {'mu_max_abs': 1e-3, 'loss_rel': 1e-3, 'terms_max_rel': 1e-2, 'recon_rel_l2': 0.10 if IMAGE_SIZE <= 128 else 0.13}
     out['f16'] = dict(one(torch.float16), dtype='f16 storage vs fp32',
                       bounds={'mu_max_abs': 1e-3, 'loss_rel': 1e-3, 'terms_max_rel': 2e-3, 'recon_rel_l2': 0.02})
+    # the f32-storage WITNESS engine (round 6: the same launch program, plain f32 convolutions — a test instrument): what the
+    # two 16-bit rows leave as storage noise it settles in exact arithmetic (every gradient tensor: tests/test_witness_gpu.py)
+    if IMAGE_SIZE <= 128:
+        out['f32_witness'] = dict(one(torch.float32), dtype='f32 storage (imm_amd/csrc/conv_f32.hip) vs fp32',
+                                  bounds={'mu_max_abs': 1e-5, 'loss_rel': 1e-5, 'terms_max_rel': 1e-4, 'recon_rel_l2': 1e-4})
     out['within_bounds'] = all(out[k] <= v for k, v in out['bounds'].items()) and \
-        all(out['f16'][k] <= v for k, v in out['f16']['bounds'].items())
+        all(out[row][k] <= v for row in ('f16', 'f32_witness') if row in out for k, v in out[row]['bounds'].items())
     return out
 
 

@@ -865,9 +865,22 @@ class IMMEngine:
         self.vgg_layers = VGG_LAYERS[:max(vnames.index(n) for n in taps) + 1] if taps else []
         nfeat = self.nfeat
         self.sse_partial = self._zeros(nfeat, L.SSE_BLOCKS)
-        nimg = 2 * B
         fuse_ok = not self.l1                    # the fused SSE+pool / unpool+tap passes exist for the squared error only
         fused_sse = set()
+        # the image-space term ('input' feature: prediction against the future image) needs the renderer's output only: with
+        # IMM_SSE_INPUT_LANE=1 its error sum runs on lane 1 beside the VGG launches instead of in the one-lane tail in front of the
+        # loss.  Round 6, measured NEUTRAL (same box, two alternations: 3.2027 / 3.2077, 3.1943 / 3.1950 ms — the 11 us launch
+        # leaves the tail, the extra fork / join nodes cost as much): off by default.
+        self._sse_input_early = ('input' in self.tap_idx and bool(self.vgg_layers) and
+                                 os.environ.get('IMM_SSE_INPUT_LANE', '0') != '0')
+        if self._sse_input_early:
+            idx0 = self.tap_idx['input']
+            self._cur_scope = 'loss'
+            self._mark(self.prog_fwd, 'fork', lane=1)
+            self._cur_lane = 1
+            self._add(self.prog_fwd, lambda: ops.masked_sse_f32(self.in_future, 3, self.pred, self.ldp, B, S, 3, self.in_mask,
+                                                                self.sse_partial[idx0], self.l1), 'sse')
+            self._cur_lane = 0
         # Round 6, built and MEASURED WITHOUT GAIN, off by default (IMM_VGG_SPLIT=1 turns it on): the
         # ground-truth half of concat([gt, pred]) (imm_model.py:126) depends on the input batch only.  With the split it runs on a
         # lane of its own (lane 2) that forks at the START of the forward program, every persistent convolution CONFINED to
@@ -970,7 +983,9 @@ class IMMEngine:
         mask = self.in_mask
         l1 = self.l1
         self._cur_scope = 'loss'
-        if 'input' in self.tap_idx:
+        if self._sse_input_early:
+            self._mark(self.prog_fwd, 'join', lane=1)
+        elif 'input' in self.tap_idx:
             idx0 = self.tap_idx['input']
             self._add(self.prog_fwd, lambda: ops.masked_sse_f32(self.in_future, 3, self.pred, self.ldp, B, S, 3, mask,
                                                                 self.sse_partial[idx0], l1), 'sse')
