@@ -661,6 +661,24 @@ class IMMEngine:
             self._issue_wgrad_chunk(chunk, name if len(chunks) == 1 else '%s [%d/%d]' % (name, ci_ + 1, len(chunks)), cus)
 
     def _issue_wgrad_chunk(self, chunk, name, cus=0):
+        # IMM_WG_LANES=n (round 6 experiment; default 1): the kernel variants of a chunk as separate launches
+        # spread over n lanes (largest group on the main lane) instead of one after the other on one stream; IMM_WG_LANE_SHARE =
+        # the share of the chip the groups on the side lanes are planned for
+        n_lanes = int(os.environ.get('IMM_WG_LANES', '1'))
+        if n_lanes > 1 and len(chunk) > 1 and not cus and self._cur_lane == 0:
+            share = float(os.environ.get('IMM_WG_LANE_SHARE', '1.0'))
+            groups = sorted(chunk, key=lambda g: -sum(m[5] for m in g[1]))
+            lanes = sorted(set(1 + (i - 1) % (n_lanes - 1) for i in range(1, len(groups))))
+            for ln in lanes:
+                self._mark(self.prog_bwd, 'fork', lane=ln)
+            for i, g in enumerate(groups):
+                self._cur_lane = 0 if i == 0 else 1 + (i - 1) % (n_lanes - 1)
+                self._issue_wgrad_chunk([g], '%s [variant %d]' % (name, g[0][0]),
+                                        cus=0 if i == 0 else max(8, int(self.n_cu * share) // 8 * 8) if share < 1.0 else 0)
+            self._cur_lane = 0
+            for ln in lanes:
+                self._mark(self.prog_bwd, 'join', lane=ln)
+            return
         multi_jobs, flops_total = [], 0.0
         for (key, pcu), members in chunk:
             kind = key // 100000                    # 0 generic kernel (one launch per job), 1 transpose-read, 2 LDS-halo

@@ -1,6 +1,6 @@
 """Every IMM_* environment switch the product path still reads, exercised in both positions: the
 kernel-dispatch ablation list IMM_CONV_DISABLE (each specialised kernel family off -> the layer falls back to the next more
-general kernel, same numbers to accumulation order), IMM_NOL, IMM_CONV_FIRST, IMM_TWO_STREAMS, IMM_VGG_SPLIT / IMM_GT_CUS / IMM_WG_CUS (confined lanes, round 6), IMM_DEBUG_STAMPS, IMM_DEBUG_SKIP_TAGS.  The switches are
+general kernel, same numbers to accumulation order), IMM_NOL, IMM_CONV_FIRST, IMM_TWO_STREAMS, IMM_VGG_SPLIT / IMM_GT_CUS / IMM_WG_CUS / IMM_WG_LANES / IMM_SSE_INPUT_LANE (lane experiments of round 6), IMM_DEBUG_STAMPS, IMM_DEBUG_SKIP_TAGS.  The switches are
 read once per process (static dispatch tables / engine construction), hence the child processes (tests/_switch_probe.py).
 IMM_DP_BUCKETS, IMM_RCCL_NATIVE and IMM_RCCL_GRAPH have their tests in test_dp_gpu.py / test_step_gpu.py; IMM_HIP_LIB and
 IMM_HIPCC_FLAGS (A/B builds) in test_host_cpu.py."""
@@ -82,9 +82,11 @@ def test_confined_lanes_are_the_same_step(base):
     """Round 6, opt-in (measured without gain: DESIGN.md item 59).  IMM_VGG_SPLIT=1: the ground-truth half of the VGG forward on
     lane 2, persistent launches confined to IMM_GT_CUS compute units (imm_set_cu_limit), the prediction half behind the renderer,
     error sums waiting for the lane's events; IMM_WG_CUS: the renderer's filter gradients planned for a share of the chip on lane 2
-    beside the encoders' backward.  Same step up to the tile choice / split counts (accumulation order); and each of them on ONE
+    beside the encoders' backward; IMM_WG_LANES: the filter-gradient kernel variants on several lanes; IMM_SSE_INPUT_LANE: the image-space
+    error sum beside the VGG launches.  Same step up to the tile choice / split counts (accumulation order); and each of them on ONE
     stream (list order alone) is bitwise the three-lane graph."""
-    for env in (dict(IMM_VGG_SPLIT=1, IMM_GT_CUS=64), dict(IMM_WG_CUS=96), dict(IMM_VGG_SPLIT=1, IMM_GT_CUS=0, IMM_WG_CUS=64)):
+    for env in (dict(IMM_VGG_SPLIT=1, IMM_GT_CUS=64), dict(IMM_WG_CUS=96), dict(IMM_VGG_SPLIT=1, IMM_GT_CUS=0, IMM_WG_CUS=64),
+                dict(IMM_WG_LANES=3, IMM_SSE_INPUT_LANE=1)):
         got = probe(**env)
         assert same(base, got, 2e-4), (env, base, got)
         one = probe(IMM_TWO_STREAMS=0, **env)
