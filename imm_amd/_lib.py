@@ -20,7 +20,7 @@ CONV_BIAS, CONV_RELU, CONV_STATS, CONV_MASK, CONV_OUT_F32 = 1, 2, 4, 8, 16
 SSE_BLOCKS = 512
 OPTIMIZERS = {'adam': 0, 'adadelta': 1, 'adagrad': 2}      # IMM_OPT_* (scripts/train.py:97-104)
 GAUSS_MODES = {'rot': 0, 'flat': 1, 'ankush': 2}     # IMM_GAUSS_* (config key gauss_mode, imm_model.py:48-72)
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 
 class ImmHipError(RuntimeError):
@@ -97,6 +97,8 @@ _SIGS = {
     'imm_pose_head_fwd': [_P, _I, _I, _P, _I, _P, _I, _I, _I, _I, _I, _F, _I, _P, _I, _P, _P, _P, _P, _I, _I, _P],
     'imm_pose_head_bwd': [_P, _I, _I, _I, _I, _I, _I, _F, _I, _P, _P, _P, _P, _I, _I, _P, _I, _I, _P, _I, _P, _P],
     'imm_vgg_conv1_1_fwd': [_P, _P, _I, _I, _I, _P, _P, _P, _I, _I, _P],
+    'imm_vgg_head_supported': [_I, _I, _I],
+    'imm_vgg_head_fwd': [_P, _P, _I, _I, _I, _P, _P, _P, _I, _P, _P, _I, _P, _P, _I, _P],
     'imm_vgg_conv1_1_bwd': [_P, _I, _I, _I, _P, _P, _P, _I, _P, _P, _I, _I, _P, _I, _P],
     'imm_image_loss_grad': [_P, _P, _I, _I, _I, _P, _P, _I, _I, _P, _I, _I, _P],
     'imm_copy_f32': [_P, _P, _L, _P],
@@ -144,6 +146,7 @@ _SIGS64 = {
     'imm_bn_bwd_workspace_bytes': [_L, _I],
     'imm_upsample2x_bwd_bn_workspace_bytes': [_I, _I, _I, _I],
     'imm_masked_sse_workspace_bytes': [_I],
+    'imm_vgg_head_scratch_bytes': [_I, _I],
 }
 
 _lib = None

@@ -188,7 +188,11 @@ __global__ __launch_bounds__(256) void conv_halo2_kernel(const Halo2Args ha) {
     const bool ok = ((unsigned)iy < (unsigned)a.hi) & ((unsigned)ix < (unsigned)a.wi);
     uint32_t in_range = base + hrel[k];
     asm volatile("" : "+v"(in_range));        // keep the add unconditional: a select, not an exec-masked block
+#ifdef H2_ABLATE   // diagnosis builds only (tools/ablate_build.sh): bit 0 = no halo bytes move, bit 1 = no output bytes move
+    const uint32_t vo = (H2_ABLATE & 1) ? H2_OOB : (ok ? in_range : H2_OOB);
+#else
     const uint32_t vo = ok ? in_range : H2_OOB;
+#endif
     h2_dma16(xr, lds_base + (uint32_t)((stage * H_U4) * 16 + (wid + 4 * k) * 1024), vo, soff);
   };
   uint32_t mrel[DM > 0 ? DM : 1];
@@ -334,7 +338,11 @@ __global__ __launch_bounds__(256) void conv_halo2_kernel(const Halo2Args ha) {
         }
         const uint4 o = pack8<ET>(v);
         const u32x4_t od = {o.x, o.y, o.z, o.w};
+#ifdef H2_ABLATE
+        h2_store16(yr, od, (H2_ABLATE & 2) ? H2_OOB : prev_voff + (uint32_t)((wm * MT + i) * a.wo * a.ldy * 2), prev_soff);
+#else
         h2_store16(yr, od, prev_voff + (uint32_t)((wm * MT + i) * a.wo * a.ldy * 2), prev_soff);
+#endif
       }
       if (rr == NR - 1) {
         // bookkeeping for the next iteration (scalar): hand this patch to the next epilogue, shift the decode queue

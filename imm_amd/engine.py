@@ -931,8 +931,18 @@ class IMMEngine:
                 self.vgg_act['conv1_1'] = (a, S)
             a = self.vgg_act['conv1_1'][0]
             hv = {'': 3, 'gt': 1, 'pred': 2}[hname]
-            self._add(prog, (lambda a=a, hv=hv: ops.vgg_conv1_1_fwd(self.in_future, self.pred, self.ldp, B, S, self.w11, self.b11, a, hv)),
-                      'vgg_conv1_1', 2.0 * nb * S * S * 9 * 64, nb * S * S * 128.0, name='vgg16/conv1_1' + sfx)
+            # The head in ONE launch (round 6, imm_vgg_head_fwd: vgg_head.hip): conv1_2's persistent workgroups produce the conv1_1
+            # halo of their patches on the matrix cores, so conv1_1's 2B-image activation (the largest tensor of the step) is neither
+            # written nor read back; only its prediction half is stored (the ReLU mask of conv1_2's data gradient).  IMM_VGG_HEAD=0 /
+            # IMM_CONV_DISABLE=vgg_head / the split program / the f32 witness keep the two launches.
+            head_fused = (not split and len(self.vgg_layers) > 1 and not self.f32 and os.environ.get('IMM_VGG_HEAD', '1') != '0'
+                          and ops.vgg_head_supported(B, S, dt))
+            self.vgg_head_fused = head_fused
+            if head_fused:
+                self.vgg_gray = torch.empty(ops.vgg_head_scratch_bytes(B, S), dtype=torch.uint8, device=self.dev)
+            else:
+                self._add(prog, (lambda a=a, hv=hv: ops.vgg_conv1_1_fwd(self.in_future, self.pred, self.ldp, B, S, self.w11, self.b11, a, hv)),
+                          'vgg_conv1_1', 2.0 * nb * S * S * 9 * 64, nb * S * S * 128.0, name='vgg16/conv1_1' + sfx)
             x, H = a, S
             for li, (name, cin, cout) in enumerate(self.vgg_layers[1:], start=1):
                 fd = ops.fwd_desc(nb, H, H, cin, cin, cout, cout, 3, 1, L.CONV_BIAS | L.CONV_RELU)
@@ -944,9 +954,17 @@ class IMMEngine:
                     self.vgg_act[name] = (y, H)
                 wt, y = self.vgg_wt[name], self.vgg_act[name][0]
                 bias = self.vgg_w['vgg16/%s/biases' % name]
-                self._add(prog, (lambda fd=fd, x=x, wt=wt, bias=bias, y=y, hs=hs: ops.conv2d(fd, x[hs], wt, bias, y[hs])),
-                          'vgg_fwd', 2.0 * nb * H * H * 9 * cin * cout, 2.0 * (nb * H * H * (cin + cout) + 9 * cin * cout),
-                          name='vgg16/' + name + sfx, desc=fd)
+                if li == 1 and head_fused:
+                    # algorithmic bytes: the two images in, conv1_1's prediction half and conv1_2's activation out
+                    self._add(prog, (lambda a=a, wt=wt, bias=bias, y=y: ops.vgg_head_fwd(
+                        self.in_future, self.pred, self.ldp, B, S, self.w11, self.b11, wt, bias, a, B, y, self.vgg_gray)),
+                              'vgg_fwd', 2.0 * nb * S * S * 9 * (64 + cin * cout),
+                              nb * S * S * 12.0 + 2.0 * (B * S * S * 64 + nb * S * S * cout + 9 * cin * cout),
+                              name='vgg16/conv1_1+' + name, variant='vgg_head')
+                else:
+                    self._add(prog, (lambda fd=fd, x=x, wt=wt, bias=bias, y=y, hs=hs: ops.conv2d(fd, x[hs], wt, bias, y[hs])),
+                              'vgg_fwd', 2.0 * nb * H * H * 9 * cin * cout, 2.0 * (nb * H * H * (cin + cout) + 9 * cin * cout),
+                              name='vgg16/' + name + sfx, desc=fd)
                 if hname == 'gt' and name in taps:
                     self._signal(prog, 'gt:' + name)
                 x = y
@@ -1468,6 +1486,15 @@ class IMMEngine:
             out[name + '_avg'] = ema[i]
         return out
 
+    def vgg_activations(self):
+        """{layer: (activation [2B, H, H, C], H)} of the last forward pass, every entry complete.  With the fused head
+        (imm_vgg_head_fwd) the step only stores the prediction half of conv1_1 — its ground-truth half has no reader in the
+        step — so it is computed here, on demand (summaries, diagnostics, tests), by the stand-alone first-layer kernel."""
+        if getattr(self, 'vgg_head_fused', False) and 'conv1_1' in self.vgg_act:
+            a = self.vgg_act['conv1_1'][0]
+            ops.vgg_conv1_1_fwd(self.in_future, self.pred, self.ldp, self.B, self.S, self.w11, self.b11, a, 1)
+        return self.vgg_act
+
     def vgg_activation_rms(self):
         """selfsup/vgg16.py:232-234: {'activation/<layer>': sqrt(mean(z^2))} of every VGG16 layer output of the last forward pass
         (both halves of the concat([gt, pred]) batch, like the reference's graph).  Summary steps only: one small reduction per layer."""
@@ -1477,7 +1504,7 @@ class IMMEngine:
             self._rms_scratch = (self._zeros(1024), self._zeros(1))
         part, out = self._rms_scratch
         res = {}
-        for name, (y, _h) in self.vgg_act.items():
+        for name, (y, _h) in self.vgg_activations().items():
             ops.rms16(y, part, out)
             res['activation/' + name] = float(out)
         return res

@@ -395,6 +395,24 @@ def gauss_render_f32(mu, batch, k, inv_std, s, out, mode='rot'):
 
 
 # ---- VGG head / loss --------------------------------------------------------------------------
+def vgg_head_supported(batch, s, dtype):
+    """conv1_1 + conv1_2 of the frozen VGG16 in one launch (vgg_head.hip) serves this shape / storage type."""
+    if dtype not in (torch.bfloat16, torch.float16):
+        return False
+    return bool(L.load().imm_vgg_head_supported(batch, s, dtype_enum(dtype)))
+
+
+def vgg_head_scratch_bytes(batch, s):
+    return int(L.load().imm_vgg_head_scratch_bytes(batch, s))
+
+
+def vgg_head_fwd(gt, pred, ldp, batch, s, w11, b11, wt12, b12, a11, store_from, y12, gray_scratch):
+    """gt f32 [B,S,S,3], pred f32 [B,S,S,ldp] -> y12 16-bit [2B,S,S,64] = relu(conv1_2(relu(conv1_1(gray(concat([gt, pred])))))),
+    a11[store_from:] = conv1_1's activation of those images (selfsup/vgg16.py:345-346, build_vgg16.py:22-26)."""
+    call('imm_vgg_head_fwd', _p(gt), _p(pred), ldp, batch, s, _p(w11), _p(b11), _p(wt12), wt12.shape[1], _p(b12), _p(a11),
+         store_from, _p(y12), _p(gray_scratch), dtype_enum(y12.dtype), _s())
+
+
 def vgg_conv1_1_fwd(gt, pred, ldp, batch, s, w, b, out, halves=3):
     call('imm_vgg_conv1_1_fwd', _p(gt), _p(pred), ldp, batch, s, _p(w), _p(b), _p(out), dtype_enum(out.dtype), halves, _s())
 

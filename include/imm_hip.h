@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define IMM_ABI_VERSION 19   /* 19: imm_set_cu_limit / imm_get_cu_limit, imm_masked_sse_pool with pool_a == NULL.  18: imm_copy_f32.  17: imm_cost_ema, imm_rms16 (summaries).  16: imm_conv2d_variant.  15: imm_conv2d_dgrad_s2, imm_conv2d_nol, imm_conv_first, imm_wgrad_job.x_scale/x_shift/x_relu; entry points removed
+#define IMM_ABI_VERSION 20   /* 20: imm_vgg_head_fwd / imm_vgg_head_supported / imm_vgg_head_scratch_bytes (conv1_1 + conv1_2 in one launch).  19: imm_set_cu_limit / imm_get_cu_limit, imm_masked_sse_pool with pool_a == NULL.  18: imm_copy_f32.  17: imm_cost_ema, imm_rms16 (summaries).  16: imm_conv2d_variant.  15: imm_conv2d_dgrad_s2, imm_conv2d_nol, imm_conv_first, imm_wgrad_job.x_scale/x_shift/x_relu; entry points removed
                                   since 14 (imm_bn_bwd_reduce_finalize, imm_conv2d_stats_workspace_bytes) finally counted */
 
 /* IMM_F32 (round 6): f32 activation storage — the exact-arithmetic WITNESS of the wiring, a test instrument (the reference computes
@@ -355,6 +355,18 @@ int imm_gauss_render_f32(const float* mu, int batch, int k, float inv_std, int s
  * the gt half does not depend on the network, so a caller may run it ahead on another stream. */
 int imm_vgg_conv1_1_fwd(const float* gt, const float* pred, int ldp, int batch, int s, const float* w9x64,
                         const float* b64, void* out, int dtype, int halves, void* stream);
+/* The head of the frozen VGG16 in one launch (vgg_head.hip): gray+normalise (build_vgg16.py:22-26) -> conv1_1 -> conv1_2
+ * (vgg16.py:345-346: 3x3 SAME + bias + ReLU each) on concat([gt, pred], 0) (imm_model.py:126).  The persistent conv1_2 workgroup
+ * produces the conv1_1 halo of its patches on the matrix cores (gray and filter as hi + lo pairs of the activation type: the f32
+ * product to 2^-16), so conv1_1's 2B x S x S x 64 activation never travels through HBM; only images >= store_from of it are
+ * stored to a11 (training: store_from = B, the prediction half = the ReLU mask of conv1_2's data gradient; 0 = all, 2B = none).
+ * wt12 = conv1_2's packed forward filter image (imm_pack_weights mode 0, kpad12 = 576), y12 16-bit [2B,S,S,64],
+ * gray_scratch >= imm_vgg_head_scratch_bytes(batch, s).  imm_vgg_head_supported: 16-bit dtype, S % 16 == 0, S >= 32. */
+int imm_vgg_head_supported(int batch, int s, int dtype);
+int64_t imm_vgg_head_scratch_bytes(int batch, int s);
+int imm_vgg_head_fwd(const float* gt, const float* pred, int ldp, int batch, int s, const float* w9x64, const float* b64,
+                     const void* wt12, int kpad12, const float* b12, void* a11, int store_from, void* y12, void* gray_scratch,
+                     int dtype, void* stream);
 /* dz 16-bit [B,S,S,64] (pred half, already ReLU-masked) -> dpred 16-bit [B,S,S,lddp]:
  * ch<3 = dgray/(3*255) + coef[input_idx]*mask[p]*(pred-gt), ch>=3 = 0.  coef is a device scalar table; input_idx = the
  * position of 'input' in perceptual.comp, or -1 when the raw image is not a loss feature; l1 != 0: sign(pred-gt)

@@ -1367,6 +1367,68 @@ def test_vgg_conv1_1(ops):
     assert float(dpred[..., 3:].float().abs().max()) == 0.0
 
 
+VGG_HEAD_CASES = [
+    # B, S, dtype, store_from (None = B), tag
+    (2, 128, torch.bfloat16, None, 'two_patches_per_workgroup'),
+    (1, 32, torch.bfloat16, None, 'one_patch_each'),
+    (1, 48, torch.bfloat16, 0, 'patch_grid_not_a_power_of_two_store_all'),
+    (5, 64, torch.bfloat16, None, 'ragged_patch_counts'),
+    (2, 64, torch.float16, None, 'f16'),
+    (1, 64, torch.bfloat16, 2, 'store_none'),
+]
+
+
+@pytest.mark.parametrize('B,S,dt,store_from,tag', VGG_HEAD_CASES, ids=[c[-1] for c in VGG_HEAD_CASES])
+def test_vgg_head_fused(ops, B, S, dt, store_from, tag):
+    """imm_vgg_head_fwd (gray -> conv1_1 -> conv1_2 in one launch, conv1_1's halo produced on the matrix cores from hi + lo
+    pairs) against (a) the oracle in fp32 and (b) the two launches it replaces (imm_vgg_conv1_1_fwd + imm_conv2d): conv1_1's
+    stored activation within one rounding of the 16-bit type of the VALU kernel's, conv1_2's output within the tolerance of
+    test_conv_forward; images below store_from are not written (selfsup/vgg16.py:345-346, build_vgg16.py:22-26)."""
+    from imm_amd import _lib as L
+    assert ops.vgg_head_supported(B, S, dt)
+    ldp = 8
+    g = torch.Generator().manual_seed(1234 + S)
+    gt = torch.rand(B, S, S, 3, generator=g) * 255
+    pred = torch.zeros(B, S, S, ldp); pred[..., :3] = torch.rand(B, S, S, 3, generator=g) * 255
+    w11 = rnd((3, 3, 1, 64), 81, 0.4, torch.float32); b11 = rnd((64,), 82, 0.1, torch.float32)
+    w12 = rnd((3, 3, 64, 64), 83, 0.05, torch.float32); b12 = rnd((64,), 84, 0.1, torch.float32)
+    sf = B if store_from is None else store_from
+    fd = ops.fwd_desc(2 * B, S, S, 64, 64, 64, 64, 3, 1, L.CONV_BIAS | L.CONV_RELU)
+    wt = torch.zeros(128, fd.kpad, dtype=dt, device=DEV)
+    ops.pack_weights(w12.to(DEV), wt, 0, 3, 3, 64, 64, 64, 128, fd.kpad)
+    gtd, pd = gt.to(DEV), pred.to(DEV)
+    w11d, b11d, b12d = w11.reshape(9, 64).to(DEV).contiguous(), b11.to(DEV), b12.to(DEV)
+    # (b) the two-launch sequence
+    a_ref = torch.empty(2 * B, S, S, 64, dtype=dt, device=DEV)
+    y_ref = torch.empty(2 * B, S, S, 64, dtype=dt, device=DEV)
+    ops.vgg_conv1_1_fwd(gtd, pd, ldp, B, S, w11d, b11d, a_ref)
+    ops.conv2d(fd, a_ref, wt, b12d, y_ref)
+    # the fused launch
+    sentinel = 7.0
+    a11 = torch.full((2 * B, S, S, 64), sentinel, dtype=dt, device=DEV)
+    y12 = torch.full((2 * B, S, S, 64), float('nan'), dtype=dt, device=DEV)
+    scratch = torch.empty(ops.vgg_head_scratch_bytes(B, S), dtype=torch.uint8, device=DEV)
+    ops.vgg_head_fwd(gtd, pd, ldp, B, S, w11d, b11d, wt, b12d, a11, sf, y12, scratch)
+    torch.cuda.synchronize()
+    assert not bool(torch.isnan(y12.float()).any()), 'every output pixel is written'
+    if sf > 0:
+        assert bool((a11[:sf].float() == sentinel).all()), 'images below store_from are not stored'
+    if sf < 2 * B:
+        # one unit in the last place of the storage type: bf16 2^-7, f16 2^-10 relative (+ a fraction of the tensor's scale near 0)
+        ulp = 2.0 ** -7 if dt == torch.bfloat16 else 2.0 ** -10
+        close(a11[sf:], a_ref[sf:], ulp, ulp * 0.05, 'conv1_1 activation (fused) vs vgg_conv1_1_fwd')
+        assert float((a11[sf:] != a_ref[sf:]).float().mean()) < 0.02, 'all but a few last-bit roundings are identical'
+    close(y12, y_ref, 1.6e-2, 2e-3, 'conv1_2 output (fused) vs conv1_1 + conv2d launches')
+    # (a) the oracle, fp32 from the images
+    ims = torch.cat([gt, pred[..., :3]], 0)
+    gray = ims.mean(dim=3, keepdim=True) / 255.0 - O.VGG_GRAY_MEAN / 255.0
+    a_o = torch.relu(O.conv2d_same(gray, w11, b11))
+    y_o = torch.relu(O.conv2d_same(a_o.to(dt).float(), w12.to(dt).float(), b12))
+    close(y12, y_o, 1.6e-2, 2e-3, 'conv1_2 output (fused) vs oracle')
+    if sf < 2 * B:
+        close(a11[sf:], a_o[sf:], 8e-3, 1e-3, 'conv1_1 activation (fused) vs oracle')
+
+
 def test_perceptual_loss_pieces(ops):
     from imm_amd import _lib as L
     B, S = 2, 32

@@ -1,6 +1,6 @@
 """Every IMM_* environment switch the product path still reads, exercised in both positions: the
 kernel-dispatch ablation list IMM_CONV_DISABLE (each specialised kernel family off -> the layer falls back to the next more
-general kernel, same numbers to accumulation order), IMM_NOL, IMM_CONV_FIRST, IMM_TWO_STREAMS, IMM_VGG_SPLIT / IMM_GT_CUS / IMM_WG_CUS / IMM_WG_LANES / IMM_SSE_INPUT_LANE (lane experiments of round 6), IMM_DEBUG_STAMPS, IMM_DEBUG_SKIP_TAGS.  The switches are
+general kernel, same numbers to accumulation order), IMM_NOL, IMM_CONV_FIRST, IMM_VGG_HEAD, IMM_TWO_STREAMS, IMM_VGG_SPLIT / IMM_GT_CUS / IMM_WG_CUS / IMM_WG_LANES / IMM_SSE_INPUT_LANE (lane experiments of round 6), IMM_DEBUG_STAMPS, IMM_DEBUG_SKIP_TAGS.  The switches are
 read once per process (static dispatch tables / engine construction), hence the child processes (tests/_switch_probe.py).
 IMM_DP_BUCKETS, IMM_RCCL_NATIVE and IMM_RCCL_GRAPH have their tests in test_dp_gpu.py / test_step_gpu.py; IMM_HIP_LIB and
 IMM_HIPCC_FLAGS (A/B builds) in test_host_cpu.py."""
@@ -48,6 +48,17 @@ def test_conv_disable_falls_back_to_the_general_kernels(base, names):
     the same step to accumulation order (loss 1e-4, parameters after two updates 1e-4 of their abs-sum)."""
     got = probe(IMM_CONV_DISABLE=names)
     assert same(base, got, 2e-4), (names, base, got)
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize('env', [{'IMM_VGG_HEAD': 0}, {'IMM_CONV_DISABLE': 'vgg_head'}], ids=['IMM_VGG_HEAD=0', 'IMM_CONV_DISABLE=vgg_head'])
+def test_vgg_head_in_one_launch_is_the_same_step(base, env):
+    """The default program runs conv1_1 + conv1_2 of the frozen VGG16 as one launch (imm_vgg_head_fwd: conv1_1's halo produced on
+    the matrix cores inside conv1_2's persistent workgroups); with it switched off the two launches it replaces run: one launch
+    more, the same step to the last-bit rounding of conv1_1's activation (selfsup/vgg16.py:345-346)."""
+    got = probe(**env)
+    assert got['n_launches'] == base['n_launches'] + 1, (got['n_launches'], base['n_launches'])
+    assert same(base, got, 2e-4), (base, got)
 
 
 @pytest.mark.timeout(300)

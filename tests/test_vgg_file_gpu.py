@@ -136,7 +136,7 @@ def test_step_with_weights_loaded_from_the_file_matches_oracle(vgg_file):
     print('\nVGG_FILE mu_maxabs %.3g loss_rel %.3g terms_rel %.3g terms %s' % (mu_err, loss_rel, terms_rel, terms_ref))
     assert mu_err < 1e-3 and loss_rel < 1e-3 and terms_rel < 1e-2
     # every tapped VGG feature of the file-loaded network against the oracle's (bf16 storage drift, no jumps)
-    for name, (y, _h) in eng.vgg_act.items():
+    for name, (y, _h) in eng.vgg_activations().items():
         ref = out['acts']['vgg'][name]
         e = float((y.float().cpu() - ref).norm() / ref.norm())
         assert e < 0.2, (name, e)

@@ -48,7 +48,7 @@ while time.time() < t_end:
         acts['opt.params'] = eng.params; acts['opt.adam_m'] = eng.adam_m; acts['opt.adam_v'] = eng.adam_v
         acts['opt.seg_norm2'] = eng.seg_norm2; acts['opt.blk_partial'] = eng.opt_blk_partial
     acts['joint'] = eng.joint; acts['mu'] = eng.mu; acts['heat'] = eng.heat; acts['wd'] = eng.wd_loss
-    for k_, (y_, _h) in eng.vgg_act.items(): acts['vgg.' + k_] = y_
+    for k_, (y_, _h) in eng.vgg_activations().items(): acts['vgg.' + k_] = y_
     if ref is None:
         ref = (g, l); aref = {k: v.clone() for k, v in acts.items()}
         torch.cuda.synchronize()      # the clones run on the default stream: they must not overlap the next replay on ts.stream
