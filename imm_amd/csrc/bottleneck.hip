@@ -47,7 +47,10 @@ __device__ __forceinline__ void gauss_grad(int mode, float dy, float dx, float i
 
 // means over the other axis, softmax + expectation, render — from the heat-map of sample b staged in LDS (sm: [h*w][K] heat |
 // [h][K] | [w][K] | [K][2])
-template <typename ET, int NTHR>
+// GM >= 0: the Gaussian mode as a compile-time constant (the launches of the bench path: 'rot'); -1: the runtime argument.  The
+// three modes' expf / powf / sqrtf sequences inlined into unrolled loops were most of these kernels' 10-35 KB of code, and a
+// few dozen workgroups walking that once through a cold instruction cache is latency on the pose lane's critical path.
+template <typename ET, int NTHR, int GM = -1>
 __device__ __forceinline__ void bt_softargmax_tail(float* sm, int b, int tid, int h, int w, int K, float inv_std, int s,
                                                    float* __restrict__ mu, float* __restrict__ py, float* __restrict__ px,
                                                    typename ET::T* __restrict__ gauss, int ldg, int mode) {
@@ -97,7 +100,7 @@ __device__ __forceinline__ void bt_softargmax_tail(float* sm, int b, int tid, in
       const int p = i / K, k = i - p * K;
       const int yy = p / s, xx = p - yy * s;
       const float dy = lin_pm1(yy, s) - smu[k * 2], dx = lin_pm1(xx, s) - smu[k * 2 + 1];
-      gauss[((int64_t)b * s * s + p) * ldg + k] = ET::from_f32(gauss_value(mode, dy, dx, inv_std));
+      gauss[((int64_t)b * s * s + p) * ldg + k] = ET::from_f32(gauss_value(GM >= 0 ? GM : mode, dy, dx, inv_std));
     }
   }
 }
@@ -125,7 +128,7 @@ __global__ __launch_bounds__(BT_THREADS) void softargmax_gauss_fwd_kernel(
 // wave v takes the tiles v, v+16, ...
 #define PH_THREADS 1024           // forward: 16 waves
 #define PH_BWD_THREADS 512        // backward: 8 waves (the filter rows of the data gradient take 64-128 registers per lane)
-template <typename ET>
+template <typename ET, int GM = -1>
 __global__ __launch_bounds__(PH_THREADS) void pose_head_fwd_kernel(
     const uint16_t* __restrict__ feat, int ldf, int C, const uint16_t* __restrict__ wt, int kpad, const float* __restrict__ bias,
     float* __restrict__ heat, int ldh, int h, int w, int K, float inv_std, int s, float* __restrict__ mu,
@@ -172,7 +175,7 @@ __global__ __launch_bounds__(PH_THREADS) void pose_head_fwd_kernel(
       }
   }
   __syncthreads();
-  bt_softargmax_tail<ET, PH_THREADS>(sm, b, tid, h, w, K, inv_std, s, mu, py, px, gauss, ldg, mode);
+  bt_softargmax_tail<ET, PH_THREADS, GM>(sm, b, tid, h, w, K, inv_std, s, mu, py, px, gauss, ldg, mode);
 }
 
 // backward: dG -> dmu (through the Gaussian) -> d row/col means (through softmax-expectation) -> dheat
@@ -180,7 +183,7 @@ __global__ __launch_bounds__(PH_THREADS) void pose_head_fwd_kernel(
 // stays in LDS as the MFMA operand of the data gradient d_feat[p][c] = sum_k dheat[p][k] W[c][k] (packed filter rows straight
 // from global memory), and its per-sample column sums (the bias gradient's partial row) are written for the final table-driven
 // reduction: one launch instead of bottleneck backward + column sum + 1x1 data gradient.
-template <typename ET, bool HEAD>
+template <typename ET, bool HEAD, int GM = -1>
 __global__ __launch_bounds__(HEAD ? PH_BWD_THREADS : BT_THREADS) void softargmax_gauss_bwd_kernel(
     const typename ET::T* __restrict__ dgauss, int ldg, int h, int w, int K, float inv_std, int s,
     const float* __restrict__ mu, const float* __restrict__ py, const float* __restrict__ px,
@@ -214,7 +217,7 @@ __global__ __launch_bounds__(HEAD ? PH_BWD_THREADS : BT_THREADS) void softargmax
       for (int c = 0; c < KC; ++c) {
         if (k0 + c < K) {
           float g, gmy, gmx;
-          gauss_grad(mode, ly - my[c], lx - mx[c], inv_std, g, gmy, gmx);
+          gauss_grad(GM >= 0 ? GM : mode, ly - my[c], lx - mx[c], inv_std, g, gmy, gmx);
           const float dg = ET::to_f32(dgp[c]);
           ay[c] += dg * gmy;
           ax[c] += dg * gmx;
@@ -392,10 +395,17 @@ extern "C" int imm_pose_head_fwd(const void* feat, int ldf, int c, const void* w
   const size_t lds = sizeof(float) * ((size_t)h * w * k + (size_t)(h + w) * k + 2 * (size_t)k);
   if (lds > kMaxDynLds) return imm_fail(IMM_E_UNSUPPORTED, "pose_head_fwd: heat-map %dx%dx%d needs %zu B LDS", h, w, k, lds);
   IMM_DISPATCH_DTYPE(dtype, {
-    if (set_dyn_lds(pose_head_fwd_kernel<ET>, lds)) return IMM_E_HIP;
-    hipLaunchKernelGGL((pose_head_fwd_kernel<ET>), dim3(batch), dim3(PH_THREADS), lds, (hipStream_t)stream, (const uint16_t*)feat,
-                       ldf, c, (const uint16_t*)wt, kpad, bias, heat, ldh, h, w, k, inv_std, s, mu, py, px, (uint16_t*)gauss_out, ldg,
-                       gauss_mode);
+    if (gauss_mode == IMM_GAUSS_ROT) {
+      if (set_dyn_lds(pose_head_fwd_kernel<ET, IMM_GAUSS_ROT>, lds)) return IMM_E_HIP;
+      hipLaunchKernelGGL((pose_head_fwd_kernel<ET, IMM_GAUSS_ROT>), dim3(batch), dim3(PH_THREADS), lds, (hipStream_t)stream,
+                         (const uint16_t*)feat, ldf, c, (const uint16_t*)wt, kpad, bias, heat, ldh, h, w, k, inv_std, s, mu, py, px,
+                         (uint16_t*)gauss_out, ldg, gauss_mode);
+    } else {
+      if (set_dyn_lds(pose_head_fwd_kernel<ET>, lds)) return IMM_E_HIP;
+      hipLaunchKernelGGL((pose_head_fwd_kernel<ET>), dim3(batch), dim3(PH_THREADS), lds, (hipStream_t)stream, (const uint16_t*)feat,
+                         ldf, c, (const uint16_t*)wt, kpad, bias, heat, ldh, h, w, k, inv_std, s, mu, py, px, (uint16_t*)gauss_out, ldg,
+                         gauss_mode);
+    }
   });
   IMM_CHECK_LAUNCH("imm_pose_head_fwd");
   return 0;
@@ -417,12 +427,19 @@ extern "C" int imm_pose_head_bwd(const void* dgauss, int ldg, int dtype, int bat
   const size_t lds = sizeof(float) * fl + (size_t)h * w * lddh * 2;
   if (lds > kMaxDynLds) return imm_fail(IMM_E_UNSUPPORTED, "pose_head_bwd: %dx%dx%d needs %zu B LDS", h, w, lddh, lds);
   IMM_DISPATCH_DTYPE(dtype, {
-    if (set_dyn_lds(softargmax_gauss_bwd_kernel<ET, true>, lds)) return IMM_E_HIP;
     // four workgroups per sample where that still leaves each at least two 16-channel tiles
     const int ysplit = (c >= 128 && batch <= 512) ? 4 : 1;
-    hipLaunchKernelGGL((softargmax_gauss_bwd_kernel<ET, true>), dim3(batch, ysplit), dim3(PH_BWD_THREADS), lds, (hipStream_t)stream,
-                       (const uint16_t*)dgauss, ldg, h, w, k, inv_std, s, mu, py, px, (uint16_t*)dheat, lddh, gauss_mode,
-                       (const uint16_t*)wt_dgrad, kpad_d, c, (uint16_t*)dfeat, lddf, bias_partial);
+    if (gauss_mode == IMM_GAUSS_ROT) {
+      if (set_dyn_lds(softargmax_gauss_bwd_kernel<ET, true, IMM_GAUSS_ROT>, lds)) return IMM_E_HIP;
+      hipLaunchKernelGGL((softargmax_gauss_bwd_kernel<ET, true, IMM_GAUSS_ROT>), dim3(batch, ysplit), dim3(PH_BWD_THREADS), lds,
+                         (hipStream_t)stream, (const uint16_t*)dgauss, ldg, h, w, k, inv_std, s, mu, py, px, (uint16_t*)dheat, lddh,
+                         gauss_mode, (const uint16_t*)wt_dgrad, kpad_d, c, (uint16_t*)dfeat, lddf, bias_partial);
+    } else {
+      if (set_dyn_lds(softargmax_gauss_bwd_kernel<ET, true>, lds)) return IMM_E_HIP;
+      hipLaunchKernelGGL((softargmax_gauss_bwd_kernel<ET, true>), dim3(batch, ysplit), dim3(PH_BWD_THREADS), lds, (hipStream_t)stream,
+                         (const uint16_t*)dgauss, ldg, h, w, k, inv_std, s, mu, py, px, (uint16_t*)dheat, lddh, gauss_mode,
+                         (const uint16_t*)wt_dgrad, kpad_d, c, (uint16_t*)dfeat, lddf, bias_partial);
+    }
   });
   IMM_CHECK_LAUNCH("imm_pose_head_bwd");
   return 0;

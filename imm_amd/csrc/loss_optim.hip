@@ -230,42 +230,34 @@ extern "C" int imm_masked_sse_f32(const float* a, int lda, const float* b, int l
 // l1 (perceptual.l2: False, imm_model.py:132): the sums are of |d|, c_k = 1000 * (1/wl - 0.01 m/wl^2) / nel multiplies sign(d).
 // mode IMM_LOSS_L2 (reconstruction_loss: 'l2', imm_model.py:385-387,399): one feature (the image), no normaliser:
 //   reconstruction = 1000 * m, total = reconstruction / 255 + weight decay, c_0 = (1000/255) * 2/nel.
-__global__ __launch_bounds__(LO_THREADS) void perceptual_finalize_kernel(const float* __restrict__ partial, int nfeat,
+#define PF_THREADS 1024
+__global__ __launch_bounds__(PF_THREADS) void perceptual_finalize_kernel(const float* __restrict__ partial, int nfeat,
                                                                          const float* __restrict__ nel, float* agg,
                                                                          int training, const float* __restrict__ wd_loss,
                                                                          int l1, int mode, const float* __restrict__ loss_scale,
                                                                          float* __restrict__ out) {
   __shared__ double sse[16];
-  __shared__ double wsum[LO_THREADS / 64][16];
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // the scalars of the tail, requested first (thread f owns feature f)
   const float nel_f = tid < nfeat ? nel[tid] : 1.f;
   const float agg_f = tid < nfeat ? agg[tid] : 1.f;
   const float ls = (tid < nfeat && loss_scale) ? loss_scale[0] : 1.f;
   const float wd = (tid == 0 && wd_loss) ? wd_loss[0] : 0.f;
-  // every feature's partials in flight at once, one wave butterfly per feature, one barrier in all (was a load + an
-  // 8-barrier tree per feature in sequence: 10.5 us on the critical path between the last error sum and the first gradient)
-  double v[16];
+  // One WAVE per feature (16 waves, nfeat <= 16): a lane's eight partials in flight at once, added in index order in f64, one
+  // butterfly, one barrier.  Round 6: the form before this one kept every feature's sums in every thread (16x unrolled loads +
+  // f64 butterflies: 28 KB of straight-line code that ONE workgroup walked through a cold instruction cache — 17 us on the
+  // critical path between the last error sum and the first gradient for a few hundred bytes of input); this one is < 2 KB.
+  if (wave < nfeat) {
+    const float* pf = partial + wave * IMM_SSE_BLOCKS + lane;
+    float x[IMM_SSE_BLOCKS / 64];
 #pragma unroll
-  for (int f = 0; f < 16; ++f) {
-    v[f] = 0.0;
-    if (f < nfeat)
-      for (int i = tid; i < IMM_SSE_BLOCKS; i += LO_THREADS) v[f] += (double)partial[f * IMM_SSE_BLOCKS + i];
-  }
+    for (int i = 0; i < IMM_SSE_BLOCKS / 64; ++i) x[i] = pf[64 * i];
+    double v = 0.0;
 #pragma unroll
-  for (int f = 0; f < 16; ++f) {
-    if (f < nfeat) {
-#pragma unroll
-      for (int o = 32; o >= 1; o >>= 1) v[f] += __shfl_xor(v[f], o, 64);
-      if ((tid & 63) == 0) wsum[tid >> 6][f] = v[f];
-    }
-  }
-  __syncthreads();
-  if (tid < nfeat) {
-    double t = 0.0;
-#pragma unroll
-    for (int w = 0; w < LO_THREADS / 64; ++w) t += wsum[w][tid];
-    sse[tid] = t;
+    for (int i = 0; i < IMM_SSE_BLOCKS / 64; ++i) v += (double)x[i];
+#pragma unroll 1
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (lane == 0) sse[wave] = v;
   }
   __syncthreads();
   // loss scaling (16-bit gradient storage with f16's range): every seed of the backward pass carries the factor S; the
@@ -312,7 +304,7 @@ extern "C" int imm_perceptual_finalize(const float* partial, int nfeat, const fl
                                        void* stream) {
   IMM_REQUIRE(partial && nel && agg && out && nfeat > 0 && nfeat <= 16, "perceptual_finalize: args");
   IMM_REQUIRE(mode == IMM_LOSS_PERCEPTUAL || (mode == IMM_LOSS_L2 && nfeat == 1 && !l1), "perceptual_finalize: mode");
-  hipLaunchKernelGGL(perceptual_finalize_kernel, dim3(1), dim3(LO_THREADS), 0, (hipStream_t)stream, partial, nfeat, nel,
+  hipLaunchKernelGGL(perceptual_finalize_kernel, dim3(1), dim3(PF_THREADS), 0, (hipStream_t)stream, partial, nfeat, nel,
                      agg, training, wd_loss, l1, mode, loss_scale, out);
   IMM_CHECK_LAUNCH("imm_perceptual_finalize");
   return 0;
