@@ -20,7 +20,7 @@ CONV_BIAS, CONV_RELU, CONV_STATS, CONV_MASK, CONV_OUT_F32 = 1, 2, 4, 8, 16
 SSE_BLOCKS = 512
 OPTIMIZERS = {'adam': 0, 'adadelta': 1, 'adagrad': 2}      # IMM_OPT_* (scripts/train.py:97-104)
 GAUSS_MODES = {'rot': 0, 'flat': 1, 'ankush': 2}     # IMM_GAUSS_* (config key gauss_mode, imm_model.py:48-72)
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 
 class ImmHipError(RuntimeError):
@@ -126,6 +126,7 @@ _SIGS = {
     'imm_unpool_tap_grad': [_P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _P, _I, _P],
     'imm_masked_sse_pool': [_P, _P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P],
     'imm_masked_sse_multi': [_I, _P, _P, _P, _P, _P, _I, _I, _P, _I, _I, _P],
+    'imm_masked_sse_all': [_I, _P, _P, _P, _P, _P, _I, _I, _P, _I, _I, _P, _I, _P, _I, _I, _P, _P],
     'imm_masked_sse': [_P, _P, _I, _I, _I, _I, _P, _I, _I, _P, _P],
     'imm_masked_sse_f32': [_P, _I, _P, _I, _I, _I, _I, _P, _I, _P, _P],
     'imm_perceptual_finalize': [_P, _I, _P, _P, _I, _P, _I, _I, _P, _P, _P],

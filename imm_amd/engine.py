@@ -29,6 +29,9 @@ from . import ops
 
 BN_EPS = 1e-3          # tf.layers.batch_normalization default (nn_utils.py:201)
 BN_MOMENTUM = 0.99
+# Partial rows of batch-norm sums that the fused finalize + apply passes reduce themselves; layers with more rows get a parallel
+# pre-reduction launch (imm_rows_reduce) in front.  IMM_BN_DIRECT_ROWS: A/B only (profiles/r06_bn_direct_rows_ab.txt).
+BN_DIRECT_ROWS = int(os.environ.get('IMM_BN_DIRECT_ROWS', '512'))
 WEIGHT_DECAY = 1e-5    # base_model.py:62-69
 INIT_STD = 0.01
 PERCEPTUAL_WS = [100.0, 1.6, 2.3, 1.8, 2.8, 100.0]   # imm_model.py:131
@@ -446,7 +449,7 @@ class IMMEngine:
             # an up-sampled block taken by the fused finalize + apply + up-sample pass never stores its own normalised tensor (nobody
             # reads it): it is not allocated either (a zero-filled `out` that looks valid).  lay.nol marks "normalise on
             # load" (the consumers read y); lay.out is None alone no longer means that.
-            fused_up = bool(up2x) and not defer_apply and nblk <= 256 and co % 32 == 0
+            fused_up = bool(up2x) and not defer_apply and nblk <= BN_DIRECT_ROWS and co % 32 == 0
             if out is None and not defer_apply and not fused_up:
                 out, ldo = self._act(B, fd.ho, fd.wo, co), co
             lay.out, lay.ldo = out, (ldo if out is not None else None)
@@ -476,7 +479,7 @@ class IMMEngine:
                 assert up2x is False and out is None
                 lay.out, lay.ldo = None, None
                 self._add(self.prog_fwd, f_fin, 'bn_finalize')
-            elif nblk <= 256 and co % 32 == 0:
+            elif nblk <= BN_DIRECT_ROWS and co % 32 == 0:
                 # few partial rows: the finalize is redone by every workgroup of the apply pass (one launch, one kernel
                 # boundary and a 6-9 us latency chain less per layer); the renderer's x2 up-sampling rides along
                 if up2x:
@@ -588,7 +591,7 @@ class IMMEngine:
                           'bn_bwd_reduce', 0.0, npix * co * 4.0)
             if co % 32 == 0:
                 rows, nrows = lay.bwd_partial, nblk
-                if nblk > 256:
+                if nblk > BN_DIRECT_ROWS:
                     g = max(32, -(-nblk // 32))
                     nrows = -(-nblk // g)
                     lay.bwd_red = rows_red = self._zeros(nrows, 2, co)
@@ -1021,11 +1024,15 @@ class IMMEngine:
         self._cur_scope = 'loss'
         if self._sse_input_early:
             self._mark(self.prog_fwd, 'join', lane=1)
-        elif 'input' in self.tap_idx:
+        tail = [name for name in taps if name not in fused_sse]
+        # the image pair's error sum rides in the launch of the deep layers' sums (imm_masked_sse_all, round 6: one launch less on the
+        # one-lane path in front of the loss; IMM_SSE_ALL=0 keeps the two launches — same partial sums bit for bit)
+        sse_all = ('input' in self.tap_idx and not self._sse_input_early and len(tail) > 1 and
+                   os.environ.get('IMM_SSE_ALL', '1') != '0')
+        if 'input' in self.tap_idx and not self._sse_input_early and not sse_all:
             idx0 = self.tap_idx['input']
             self._add(self.prog_fwd, lambda: ops.masked_sse_f32(self.in_future, 3, self.pred, self.ldp, B, S, 3, mask,
                                                                 self.sse_partial[idx0], l1), 'sse')
-        tail = [name for name in taps if name not in fused_sse]
         if self.vgg_split:
             # the last launch of the ground-truth lane produced the deepest tapped activation: the lane is joined here (every tap
             # that is not pooled next — conv3_2, conv4_2, conv5_2 — is read by the error sums below)
@@ -1039,8 +1046,14 @@ class IMMEngine:
                 y, H = self.vgg_act[name]
                 feats.append((y[:B], y[B:], H, y.shape[-1], self.sse_partial[self.tap_idx[name]]))
             self.sse_multi = ops.SseMulti(feats)
-            self._add(self.prog_fwd, lambda: ops.masked_sse_multi(self.sse_multi, B, mask, S, l1), 'sse', 0.0,
-                      sum(2 * B * f[2] * f[2] * f[3] * 2.0 for f in feats))
+            if sse_all:
+                idx0 = self.tap_idx['input']
+                self._add(self.prog_fwd, lambda: ops.masked_sse_all(self.sse_multi, B, mask, S, self.in_future, 3, self.pred, self.ldp, 3,
+                                                                    self.sse_partial[idx0], l1), 'sse', 0.0,
+                          sum(2 * B * f[2] * f[2] * f[3] * 2.0 for f in feats) + B * S * S * (3 + self.ldp + 1) * 4.0)
+            else:
+                self._add(self.prog_fwd, lambda: ops.masked_sse_multi(self.sse_multi, B, mask, S, l1), 'sse', 0.0,
+                          sum(2 * B * f[2] * f[2] * f[3] * 2.0 for f in feats))
             tail = []
         for name in tail:
             idx = self.tap_idx[name]

@@ -451,6 +451,13 @@ def masked_sse_multi(g, batch, mask, S, l1=False):
          C.cast(g.p, C.c_void_p), dtype_enum(g.dtype), batch, _p(mask), S, int(l1), _s())
 
 
+def masked_sse_all(g, batch, mask, S, img_a, lda, img_b, ldb, img_c, img_partial, l1=False):
+    """masked_sse_multi(g, ...) and masked_sse_f32(img_a, lda, img_b, ldb, batch, S, img_c, mask, img_partial) in one launch."""
+    call('imm_masked_sse_all', g.n, C.cast(g.a, C.c_void_p), C.cast(g.b, C.c_void_p), C.cast(g.s, C.c_void_p), C.cast(g.c, C.c_void_p),
+         C.cast(g.p, C.c_void_p), dtype_enum(g.dtype), batch, _p(mask), S, int(l1), _p(img_a), lda, _p(img_b), ldb, img_c,
+         _p(img_partial), _s())
+
+
 def masked_sse_f32(a, lda, b, ldb, batch, s, c, mask, partial, l1=False):
     call('imm_masked_sse_f32', _p(a), lda, _p(b), ldb, batch, s, c, _p(mask), int(l1), _p(partial), _s())
 

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define IMM_ABI_VERSION 20   /* 20: imm_vgg_head_fwd / imm_vgg_head_supported / imm_vgg_head_scratch_bytes (conv1_1 + conv1_2 in one launch).  19: imm_set_cu_limit / imm_get_cu_limit, imm_masked_sse_pool with pool_a == NULL.  18: imm_copy_f32.  17: imm_cost_ema, imm_rms16 (summaries).  16: imm_conv2d_variant.  15: imm_conv2d_dgrad_s2, imm_conv2d_nol, imm_conv_first, imm_wgrad_job.x_scale/x_shift/x_relu; entry points removed
+#define IMM_ABI_VERSION 21   /* 21: imm_masked_sse_all.  20: imm_vgg_head_fwd / imm_vgg_head_supported / imm_vgg_head_scratch_bytes (conv1_1 + conv1_2 in one launch).  19: imm_set_cu_limit / imm_get_cu_limit, imm_masked_sse_pool with pool_a == NULL.  18: imm_copy_f32.  17: imm_cost_ema, imm_rms16 (summaries).  16: imm_conv2d_variant.  15: imm_conv2d_dgrad_s2, imm_conv2d_nol, imm_conv_first, imm_wgrad_job.x_scale/x_shift/x_relu; entry points removed
                                   since 14 (imm_bn_bwd_reduce_finalize, imm_conv2d_stats_workspace_bytes) finally counted */
 
 /* IMM_F32 (round 6): f32 activation storage — the exact-arithmetic WITNESS of the wiring, a test instrument (the reference computes
@@ -388,6 +388,11 @@ int imm_image_loss_grad(const float* gt, const float* pred, int ldp, int batch, 
  * size arrays are HOST arrays (copied into the kernel arguments). */
 int imm_masked_sse_multi(int n, const void* const* a, const void* const* b, const int32_t* s_host, const int32_t* c_host,
                          float* const* partial, int dtype, int batch, const float* mask, int S, int l1, void* stream);
+/* imm_masked_sse_multi AND imm_masked_sse_f32 (the f32 image pair of side S: the 'input' feature, imm_model.py:126-131) as ONE launch:
+ * the error sums that sit back to back in front of the loss; every partial sum is bit for bit that of the two launches. */
+int imm_masked_sse_all(int n, const void* const* a, const void* const* b, const int32_t* s_host, const int32_t* c_host,
+                       float* const* partial, int dtype, int batch, const float* mask, int S, int l1,
+                       const float* img_a, int lda, const float* img_b, int ldb, int img_c, float* img_partial, void* stream);
 int imm_masked_sse(const void* a, const void* b, int dtype, int batch, int s, int c, const float* mask, int S, int l1,
                    float* partial, void* stream);
 /* imm_masked_sse fused with the 2x2/2 max-pool that follows the tapped VGG layer (conv1_2, conv2_2): reads the two feature

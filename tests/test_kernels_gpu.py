@@ -827,6 +827,21 @@ def test_masked_sse_multi_equals_single_launches(ops):
         torch.cuda.synchronize()
         for (_a, _b, _s, _c, part), ref in zip(feats, single):
             assert torch.equal(part, ref)
+        # imm_masked_sse_all: the same launch + the f32 image pair of imm_masked_sse_f32 (the 'input' feature), bit for bit
+        ldp = 8
+        gt = (torch.rand(B, S, S, 3, generator=g) * 255).to(DEV)
+        pred = torch.zeros(B, S, S, ldp); pred[..., :3] = torch.rand(B, S, S, 3, generator=g) * 255
+        pred = pred.to(DEV)
+        img_ref = torch.empty(L.SSE_BLOCKS, device=DEV)
+        ops.masked_sse_f32(gt, 3, pred, ldp, B, S, 3, mask, img_ref, l1=l1)
+        img_part = torch.full((L.SSE_BLOCKS,), float('nan'), device=DEV)
+        for (_a, _b, _s, _c, part) in feats:
+            part.fill_(float('nan'))
+        ops.masked_sse_all(ops.SseMulti(feats), B, mask, S, gt, 3, pred, ldp, 3, img_part, l1=l1)
+        torch.cuda.synchronize()
+        assert torch.equal(img_part, img_ref)
+        for (_a, _b, _s, _c, part), ref in zip(feats, single):
+            assert torch.equal(part, ref)
 
 
 @pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16], ids=['bf16', 'f16'])

@@ -1,6 +1,6 @@
 """Every IMM_* environment switch the product path still reads, exercised in both positions: the
 kernel-dispatch ablation list IMM_CONV_DISABLE (each specialised kernel family off -> the layer falls back to the next more
-general kernel, same numbers to accumulation order), IMM_NOL, IMM_CONV_FIRST, IMM_VGG_HEAD, IMM_TWO_STREAMS, IMM_VGG_SPLIT / IMM_GT_CUS / IMM_WG_CUS / IMM_WG_LANES / IMM_SSE_INPUT_LANE (lane experiments of round 6), IMM_DEBUG_STAMPS, IMM_DEBUG_SKIP_TAGS.  The switches are
+general kernel, same numbers to accumulation order), IMM_NOL, IMM_CONV_FIRST, IMM_VGG_HEAD, IMM_SSE_ALL, IMM_BN_DIRECT_ROWS, IMM_TWO_STREAMS, IMM_VGG_SPLIT / IMM_GT_CUS / IMM_WG_CUS / IMM_WG_LANES / IMM_SSE_INPUT_LANE (lane experiments of round 6), IMM_DEBUG_STAMPS, IMM_DEBUG_SKIP_TAGS.  The switches are
 read once per process (static dispatch tables / engine construction), hence the child processes (tests/_switch_probe.py).
 IMM_DP_BUCKETS, IMM_RCCL_NATIVE and IMM_RCCL_GRAPH have their tests in test_dp_gpu.py / test_step_gpu.py; IMM_HIP_LIB and
 IMM_HIPCC_FLAGS (A/B builds) in test_host_cpu.py."""
@@ -59,6 +59,27 @@ def test_vgg_head_in_one_launch_is_the_same_step(base, env):
     got = probe(**env)
     assert got['n_launches'] == base['n_launches'] + 1, (got['n_launches'], base['n_launches'])
     assert same(base, got, 2e-4), (base, got)
+
+
+@pytest.mark.timeout(600)
+def test_bn_direct_rows_threshold_is_the_same_step():
+    """IMM_BN_DIRECT_ROWS (default 512): layers whose convolution leaves more partial rows of batch-norm sums get a parallel
+    pre-reduction launch (imm_rows_reduce) in front of the fused finalize + apply pass — the same sums grouped differently
+    (batch 8: the 128 x 128 layers' persistent grids leave 512 rows)."""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    r512, r256, r1024 = probe(PROBE_BATCH=8), probe(PROBE_BATCH=8, IMM_BN_DIRECT_ROWS=256), probe(PROBE_BATCH=8, IMM_BN_DIRECT_ROWS=1024)
+    assert r256['n_launches'] > r512['n_launches'] >= r1024['n_launches'], (r256['n_launches'], r512['n_launches'], r1024['n_launches'])
+    assert same(r512, r256, 2e-4) and same(r512, r1024, 2e-4), (r512, r256, r1024)
+
+
+@pytest.mark.timeout(300)
+def test_error_sums_in_one_launch_are_the_same_step(base):
+    """IMM_SSE_ALL=0: the image pair's error sum and the deep layers' error sums as the two launches imm_masked_sse_all replaces
+    (imm_model.py:126-147): one launch more, every partial sum — and so the step — bit for bit the same."""
+    got = probe(IMM_SSE_ALL=0)
+    assert got['n_launches'] == base['n_launches'] + 1, (got['n_launches'], base['n_launches'])
+    assert all(got[k] == base[k] for k in ('loss0', 'loss1', 'mu_abs_sum', 'params_abs_sum')), (base, got)
 
 
 @pytest.mark.timeout(300)
