@@ -53,6 +53,15 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 #ifndef IMM_H6_ABLATE
 #define IMM_H6_ABLATE 0
 #endif
+// IMM_H6_ROLL (round 6, default 1): the nine taps of a slice are walked COLUMN by column (kx outer, ky inner) and the A fragments are
+// a rolling window of six halo rows per column: tap (ky, kx) multiplies rows ky .. ky+3, so ky = 1 / 2 each need ONE new row instead
+// of four — 6 instead of 12 A reads per column, 18 instead of 24 ds_read_b128 per three k-steps.  The LDS pipeline runs about as
+// long as the matrix pipeline in this kernel (MFMA-only 41.5 us, everything but the MFMAs 36.7 us, together
+// 63.4 for conv4_2), so a quarter fewer operand reads is time.  The filter image is unchanged: the DMA picks memory tap 3 ky + kx
+// for stream position 3 kx + ky.  -DIMM_H6_ROLL=0: the row-major walk with four fresh A rows per k-step (A/B builds).
+#ifndef IMM_H6_ROLL
+#define IMM_H6_ROLL 1
+#endif
 
 
 struct H6Args {
@@ -128,7 +137,8 @@ __global__ __launch_bounds__(512) void conv_hdeep6_kernel(const H6Args ha) {
   bool in_loop = false;
   auto dma_b = [&](int ssx, int u, int grp, int pos) {
     if ((ABL & 1) && in_loop) return;
-    const int h = u / 9, tp = u - h * 9;
+    const int h = u / 9, tq = u - h * 9;
+    const int tp = IMM_H6_ROLL ? (tq % 3) * 3 + tq / 3 : tq;      // memory tap (3 ky + kx) of stream position tq
     const uint32_t soff = (uint32_t)((tp * ci + ssx * 64 + h * 32) * 2);
     h6_dma16(wr, lds_base + (uint32_t)(H6_RING + grp * H6_GROUP + pos * H6_BSTAGE + wid * 1024), b_voff, soff);
   };
@@ -185,21 +195,45 @@ __global__ __launch_bounds__(512) void conv_hdeep6_kernel(const H6Args ha) {
   };
   frag_offsets();
 
+#if IMM_H6_ROLL
+  uint4 aw[2][MT + 2], bf[2][NT];                      // [column parity][halo row of the column's window], [k-step parity][tile]
+#else
   uint4 af[2][MT], bf[2][NT];                          // [fragment buffer][tile]
+#endif
   const char* const lds = (const char*)smem;
   // fragments of k-step u (of the super-slice stream) from filter group base vb (bytes)
   auto read_frags = [&](const int buf, const int u, const uint32_t vb) __attribute__((always_inline)) {
     if ((ABL & 2) && in_loop) return;
-    const int h = u / 9, tp = u - h * 9, ky = tp / 3, kx = tp - ky * 3, pos = u % 6;
+    const int h = u / 9, tp = u - h * 9, pos = u % 6;
+#if IMM_H6_ROLL
+    // stream position tp = 3 kx + ky; column (u / 3) keeps its six halo rows in aw[(u / 3) & 1]: ky = 0 brings rows 0..3, ky = 1 row 4,
+    // ky = 2 row 5 (the rows a k-step multiplies are ky .. ky + 3)
+    const int kx = tp / 3, ky = tp - kx * 3, set = (u / 3) & 1;
+    if (ky == 0) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i) aw[set][i] = *(const uint4*)(lds + aoff[kx] + (h * H6_HSTAGE + i * H6_ROWB));
+    } else {
+      aw[set][MT - 1 + ky] = *(const uint4*)(lds + aoff[kx] + (h * H6_HSTAGE + (MT - 1 + ky) * H6_ROWB));
+    }
+#else
+    const int ky = tp / 3, kx = tp - ky * 3;
 #pragma unroll
     for (int i = 0; i < MT; ++i) af[buf][i] = *(const uint4*)(lds + aoff[kx] + (h * H6_HSTAGE + (i + ky) * H6_ROWB));
+#endif
 #pragma unroll
     for (int j = 0; j < NT; ++j) bf[buf][j] = *(const uint4*)(lds + vb + (pos * H6_BSTAGE + j * 256));
   };
-  // MFMAs m0 .. m1-1 of the 16 of a k-step (tile m: pixel row m % 4, channel tile m / 4)
+  // MFMAs m0 .. m1-1 of the 16 of a k-step (tile m: pixel row m % 4, channel tile m / 4); uu = the k-step's stream position
+#if IMM_H6_ROLL
+#define H6_MFMA(buf, m0, m1)                                                                             \
+  if (!(ABL & 8)) _Pragma("unroll") for (int m = (m0); m < (m1); ++m)                                      \
+    acc[m % MT][m / MT] = ET::mfma(bf[(ABL & 2) ? 0 : buf][m / MT],                                       \
+                                   aw[(ABL & 2) ? 0 : (u / 3) & 1][(ABL & 2) ? m % MT : m % MT + u % 3], acc[m % MT][m / MT])
+#else
 #define H6_MFMA(buf, m0, m1)                                                                             \
   if (!(ABL & 8)) _Pragma("unroll") for (int m = (m0); m < (m1); ++m)                                      \
     acc[m % MT][m / MT] = ET::mfma(bf[(ABL & 2) ? 0 : buf][m / MT], af[(ABL & 2) ? 0 : buf][m % MT], acc[m % MT][m / MT])
+#endif
 #define H6_FENCE() __builtin_amdgcn_sched_barrier(0)
 
   // this wave's pieces of halo slice 0 and filter stage 0 are in (stages 1..5 may be outstanding), then everybody's; the wait
@@ -247,10 +281,17 @@ __global__ __launch_bounds__(512) void conv_hdeep6_kernel(const H6Args ha) {
           }
           read_frags(cur ^ 1, u + 1, vB);
           H6_MFMA(cur, 0, 4);
-#pragma unroll
-          for (int m = 0; m < 4; ++m) {
+          {
+            // the next k-step's operand reads between this one's first MFMAs: 8 (a new column: four A rows) or 5 (one A row)
+            constexpr int nrd = (IMM_H6_ROLL && (u + 1) % 3 != 0) ? 5 : 8;
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, nrd >= 6 ? 2 : 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if constexpr (nrd >= 8) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
           }
           if constexpr (pos < 2) {
             // pieces 3 + 3 pos .. 5 + 3 pos of the slot opened at the last barrier = filter stages 3 pos .. 3 pos + 2 of the interval
