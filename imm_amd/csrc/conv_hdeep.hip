@@ -93,9 +93,19 @@ __device__ __forceinline__ float hd_row_sum16(float x) {
 // (min(ky', 1), min(kx', 1)): dy[i - (ky >> 1)][j - (kx >> 1)] with ky = 2 - ky'.  Nine taps of matrix work per tile — the
 // algorithmic count; the im2col forms it replaces ran four launches' worth of gathers at 1-7 % matrix duty with 6-39 VALU
 // instructions per MFMA (profiles/r03_v3_pmc_sq_ratios.txt).  The epilogue scatters class (py, px) to pixel (2i+py, 2j+px).
+// IMM_HD_ROLL (round 6, default 1; conv_hdeep6.hip's IMM_H6_ROLL for the row-at-a-time variants): the barrier interval of a ROW3
+// kernel becomes one filter COLUMN — taps (0, kx), (1, kx), (2, kx) — and the A fragments a rolling window of six halo rows per
+// channel half: tap (ky, kx) multiplies rows ky .. ky + 3, so ky = 1 / 2 need one new row each: 12 instead of 24 A reads per
+// interval (with NT = 2: 24 instead of 36 ds_read_b128).  Ring stage 3 kx + ky holds memory tap 3 ky + kx (the DMA's choice; the
+// packed filter image is unchanged).  Not for MAP8 (an operand row is two image rows: another reuse pattern) and S2D (halo offsets
+// min(k', 1)).  -DIMM_HD_ROLL=0: the row walk (A/B builds).
+#ifndef IMM_HD_ROLL
+#define IMM_HD_ROLL 1
+#endif
 template <typename ET, int BN, int NW, int PH, bool MAP8 = false, int NSB_ = 0, bool PERSIST = false, bool ROW3 = false, bool S2D = false>
 __global__ __launch_bounds__(NW * 64) void conv_hdeep_kernel(const HdArgs ha) {
   const ConvArgs& a = ha.c;
+  constexpr bool COL = IMM_HD_ROLL && ROW3 && !S2D && !MAP8;   // column-at-a-time intervals with a rolling A window
   static_assert(!S2D || (!MAP8 && !PERSIST && NW == 4 && BN == 64), "stride-2 data gradient: 8x16 class patches x 64 channels, one tile per workgroup");
   constexpr int NCLS = S2D ? 4 : 1;                    // accumulator sets (parity classes)
   static_assert((NW == 8 && PH == 16) || (NW == 4 && PH == 8), "wave (wm, wn) owns patch rows 4wm..4wm+3 x BN/2 channels");
@@ -196,7 +206,7 @@ __global__ __launch_bounds__(NW * 64) void conv_hdeep_kernel(const HdArgs ha) {
 #pragma unroll
   for (int k = 0; k < NPIECE; ++k) issue_halo_piece(0, 0, k, true);
 #pragma unroll
-  for (int t = 0; t < HD_NSB; ++t) issue_b(t, t, true);
+  for (int t = 0; t < HD_NSB; ++t) issue_b(COL ? (t % 3) * 3 + t / 3 : t, t, true);   // COL: stage 3 kx + ky <- memory tap 3 ky + kx
 
   // The accumulators START at the bias: its loads are issued here, behind the prologue DMA (an epilogue that begins with a
   // dependent global load costs its whole latency: ~0.6 us of the 2.2 us measured per tile), and the epilogue has no adds.
@@ -246,11 +256,21 @@ __global__ __launch_bounds__(NW * 64) void conv_hdeep_kernel(const HdArgs ha) {
   //     DMA filter tap t+NSB -> stage t % NSB, one halo piece of the next slice
   //     ds_read (t+1, 0)
   //     MFMA (t, 1)
-  uint4 af[2][MT], bf[2][NT];                          // [k-step][tile]
+  uint4 af[2][COL ? MT + 2 : MT], bf[2][NT];          // [k-step][tile]  (COL: [channel half][halo row of the column's window])
   auto read_frags = [&](const int ks, const uint4* Hs, const uint4* Bs, const int ky_, const int kx_) __attribute__((always_inline)) {
     const int ky = S2D ? (ky_ > 0 ? 1 : 0) : ky_, kx = S2D ? (kx_ > 0 ? 1 : 0) : kx_;   // S2D: halo offset min(k', 1), see the header
+    if constexpr (COL) {
+      // ky = 0 opens the column: rows 0..3; ky = 1 / 2 add row 4 / 5 (a k-step multiplies rows ky .. ky + 3)
+      if (ky == 0) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) af[ks][i] = Hs[(aoff[kx] ^ (ks * 4)) + i * STEP_I];
+      } else {
+        af[ks][MT - 1 + ky] = Hs[(aoff[kx] ^ (ks * 4)) + (MT - 1 + ky) * STEP_I];
+      }
+    } else {
 #pragma unroll
     for (int i = 0; i < MT; ++i) af[ks][i] = Hs[(aoff[kx] ^ (ks * 4)) + i * STEP_I + ky * STEP_KY];
+    }
 #pragma unroll
     for (int j = 0; j < NT; ++j) bf[ks][j] = Bs[boff[j][ks]];
   };
@@ -284,9 +304,11 @@ __global__ __launch_bounds__(NW * 64) void conv_hdeep_kernel(const HdArgs ha) {
           __builtin_amdgcn_sched_barrier(0);
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // fragments of k-step j are in registers
           __builtin_amdgcn_sched_barrier(0);
+          // (COL: the outer index `ky` of this loop nest is the filter COLUMN kx and (j >> 1) the row; stage = 3 outer + inner either way)
           if (j < 5) {
             const int nkx = (j + 1) >> 1;
-            read_frags(cur ^ 1, Hc, smem + BRING_U4 + (ky * 3 + nkx) * B_U4, ky, nkx);
+            if constexpr (COL) read_frags(cur ^ 1, Hc, smem + BRING_U4 + (ky * 3 + nkx) * B_U4, nkx, ky);
+            else read_frags(cur ^ 1, Hc, smem + BRING_U4 + (ky * 3 + nkx) * B_U4, ky, nkx);
           } else {
             // every fragment of this row has been read: its three stages are free; the next row's taps (requested one
             // slice = three rows ago) and, before the last row, the next slice's halo (requested after the first) must be in
@@ -295,19 +317,22 @@ __global__ __launch_bounds__(NW * 64) void conv_hdeep_kernel(const HdArgs ha) {
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int x3 = 0; x3 < 3; ++x3) issue_b((cc + 1) * 9 + ky * 3 + x3, ky * 3 + x3, next_slice);
+            for (int x3 = 0; x3 < 3; ++x3) issue_b((cc + 1) * 9 + (COL ? x3 * 3 + ky : ky * 3 + x3), ky * 3 + x3, next_slice);
             if (ky == 0) {
 #pragma unroll
               for (int k = 0; k < NPIECE; ++k) issue_halo_piece(cc + 1, (gs + 1) & 1, k, next_slice);
             }
-            if (ky < 2) read_frags(0, Hc, smem + BRING_U4 + ((ky + 1) * 3) * B_U4, ky + 1, 0);
-            else read_frags(0, Hnx, smem + BRING_U4, 0, 0);           // past the last slice: landed no-op data, never used
+            if (ky < 2) {
+              if constexpr (COL) read_frags(0, Hc, smem + BRING_U4 + ((ky + 1) * 3) * B_U4, 0, ky + 1);
+              else read_frags(0, Hc, smem + BRING_U4 + ((ky + 1) * 3) * B_U4, ky + 1, 0);
+            } else read_frags(0, Hnx, smem + BRING_U4, 0, 0);         // past the last slice: landed no-op data, never used
           }
           const int cls = S2D ? ((ky & 1) * 2 + ((j >> 1) & 1)) : 0;     // parity class of tap (ky, kx = j >> 1)
+          const int arow = COL ? (j >> 1) : 0;                            // COL: tap row = first window row of this k-step
 #pragma unroll
           for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int jj = 0; jj < NT; ++jj) acc[cls][i][jj] = ET::mfma(bf[cur][jj], af[cur][i], acc[cls][i][jj]);
+            for (int jj = 0; jj < NT; ++jj) acc[cls][i][jj] = ET::mfma(bf[cur][jj], af[cur][i + arow], acc[cls][i][jj]);
 #pragma unroll
           for (int m = 0; m < MT * NT; ++m) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
