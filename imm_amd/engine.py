@@ -438,8 +438,15 @@ class IMMEngine:
         lay.y = self._zeros(B, fd.ho, fd.wo, ldy, dtype=torch.float32 if out_f32 else dt)
         flops = 2.0 * npix * k * kw * ci_real * co
         if bn:
-            nblk = (ops.conv_first_stats_blocks(B, H) if first_src is not None else
-                    ops.conv_stats_blocks(fd) if nol_src is None else ops.conv2d_nol_stats_blocks(fd))
+            cus_q = int(getattr(self, '_cur_cus', 0))
+            if cus_q:
+                ops.set_cu_limit(cus_q)         # the partial rows of the tile plan the launch will take under its CU limit
+            try:
+                nblk = (ops.conv_first_stats_blocks(B, H) if first_src is not None else
+                        ops.conv_stats_blocks(fd) if nol_src is None else ops.conv2d_nol_stats_blocks(fd))
+            finally:
+                if cus_q:
+                    ops.set_cu_limit(0)
             lay.stats = self._zeros(nblk, 2, co)
             lay.scale, lay.shift, lay.mean, lay.rstd = (self._zeros(co) for _ in range(4))
             mm, mv = self._zeros(co), self._zeros(co)
