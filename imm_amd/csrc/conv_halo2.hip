@@ -414,6 +414,299 @@ __global__ __launch_bounds__(256) void conv_halo2_kernel(const Halo2Args ha) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// conv_halo2x_kernel — the 64 -> 64 channel instantiation on v_mfma_f32_32x32x16 (round 6).
+//
+// Why: this kernel family runs ONE wave per SIMD (352-400 registers: nine filter taps + two accumulator sets), and at one wave per
+// SIMD v_mfma_f32_16x16x32 sustains 1.09-1.25 PFLOP/s on this part against 1.58-1.70 for v_mfma_f32_32x32x16 (two waves per SIMD:
+// 1.7-1.9 either way; tools/probes/mfma_rate_probe.hip, profiles/r06_mfma_rate_probe.txt).  VGG conv1_2 (77 GFLOP) sat exactly on
+// that ceiling: 62 us = 1.25 PFLOP/s with no input bytes moving (profiles/r06_halo2_ablation.txt), 213 MB of HBM traffic = ~45 us.
+//
+// Same program as conv_halo2_kernel<64, 64> (persistent workgroup, filter in registers, NS-deep halo ring, epilogue of patch p-1
+// interleaved into the MFMA loop of patch p, every loop VMEM op from inline asm with a fixed count per step); what changes is the
+// tile algebra.  Wave (wm, wn) still owns patch rows 4wm .. 4wm+3 x channels 32wn .. 32wn+31, now as TWO 32 x 32 tiles:
+//   tile t = output rows (t, t + 2) of the wave's four  x 16 columns  = 32 pixels;   lane: pixel p = lane & 31 (row half p >> 4,
+//   column p & 15), k group h5 = lane >> 5 (8 of the 16 channels of a k-step).
+//   A operand of "fragment row" r (r = 0..3) = halo rows (r, r + 2) x 16 columns: tile 0 uses it for vertical tap ky = r, tile 1
+//   for ky = r - 1 — four fragment rows x 3 column shifts x 4 k-steps = 48 ds_read_b128 per patch and wave (the 16x16 form: 36).
+//   B operand (registers): MFMA row rho <-> channel 32wn + 16 ((rho >> 2) & 1) + 4 (rho >> 3) + (rho & 3), so that a lane, which
+//   holds D rows (reg & 3) + 8 (reg >> 2) + 4 h5, owns the 16 CONSECUTIVE channels 32wn + 16 h5 + reg: two 16-byte stores per tile.
+//   LDS halo image: [halo row][pixel][chunk ^ ((hx >> 1) & 7)] — the 16 lanes a ds_read_b128 serves together ({0-3, 12-15, 20-27}:
+//   columns 0-3 and 12-15 of one halo row, 4-11 of the other) then hit 16 distinct 16-byte slots mod 256 B (checked by enumeration
+//   for every wave, fragment row, column shift and k-step).
+// Accumulation order over the taps differs from the 16x16 form (results to rounding).  No batch-norm partial sums (the 64 -> 64
+// layers that need them keep the 16x16 form).
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+template <typename ET> struct H2xMfma;
+template <> struct H2xMfma<BF16> {
+  __device__ static __forceinline__ f32x16_t mfma(uint4 a, uint4 b, f32x16_t c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+  }
+};
+template <> struct H2xMfma<F16> {
+  __device__ static __forceinline__ f32x16_t mfma(uint4 a, uint4 b, f32x16_t c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+  }
+};
+__device__ __forceinline__ int h2x_swz(int hx) { return (hx >> 1) & 7; }
+
+#ifndef H2X_ABLATE   // diagnosis builds: 1 no halo bytes move, 2 no output bytes move, 4 no MFMAs, 8 no fragment reads inside the row loop
+#define H2X_ABLATE 0
+#endif
+template <typename ET, bool MASK, int NS>
+__global__ __launch_bounds__(256) void conv_halo2x_kernel(const Halo2Args ha) {
+  const ConvArgs& a = ha.c;
+  constexpr int CI = 64, BN = 64, C8 = 8, KS = 4, KH = 3, KW = 3;
+  constexpr int MT = 4, NF = 4;                    // patch rows per wave; fragment rows per wave and patch
+  constexpr int HW = H2_PW + 2, HROWS = H2_PH + 2;
+  constexpr int PIXB = CI * 2, ROWB = HW * PIXB;
+  constexpr int PIX_PER_DMA = 64 / C8;
+  constexpr int HP = h2_halo_slots(CI, KH, KW);
+  constexpr int HALO_DMA = HP / PIX_PER_DMA, DH = HALO_DMA / 4;
+  constexpr int H_U4 = HP * C8;
+  constexpr int O8 = BN / 8;
+  constexpr int M_U4 = MASK ? H2_PH * H2_PW * O8 : 0;
+  constexpr int MASK_DMA = M_U4 / 64, DM = MASK_DMA / 4;
+  constexpr int WAITN = (NS - 2) * (DH + DM + MT);
+  static_assert(HALO_DMA % 4 == 0 && MASK_DMA % 4 == 0 && WAITN < 64, "per-wave VMEM schedule");
+  extern __shared__ __attribute__((aligned(16))) uint4 smem[];   // [NS][H_U4] halo ring | [NS][M_U4] mask ring
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid >> 1, wn = wid & 1;
+  const int px = lane & 15, half = (lane >> 4) & 1, h5 = lane >> 5;
+  const uint64_t xa = (uint64_t)a.x, ya = (uint64_t)a.y, ma = (uint64_t)a.mask;
+  const u32x4_t xr = {(uint32_t)xa, (uint32_t)(xa >> 32) & 0xffffu, a.x_bytes, 0x00020000u};
+  const u32x4_t yr = {(uint32_t)ya, (uint32_t)(ya >> 32) & 0xffffu, ha.y_bytes, 0x00020000u};
+  const u32x4_t mr = {(uint32_t)ma, (uint32_t)(ma >> 32) & 0xffffu, ha.mask_bytes, 0x00020000u};
+  const uint32_t lds_base = (uint32_t)(size_t)(lds_void_t*)smem;
+  const int G = gridDim.x, per_img = ha.patches_x * ha.patches_y;
+  const bool xcd_mode = (G & 7) == 0;
+  const int xq = ha.n_patches >> 3, xrem = ha.n_patches & 7, xid = blockIdx.x & 7;
+  const int band0 = xid * xq + (xid < xrem ? xid : xrem), band_n = xq + (xid < xrem ? 1 : 0);
+  auto seq_patch = [&](int seq) -> int {
+    if (xcd_mode) {
+      const int local = (int)(blockIdx.x >> 3) + seq * (G >> 3);
+      return local < band_n ? band0 + local : -1;
+    }
+    const int pt = blockIdx.x + seq * G;
+    return pt < ha.n_patches ? pt : -1;
+  };
+  struct Pd { int img, y0, x0; };
+  const bool pow2 = ha.lg_px >= 0;
+  auto decode = [&](int patch) -> Pd {
+    Pd d;
+    if (patch < 0) { d.img = 0; d.y0 = 0x4000; d.x0 = 0; return d; }
+    int pr, py;
+    if (pow2) { d.img = patch >> ha.lg_pi; pr = patch & (per_img - 1); py = pr >> ha.lg_px; d.x0 = (pr & (ha.patches_x - 1)) * H2_PW; }
+    else { d.img = patch / per_img; pr = patch - d.img * per_img; py = pr / ha.patches_x; d.x0 = (pr - py * ha.patches_x) * H2_PW; }
+    d.y0 = py * H2_PH;
+    return d;
+  };
+
+  // ---- filter -> registers: B operand of a 32x32x16 MFMA = 32 channels x 16 k; lane: row rho = lane & 31, k group h5 ---------
+  u32x4_t bw[KH * KW][KS];
+  {
+    const int rho = lane & 31;
+    const int n = wn * 32 + 16 * ((rho >> 2) & 1) + 4 * (rho >> 3) + (rho & 3);
+    const uint16_t* wrow = a.wt + (size_t)n * a.kpad + h5 * 8;
+#pragma unroll
+    for (int tap = 0; tap < KH * KW; ++tap)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) bw[tap][ks] = *(const u32x4_t*)(wrow + tap * CI + ks * 16);
+  }
+  const bool f_bias = a.flags & IMM_CONV_BIAS;
+  const float relu_floor = (a.flags & IMM_CONV_RELU) ? 0.f : -__builtin_huge_valf();
+  float bv[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) bv[r] = f_bias ? a.bias[wn * 32 + 16 * h5 + r] : 0.f;
+#pragma unroll
+  for (int tap = 0; tap < KH * KW; ++tap)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(bw[tap][ks]));
+#pragma unroll
+  for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(bv[r]));
+
+  // ---- DMA pieces (conv_halo2_kernel's, with this kernel's chunk swizzle) ---------------------------------------------
+  int hyx[DH];
+  uint32_t hrel[DH];
+#pragma unroll
+  for (int k = 0; k < DH; ++k) {
+    const int hp = (wid + 4 * k) * PIX_PER_DMA + lane / C8;
+    const int hy = hp / HW, hx = hp - hy * HW;
+    const int sc = (lane % C8) ^ h2x_swz(hx);
+    hyx[k] = ((hp < HROWS * HW ? hy : 0x4000) << 16) | hx;
+    hrel[k] = (uint32_t)((hy * a.wi + hx) * a.ldx * 2 + sc * 16);
+  }
+  auto halo_piece = [&](const Pd& d, int stage, int k) {
+    const int y0 = d.y0 - 1, x0 = d.x0 - 1;
+    const uint32_t soff = (uint32_t)(d.img * a.hi * a.wi) * (uint32_t)(a.ldx * 2);
+    const uint32_t base = (uint32_t)((y0 * a.wi + x0) * a.ldx * 2);
+    const int iy = y0 + (hyx[k] >> 16), ix = x0 + (hyx[k] & 0xffff);
+    const bool ok = ((unsigned)iy < (unsigned)a.hi) & ((unsigned)ix < (unsigned)a.wi);
+    uint32_t in_range = base + hrel[k];
+    asm volatile("" : "+v"(in_range));
+    const uint32_t vo = (H2X_ABLATE & 1) ? H2_OOB : (ok ? in_range : H2_OOB);
+    h2_dma16(xr, lds_base + (uint32_t)((stage * H_U4) * 16 + (wid + 4 * k) * 1024), vo, soff);
+  };
+  uint32_t mrel[DM > 0 ? DM : 1];
+  if constexpr (MASK) {
+#pragma unroll
+    for (int k = 0; k < DM; ++k) {
+      const int mp = (wid + 4 * k) * (64 / O8) + lane / O8;
+      const int row = mp >> 4, x = mp & 15;
+      const int c = (lane % O8) ^ (x & (O8 - 1));
+      mrel[k] = (uint32_t)((row * a.wo + x) * a.ldmask * 2 + c * 16);
+    }
+  }
+  auto mask_piece = [&](const Pd& d, int stage, int k) {
+    if constexpr (MASK) {
+      const uint32_t soff = (uint32_t)(d.img * a.ho * a.wo) * (uint32_t)(a.ldmask * 2);
+      const uint32_t vo = d.y0 < 0x4000 ? (uint32_t)((d.y0 * a.wo + d.x0) * a.ldmask * 2) + mrel[k] : H2_OOB;
+      h2_dma16(mr, lds_base + (uint32_t)((NS * H_U4 + stage * M_U4) * 16 + (wid + 4 * k) * 1024), vo, soff);
+    }
+  };
+
+  // per-lane byte offset of the A fragment of fragment row 0 (halo rows wm*4 + 2*half), column shift kx, k-step 0; k-step ks = XOR
+  // ks * 32 (chunk 2 ks + h5 = (2 ks) ^ h5, the swizzle is an XOR too), fragment row r = + r * ROWB
+  int lrel[KW];
+#pragma unroll
+  for (int kx = 0; kx < KW; ++kx) lrel[kx] = ((wm * MT + 2 * half) * HW + px + kx) * PIXB + ((h5 ^ h2x_swz(px + kx)) << 4);
+  // mask ring: pixel (row, x) of the patch, chunk c at slot c ^ (x & 7); this lane's 16 channels = chunks 4 wn + 2 h5, + 1
+  const int moff0 = px * O8 + ((wn * 4 + 2 * h5) ^ (px & (O8 - 1))), moff1 = px * O8 + ((wn * 4 + 2 * h5 + 1) ^ (px & (O8 - 1)));
+  const uint32_t ovoff = (uint32_t)(((2 * half * a.wo + px) * a.ldy + wn * 32 + 16 * h5) * 2);   // lane part of the output address
+
+  // ---- prologue ------------------------------------------------------------------------------------------------------
+  const u32x4_t zero4 = {0u, 0u, 0u, 0u};
+  Pd dq[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) dq[s] = decode(seq_patch(s));
+  const Pd none = decode(-1);
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s) {
+#pragma unroll
+    for (int k = 0; k < DH; ++k) halo_piece(dq[s], s, k);
+#pragma unroll
+    for (int k = 0; k < DM; ++k) mask_piece(s >= 1 ? dq[s - 1] : none, s >= 1 ? s - 1 : NS - 1, k);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) h2_store16(yr, zero4, H2_OOB, 0u);
+  }
+
+  f32x16_t acc[2][2];                          // [accumulator set][tile]
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[1][t][r] = 0.f;
+  int it = 0, hs = 0;
+  uint32_t prev_voff = H2_OOB, prev_soff = 0u;
+
+  auto step = [&](auto phase, auto mma) {
+    constexpr int PH = decltype(phase)::value;
+    constexpr bool MMA = decltype(mma)::value;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAITN) : "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    const int hprev = hs == 0 ? NS - 1 : hs - 1;
+    const int hprev2 = hprev == 0 ? NS - 1 : hprev - 1;
+    const uint4* Ml = smem + NS * H_U4 + hprev * M_U4;
+    const uint4* rowp[KW][KS];
+#pragma unroll
+    for (int kx = 0; kx < KW; ++kx)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+        rowp[kx][ks] = (const uint4*)((const char*)smem + hs * (H_U4 * 16) + (lrel[kx] ^ (ks * 32)));
+    // The 48 fragment reads of a patch as TWELVE units (fragment row rr = u / 3, column shift kx = u % 3) of four k-steps each, in a
+    // four-deep register ring: unit u + 3 is requested while unit u's 4-8 MFMAs run (the row-at-a-time double buffer of the
+    // 16x16 form — twelve reads in front of 12-24 MFMAs — left this wave's in-order issue behind its own LDS queue: 86 us against
+    // 50 with the reads compiled out and 44 with the MFMAs compiled out, profiles/r06_halo2x_ablation.txt)
+    constexpr int NU = NF * KW, PD = 3;
+    uint4 fa[4][KS];
+    auto load_unit = [&](const int u) __attribute__((always_inline)) {
+      const int rr = u / KW, kx = u - rr * KW;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) fa[u & 3][ks] = rowp[kx][ks][rr * (ROWB / 16)];
+    };
+    if constexpr (MMA) {
+#pragma unroll
+      for (int u = 0; u < PD; ++u) load_unit(u);
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[PH][t][r] = 0.f;
+    __builtin_amdgcn_sched_barrier(0);
+
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const int rr = u / KW, kx = u - rr * KW;
+      int n_mfma = 0;
+      if constexpr (MMA) {
+        if (u + PD < NU && !(H2X_ABLATE & 8)) load_unit(u + PD);
+        if (u < DH) halo_piece(dq[NS - 1], hprev, u);
+        if (u >= DH && u - DH < DM) mask_piece(dq[NS - 2], hprev2, u - DH);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            const int ky = rr - t;                     // fragment row rr = halo rows (rr, rr + 2): tile t's vertical tap rr - t
+            if (ky >= 0 && ky < KH && !(H2X_ABLATE & 4)) {
+              acc[PH][t] = H2xMfma<ET>::mfma(__builtin_bit_cast(uint4, bw[ky * KW + kx][ks]), fa[(H2X_ABLATE & 8) ? (u < PD ? u : 0) : (u & 3)][ks], acc[PH][t]);   // D[n][pixel]
+              n_mfma += 1;
+            }
+          }
+      }
+      // ---- epilogue of the previous patch, one of its four 16-byte stores per fragment row: tile e >> 1, channel half e & 1 ------
+      if (kx == 0) {
+        const int e = rr, t = e >> 1, ch = e & 1;
+        float v[8];
+#pragma unroll
+        for (int q8 = 0; q8 < 8; ++q8) v[q8] = fmaxf(acc[PH ^ 1][t][ch * 8 + q8] + bv[ch * 8 + q8], relu_floor);
+        if constexpr (MASK) {
+          const uint4 mk = Ml[(wm * MT + t + 2 * half) * 16 * O8 + (ch ? moff1 : moff0)];   // this lane's pixel: patch row wm*4 + t + 2*half
+          float mf[8];
+          unpack8<ET>(mk, mf);
+#pragma unroll
+          for (int q8 = 0; q8 < 8; ++q8) v[q8] = (mf[q8] > 0.f) ? v[q8] : 0.f;
+        }
+        const uint4 o = pack8<ET>(v);
+        const u32x4_t od = {o.x, o.y, o.z, o.w};
+        h2_store16(yr, od, (H2X_ABLATE & 2) ? H2_OOB : prev_voff + (uint32_t)((wm * MT + t) * a.wo * a.ldy * 2 + ch * 16), prev_soff);
+      }
+      if (u == NU - 1) {
+        if constexpr (MMA) {
+          prev_voff = (uint32_t)((dq[0].y0 * a.wo + dq[0].x0) * a.ldy * 2) + ovoff;
+          prev_soff = (uint32_t)(dq[0].img * a.ho * a.wo) * (uint32_t)(a.ldy * 2);
+#pragma unroll
+          for (int s_ = 0; s_ + 1 < NS; ++s_) dq[s_] = dq[s_ + 1];
+          dq[NS - 1] = decode(seq_patch(it + NS));
+        }
+      }
+      if constexpr (MMA) {
+#pragma unroll
+        for (int m = 0; m < 2 * KS; ++m) {
+          if (m < n_mfma) {
+            __builtin_amdgcn_sched_group_barrier(H2_SG_MFMA, 1, 0);
+            if (m < KS) __builtin_amdgcn_sched_group_barrier(H2_SG_DSREAD, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(H2_SG_VALU | H2_SG_SALU, 4, 0);
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    hs = hs + 1 == NS ? 0 : hs + 1;
+    ++it;
+  };
+  for (;;) {
+    step(H2Int<0>(), H2Int<1>());
+    if (dq[0].y0 >= 0x4000) { step(H2Int<1>(), H2Int<0>()); break; }
+    step(H2Int<1>(), H2Int<1>());
+    if (dq[0].y0 >= 0x4000) { step(H2Int<0>(), H2Int<0>()); break; }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // no LDS-DMA may outlive the workgroup
+}
+
+// ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
 // Halo ring depth (prefetch distance NS-1 patches): bytes in flight per CU, not arithmetic, set the speed of these
@@ -454,6 +747,13 @@ bool imm_halo2_applicable(const imm_conv_desc* d) {
   if ((d->flags & IMM_CONV_MASK) && (d->ci != d->co || d->ldmask % 8)) return false;
   const int64_t px = (int64_t)d->batch * d->hi * d->wi;
   return px * d->ldx * 2 < (1LL << 31) && px * d->ldy * 2 < (1LL << 31) && px * (int64_t)d->ldmask * 2 < (1LL << 31);
+}
+
+// IMM_HALO2X=1: the 64 -> 64 launches without batch-norm partial sums take conv_halo2x_kernel (32x32x16 tiles).  OFF by default:
+// measured 79-81 us against 75-78 for VGG conv1_2 (profiles/r06_halo2x_ablation.txt)
+bool imm_halo2_x32(const imm_conv_desc* d) {
+  static const bool on = getenv("IMM_HALO2X") && getenv("IMM_HALO2X")[0] == '1';
+  return on && imm_halo2_applicable(d) && d->ci == 64 && d->co == 64 && d->kh == 3 && d->kw == 3 && !(d->flags & IMM_CONV_STATS);
 }
 
 static size_t h2_lds(int ci, int bn, bool mask, int ns, int kh = 3, int kw = 3) {
@@ -540,6 +840,19 @@ static void h2_launch(const imm_conv_desc* d, const ConvArgs& a, hipStream_t s) 
     ha.lg_px = __builtin_ctz(ha.patches_x); ha.lg_pi = __builtin_ctz(per_img);
   }
   const int grid = imm_halo2_grid(d);
+  if (imm_halo2_x32(d)) {     // 64 -> 64 channels without batch-norm sums: the 32x32x16 form (one workgroup per CU either way)
+    const bool mask = d->flags & IMM_CONV_MASK;
+    const size_t lds = h2_lds(64, 64, mask, h2_ns(mask));
+    static bool attr_set[2] = {false, false};       // (per element type: this function is a template)
+    if (!attr_set[mask]) {
+      if (mask) (void)hipFuncSetAttribute((const void*)conv_halo2x_kernel<ET, true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      else (void)hipFuncSetAttribute((const void*)conv_halo2x_kernel<ET, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr_set[mask] = true;
+    }
+    if (mask) hipLaunchKernelGGL((conv_halo2x_kernel<ET, true, 3>), dim3(grid), dim3(256), lds, s, ha);
+    else hipLaunchKernelGGL((conv_halo2x_kernel<ET, false, 4>), dim3(grid), dim3(256), lds, s, ha);
+    return;
+  }
   h2_dispatch(d, [&](auto ci, auto bn, auto mk, auto st, auto ns, auto kh, auto kw) {
     constexpr int CI = decltype(ci)::value, BN = decltype(bn)::value, NS = decltype(ns)::value;
     constexpr int KH = decltype(kh)::value, KW = decltype(kw)::value;

@@ -35,6 +35,7 @@ bool imm_hdeep_s2d_applicable(const imm_conv_desc* d);
 void imm_conv_hdeep_s2d_launch(int dtype, const imm_conv_desc* d, const ConvArgs& a, hipStream_t s);
 bool imm_halo2_applicable(const imm_conv_desc* d);                                 // conv_halo2.hip
 int imm_halo2_grid(const imm_conv_desc* d);
+bool imm_halo2_x32(const imm_conv_desc* d);
 void imm_conv_halo2_launch(int dtype, const imm_conv_desc* d, const ConvArgs& a, hipStream_t s);
 
 __device__ __forceinline__ int lds_chunk_idx(int row, int chunk) {
@@ -371,7 +372,7 @@ extern "C" int imm_conv2d_variant(const imm_conv_desc* d, int dtype) {
   if (validate_desc(d)) return IMM_E_INVALID;
   if (dtype == IMM_F32) return 800000;                 // family 8: the plain f32 kernels of the witness engine (conv_f32.hip)
   IMM_REQUIRE(dtype == IMM_BF16 || dtype == IMM_F16, "unknown dtype %d", dtype);
-  if (imm_halo2_applicable(d)) return 400000 + (d->kw == 1 ? 10000 : 0) + d->ci * 100 + (d->co > 32 ? 64 : 32);
+  if (imm_halo2_applicable(d)) return 400000 + (d->kw == 1 ? 10000 : 0) + (imm_halo2_x32(d) ? 20000 : 0) + d->ci * 100 + (d->co > 32 ? 64 : 32);   // + 20000: the 32x32x16 form
   if (imm_halo_applicable(d)) return 300000 + (d->stride == 2 ? 10000 : 0) + d->ci * 100 + (d->co > 32 ? 64 : d->co > 16 ? 32 : 16);
   if (imm_hdeep_applicable(d)) return imm_hdeep_variant(d);
   if (imm_s2f_applicable(d)) return imm_s2f_variant(d);

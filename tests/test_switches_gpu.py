@@ -1,6 +1,6 @@
 """Every IMM_* environment switch the product path still reads, exercised in both positions: the
 kernel-dispatch ablation list IMM_CONV_DISABLE (each specialised kernel family off -> the layer falls back to the next more
-general kernel, same numbers to accumulation order), IMM_NOL, IMM_CONV_FIRST, IMM_VGG_HEAD, IMM_SSE_ALL, IMM_BN_DIRECT_ROWS, IMM_TWO_STREAMS, IMM_VGG_SPLIT / IMM_GT_CUS / IMM_WG_CUS / IMM_WG_LANES / IMM_SSE_INPUT_LANE (lane experiments of round 6), IMM_DEBUG_STAMPS, IMM_DEBUG_SKIP_TAGS.  The switches are
+general kernel, same numbers to accumulation order), IMM_NOL, IMM_CONV_FIRST, IMM_VGG_HEAD, IMM_SSE_ALL, IMM_BN_DIRECT_ROWS, IMM_HALO2X, IMM_TWO_STREAMS, IMM_VGG_SPLIT / IMM_GT_CUS / IMM_WG_CUS / IMM_WG_LANES / IMM_SSE_INPUT_LANE (lane experiments of round 6), IMM_DEBUG_STAMPS, IMM_DEBUG_SKIP_TAGS.  The switches are
 read once per process (static dispatch tables / engine construction), hence the child processes (tests/_switch_probe.py).
 IMM_DP_BUCKETS, IMM_RCCL_NATIVE and IMM_RCCL_GRAPH have their tests in test_dp_gpu.py / test_step_gpu.py; IMM_HIP_LIB and
 IMM_HIPCC_FLAGS (A/B builds) in test_host_cpu.py."""
@@ -71,6 +71,16 @@ def test_bn_direct_rows_threshold_is_the_same_step():
     r512, r256, r1024 = probe(PROBE_BATCH=8), probe(PROBE_BATCH=8, IMM_BN_DIRECT_ROWS=256), probe(PROBE_BATCH=8, IMM_BN_DIRECT_ROWS=1024)
     assert r256['n_launches'] > r512['n_launches'] >= r1024['n_launches'], (r256['n_launches'], r512['n_launches'], r1024['n_launches'])
     assert same(r512, r256, 2e-4) and same(r512, r1024, 2e-4), (r512, r256, r1024)
+
+
+@pytest.mark.timeout(300)
+def test_halo2_on_32x32_tiles_is_the_same_step(base):
+    """IMM_HALO2X=1: the 64 -> 64 channel launches of conv_halo2 without batch-norm sums (VGG conv1_2's data gradient; its forward
+    when the head is two launches) on v_mfma_f32_32x32x16 tiles (conv_halo2x_kernel: built and measured in round 6, slower, off by
+    default) — the same step to the accumulation order of the nine taps (selfsup/vgg16.py:346)."""
+    for env in ({'IMM_HALO2X': 1}, {'IMM_HALO2X': 1, 'IMM_VGG_HEAD': 0}):
+        got = probe(**env)
+        assert same(base, got, 2e-4), (env, base, got)
 
 
 @pytest.mark.timeout(300)
